@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Headline benchmark: tracklet-pairs/sec scored at BASELINE.json cfg2
+(synthetic VidVRD shape: N=32 tracklets, T=150 frames, D=2048 RoI dims, fp32).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" = one pass of the hot path over one batch of `--videos` synthetic videos per GPU
+(inputs resident in HBM): tracklet tensors -> [pair builder + temporal encoder +
+relationness/span heads + RelOIPool + predicate head] (tspn_forward_fused_f32) + PPN
+pair-matrix/top-k.  Videos shard across ranks (weak scaling, no collective in the forward);
+with N>1 each step ends with ONE RCCL all-gather of the per-pair predicate logits and the
+top-k pair indices (the "final result gather").
+
+Printed JSON (rank 0): see the task contract; extras:
+  roofline     dominant kernel = conv3_mfma (tracklet projections, fp32 MFMA implicit GEMM);
+               achieved = executed FLOP per launch / HIP-event time of that launch inside the
+               timed steps (events recorded on the launch stream by the C ABI's hook).
+  cpu_baseline the oracle's reference-faithful dense forward on a bounded sample of pairs,
+               all host cores, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import tspn_mi355x as tspn  # noqa: E402
+
+N_TRK, T_FRAMES, D_ROI, A_ANCH, K_PRED = 32, 150, 2048, 4, 132
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+DPN_PRE = "relpn.duration_proposal_network.dpn_head."
+PPN_PRE = "relpn.pair_proposal_network.ppn_head."
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--videos", type=int, default=8, help="videos per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time")
+    return ap.parse_args()
+
+
+def cpu_baseline(weights, target_s):
+    """Reference-faithful dense forward (oracle.forward_dense: materialise [P,4096,150] ->
+    DPNHead -> heads; RelOIPool; predicate head) on a bounded sample of cfg2 pairs."""
+    import oracle
+    torch.set_num_threads(os.cpu_count() or 1)
+    v = tspn.synth.make_video(1, N_TRK, T_FRAMES, D_ROI)
+    feats, boxes = torch.from_numpy(v["tracklet_feats"]), torch.from_numpy(v["tracklet_boxes"])
+    w = {k: torch.from_numpy(x) for k, x in weights.items()}
+    pairs = oracle.pair_index(N_TRK)
+
+    def run(p):
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            oracle.forward_dense(feats, boxes, pairs[:p], w)
+        return time.perf_counter() - t0
+
+    run(2)  # warm
+    probe = 8
+    dt = run(probe)
+    p = int(max(probe, min(N_TRK * (N_TRK - 1), probe * target_s / max(dt, 1e-3))))
+    dt = run(p)
+    return {"value": p / dt, "unit": "tracklet-pairs/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{p} of 992 pairs of one cfg2 video, dense reference formulation "
+                      f"(oracle.forward_dense), {dt:.1f} s, torch {torch.__version__} CPU"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs a HIP device (no CPU fallback)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    B, N, T, D, C = args.videos, N_TRK, T_FRAMES, D_ROI, 2 * D_ROI
+    P_vid = N * (N - 1)
+
+    # ---- weights (seed 0) and inputs (seed 1 + global video index), random-init / synthetic
+    sd = tspn.synth.make_weights(0, c=C, a=A_ANCH, k=K_PRED)
+    wnp = {"conv_w": sd[DPN_PRE + "conv.weight"], "conv_b": sd[DPN_PRE + "conv.bias"],
+           "dur_w": sd[DPN_PRE + "duration_pred.weight"], "dur_b": sd[DPN_PRE + "duration_pred.bias"],
+           "rel_w": sd[DPN_PRE + "relness_pred.weight"], "rel_b": sd[DPN_PRE + "relness_pred.bias"],
+           "cls_w": sd["classifier.rel_predictor.weight"], "cls_b": sd["classifier.rel_predictor.bias"]}
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    conv_w = d(wnp["conv_w"])
+    packed = tspn.ops.pack_conv3(conv_w, split=D)
+    del conv_w
+    conv_b = d(wnp["conv_b"])
+    head_w = d(np.concatenate([wnp["rel_w"][:, :, 0], wnp["dur_w"][:, :, 0]]))
+    head_b = d(np.concatenate([wnp["rel_b"], wnp["dur_b"]]))
+    cls_w, cls_b = d(wnp["cls_w"]), d(wnp["cls_b"])
+    ppn_w = {k[len(PPN_PRE):]: d(v) for k, v in sd.items() if k.startswith(PPN_PRE)}
+
+    vids = [tspn.synth.make_video(1 + rank * B + b, N, T, D) for b in range(B)]
+    feats = d(np.concatenate([v["tracklet_feats"] for v in vids]))
+    cls = d(np.stack([v["track_cls_logits"] for v in vids]))
+    del vids
+    pairs = torch.cat([tspn.ops.pair_index(N, dev, base=b * N) for b in range(B)]).contiguous()
+    P = pairs.shape[0]
+
+    ws = torch.empty(tspn.ops.fused_workspace_bytes(B, N, T, D, A_ANCH, K_PRED, P), dtype=torch.uint8,
+                     device=dev)
+    out_heads = torch.empty((P, 3 * A_ANCH, T), dtype=torch.float32, device=dev)
+    out_logits = torch.empty((P, K_PRED), dtype=torch.float32, device=dev)
+    total_steps = args.warmup + args.steps
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+              for _ in range(total_steps)]
+    for a, b in events:  # create the HIP event handles
+        a.record(); b.record()
+    torch.cuda.synchronize()
+
+    def step(i):
+        tspn.ops.forward_fused(feats, pairs, B, N, packed, conv_b, head_w, head_b, cls_w, cls_b,
+                               workspace=ws, out_heads=out_heads, out_logits=out_logits,
+                               check_pairs=False, conv_events=events[i])
+        _, idx = tspn.ops.ppn_pair_matrix_topk(cls, ppn_w, 256)
+        if world > 1:  # the one collective of the path: final result gather over RCCL
+            tspn.dist.gather_results(out_logits.view(B, P_vid, K_PRED), world * B)
+            tspn.dist.gather_results(idx, world * B)
+
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, total_steps):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # dominant kernel: conv3_mfma (tracklet projections), HIP events inside the timed steps
+    conv_ms = [a.elapsed_time(b) for a, b in events[args.warmup:]]
+    conv_avg_s = float(np.mean(conv_ms)) * 1e-3
+    conv_flop = 2.0 * (2 * C) * (3 * D) * (B * N * T)  # executed: M=2C, K=3D, columns=B*N*T
+    achieved = conv_flop / conv_avg_s / 1e12
+
+    if rank == 0:
+        pairs_total = world * P * args.steps
+        out = {
+            "metric": "tracklet-pairs/sec scored (N=32, T=150, D=2048)",
+            "value": pairs_total / elapsed,
+            "unit": "tracklet-pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE cfg2: synthetic VidVRD shape N=32 T=150 D=2048 (C=4096, A=4, "
+                                   "K=132), fp32, random-init weights",
+                       "videos_per_gpu_per_step": B, "pairs_per_video": P_vid,
+                       "path": "fused/factorised (tspn_forward_fused_f32) + PPN top-k"
+                               + (" + RCCL all-gather of logits/top-k" if world > 1 else ""),
+                       "dense_equivalent_gflop_per_pair": (2.0 * T * C * (3 * C + 3 * A_ANCH) + 2.0 * C * K_PRED) / 1e9,
+                       "executed_gflop_per_pair": (conv_flop + 2.0 * P * T * C * 16 + 2.0 * P * C * K_PRED) / P / 1e9},
+            "roofline": {"bound": "mfma", "kernel": "conv3_mfma_kernel (fp32 32x32x2 MFMA implicit GEMM)",
+                         "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "flop_per_launch": conv_flop, "avg_launch_ms": conv_avg_s * 1e3,
+                         "share_of_step": conv_avg_s / (elapsed / args.steps)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wnp, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

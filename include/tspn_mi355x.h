@@ -1,0 +1,201 @@
+/*
+ * tspn_mi355x.h — C ABI of the MI355X-native TSPN relation-scoring hot path.
+ *
+ * The reference (sangminwoo/Temporal-Span-Proposal-Network-VidVRD) is pure
+ * Python and has no FFI / operator layer: the seam it offers is the
+ * `BaseModel.forward()` nn.Module API (lib/modeling/model.py:20-24).  This
+ * header is the native boundary *under* that API: each entry point replaces the
+ * torch-op sequence cited next to it.  The Python host
+ * (temporal-span-proposal-network-vidvrd_amd/_abi.py) binds these symbols with
+ * ctypes; INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions
+ *   - All pointers are raw DEVICE pointers (HBM) owned by the caller (torch's
+ *     allocator); the library borrows them for the duration of the call and
+ *     allocates nothing.  Scratch space is passed in explicitly (see the
+ *     *_workspace_bytes helpers).
+ *   - All tensors are dense, row-major, fp32 unless stated; sizes are int64.
+ *   - `stream` is a hipStream_t passed as void* (torch's current stream).  The
+ *     functions enqueue work and return; they never synchronise, never touch
+ *     the null stream implicitly, and are re-entrant.
+ *   - Return value: 0 on success, negative TSPN_E* on failure;
+ *     tspn_last_error() returns a thread-local message.  No C++ exception
+ *     crosses this boundary.
+ *   - Target: gfx950 only.
+ */
+#ifndef TSPN_MI355X_H
+#define TSPN_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSPN_ABI_VERSION 1
+
+enum {
+  TSPN_OK = 0,
+  TSPN_EINVAL = -1,       /* bad argument (null pointer, negative size, misalignment) */
+  TSPN_EUNSUPPORTED = -2, /* shape outside what the kernels implement */
+  TSPN_EWORKSPACE = -3,   /* workspace too small */
+  TSPN_ELAUNCH = -4       /* HIP runtime error at launch */
+};
+
+#define TSPN_GEOM_CHANNELS 8
+
+int tspn_version(void);
+const char* tspn_last_error(void);
+const char* tspn_error_string(int code);
+
+/* ---- a2: predicate head -------------------------------------------------
+ * Replaces RelationPredictor.forward (lib/modeling/model.py:85-88):
+ *   out[P,K] = sigmoid(x[P,F] @ W[K,F]^T + b[K])       (apply_sigmoid != 0)
+ * `ldx` = row stride of x in elements (>= F).  W is the nn.Linear weight as
+ * stored in the state_dict (classifier.rel_predictor.weight), no packing.
+ * Split-K partial slabs live in `workspace`
+ * (tspn_predicate_head_workspace_bytes).                                     */
+size_t tspn_predicate_head_workspace_bytes(int64_t P, int64_t F, int64_t K);
+int tspn_predicate_head_f32(const float* x, int64_t P, int64_t F, int64_t ldx,
+                            const float* W, const float* b, int64_t K,
+                            float* out, int apply_sigmoid,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- a15: block-L1 feature preprocessing --------------------------------
+ * Replaces VRDataset._feature_preprocess (lib/dataset/vrdataset.py:219-243,
+ * lib/utils/miscellaneous.py:32-35), in place on feats[P, ld>=F].           */
+int tspn_feature_preprocess_f32(float* feats, int64_t P, int64_t F, int64_t ld,
+                                int64_t first, int64_t block, int64_t nblocks,
+                                void* stream);
+
+/* ---- a5/a6: PPN pair matrix + top-k pair indices ------------------------
+ * Replaces PPNHead.forward + the sort in PPN._forward_test
+ * (lib/modeling/relpn/ppn.py:107-112, 84-85) for a batch of `B` segments with
+ * N tracklets each:
+ *   mat[b] = sigmoid(MLP_s(cls[b]) @ MLP_o(cls[b])^T)        [B,N,N]
+ *   idx[b] = first `topk` flat indices (s*N+o) of mat[b] in descending order,
+ *            ties broken lower-index-first                   [B,topk] int64
+ * MLP = Linear(Cin,H)+ReLU+Linear(H,Cout); weights as in the state_dict
+ * (sub_emb.0.weight [H,Cin], sub_emb.2.weight [Cout,H], ...).
+ * Limits: N <= 128, Cin,H,Cout <= 256, topk <= N*N.                         */
+int tspn_ppn_pair_matrix_topk_f32(const float* cls, int64_t B, int64_t N, int64_t Cin,
+                                  int64_t H, int64_t Cout,
+                                  const float* ws1, const float* bs1,
+                                  const float* ws2, const float* bs2,
+                                  const float* wo1, const float* bo1,
+                                  const float* wo2, const float* bo2,
+                                  int64_t topk, float* out_mat, int64_t* out_idx,
+                                  void* stream);
+
+/* ---- a16: trajectory (cubic) IoU ----------------------------------------
+ * Replaces cubic_iou/_intersect/_union (lib/modeling/trajectory.py:85-141):
+ *   out[B,N1,N2] float32, boxes [B,N,T,4] (l,t,r,b), +1 pixel-inclusive,
+ *   intersection accumulated over t in fp32 in frame order.
+ * boxes2 == NULL means boxes2 = boxes1 (N2 = N1).                            */
+int tspn_traj_iou_f32(const float* boxes1, int64_t N1, const float* boxes2, int64_t N2,
+                      int64_t B, int64_t T, float* out, void* stream);
+
+/* ---- pair order ---------------------------------------------------------
+ * All ordered pairs (i,j), i != j, i-major (lib/modeling/predict.py:133-140):
+ * pairs[N*(N-1), 2] int64, tracklet ids offset by `base`.                   */
+int tspn_pair_index_i64(int64_t N, int64_t base, int64_t* pairs, void* stream);
+
+/* ---- N^2 pair builder (materialising form) ------------------------------
+ * Builds what DPNHead consumes (rel_feats "NxCxT", lib/modeling/relpn/dpn_anchor.py:38):
+ *   out_feat[P, 2D, T] = cat(feats[pairs[p,0]]^T, feats[pairs[p,1]]^T)
+ *   out_geom[P, 8, T]  = relative box geometry (may be NULL)
+ * feats [NT, T, D], boxes [NT, T, 4] (may be NULL iff out_geom is NULL),
+ * pairs int64 [P,2] with ids in [0, NT).  out_feat may be NULL.             */
+int tspn_pair_gather_f32(const float* feats, const float* boxes, int64_t NT, int64_t T,
+                         int64_t D, const int64_t* pairs, int64_t P,
+                         float* out_feat, float* out_geom, void* stream);
+
+/* ---- weight packing for the k=3 temporal conv ---------------------------
+ * packed[3][Cin][M] <- W[M][Cin][3] (nn.Conv1d weight layout).  `packed` has
+ * M*Cin*3 floats.  With split > 0 the input channels are split at `split`
+ * and the two halves stacked along M (factorised pair form):
+ *   packed[3][split][2M]: rows [0,M) = W[:, :split, :], rows [M,2M) = W[:, split:, :]
+ * (requires Cin == 2*split).                                                */
+int tspn_pack_conv3_f32(const float* W, int64_t M, int64_t Cin, int64_t split,
+                        float* packed, void* stream);
+
+/* ---- a8: temporal context encoder (k=3 conv as implicit GEMM on MFMA) ----
+ * Replaces self.conv + F.relu of DPNHead.forward (lib/modeling/relpn/dpn.py:70):
+ *   y[B, M, T] = act(bias[M] + sum_{tap,ci} packed[tap][ci][m] * x[B, ci, t+tap-1])
+ * zero padding outside [0,T).  bias may be NULL; relu != 0 applies ReLU.    */
+int tspn_conv3_f32(const float* x, int64_t B, int64_t Cin, int64_t T,
+                   const float* packed, int64_t M, const float* bias, int relu,
+                   float* y, void* stream);
+
+/* ---- a8/a10: relationness + span-regression heads -----------------------
+ * Replaces duration_pred (lib/modeling/relpn/dpn.py:71) and relness_pred
+ * (lib/modeling/relpn/dpn_anchor.py:105) as ONE [H, C] 1x1 GEMM:
+ *   out[P, H, T] = bh[H] + Wh[H, C] @ h_p[C, T]
+ * with h_p formed on the fly (never stored):
+ *   mode 0 (dense):      h_p = a[ia[p]]                         (a = ReLU'd encoder output [*,C,T])
+ *   mode 1 (factorised): h_p = relu(a[ia[p]] + b[ib[p]] + bias) (a,b = tracklet projections)
+ * a, b are [*, lda, T] tensors whose first C channels are used
+ * (row stride lda*T floats); ia/ib are int64 row ids read at ia[p*idx_stride]
+ * (NULL = identity; idx_stride = 2 walks one column of a [P,2] pair table).
+ * H <= 16.                                                                  */
+int tspn_heads_f32(int mode, const float* a, const float* b, int64_t lda,
+                   const int64_t* ia, const int64_t* ib, int64_t idx_stride, const float* bias,
+                   const float* Wh, const float* bh, int64_t H,
+                   int64_t P, int64_t C, int64_t T, float* out, void* stream);
+
+/* ---- a3: RelOIPool over time --------------------------------------------
+ * mean over t of x[R, T, D] -> out[R, D]   (layout_tc = 1, tracklet layout)
+ * mean over t of x[R, C, T] -> out[R, C]   (layout_tc = 0, channels-first)  */
+int tspn_temporal_mean_f32(const float* x, int64_t R, int64_t T, int64_t Cdim,
+                           int layout_tc, float* out, void* stream);
+
+/* gather rows: out[P, 2D] = cat(src[pairs[p,0]], src[pairs[p,1]])           */
+int tspn_pair_rows_f32(const float* src, int64_t NT, int64_t D, const int64_t* pairs,
+                       int64_t P, float* out, void* stream);
+
+/* [R,T,D] -> [R,D,T] (tracklet layout -> channels-first)                     */
+int tspn_transpose_td_f32(const float* x, int64_t R, int64_t T, int64_t D, float* out,
+                          void* stream);
+
+/* ---- whole relation-scoring pass on tracklet tensors --------------------
+ * The fused/factorised product path for `B` videos of N
+ * tracklets each: pair builder + temporal encoder + relationness/span heads
+ * + RelOIPool + predicate head, without materialising [P, 2D, T].           */
+typedef struct tspn_fused_desc {
+  int64_t B, N, T, D;          /* videos, tracklets per video, frames, RoI dim; C = 2D */
+  int64_t A, K;                /* anchors per location; predicates */
+  const float* feats;          /* [B*N, T, D] */
+  const int64_t* pairs;        /* [P,2] global tracklet ids (video b: b*N + local) */
+  int64_t P;
+  const float* conv_packed;    /* tspn_pack_conv3_f32(conv.weight [C,C,3], split=D): [3][D][2C] */
+  const float* conv_bias;      /* [C] */
+  const float* head_w;         /* [3A, C]: rows [0,A) relness_pred, [A,3A) duration_pred */
+  const float* head_b;         /* [3A] */
+  const float* cls_w;          /* [K, C] */
+  const float* cls_b;          /* [K] */
+  float* out_heads;            /* [P, 3A, T] */
+  float* out_logits;           /* [P, K] */
+  void* workspace;
+  size_t workspace_bytes;
+  /* optional profiling hooks: hipEvent_t recorded on `stream` immediately before / after the
+   * dominant kernel (the tracklet-projection implicit GEMM); NULL = off */
+  void* ev_conv_begin;
+  void* ev_conv_end;
+} tspn_fused_desc;
+
+size_t tspn_forward_fused_workspace_bytes(const tspn_fused_desc* d);
+int tspn_forward_fused_f32(const tspn_fused_desc* d, void* stream);
+
+/* ---- dense reference-faithful encoder + heads on a materialised [P,C,T] --
+ * DPNHead.forward (lib/modeling/relpn/dpn.py:69-73) on arbitrary pair feats:
+ * conv3+ReLU into `h_ws` [P,C,T] (caller scratch), then tspn_heads_f32 mode 0. */
+int tspn_temporal_encoder_heads_f32(const float* x, int64_t P, int64_t C, int64_t T,
+                                    const float* conv_packed, const float* conv_bias,
+                                    const float* head_w, const float* head_b, int64_t H,
+                                    float* h_ws, float* out_heads, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSPN_MI355X_H */

@@ -1,0 +1,122 @@
+// Whole relation-scoring pass drivers (gfx950): they only sequence the kernels
+// of this library on the caller's stream — no allocation, no synchronisation.
+//
+// tspn_forward_fused_f32: the product path on tracklet tensors.  The k=3
+// temporal conv of DPNHead (reference lib/modeling/relpn/dpn.py:70) is linear
+// in its input channels, and the pair feature is the channel concatenation
+// (subject ‖ object), so
+//     conv(cat(f_s, f_o)) = W[:, :D] * f_s  +  W[:, D:] * f_o
+// The N per-tracklet projections U = W_s*f + bias and V = W_o*f are computed
+// once (one MFMA implicit GEMM with M = 2C) instead of N(N-1) times, and the
+// pair stage forms relu(U[s] + V[o]) in registers on the way into the heads'
+// MFMAs.  The N^2 x C x T pair tensor and its ReLU image never touch HBM.
+//
+// tspn_temporal_encoder_heads_f32: the reference-faithful dense form on an
+// arbitrary materialised [P, C, T] (what DPNHead.forward would be handed).
+#include <algorithm>
+
+#include "tspn_common.h"
+
+namespace {
+
+struct FusedLayout {
+  size_t xt, y, bias2, fbar, pooled, lin, total;
+  size_t lin_bytes;
+};
+
+FusedLayout layout_of(const tspn_fused_desc* d) {
+  FusedLayout L{};
+  const size_t NT = (size_t)d->B * d->N, T = d->T, D = d->D, C = 2 * D;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    const size_t o = off;
+    off += tspn::align_up(bytes, 256);
+    return o;
+  };
+  L.xt = take(NT * D * T * sizeof(float));
+  L.y = take(NT * 2 * C * T * sizeof(float));
+  L.bias2 = take(2 * C * sizeof(float));
+  L.fbar = take(NT * D * sizeof(float));
+  L.pooled = take((size_t)d->P * C * sizeof(float));
+  L.lin_bytes = tspn_predicate_head_workspace_bytes(d->P, (int64_t)C, d->K);
+  L.lin = take(L.lin_bytes);
+  L.total = off;
+  return L;
+}
+
+int check_desc(const tspn_fused_desc* d) {
+  TSPN_REQUIRE(d != nullptr, TSPN_EINVAL, "tspn_forward_fused: null descriptor");
+  TSPN_REQUIRE(d->B >= 0 && d->N >= 0 && d->T > 0 && d->D > 0 && d->A > 0 && d->K > 0 &&
+                   d->P >= 0,
+               TSPN_EINVAL, "tspn_forward_fused: bad sizes B=%lld N=%lld T=%lld D=%lld A=%lld K=%lld P=%lld",
+               (long long)d->B, (long long)d->N, (long long)d->T, (long long)d->D, (long long)d->A,
+               (long long)d->K, (long long)d->P);
+  TSPN_REQUIRE(3 * d->A <= 16, TSPN_EUNSUPPORTED, "tspn_forward_fused: 3*A=%lld > 16",
+               (long long)(3 * d->A));
+  return TSPN_OK;
+}
+
+}  // namespace
+
+extern "C" size_t tspn_forward_fused_workspace_bytes(const tspn_fused_desc* d) {
+  if (check_desc(d) != TSPN_OK) return 0;
+  return layout_of(d).total;
+}
+
+extern "C" int tspn_forward_fused_f32(const tspn_fused_desc* d, void* stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  if (d->P == 0 || d->B * d->N == 0) return TSPN_OK;
+  TSPN_REQUIRE(d->feats && d->pairs && d->conv_packed && d->conv_bias && d->head_w && d->head_b &&
+                   d->cls_w && d->cls_b && d->out_heads && d->out_logits,
+               TSPN_EINVAL, "tspn_forward_fused: null pointer in descriptor");
+  const FusedLayout L = layout_of(d);
+  TSPN_REQUIRE(d->workspace && d->workspace_bytes >= L.total, TSPN_EWORKSPACE,
+               "tspn_forward_fused: workspace %zu < %zu bytes", d->workspace_bytes, L.total);
+  TSPN_REQUIRE((reinterpret_cast<uintptr_t>(d->workspace) & 255) == 0, TSPN_EINVAL,
+               "tspn_forward_fused: workspace must be 256-byte aligned");
+  char* ws = static_cast<char*>(d->workspace);
+  float* xt = reinterpret_cast<float*>(ws + L.xt);
+  float* y = reinterpret_cast<float*>(ws + L.y);
+  float* bias2 = reinterpret_cast<float*>(ws + L.bias2);
+  float* fbar = reinterpret_cast<float*>(ws + L.fbar);
+  float* pooled = reinterpret_cast<float*>(ws + L.pooled);
+  void* lin = ws + L.lin;
+  const int64_t NT = d->B * d->N, T = d->T, D = d->D, C = 2 * D, H = 3 * d->A;
+  hipStream_t s = TSPN_STREAM(stream);
+
+  // bias of the encoder goes with the subject projection: bias2 = [conv_bias, 0]
+  hipError_t e = hipMemsetAsync(bias2 + C, 0, C * sizeof(float), s);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(bias2, d->conv_bias, C * sizeof(float), hipMemcpyDeviceToDevice, s);
+  if (e != hipSuccess)
+    return tspn::fail(TSPN_ELAUNCH, "tspn_forward_fused: bias staging: %s", hipGetErrorString(e));
+
+  // 1. tracklet layout [NT,T,D] -> channels-first [NT,D,T]
+  if ((rc = tspn_transpose_td_f32(d->feats, NT, T, D, xt, stream))) return rc;
+  // 2. per-tracklet projections  y[NT, 2C, T]: rows [0,C) = U (+bias), rows [C,2C) = V
+  if (d->ev_conv_begin) (void)hipEventRecord(static_cast<hipEvent_t>(d->ev_conv_begin), s);
+  if ((rc = tspn_conv3_f32(xt, NT, D, T, d->conv_packed, 2 * C, bias2, 0, y, stream))) return rc;
+  if (d->ev_conv_end) (void)hipEventRecord(static_cast<hipEvent_t>(d->ev_conv_end), s);
+  // 3. pair stage + relationness / span heads
+  if ((rc = tspn_heads_f32(1, y, y + C * T, 2 * C, d->pairs, d->pairs + 1, 2, nullptr, d->head_w,
+                           d->head_b, H, d->P, C, T, d->out_heads, stream)))
+    return rc;
+  // 4. RelOIPool over the segment on the pair feats (= cat of tracklet means) + predicate head
+  if ((rc = tspn_temporal_mean_f32(d->feats, NT, T, D, 1, fbar, stream))) return rc;
+  if ((rc = tspn_pair_rows_f32(fbar, NT, D, d->pairs, d->P, pooled, stream))) return rc;
+  return tspn_predicate_head_f32(pooled, d->P, C, C, d->cls_w, d->cls_b, d->K, d->out_logits, 1,
+                                 lin, L.lin_bytes, stream);
+}
+
+extern "C" int tspn_temporal_encoder_heads_f32(const float* x, int64_t P, int64_t C, int64_t T,
+                                               const float* conv_packed, const float* conv_bias,
+                                               const float* head_w, const float* head_b, int64_t H,
+                                               float* h_ws, float* out_heads, void* stream) {
+  TSPN_REQUIRE(x && conv_packed && head_w && h_ws && out_heads, TSPN_EINVAL,
+               "tspn_temporal_encoder_heads_f32: null pointer");
+  int rc = tspn_conv3_f32(x, P, C, T, conv_packed, C, conv_bias, 1, h_ws, stream);
+  if (rc) return rc;
+  return tspn_heads_f32(0, h_ws, nullptr, C, nullptr, nullptr, 1, nullptr, head_w, head_b, H, P, C,
+                        T, out_heads, stream);
+}

@@ -1,0 +1,445 @@
+"""Drop-in `BaseModel` for the TSPN relation-scoring hot path on MI355X.
+
+Mirrors the reference's module tree so that `BaseModel(cfg)`, `forward(pair_list,
+target_list)`, the return conventions and the `state_dict` key names are the same
+(reference lib/modeling/model.py:7-88, relpn/relpn.py:9-60, relpn/ppn.py:7-112,
+relpn/dpn.py:9-81), while every tensor operation of the eval
+forward runs in the hand-written HIP library (ops.py -> C ABI).  The nn.Linear /
+nn.Conv1d objects below are parameter holders only; their own forward is never
+called.
+
+Differences from the reference, all in code the reference cannot execute:
+  * USE_DPN=True: the reference raises NameError (relpn/dpn.py:24-28).  Here the
+    temporal branch runs: pair builder -> temporal encoder -> relationness +
+    span-regression heads, RelOIPool over the segment, predicate head
+    (semantics frozen in DESIGN.md §2).
+  * `relness_pred` (relpn/dpn_anchor.py:88-90) is an extra parameter; reference
+    checkpoints that lack it still load (see DPNHead._load_from_state_dict).
+There is no CPU execution path: without the HIP library or a HIP device,
+forward raises.
+"""
+from collections import namedtuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+TemporalProposals = namedtuple("TemporalProposals", ["relness", "duration", "heads"])
+TemporalProposals.__doc__ = """Per-segment output of the temporal branch:
+relness [P,A,T] relationness logits, duration [P,2A,T] span regression (views of heads [P,3A,T])."""
+
+
+def _compute_device(*tensors):
+    """Device the HIP path runs on: that of the first HIP tensor seen, else the current HIP device."""
+    for t in tensors:
+        if isinstance(t, torch.Tensor) and t.is_cuda:
+            return t.device
+    if not torch.cuda.is_available():
+        raise RuntimeError("TSPN BaseModel: no HIP device available; this build has no CPU path "
+                           "(the reference's CPU forward is restated only as the test oracle)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _f32(t, device):
+    if isinstance(t, np.ndarray):
+        t = torch.from_numpy(t)
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+class _DeviceCache:
+    """Device-resident (and packed) copies of parameters, refreshed when a parameter changes."""
+
+    def __init__(self):
+        self._store = {}
+
+    def get(self, key, params, device, build):
+        sig = tuple((p.data_ptr(), p._version, str(p.device)) for p in params) + (str(device),)
+        hit = self._store.get(key)
+        if hit is not None and hit[0] == sig:
+            return hit[1]
+        with torch.no_grad():
+            value = build([_f32(p.detach(), device) for p in params])
+        self._store[key] = (sig, value)
+        return value
+
+    def clear(self):
+        self._store.clear()
+
+
+class _PredicateHeadFn(torch.autograd.Function):
+    """HIP forward; backward with plain torch GEMMs (training is outside the measured path)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        out = ops.predicate_head(x, w, b, apply_sigmoid=True)
+        ctx.save_for_backward(x, w, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, out = ctx.saved_tensors
+        gz = g * out * (1.0 - out)
+        return gz @ w, gz.t() @ x, gz.sum(0)
+
+
+class RelationPredictor(nn.Module):
+    """Predicate-classification head (reference lib/modeling/model.py:76-88)."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.rel_predictor = nn.Linear(in_channels, out_channels)
+        nn.init.normal_(self.rel_predictor.weight, std=0.01)
+        nn.init.constant_(self.rel_predictor.bias, 0)
+        self._cache = _DeviceCache()
+
+    def forward(self, reloi_feats):
+        dev = _compute_device(reloi_feats, self.rel_predictor.weight)
+        x = _f32(reloi_feats, dev)
+        w, b = self.rel_predictor.weight, self.rel_predictor.bias
+        if torch.is_grad_enabled() and (w.requires_grad or x.requires_grad):
+            if not w.is_cuda:
+                raise RuntimeError("training needs the model on the HIP device (model.cuda())")
+            out = _PredicateHeadFn.apply(x, w.contiguous(), b.contiguous())
+        else:
+            wd, bd = self._cache.get("cls", (w, b), dev, lambda ts: ts)
+            out = ops.predicate_head(x, wd, bd, apply_sigmoid=True)
+        return out.to(reloi_feats.device)
+
+
+class RelOIPool:
+    """Relation-of-interest pooling (reference lib/modeling/model.py:68-73).
+
+    2-D feats [P,F] pass through (duration_proposals None).  Temporal feats
+    [P,C,T] are averaged over the segment (build-defined)."""
+
+    def __call__(self, feats, duration_proposals):
+        if duration_proposals is None:
+            return feats
+        return [ops.temporal_mean(f, layout_tc=False) if f.dim() == 3 else f for f in feats]
+
+
+class PPNHead(nn.Module):
+    """Tracklet-level relationness embeddings (reference lib/modeling/relpn/ppn.py:92-112)."""
+
+    def __init__(self, in_channels, hidden_channels, out_channels):
+        super().__init__()
+        self.sub_emb = nn.Sequential(nn.Linear(in_channels, hidden_channels), nn.ReLU(True),
+                                     nn.Linear(hidden_channels, out_channels))
+        self.obj_emb = nn.Sequential(nn.Linear(in_channels, hidden_channels), nn.ReLU(True),
+                                     nn.Linear(hidden_channels, out_channels))
+
+    def weights(self):
+        names = ["sub_emb.0.weight", "sub_emb.0.bias", "sub_emb.2.weight", "sub_emb.2.bias",
+                 "obj_emb.0.weight", "obj_emb.0.bias", "obj_emb.2.weight", "obj_emb.2.bias"]
+        sd = dict(self.named_parameters())
+        return names, [sd[n] for n in names]
+
+    def forward(self, sub_logits, obj_logits):
+        """Autograd (training) form with torch ops on the device; eval goes through PPN.propose."""
+        s = self.sub_emb(sub_logits)
+        o = self.obj_emb(obj_logits)
+        return torch.sigmoid(torch.mm(s, o.t()))
+
+
+class PPN(nn.Module):
+    """Pair Proposal Network (reference lib/modeling/relpn/ppn.py:7-90)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.num_pair_proposals = cfg.RELPN.PPN.NUM_PAIR_PROPOSALS
+        self.ppn_head = PPNHead(cfg.RELPN.PPN.IN_CHANNELS, cfg.RELPN.PPN.HIDDEN_CHANNELS,
+                                cfg.RELPN.PPN.OUT_CHANNELS)
+        # the reference also constructs (and never calls) a balanced sampler: ppn.py:20-23
+        self.batch_size_per_segment = cfg.RELPN.PPN.BATCH_SIZE_PER_SEGMENT
+        self.positive_fraction = cfg.RELPN.PPN.POSITIVE_FRACTION
+        self._cache = _DeviceCache()
+
+    def propose(self, cls_logits):
+        """Eval: one fused HIP launch per group of equal-N segments -> (matrices, top-k indices)."""
+        names, params = self.ppn_head.weights()
+        dev = _compute_device(*cls_logits, params[0])
+        w = self._cache.get("ppn", params, dev, lambda ts: dict(zip(names, ts)))
+        mats, idxs = [None] * len(cls_logits), [None] * len(cls_logits)
+        groups = {}
+        for i, c in enumerate(cls_logits):
+            groups.setdefault(tuple(c.shape), []).append(i)
+        for shape, members in groups.items():
+            batch = torch.stack([_f32(cls_logits[i], dev) for i in members])
+            mat, idx = ops.ppn_pair_matrix_topk(batch, w, self.num_pair_proposals)
+            for k, i in enumerate(members):
+                mats[i] = mat[k].to(cls_logits[i].device)
+                idxs[i] = idx[k].to(cls_logits[i].device)
+        return mats, idxs
+
+    @staticmethod
+    def _gt_matrices(pair_list, target_list):
+        """N x N 0/1 matrices: 1 where any predicate is set for (s,o) (ppn.py:36-49, host side)."""
+        out = []
+        for plist, tlist in zip(pair_list, target_list):
+            pairs = torch.as_tensor(np.asarray(plist.get_field("tracklet_pairs"))).long().cpu()
+            n = int(plist.get_field("num_tracklets"))
+            pos = (tlist.target.detach().sum(dim=1) > 0).cpu()
+            gt = torch.zeros(n, n)
+            sel = pairs[: len(pos)][pos]
+            gt[sel[:, 0], sel[:, 1]] = 1
+            out.append(gt)
+        return out
+
+    def forward(self, pair_list, target_list=None):
+        cls_logits = [plist.get_field("track_cls_logits") for plist in pair_list]
+        if not self.training:
+            _, idx = self.propose(cls_logits)
+            return idx, {}
+        gts = self._gt_matrices(pair_list, target_list)
+        proposals, loss = [], 0
+        for c, gt in zip(cls_logits, gts):
+            pm = self.ppn_head(c, c)
+            loss = loss + F.binary_cross_entropy(pm, gt.to(pm.device))
+            order = torch.sort(pm.detach().view(-1), descending=True, stable=True)[1]
+            proposals.append(order[: self.num_pair_proposals])
+        return proposals, {"loss_pair": loss}
+
+
+class DPNHead(nn.Module):
+    """Temporal context encoder + span-regression (+ relationness) heads
+    (reference lib/modeling/relpn/dpn.py:55-73; relness_pred from relpn/dpn_anchor.py:82-108)."""
+
+    def __init__(self, in_channels, num_windows):
+        super().__init__()
+        self.conv = nn.Conv1d(in_channels, in_channels, kernel_size=3, stride=1, padding=1)
+        self.duration_pred = nn.Conv1d(in_channels, num_windows * 2, kernel_size=1, stride=1)
+        self.relness_pred = nn.Conv1d(in_channels, num_windows, kernel_size=1, stride=1)
+        for layer in (self.conv, self.duration_pred, self.relness_pred):
+            nn.init.normal_(layer.weight, std=0.01)
+            nn.init.constant_(layer.bias, 0)
+        self.in_channels = in_channels
+        self.num_windows = num_windows
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys,
+                              unexpected_keys, error_msgs):
+        # reference checkpoints (dpn.py) carry no relness_pred: keep the initialised values
+        for leaf in ("relness_pred.weight", "relness_pred.bias"):
+            if prefix + leaf not in state_dict:
+                state_dict[prefix + leaf] = dict(self.named_parameters())[leaf].detach().clone()
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys,
+                                      unexpected_keys, error_msgs)
+
+    def head_params(self):
+        return (self.relness_pred.weight, self.relness_pred.bias,
+                self.duration_pred.weight, self.duration_pred.bias)
+
+
+class DPN(nn.Module):
+    """Duration Proposal Network (reference lib/modeling/relpn/dpn.py:9-52), runnable."""
+
+    def __init__(self, cfg, in_channels, num_windows):
+        super().__init__()
+        self.dpn_head = DPNHead(in_channels, num_windows)
+        self.top_k_proposals = cfg.RELPN.DPN.NUM_DURATION_PROPOSALS  # RelNMS stub: rel_nms.py:11
+        self._cache = _DeviceCache()
+
+    # packed device weights -------------------------------------------------
+    def _head_weights(self, dev):
+        def build(ts):
+            rw, rb, dw, db = ts
+            return (torch.cat([rw[:, :, 0], dw[:, :, 0]], dim=0).contiguous(),
+                    torch.cat([rb, db]).contiguous())
+        return self._cache.get("heads", self.dpn_head.head_params(), dev, build)
+
+    def _conv_dense(self, dev):
+        c = self.dpn_head.conv
+        return self._cache.get("conv_dense", (c.weight, c.bias), dev,
+                               lambda ts: (ops.pack_conv3(ts[0]), ts[1]))
+
+    def _conv_split(self, dev):
+        c = self.dpn_head.conv
+        half = self.dpn_head.in_channels // 2
+        return self._cache.get("conv_split", (c.weight, c.bias), dev,
+                               lambda ts: (ops.pack_conv3(ts[0], split=half), ts[1]))
+
+    def _wrap(self, heads):
+        a = self.dpn_head.num_windows
+        return TemporalProposals(heads[:, :a], heads[:, a:], heads)
+
+    def forward_dense(self, feats):
+        """feats: list of materialised [P,C,T] pair tensors (the layout DPNHead consumes)."""
+        out = []
+        for f in feats:
+            dev = _compute_device(f, self.dpn_head.conv.weight)
+            packed, cbias = self._conv_dense(dev)
+            hw, hb = self._head_weights(dev)
+            out.append(self._wrap(ops.temporal_encoder_heads(_f32(f, dev), packed, cbias, hw, hb)))
+        return out
+
+    def forward(self, pair_list, target_list=None):
+        if self.training:
+            raise NotImplementedError(
+                "training the temporal (DPN) branch is outside the hot-path scope of this build "
+                "(the reference's own DPN training path raises NameError, relpn/dpn.py:24-28)")
+        return self.forward_dense([plist.features for plist in pair_list]), {}
+
+
+class RelPN(nn.Module):
+    """PPN + DPN dispatcher (reference lib/modeling/relpn/relpn.py:9-60)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.use_ppn = cfg.RELPN.USE_PPN
+        self.use_dpn = cfg.RELPN.USE_DPN
+        self.pair_proposal_network = PPN(cfg)
+        self.duration_proposal_network = DPN(cfg, in_channels=cfg.RELPN.DPN.IN_CHANNELS,
+                                             num_windows=cfg.RELPN.DPN.NUM_ANCHORS_PER_LOCATION)
+
+    def forward(self, pair_list, target_list=None):
+        losses, pair_props, dur_props = {}, None, None
+        if self.use_ppn:
+            pair_props, l = self.pair_proposal_network(pair_list, target_list)
+            losses.update(l)
+        if self.use_dpn:
+            dur_props, l = self.duration_proposal_network(pair_list, target_list)
+            losses.update(l)
+        return pair_props, dur_props, losses
+
+
+def make_relpn(cfg):
+    return RelPN(cfg)
+
+
+class BaseModel(nn.Module):
+    """RelPN -> RelOIPool -> predicate classifier (reference lib/modeling/model.py:7-65)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.use_ppn = cfg.RELPN.USE_PPN
+        self.use_dpn = cfg.RELPN.USE_DPN
+        self.relpn = make_relpn(cfg)
+        self.rel_of_interest_pool = RelOIPool()
+        self.classifier = RelationPredictor(in_channels=cfg.PREDICT.FEATURE_DIM,
+                                            out_channels=cfg.PREDICT.PREDICATE_NUM)
+
+    def forward(self, pair_list, target_list=None):
+        if self.training:
+            return self._forward_train(pair_list, target_list)
+        return self._forward_test(pair_list)
+
+    # ------------------------------------------------------------------ train
+    def _forward_train(self, pair_list, target_list):
+        loss_dict = {}
+        duration_proposals = None
+        feats = [plist.features for plist in pair_list]
+        targets = [tlist.target for tlist in target_list]
+        if self.use_ppn or self.use_dpn:
+            _, duration_proposals, relpn_losses = self.relpn(pair_list, target_list)
+            loss_dict.update(relpn_losses)
+        reloi_feats = self.rel_of_interest_pool(feats, duration_proposals)
+        loss_relation = 0
+        for reloi_feat, target in zip(reloi_feats, targets):
+            rel_logit = self.classifier(reloi_feat)
+            loss_relation = loss_relation + F.binary_cross_entropy(rel_logit, target)
+        loss_dict["loss_rel"] = loss_relation
+        return loss_dict
+
+    # ------------------------------------------------------------------- eval
+    @staticmethod
+    def _is_tracklet_sample(plist):
+        return plist.has_field("tracklet_feats")
+
+    def _forward_test(self, pair_list):
+        with torch.no_grad():
+            if self.use_dpn and len(pair_list) and all(self._is_tracklet_sample(p) for p in pair_list):
+                return self._forward_test_fused(pair_list)
+            if self.use_dpn and any(p.features.dim() != 3 for p in pair_list):
+                raise ValueError(
+                    "RELPN.USE_DPN=True needs temporal inputs: either PairList.features of shape "
+                    "[P,C,T] or the fields 'tracklet_feats' [N,T,D] (+ 'tracklet_boxes'); got 2-D "
+                    "features (the reference raises NameError here, relpn/dpn.py:24-28)")
+            feats = [plist.features for plist in pair_list]
+            pair_proposals, duration_proposals, _ = self.relpn(pair_list)
+            reloi_feats = self.rel_of_interest_pool(
+                [_f32(f, _compute_device(f, self.classifier.rel_predictor.weight)) if f.dim() == 3 else f
+                 for f in feats], duration_proposals)
+            rel_logits = [self.classifier(r).to(f.device) for r, f in zip(reloi_feats, feats)]
+            if duration_proposals is not None:
+                duration_proposals = [TemporalProposals(*(t.to(f.device) for t in d))
+                                      for d, f in zip(duration_proposals, feats)]
+            return pair_proposals, duration_proposals, rel_logits
+
+    def _forward_test_fused(self, pair_list):
+        """Temporal path on tracklet tensors: one fused HIP pass per group of equal-shape segments."""
+        dpn = self.relpn.duration_proposal_network
+        cls = self.classifier.rel_predictor
+        first = pair_list[0].get_field("tracklet_feats")
+        dev = _compute_device(first, dpn.dpn_head.conv.weight)
+        d_feat = first.shape[2]
+        if 2 * d_feat != dpn.dpn_head.in_channels:
+            raise ValueError(f"tracklet_feats dim D={d_feat} needs RELPN.DPN.IN_CHANNELS = 2*D "
+                             f"(got {dpn.dpn_head.in_channels})")
+        if cls.in_features != 2 * d_feat:
+            raise ValueError(f"PREDICT.FEATURE_DIM must equal 2*D = {2 * d_feat} on the temporal path "
+                             f"(got {cls.in_features})")
+        packed, cbias = dpn._conv_split(dev)
+        hw, hb = dpn._head_weights(dev)
+        cw, cb = self.classifier._cache.get("cls", (cls.weight, cls.bias), dev, lambda ts: ts)
+
+        pair_proposals = None
+        if self.use_ppn:
+            pair_proposals, _ = self.relpn.pair_proposal_network(pair_list)
+
+        n_seg = len(pair_list)
+        durations, logits = [None] * n_seg, [None] * n_seg
+        def custom_pairs(plist):
+            if not plist.has_field("tracklet_pairs"):
+                return None
+            p = plist.get_field("tracklet_pairs")
+            if p is None:
+                return None
+            if isinstance(p, torch.Tensor):
+                return p.detach().cpu().long()
+            return torch.as_tensor(np.asarray(p)).long()
+
+        groups = {}
+        for i, plist in enumerate(pair_list):
+            f = plist.get_field("tracklet_feats")
+            # segments with an explicit pair table are scored on their own
+            key = (tuple(f.shape), i + 1 if custom_pairs(plist) is not None else 0)
+            groups.setdefault(key, []).append(i)
+        for (shape, _), members in groups.items():
+            n, t, d = shape
+            feats = torch.cat([_f32(pair_list[i].get_field("tracklet_feats"), dev) for i in members])
+            pairs = []
+            for k, i in enumerate(members):
+                p = custom_pairs(pair_list[i])
+                if p is None:
+                    pairs.append(ops.pair_index(n, dev, base=k * n))
+                else:
+                    if p.dim() != 2 or p.shape[1] != 2:
+                        raise ValueError("tracklet_pairs must be [P,2]")
+                    if p.numel() and (int(p.min()) < 0 or int(p.max()) >= n):
+                        raise IndexError("tracklet_pairs index out of range")
+                    pairs.append(p.to(dev) + k * n)
+            counts = [p.shape[0] for p in pairs]
+            allp = torch.cat(pairs).contiguous()
+            heads, lg = ops.forward_fused(feats, allp, len(members), n, packed, cbias, hw, hb, cw, cb,
+                                          check_pairs=False)
+            off = 0
+            for k, i in enumerate(members):
+                src_dev = pair_list[i].get_field("tracklet_feats").device
+                h = heads[off:off + counts[k]].to(src_dev)
+                durations[i] = dpn._wrap(h)
+                logits[i] = lg[off:off + counts[k]].to(src_dev)
+                off += counts[k]
+        return pair_proposals, durations, logits
+
+    def pair_geometry(self, pair_list):
+        """Relative box geometry [P,8,T] per segment from 'tracklet_boxes' (pair builder side output)."""
+        out = []
+        for plist in pair_list:
+            boxes = plist.get_field("tracklet_boxes")
+            dev = _compute_device(boxes)
+            n = boxes.shape[0]
+            _, g = ops.pair_gather(None, _f32(boxes, dev), ops.pair_index(n, dev), want_feat=False)
+            out.append(g.to(boxes.device))
+        return out

@@ -1,0 +1,328 @@
+"""Tensor-level wrappers over the C ABI (device tensors in, device tensors out).
+
+PyTorch is plumbing here: it owns HBM allocations and the HIP stream; every
+operator below runs in the hand-written HIP library.  Inputs must already be
+fp32 / int64, contiguous, on a HIP device — anything else raises; there is no
+CPU path.
+"""
+import ctypes
+
+import torch
+
+from . import _abi
+
+__all__ = [
+    "predicate_head", "feature_preprocess_", "ppn_pair_matrix_topk", "traj_iou", "pair_index",
+    "pair_gather", "pack_conv3", "conv3", "heads", "temporal_mean", "pair_rows", "transpose_td",
+    "forward_fused", "temporal_encoder_heads", "fused_workspace_bytes",
+]
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, name, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: tensor is on {t.device}; the TSPN HIP path needs a HIP device "
+                           "tensor (there is no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous")
+    return t
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _ws(nbytes, device):
+    # torch's caching allocator returns >= 256-B aligned blocks
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def predicate_head(x, weight, bias, apply_sigmoid=True):
+    """sigmoid(x @ W.T + b) — RelationPredictor.forward (reference lib/modeling/model.py:85-88)."""
+    _dev(x, "x"); _dev(weight, "weight")
+    if bias is not None:
+        _dev(bias, "bias")
+    if x.dim() != 2 or weight.dim() != 2 or x.shape[1] != weight.shape[1]:
+        raise ValueError(f"predicate_head: shapes {tuple(x.shape)} x {tuple(weight.shape)}^T do not match")
+    if bias is not None and bias.shape != (weight.shape[0],):
+        raise ValueError("predicate_head: bias shape mismatch")
+    P, F = x.shape
+    K = weight.shape[0]
+    out = torch.empty((P, K), dtype=torch.float32, device=x.device)
+    l = _abi.lib()
+    nbytes = l.tspn_predicate_head_workspace_bytes(P, F, K)
+    ws = _ws(nbytes, x.device)
+    _abi.check(l.tspn_predicate_head_f32(_p(x), P, F, F, _p(weight), _p(bias), K, _p(out),
+                                         1 if apply_sigmoid else 0, _p(ws), ws.numel(), _stream()))
+    return out
+
+
+def feature_preprocess_(feats, first=70, block=1000, nblocks=8):
+    """In-place block-L1 normalisation — VRDataset._feature_preprocess (lib/dataset/vrdataset.py:219-243)."""
+    _dev(feats, "feats")
+    if feats.dim() != 2:
+        raise ValueError("feature_preprocess_: feats must be [P,F]")
+    P, F = feats.shape
+    _abi.check(_abi.lib().tspn_feature_preprocess_f32(_p(feats), P, F, F, first, block, nblocks, _stream()))
+    return feats
+
+
+def ppn_pair_matrix_topk(cls_logits, w, topk):
+    """PPNHead + top-k (lib/modeling/relpn/ppn.py:107-112, 84-85).
+
+    cls_logits [B,N,Cin] or [N,Cin]; `w` = dict with keys sub_emb.0.weight ... obj_emb.2.bias.
+    Returns (pair_matrix [B,N,N], idx int64 [B,min(topk,N*N)]) (batch dim dropped for 2-D input).
+    """
+    squeeze = cls_logits.dim() == 2
+    c = cls_logits.unsqueeze(0) if squeeze else cls_logits
+    _dev(c, "cls_logits")
+    B, N, Cin = c.shape
+    ks = ["sub_emb.0.weight", "sub_emb.0.bias", "sub_emb.2.weight", "sub_emb.2.bias",
+          "obj_emb.0.weight", "obj_emb.0.bias", "obj_emb.2.weight", "obj_emb.2.bias"]
+    ts = [_dev(w[k], k) for k in ks]
+    H, Cout = ts[0].shape[0], ts[2].shape[0]
+    if ts[0].shape != (H, Cin) or ts[2].shape != (Cout, H) or ts[4].shape != (H, Cin) or ts[6].shape != (Cout, H):
+        raise ValueError("ppn_pair_matrix_topk: weight shapes do not match the input")
+    k = min(int(topk), N * N)
+    mat = torch.empty((B, N, N), dtype=torch.float32, device=c.device)
+    idx = torch.empty((B, k), dtype=torch.int64, device=c.device)
+    _abi.check(_abi.lib().tspn_ppn_pair_matrix_topk_f32(
+        _p(c), B, N, Cin, H, Cout, *[_p(t) for t in ts], k, _p(mat), _p(idx), _stream()))
+    return (mat[0], idx[0]) if squeeze else (mat, idx)
+
+
+def traj_iou(boxes1, boxes2=None):
+    """cubic_iou (lib/modeling/trajectory.py:127-141); boxes [N,T,4] or [B,N,T,4] -> [.., N1, N2]."""
+    squeeze = boxes1.dim() == 3
+    b1 = boxes1.unsqueeze(0) if squeeze else boxes1
+    _dev(b1, "boxes1")
+    B, N1, T, four = b1.shape
+    if four != 4:
+        raise ValueError("traj_iou: last dim must be 4")
+    if boxes2 is None:
+        b2, N2 = None, N1
+    else:
+        b2 = boxes2.unsqueeze(0) if squeeze else boxes2
+        _dev(b2, "boxes2")
+        if b2.shape[0] != B or b2.shape[2] != T or b2.shape[3] != 4:
+            raise ValueError("traj_iou: boxes2 shape mismatch")
+        N2 = b2.shape[1]
+    out = torch.empty((B, N1, N2), dtype=torch.float32, device=b1.device)
+    _abi.check(_abi.lib().tspn_traj_iou_f32(_p(b1), N1, _p(b2), N2, B, T, _p(out), _stream()))
+    return out[0] if squeeze else out
+
+
+def pair_index(n, device, base=0):
+    """All ordered pairs (i,j), i != j, i-major (lib/modeling/predict.py:133-140), int64 [n(n-1), 2]."""
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError("pair_index: needs a HIP device (no CPU fallback)")
+    out = torch.empty((max(n * (n - 1), 0), 2), dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        _abi.check(_abi.lib().tspn_pair_index_i64(n, base, _p(out), _stream()))
+    return out
+
+
+def pair_gather(tracklet_feats, tracklet_boxes, pairs, want_feat=True, want_geom=True):
+    """N^2 pair builder: -> (pair_feats [P,2D,T] | None, pair_geom [P,8,T] | None)."""
+    _dev(pairs, "pairs", torch.int64)
+    P = pairs.shape[0]
+    if pairs.dim() != 2 or pairs.shape[1] != 2:
+        raise ValueError("pair_gather: pairs must be [P,2]")
+    feat = geom = None
+    NT = T = D = None
+    if want_feat:
+        _dev(tracklet_feats, "tracklet_feats")
+        NT, T, D = tracklet_feats.shape
+        feat = torch.empty((P, 2 * D, T), dtype=torch.float32, device=pairs.device)
+    if want_geom:
+        _dev(tracklet_boxes, "tracklet_boxes")
+        if tracklet_boxes.dim() != 3 or tracklet_boxes.shape[2] != 4:
+            raise ValueError("pair_gather: tracklet_boxes must be [N,T,4]")
+        if NT is not None and tuple(tracklet_boxes.shape[:2]) != (NT, T):
+            raise ValueError("pair_gather: feats / boxes shape mismatch")
+        NT, T = tracklet_boxes.shape[:2]
+        geom = torch.empty((P, _abi.GEOM_CHANNELS, T), dtype=torch.float32, device=pairs.device)
+        D = D or 1
+    if NT is None:
+        return None, None
+    if P and (int(pairs.min()) < 0 or int(pairs.max()) >= NT):
+        raise IndexError("pair_gather: pair index out of range")
+    _abi.check(_abi.lib().tspn_pair_gather_f32(
+        _p(tracklet_feats if want_feat else None), _p(tracklet_boxes if want_geom else None),
+        NT, T, D, _p(pairs), P, _p(feat), _p(geom), _stream()))
+    return feat, geom
+
+
+def pack_conv3(weight, split=0):
+    """nn.Conv1d weight [M,Cin,3] -> MFMA staging layout [3][Cin'][M'] (see tspn_pack_conv3_f32)."""
+    _dev(weight, "conv weight")
+    if weight.dim() != 3 or weight.shape[2] != 3:
+        raise ValueError("pack_conv3: weight must be [M,Cin,3]")
+    M, Cin, _ = weight.shape
+    if split:
+        shape = (3, split, 2 * M)
+    else:
+        shape = (3, Cin, M)
+    packed = torch.empty(shape, dtype=torch.float32, device=weight.device)
+    _abi.check(_abi.lib().tspn_pack_conv3_f32(_p(weight), M, Cin, split, _p(packed), _stream()))
+    return packed
+
+
+def conv3(x, packed, bias=None, relu=False):
+    """y[B,M,T] = act(bias + conv1d_k3(x[B,Cin,T])) with packed weights [3,Cin,M]."""
+    _dev(x, "x"); _dev(packed, "packed")
+    if bias is not None:
+        _dev(bias, "bias")
+    B, Cin, T = x.shape
+    if packed.dim() != 3 or packed.shape[0] != 3 or packed.shape[1] != Cin:
+        raise ValueError(f"conv3: packed weights {tuple(packed.shape)} do not match Cin={Cin}")
+    M = packed.shape[2]
+    if bias is not None and bias.shape != (M,):
+        raise ValueError("conv3: bias shape mismatch")
+    y = torch.empty((B, M, T), dtype=torch.float32, device=x.device)
+    _abi.check(_abi.lib().tspn_conv3_f32(_p(x), B, Cin, T, _p(packed), M, _p(bias), 1 if relu else 0,
+                                         _p(y), _stream()))
+    return y
+
+
+def heads(a, head_w, head_b, b=None, ia=None, ib=None, bias=None, channels=None, num_pairs=None):
+    """out[P,H,T] = head_b + head_w @ h_p; h_p = a[ia[p]] (dense) or relu(a[ia[p]] + b[ib[p]] + bias)."""
+    _dev(a, "a"); _dev(head_w, "head_w")
+    mode = 0 if b is None else 1
+    lda, T = a.shape[1], a.shape[2]
+    C = channels if channels is not None else lda
+    H = head_w.shape[0]
+    if head_w.shape[1] != C:
+        raise ValueError("heads: head_w / channel mismatch")
+    for nm, t in (("ia", ia), ("ib", ib)):
+        if t is not None:
+            _dev(t, nm, torch.int64)
+    if b is not None:
+        _dev(b, "b")
+        if b.shape[1:] != a.shape[1:]:
+            raise ValueError("heads: a / b shape mismatch")
+    if num_pairs is None:
+        num_pairs = ia.shape[0] if ia is not None else a.shape[0]
+    out = torch.empty((num_pairs, H, T), dtype=torch.float32, device=a.device)
+    _abi.check(_abi.lib().tspn_heads_f32(mode, _p(a), _p(b), lda, _p(ia), _p(ib), 1, _p(bias),
+                                         _p(head_w), _p(head_b), H, num_pairs, C, T, _p(out), _stream()))
+    return out
+
+
+def temporal_mean(x, layout_tc):
+    """Mean over frames: x[R,T,D] -> [R,D] (layout_tc=True) or x[R,C,T] -> [R,C]."""
+    _dev(x, "x")
+    if layout_tc:
+        R, T, Cd = x.shape
+    else:
+        R, Cd, T = x.shape
+    out = torch.empty((R, Cd), dtype=torch.float32, device=x.device)
+    _abi.check(_abi.lib().tspn_temporal_mean_f32(_p(x), R, T, Cd, 1 if layout_tc else 0, _p(out), _stream()))
+    return out
+
+
+def pair_rows(src, pairs):
+    """out[P,2D] = cat(src[pairs[:,0]], src[pairs[:,1]])."""
+    _dev(src, "src"); _dev(pairs, "pairs", torch.int64)
+    NT, D = src.shape
+    P = pairs.shape[0]
+    out = torch.empty((P, 2 * D), dtype=torch.float32, device=src.device)
+    _abi.check(_abi.lib().tspn_pair_rows_f32(_p(src), NT, D, _p(pairs), P, _p(out), _stream()))
+    return out
+
+
+def transpose_td(x):
+    """[R,T,D] -> [R,D,T]."""
+    _dev(x, "x")
+    R, T, D = x.shape
+    out = torch.empty((R, D, T), dtype=torch.float32, device=x.device)
+    _abi.check(_abi.lib().tspn_transpose_td_f32(_p(x), R, T, D, _p(out), _stream()))
+    return out
+
+
+def _fused_desc(feats, pairs, B, N, conv_packed, conv_bias, head_w, head_b, cls_w, cls_b):
+    _dev(feats, "tracklet_feats"); _dev(pairs, "pairs", torch.int64)
+    for nm, t in (("conv_packed", conv_packed), ("conv_bias", conv_bias), ("head_w", head_w),
+                  ("head_b", head_b), ("cls_w", cls_w), ("cls_b", cls_b)):
+        _dev(t, nm)
+    NT, T, D = feats.shape
+    if NT != B * N:
+        raise ValueError(f"forward_fused: feats has {NT} tracklets, expected B*N = {B * N}")
+    C = 2 * D
+    H = head_w.shape[0]
+    if H % 3 or head_w.shape[1] != C or head_b.shape != (H,):
+        raise ValueError("forward_fused: head_w must be [3A, 2D]")
+    if tuple(conv_packed.shape) != (3, D, 2 * C) or conv_bias.shape != (C,):
+        raise ValueError(f"forward_fused: conv_packed must be [3, D={D}, 4D={2 * C}] (pack_conv3(w, split=D))")
+    if cls_w.dim() != 2 or cls_w.shape[1] != C or cls_b.shape != (cls_w.shape[0],):
+        raise ValueError("forward_fused: cls_w must be [K, 2D]")
+    d = _abi.FusedDesc()
+    d.B, d.N, d.T, d.D = B, N, T, D
+    d.A, d.K = H // 3, cls_w.shape[0]
+    d.feats, d.pairs, d.P = feats.data_ptr(), pairs.data_ptr(), pairs.shape[0]
+    d.conv_packed, d.conv_bias = conv_packed.data_ptr(), conv_bias.data_ptr()
+    d.head_w, d.head_b = head_w.data_ptr(), head_b.data_ptr()
+    d.cls_w, d.cls_b = cls_w.data_ptr(), cls_b.data_ptr()
+    return d
+
+
+def fused_workspace_bytes(B, N, T, D, A, K, P):
+    d = _abi.FusedDesc()
+    d.B, d.N, d.T, d.D, d.A, d.K, d.P = B, N, T, D, A, K, P
+    return _abi.lib().tspn_forward_fused_workspace_bytes(ctypes.byref(d))
+
+
+def forward_fused(feats, pairs, B, N, conv_packed, conv_bias, head_w, head_b, cls_w, cls_b,
+                  workspace=None, out_heads=None, out_logits=None, check_pairs=True,
+                  conv_events=None):
+    """Whole scoring pass on tracklet tensors (tspn_forward_fused_f32).
+
+    feats [B*N,T,D]; pairs int64 [P,2] global tracklet ids.
+    `conv_events`: optional (begin, end) torch.cuda.Event pair (enable_timing=True, already
+    recorded once so the handles exist) re-recorded around the dominant kernel.
+    Returns (heads [P,3A,T], rel_logits [P,K]).
+    """
+    d = _fused_desc(feats, pairs, B, N, conv_packed, conv_bias, head_w, head_b, cls_w, cls_b)
+    P, T = pairs.shape[0], feats.shape[1]
+    if check_pairs and P and (int(pairs.min()) < 0 or int(pairs.max()) >= B * N):
+        raise IndexError("forward_fused: pair index out of range")
+    l = _abi.lib()
+    need = l.tspn_forward_fused_workspace_bytes(ctypes.byref(d))
+    if workspace is None:
+        workspace = _ws(need, feats.device)
+    elif workspace.numel() * workspace.element_size() < need:
+        raise ValueError(f"forward_fused: workspace too small ({workspace.numel()} < {need})")
+    if out_heads is None:
+        out_heads = torch.empty((P, 3 * d.A, T), dtype=torch.float32, device=feats.device)
+    if out_logits is None:
+        out_logits = torch.empty((P, d.K), dtype=torch.float32, device=feats.device)
+    d.out_heads, d.out_logits = out_heads.data_ptr(), out_logits.data_ptr()
+    d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
+    if conv_events is not None:
+        d.ev_conv_begin, d.ev_conv_end = conv_events[0].cuda_event, conv_events[1].cuda_event
+    _abi.check(l.tspn_forward_fused_f32(ctypes.byref(d), _stream()))
+    return out_heads, out_logits
+
+
+def temporal_encoder_heads(x, conv_packed, conv_bias, head_w, head_b, h_ws=None):
+    """DPNHead.forward on a materialised x[P,C,T] (lib/modeling/relpn/dpn.py:69-73) -> [P,H,T]."""
+    _dev(x, "x"); _dev(conv_packed, "conv_packed"); _dev(head_w, "head_w")
+    P, C, T = x.shape
+    if tuple(conv_packed.shape) != (3, C, C):
+        raise ValueError("temporal_encoder_heads: conv_packed must be [3,C,C]")
+    H = head_w.shape[0]
+    if h_ws is None:
+        h_ws = torch.empty_like(x)
+    out = torch.empty((P, H, T), dtype=torch.float32, device=x.device)
+    _abi.check(_abi.lib().tspn_temporal_encoder_heads_f32(
+        _p(x), P, C, T, _p(conv_packed), _p(conv_bias), _p(head_w), _p(head_b), H, _p(h_ws), _p(out),
+        _stream()))
+    return out

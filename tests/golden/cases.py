@@ -1,0 +1,88 @@
+"""Input builders shared by make_golden.py (which feeds them to the reference) and the
+tests (which feed them to the oracle / the HIP path).  Everything is regenerated from the
+hash RNG, so the committed .npz files hold only the reference's outputs.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import tspn_mi355x as tspn  # noqa: E402
+
+GOLDEN_DIR = os.path.dirname(os.path.abspath(__file__))
+
+# effective values of the reference's configs/baseline.yaml on top of lib/config/defaults.py
+# (SURVEY.md §5 "Config / flags"); the tests must not read /root/reference.
+BASELINE_OVERRIDES = {
+    "DATASET.TRAIN_BATCH_SIZE": 1, "DATASET.TEST_BATCH_SIZE": 1, "DATASET.LOGIT_ONLY": True,
+    "RELPN.USE_PPN": False, "RELPN.USE_DPN": False,
+    "RELPN.PPN.BATCH_SIZE_PER_SEGMENT": 256, "RELPN.PPN.POSITIVE_FRACTION": 0.25,
+    "RELPN.PPN.NUM_PAIR_PROPOSALS": 256, "RELPN.DPN.NUM_DURATION_PROPOSALS": 64,
+    "PREDICT.TOPK_PER_PAIR": 20, "PREDICT.TOPK_PER_SEG": 200,
+}
+
+
+def baseline_cfg(**extra):
+    over = dict(BASELINE_OVERRIDES)
+    over.update(extra)
+    return tspn.load_cfg(None, **over)
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN_DIR, name))
+
+
+def ref_pairs(n):
+    return np.array([(i, j) for i in range(n) for j in range(n) if i != j], dtype=np.int64)
+
+
+def g1_inputs():
+    """cfg1: N=8 -> P=56 rows of the 11070-d baseline feature, one zero-norm block."""
+    n, p, f, k = 8, 56, 11070, 132
+    raw = tspn.synth.make_baseline_features(1, p, f)
+    raw[3, 70:1070] = 0.0
+    sd = tspn.synth.make_weights(0, c=1024, k=k, feat_dim=f, bias_std=0.02)
+    cls = tspn.synth.make_video(1, n, 2, 2)["track_cls_logits"]
+    tgt = (tspn.hashrng.uniform(1, "targets", (p, k)) < 0.02).astype(np.float32)
+    return {"n": n, "raw": raw, "state_dict": sd, "cls": cls, "targets": tgt}
+
+
+def g2_inputs(seed):
+    n, f, k = 32, 64, 132
+    sd = tspn.synth.make_weights(0, c=1024, k=k, feat_dim=f, bias_std=0.02)
+    feats = tspn.hashrng.uniform(2, "ppn_feats", (n * (n - 1), f))
+    cls = 8.0 * tspn.synth.make_video(int(seed), n, 2, 2)["track_cls_logits"]
+    tgt = (tspn.hashrng.uniform(2, "targets", (n * (n - 1), k)) < 0.01).astype(np.float32)
+    return {"n": n, "feats": feats, "state_dict": sd, "cls": cls, "targets": tgt,
+            "pairs": ref_pairs(n)}
+
+
+G3_SHAPES = {"small": (56, 64, 30, 3), "mid": (96, 128, 150, 4)}
+
+
+def g3_inputs(tag):
+    p, c, t, seed = G3_SHAPES[tag]
+    sd = tspn.synth.make_weights(0, c=c, bias_std=0.02)
+    x = tspn.hashrng.uniform(seed, "dpn_x", (p, c, t))
+    return {"x": x, "state_dict": sd, "c": c}
+
+
+def g4_inputs():
+    return (tspn.synth.make_video(5, 32, 150, 2)["tracklet_boxes"],
+            tspn.synth.make_video(6, 12, 150, 2)["tracklet_boxes"])
+
+
+G5_SPECS = [((15, 30, 45, 60), 7.5, 60), ((8, 16, 32, 64), 8, 150), ((4, 8, 16), 8, 30)]
+
+
+def g6_inputs():
+    n, k = 12, 132
+    p = n * (n - 1)
+    perm = np.argsort(tspn.hashrng.bits(7, "decode_logits", p * k), kind="stable")
+    rel_logit = ((perm.astype(np.float64) + 0.5) / (p * k)).astype(np.float32).reshape(p, k)
+    feat70 = tspn.hashrng.uniform(7, "decode_feat70", (p, 70))
+    return {"n": n, "rel_logit": rel_logit, "feat70": feat70, "pairs": ref_pairs(n)}

@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors in tests/golden/ from the REFERENCE's own modules.
+
+Runs only in the build container (needs /root/reference; it never ships to the
+GPU box).  Inputs and weights come from the build-owned hash RNG
+(temporal-span-proposal-network-vidvrd_amd/hashrng.py, synth.py), so only the
+reference's OUTPUTS are stored; tests regenerate the inputs.
+
+What is imported from the reference (torch + numpy only):
+    lib.modeling.model            BaseModel, RelationPredictor
+    lib.modeling.relpn.ppn        PPN, PPNHead
+    lib.modeling.relpn.dpn        DPNHead
+    lib.modeling.relpn.anchor_generator   AnchorGenerator
+    lib.modeling.relpn.sampler    BalancedPositiveNegativePairSampler
+    lib.modeling.trajectory       cubic_iou
+    lib.dataset.vrdataset         VRDataset._feature_preprocess
+    lib.dataset.list_pair / list_target   PairList, TargetList
+    lib.modeling                  segment_video
+Third-party modules the reference imports but does not use on these code paths
+(dlib, h5py, IPython) are absent here; empty module objects stand in for the
+*import statement only*.  `np.float` (removed in numpy 1.24, used by
+anchor_generator.py:72,80) is aliased to `float`.  The decode golden restates
+lib/modeling/predict.py:66-106 line by line because predict.py cannot run
+without the dataset.
+
+Usage:  python tests/golden/make_golden.py        (writes tests/golden/*.npz)
+"""
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("TSPN_REFERENCE", "/root/reference")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import tspn_mi355x as tspn  # noqa: E402
+sys.path.insert(0, HERE)
+import cases  # noqa: E402
+
+if not hasattr(np, "float"):
+    np.float = float
+
+for _name, _attrs in (("dlib", ("drectangle", "correlation_tracker")), ("h5py", ()), ("IPython", ())):
+    if _name not in sys.modules:
+        _m = types.ModuleType(_name)
+        for _a in _attrs:
+            setattr(_m, _a, object)
+        sys.modules[_name] = _m
+
+from lib.modeling import segment_video  # noqa: E402
+from lib.modeling.model import BaseModel as RefBaseModel  # noqa: E402
+from lib.modeling.relpn.dpn import DPNHead as RefDPNHead  # noqa: E402
+from lib.modeling.relpn.anchor_generator import AnchorGenerator as RefAnchorGenerator  # noqa: E402
+from lib.modeling.relpn.sampler import BalancedPositiveNegativePairSampler as RefSampler  # noqa: E402
+from lib.modeling.trajectory import cubic_iou as ref_cubic_iou  # noqa: E402
+from lib.dataset.list_pair import PairList as RefPairList  # noqa: E402
+from lib.dataset.list_target import TargetList as RefTargetList  # noqa: E402
+from lib.dataset.vrdataset import VRDataset as RefVRDataset  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+
+def t(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+    print(f"wrote {path}: " + ", ".join(f"{k}{tuple(np.asarray(v).shape)}" for k, v in arrays.items()))
+
+
+def load_sd(model, sd, strict=True):
+    sd = {k: t(v) for k, v in sd.items()}
+    if not strict:
+        own = model.state_dict()
+        sd = {k: v for k, v in sd.items() if k in own}
+    model.load_state_dict(sd, strict=True)
+
+
+def min_gap_desc(values):
+    v = np.sort(np.asarray(values, dtype=np.float64).ravel())[::-1]
+    return float(np.min(v[:-1] - v[1:]))
+
+
+def ref_cfg(**over):
+    """defaults restated in the build's config module + the reference's own configs/baseline.yaml."""
+    cfg = tspn.load_cfg(os.path.join(REF, "configs", "baseline.yaml"), **over)
+    chk = cases.baseline_cfg(**over)
+    for sec in ("RELPN", "PREDICT", "DATASET"):  # the sections the hot path reads
+        assert cfg[sec] == chk[sec], f"tests/golden/cases.py BASELINE_OVERRIDES drifted from configs/baseline.yaml ({sec})"
+    return cfg
+
+
+# --------------------------------------------------------------------------- #
+def g1_baseline():
+    """cfg1: configs/baseline.yaml, N=8 -> P=56, F=11070: BaseModel eval + train forward."""
+    cfg = ref_cfg()
+    c = cases.g1_inputs()
+    feats = RefVRDataset._feature_preprocess(None, t(c["raw"].copy()))
+    feats = (feats if isinstance(feats, torch.Tensor) else t(feats)).float()
+    model = RefBaseModel(cfg)
+    load_sd(model, c["state_dict"], strict=False)
+    model.eval()
+    plist = RefPairList(feats)
+    plist.add_field("track_cls_logits", t(c["cls"]))
+    with torch.no_grad():
+        pp, dp, logits = model([plist], None)
+    assert pp is None and dp is None
+    model.train()
+    loss = model([plist], [RefTargetList(t(c["targets"]))])
+    save("g1_baseline_cfg1.npz", preprocessed_rows=feats[:4, :1200].numpy(),
+         preprocessed_checksum=np.array([feats.double().sum().item(), feats.double().abs().max().item()]),
+         rel_logits=logits[0].numpy(), loss_rel=np.array(loss["loss_rel"].item()))
+
+
+def g2_ppn():
+    """USE_PPN=True, N=32: pair matrix [32,32] + top-256 flat indices; plus the train-mode losses.
+    Only the order of the first 256 entries (and the 256/257 boundary) is observable, so the first
+    input seed whose top-257 values are separated by much more than fp32 GEMM noise is used."""
+    cfg = ref_cfg(**{"RELPN.USE_PPN": True, "PREDICT.FEATURE_DIM": 64})
+    model = RefBaseModel(cfg)
+    for seed in range(2, 200):
+        c = cases.g2_inputs(seed)
+        load_sd(model, c["state_dict"], strict=False)
+        model.eval()
+        plist = RefPairList(t(c["feats"]))
+        plist.add_field("track_cls_logits", t(c["cls"]))
+        plist.add_field("tracklet_pairs", c["pairs"])
+        plist.add_field("num_tracklets", c["n"])
+        with torch.no_grad():
+            pp, dp, logits = model([plist], None)
+            mat = model.relpn.pair_proposal_network.ppn_head(t(c["cls"]), t(c["cls"]))
+        top = np.sort(mat.numpy().astype(np.float64).ravel())[::-1][:257]
+        gap = float(np.min(top[:-1] - top[1:]))
+        if gap > 2e-5:
+            break
+    else:
+        raise AssertionError("no tie-free PPN input found")
+    stable = torch.sort(mat.view(-1), descending=True, stable=True)[1][:256]
+    assert torch.equal(pp[0], stable)
+    model.train()
+    loss = model([plist], [RefTargetList(t(c["targets"]))])
+    save("g2_ppn_n32.npz", pair_matrix=mat.numpy(), topk=pp[0].numpy(), min_gap=np.array(gap),
+         input_seed=np.array(seed), rel_logits_head=logits[0][:8].numpy(),
+         loss_pair=np.array(loss["loss_pair"].item()), loss_rel=np.array(loss["loss_rel"].item()))
+
+
+def g3_dpn():
+    """DPNHead (reference relpn/dpn.py:55-73) at small and mid shapes."""
+    out = {}
+    pre = "relpn.duration_proposal_network.dpn_head."
+    for tag in cases.G3_SHAPES:
+        c = cases.g3_inputs(tag)
+        head = RefDPNHead(c["c"], 4)
+        head.load_state_dict({k[len(pre):]: t(v) for k, v in c["state_dict"].items()
+                              if k.startswith(pre) and "relness" not in k})
+        with torch.no_grad():
+            y = head(t(c["x"]))
+        out[f"{tag}_duration"] = y.numpy()
+    save("g3_dpn_head.npz", **out)
+
+
+def g4_iou():
+    """cubic_iou (reference trajectory.py:127-141), N=32, T=150, integer-valued boxes; and a
+    second call with two different trajectory lists."""
+    b, b2 = cases.g4_inputs()
+    iou = ref_cubic_iou(b, b)
+    iou12 = ref_cubic_iou(b, b2)
+    assert iou.dtype == np.float32
+    save("g4_cubic_iou.npz", iou=iou, iou_cross=iou12)
+
+
+def g5_anchors():
+    """AnchorGenerator (reference relpn/anchor_generator.py:31-64) for three (sizes, stride, T)."""
+    out = {}
+    for i, (sizes, stride, tw) in enumerate(cases.G5_SPECS):
+        gen = RefAnchorGenerator(sizes, stride)
+        out[f"anchors_{i}"] = gen(torch.zeros(2, 4, tw))[0].numpy()
+    save("g5_anchors.npz", **out)
+
+
+def g6_decode():
+    """Top-k triplet decode, restated from reference predict.py:66-106 (cannot be imported without
+    the dataset): tie-free inputs, N=12."""
+    c = cases.g6_inputs()
+    rel_logit, feature, tracklet_pair = t(c["rel_logit"]), t(c["feat70"]), t(c["pairs"])
+    num_tracklet = c["n"]
+    topk_per_pair, topk_per_seg = 20, 200
+    assert min_gap_desc(rel_logit.numpy()) > 0, "ties in decode input"
+    # ---- begin restatement of predict.py:66-106
+    sub_logit = feature[:, :35]
+    obj_logit = feature[:, 35:70]
+    topk_pred_per_pair = torch.sort(rel_logit, descending=True, dim=-1)
+    topk_score_per_pair = topk_pred_per_pair[0][:, :topk_per_pair]
+    topk_idx_per_pair = topk_pred_per_pair[1][:, :topk_per_pair]
+    r, c_ = topk_score_per_pair.shape
+    topk_pred_per_seg = torch.sort(topk_score_per_pair.flatten(), descending=True, dim=-1)
+    topk_idx_per_seg = topk_pred_per_seg[1][:topk_per_seg]
+    topk_idx = torch.tensor([(idx // c_, idx % c_) for idx in topk_idx_per_seg])
+    top_pair_idx = topk_idx[:, 0]
+    top_pair_tid = tracklet_pair[top_pair_idx]
+    top_sub_logit = sub_logit[(num_tracklet - 1) * top_pair_tid[:, 0]]
+    top_obj_logit = obj_logit[(num_tracklet - 1) * top_pair_tid[:, 1]]
+    top_sub_label = torch.argmax(top_sub_logit, dim=1)
+    top_obj_label = torch.argmax(top_obj_logit, dim=1)
+    top_rel_label = torch.tensor([topk_idx_per_pair[idx[0], idx[1]] for idx in topk_idx])
+    top_triplet_label = torch.stack([top_sub_label, top_rel_label, top_obj_label]).t()
+    top_rel_score = torch.tensor([topk_score_per_pair[idx[0], idx[1]] for idx in topk_idx])
+    # ---- end restatement
+    save("g6_decode.npz", scores=top_rel_score.numpy(), triplets=top_triplet_label.numpy(),
+         pair_tids=top_pair_tid.numpy())
+
+
+def g7_misc():
+    """Known answers: segment_video (lib/modeling/__init__.py:35-41), sampler mask counts
+    (relpn/sampler.py:3-66), PairList.to / __getitem__ behaviour."""
+    segs = {f"segs_{a}_{b}": np.array(segment_video(a, b), dtype=np.int64).reshape(-1, 2)
+            for a, b in ((0, 30), (0, 45), (0, 150), (0, 29))}
+    sampler = RefSampler(256, 0.25)
+    labels = torch.cat([torch.ones(100), torch.zeros(900)]).long()
+    pos, neg = sampler([labels])
+    save("g7_misc.npz", sampler_counts=np.array([int(pos[0].sum()), int(neg[0].sum())]), **segs)
+
+
+def main():
+    g1_baseline()
+    g2_ppn()
+    g3_dpn()
+    g4_iou()
+    g5_anchors()
+    g6_decode()
+    g7_misc()
+
+
+if __name__ == "__main__":
+    main()

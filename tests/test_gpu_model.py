@@ -1,0 +1,177 @@
+"""`BaseModel.forward()` drop-in behaviour on the GPU against the reference-generated goldens
+and the oracle (the tests read like calls the reference's train.py / predict.py make)."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+DPN_PRE = "relpn.duration_proposal_network.dpn_head."
+
+
+def t(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def load(model, sd):
+    own = model.state_dict()
+    model.load_state_dict({k: t(v) for k, v in sd.items() if k in own})
+
+
+def test_baseline_yaml_forward_cpu_inputs_like_predict_py(tspn, device):
+    """predict.py:21-57: model never .cuda()'d, CPU PairList in, CPU results out."""
+    g = cases.load("g1_baseline_cfg1.npz")
+    c = cases.g1_inputs()
+    model = tspn.BaseModel(cases.baseline_cfg())
+    load(model, c["state_dict"])
+    model.eval()
+    feats = oracle.feature_preprocess(t(c["raw"]))
+    plist = tspn.PairList(feats)
+    plist.add_field("track_cls_logits", t(c["cls"]))
+    with torch.no_grad():
+        pp, dp, logits = model([plist], None)
+    assert pp is None and dp is None and len(logits) == 1
+    assert logits[0].device.type == "cpu" and logits[0].shape == (56, 132)
+    np.testing.assert_allclose(logits[0].numpy(), g["rel_logits"], rtol=0, atol=2e-6)
+
+
+def test_baseline_train_loss_and_grads_like_train_py(tspn, device):
+    """train.py:44-78: model.cuda(), inputs .to(gpu), loss dict, backward."""
+    g = cases.load("g1_baseline_cfg1.npz")
+    c = cases.g1_inputs()
+    model = tspn.BaseModel(cases.baseline_cfg()).to(device)
+    load(model, c["state_dict"])
+    model.train()
+    feats = oracle.feature_preprocess(t(c["raw"]))
+    plist = tspn.PairList(feats).to(device)
+    tlist = tspn.TargetList(t(c["targets"])).to(device)
+    loss = model([plist], [tlist])
+    assert set(loss) == {"loss_rel"}
+    np.testing.assert_allclose(loss["loss_rel"].item(), g["loss_rel"], rtol=2e-5)
+    loss["loss_rel"].backward()
+    w = model.classifier.rel_predictor.weight
+    # gradient against torch autograd of the same math
+    wr = t(c["state_dict"]["classifier.rel_predictor.weight"]).clone().requires_grad_(True)
+    br = t(c["state_dict"]["classifier.rel_predictor.bias"]).clone().requires_grad_(True)
+    ref = torch.nn.functional.binary_cross_entropy(torch.sigmoid(feats @ wr.t() + br), t(c["targets"]))
+    ref.backward()
+    np.testing.assert_allclose(w.grad.cpu().numpy(), wr.grad.numpy(), rtol=0, atol=1e-7)
+    np.testing.assert_allclose(model.classifier.rel_predictor.bias.grad.cpu().numpy(), br.grad.numpy(),
+                               rtol=0, atol=1e-7)
+
+
+def test_use_ppn_eval_and_train(tspn, device):
+    g = cases.load("g2_ppn_n32.npz")
+    c = cases.g2_inputs(int(g["input_seed"]))
+    cfg = cases.baseline_cfg(**{"RELPN.USE_PPN": True, "PREDICT.FEATURE_DIM": 64})
+    model = tspn.BaseModel(cfg)
+    load(model, c["state_dict"])
+    model.eval()
+
+    def sample():
+        plist = tspn.PairList(t(c["feats"]))
+        plist.add_field("track_cls_logits", t(c["cls"]))
+        plist.add_field("tracklet_pairs", c["pairs"])
+        plist.add_field("num_tracklets", np.int64(c["n"]))
+        return plist
+
+    with torch.no_grad():
+        pp, dp, logits = model([sample(), sample()], None)
+    assert dp is None and len(pp) == 2
+    for idx in pp:
+        assert idx.dtype == torch.int64 and idx.shape == (256,)
+        np.testing.assert_array_equal(idx.numpy(), g["topk"])
+    np.testing.assert_allclose(logits[0][:8].numpy(), g["rel_logits_head"], rtol=0, atol=2e-6)
+    model.to(device).train()
+    loss = model([sample().to(device)], [tspn.TargetList(t(c["targets"])).to(device)])
+    assert set(loss) == {"loss_pair", "loss_rel"}
+    np.testing.assert_allclose(loss["loss_pair"].item(), g["loss_pair"], rtol=2e-5)
+    np.testing.assert_allclose(loss["loss_rel"].item(), g["loss_rel"], rtol=2e-5)
+    sum(loss.values()).backward()
+    assert model.relpn.pair_proposal_network.ppn_head.sub_emb[0].weight.grad is not None
+
+
+def temporal_cfg(D, use_ppn=True):
+    return cases.baseline_cfg(**{"RELPN.USE_PPN": use_ppn, "RELPN.USE_DPN": True,
+                                 "RELPN.DPN.IN_CHANNELS": 2 * D, "PREDICT.FEATURE_DIM": 2 * D})
+
+
+def oracle_weights(sd):
+    return {"conv_w": t(sd[DPN_PRE + "conv.weight"]), "conv_b": t(sd[DPN_PRE + "conv.bias"]),
+            "dur_w": t(sd[DPN_PRE + "duration_pred.weight"]), "dur_b": t(sd[DPN_PRE + "duration_pred.bias"]),
+            "rel_w": t(sd[DPN_PRE + "relness_pred.weight"]), "rel_b": t(sd[DPN_PRE + "relness_pred.bias"]),
+            "cls_w": t(sd["classifier.rel_predictor.weight"]), "cls_b": t(sd["classifier.rel_predictor.bias"])}
+
+
+def test_temporal_forward_tracklets_fused(tspn, device):
+    """USE_DPN=True on tracklet tensors: ragged batch (different N, T per segment)."""
+    D = 24
+    sd = tspn.synth.make_weights(0, c=2 * D, bias_std=0.05)
+    model = tspn.BaseModel(temporal_cfg(D))
+    load(model, sd)
+    model.eval()
+    shapes = [(6, 30), (4, 17), (6, 30)]
+    vids = [tspn.synth.make_video(70 + i, n, tt, D) for i, (n, tt) in enumerate(shapes)]
+    plists = [tspn.PairList.from_tracklets(t(v["tracklet_feats"]), t(v["tracklet_boxes"]),
+                                           t(v["track_cls_logits"])) for v in vids]
+    pp, dp, logits = model(plists, None)
+    w = oracle_weights(sd)
+    for i, v in enumerate(vids):
+        n = shapes[i][0]
+        ref = oracle.forward_dense(t(v["tracklet_feats"]), t(v["tracklet_boxes"]), oracle.pair_index(n), w)
+        assert dp[i].relness.shape == ref["relness"].shape and dp[i].duration.shape == ref["duration"].shape
+        np.testing.assert_allclose(dp[i].relness.numpy(), ref["relness"].numpy(), rtol=0, atol=1e-5)
+        np.testing.assert_allclose(dp[i].duration.numpy(), ref["duration"].numpy(), rtol=0, atol=1e-5)
+        np.testing.assert_allclose(logits[i].numpy(), ref["rel_logits"].numpy(), rtol=0, atol=1e-5)
+        assert pp[i].shape == (min(256, n * n),)
+    geo = model.pair_geometry(plists)
+    ref_g = oracle.pair_geometry(t(vids[1]["tracklet_boxes"]), oracle.pair_index(4))
+    np.testing.assert_allclose(geo[1].numpy(), ref_g.numpy(), rtol=2e-6, atol=2e-6)
+
+
+def test_temporal_forward_materialised_features_dense(tspn, device):
+    """USE_DPN=True with PairList.features = [P,C,T] (the layout DPNHead is documented to take)."""
+    D, N, T = 16, 5, 30
+    sd = tspn.synth.make_weights(0, c=2 * D, bias_std=0.05)
+    model = tspn.BaseModel(temporal_cfg(D, use_ppn=False))
+    load(model, sd)
+    model.eval()
+    v = tspn.synth.make_video(80, N, T, D)
+    pairs = oracle.pair_index(N)
+    pf, _ = oracle.pair_gather(t(v["tracklet_feats"]), t(v["tracklet_boxes"]), pairs)
+    pp, dp, logits = model([tspn.PairList(pf)], None)
+    ref = oracle.forward_dense(t(v["tracklet_feats"]), t(v["tracklet_boxes"]), pairs, oracle_weights(sd))
+    assert pp is None
+    np.testing.assert_allclose(dp[0].duration.numpy(), ref["duration"].numpy(), rtol=0, atol=1e-5)
+    np.testing.assert_allclose(dp[0].relness.numpy(), ref["relness"].numpy(), rtol=0, atol=1e-5)
+    np.testing.assert_allclose(logits[0].numpy(), ref["rel_logits"].numpy(), rtol=0, atol=1e-5)
+
+
+def test_temporal_custom_pairs_and_errors(tspn, device):
+    D, N, T = 8, 5, 12
+    sd = tspn.synth.make_weights(0, c=2 * D, bias_std=0.05)
+    model = tspn.BaseModel(temporal_cfg(D, use_ppn=False))
+    load(model, sd)
+    model.eval()
+    v = tspn.synth.make_video(81, N, T, D)
+    sub = oracle.pair_index(N)[[3, 0, 17]]
+    plist = tspn.PairList.from_tracklets(t(v["tracklet_feats"]), tracklet_pairs=sub.numpy())
+    _, dp, logits = model([plist], None)
+    ref = oracle.forward_dense(t(v["tracklet_feats"]), t(v["tracklet_boxes"]), sub, oracle_weights(sd))
+    np.testing.assert_allclose(dp[0].duration.numpy(), ref["duration"].numpy(), rtol=0, atol=1e-5)
+    np.testing.assert_allclose(logits[0].numpy(), ref["rel_logits"].numpy(), rtol=0, atol=1e-5)
+    with pytest.raises(ValueError):  # 2-D features with USE_DPN=True (reference: NameError)
+        model([tspn.PairList(torch.zeros(4, 2 * D))], None)
+    bad = tspn.PairList.from_tracklets(torch.zeros(3, 4, D + 1))
+    with pytest.raises(ValueError):
+        model([bad], None)
+
+
+def test_reference_checkpoint_without_relness_loads(tspn, device):
+    model = tspn.BaseModel(cases.baseline_cfg())
+    sd = {("module." + k): v for k, v in model.state_dict().items() if "relness_pred" not in k}
+    stripped = {k[len("module."):]: v for k, v in sd.items()}  # lib/utils/serialize.py:13-16
+    model.load_state_dict(stripped)  # strict

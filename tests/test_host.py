@@ -1,0 +1,164 @@
+"""Host-side logic that needs no GPU: config surface, container types, state_dict contract,
+the C-ABI library's exports and error paths, and the no-CPU-fallback rule."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+
+EXPECTED_KEYS = {
+    "relpn.pair_proposal_network.ppn_head.sub_emb.0.weight": (64, 35),
+    "relpn.pair_proposal_network.ppn_head.sub_emb.0.bias": (64,),
+    "relpn.pair_proposal_network.ppn_head.sub_emb.2.weight": (35, 64),
+    "relpn.pair_proposal_network.ppn_head.sub_emb.2.bias": (35,),
+    "relpn.pair_proposal_network.ppn_head.obj_emb.0.weight": (64, 35),
+    "relpn.pair_proposal_network.ppn_head.obj_emb.0.bias": (64,),
+    "relpn.pair_proposal_network.ppn_head.obj_emb.2.weight": (35, 64),
+    "relpn.pair_proposal_network.ppn_head.obj_emb.2.bias": (35,),
+    "relpn.duration_proposal_network.dpn_head.conv.weight": (1024, 1024, 3),
+    "relpn.duration_proposal_network.dpn_head.conv.bias": (1024,),
+    "relpn.duration_proposal_network.dpn_head.duration_pred.weight": (8, 1024, 1),
+    "relpn.duration_proposal_network.dpn_head.duration_pred.bias": (8,),
+    "classifier.rel_predictor.weight": (132, 11070),
+    "classifier.rel_predictor.bias": (132,),
+}  # SURVEY.md §8b (probed from the reference's BaseModel.state_dict())
+
+
+def test_config_defaults_and_yaml_overlay(tspn, tmp_path):
+    cfg = tspn.default_cfg()
+    assert cfg.RELPN.USE_PPN is True and cfg.RELPN.USE_DPN is True  # defaults.py:52,61
+    assert cfg.PREDICT.FEATURE_DIM == 11070 and cfg.PREDICT.PREDICATE_NUM == 132
+    assert cfg.RELPN.DPN.IN_CHANNELS == 1024 and cfg.RELPN.DPN.NUM_ANCHORS_PER_LOCATION == 4
+    y = tmp_path / "baseline.yaml"
+    y.write_text("RELPN:\n  USE_PPN: False\n  USE_DPN: False\n  PPN:\n    POSITIVE_FRACTION: 0.25\n"
+                 "PREDICT:\n  TOPK_PER_SEG: 200\nSOLVER:\n  BASE_LR: 1e-2\n")
+    cfg = tspn.load_cfg(str(y), **{"RELPN.DPN.IN_CHANNELS": 64})
+    assert cfg.RELPN.USE_PPN is False and cfg.RELPN.PPN.POSITIVE_FRACTION == 0.25
+    assert cfg.RELPN.PPN.NUM_PAIR_PROPOSALS == 256  # untouched default survives the overlay
+    assert cfg.RELPN.DPN.IN_CHANNELS == 64 and cfg.SOLVER.BASE_LR == "1e-2"
+    with pytest.raises(AttributeError):
+        cfg.RELPN.NOPE
+    (tmp_path / "evil.yaml").write_text("!!python/object/new:os.system [echo]\n")
+    with pytest.raises(Exception):  # safe_load refuses python tags (cf. configs/baseline_config.yaml)
+        tspn.load_cfg(str(tmp_path / "evil.yaml"))
+
+
+def test_state_dict_contract(tspn):
+    model = tspn.BaseModel(cases.baseline_cfg())
+    sd = model.state_dict()
+    for k, shape in EXPECTED_KEYS.items():
+        assert k in sd and tuple(sd[k].shape) == shape, k
+    extra = set(sd) - set(EXPECTED_KEYS)
+    assert extra == {"relpn.duration_proposal_network.dpn_head.relness_pred.weight",
+                     "relpn.duration_proposal_network.dpn_head.relness_pred.bias"}
+    # a reference checkpoint (no relness_pred, DDP 'module.' prefix stripped by serialize.py:13-16)
+    ref_ckpt = {k: torch.full_like(v, 0.5) for k, v in sd.items() if k in EXPECTED_KEYS}
+    model.load_state_dict(ref_ckpt)  # strict=True must accept it
+    assert float(model.classifier.rel_predictor.weight[0, 0]) == 0.5
+    with pytest.raises(RuntimeError):
+        model.load_state_dict({k: v for k, v in ref_ckpt.items() if "classifier" not in k})
+    # initialisers: N(0, 0.01^2) / zero bias (model.py:81-83, dpn.py:65-67)
+    fresh = tspn.BaseModel(cases.baseline_cfg())
+    w = fresh.classifier.rel_predictor.weight
+    assert abs(float(w.std()) - 0.01) < 5e-4 and float(fresh.classifier.rel_predictor.bias.abs().max()) == 0
+    assert float(fresh.relpn.duration_proposal_network.dpn_head.conv.bias.abs().max()) == 0
+
+
+def test_pair_list_semantics(tspn):
+    feats = torch.arange(12.0).reshape(4, 3)
+    pl = tspn.PairList(feats)
+    pl.add_field("track_cls_logits", torch.ones(2, 35))
+    pl.add_field("tracklet_pairs", np.array([[0, 1], [1, 0], [0, 1], [1, 0]]))
+    pl.add_field("num_tracklets", np.int64(2))
+    assert len(pl) == 4 and pl.has_field("tracklet_pairs") and not pl.has_field("x")
+    assert pl.fields() == ["track_cls_logits", "tracklet_pairs", "num_tracklets"]
+    moved = pl.to("cpu")
+    assert isinstance(moved, tspn.PairList) and moved is not pl
+    assert isinstance(moved.get_field("tracklet_pairs"), np.ndarray)  # numpy fields stay on the host
+    sub = tspn.PairList(feats)
+    sub.add_field("tracklet_pairs", np.array([[0, 1], [1, 0], [0, 1], [1, 0]]))
+    sl = sub[1:3]
+    assert len(sl) == 2 and sl.get_field("tracklet_pairs").shape == (2, 2)
+    only = pl.copy_with_fields("num_tracklets")
+    assert only.fields() == ["num_tracklets"]
+    with pytest.raises(KeyError):
+        pl.copy_with_fields(["missing"])
+    assert pl.copy_with_fields(["missing"], skip_missing=True).fields() == []
+    assert repr(pl) == "PairList(num_feats=4)"
+    tl = tspn.TargetList(torch.zeros(4, 132))
+    assert len(tl) == 4 and repr(tl) == "TargetList(num_targets=4)"
+    tr = tspn.PairList.from_tracklets(torch.zeros(5, 30, 8))
+    assert len(tr) == 20 and tr.get_field("num_tracklets") == 5 and tr.features.shape == (20, 0)
+
+
+def test_abi_library_exports_every_declared_symbol(tspn):
+    names = tspn._abi.header_symbols()
+    assert len(names) >= 19 and "tspn_forward_fused_f32" in names
+    assert set(names) == set(tspn._abi.PROTOTYPES), "ctypes prototypes out of sync with include/tspn_mi355x.h"
+    assert os.path.exists(tspn._abi.LIB_PATH), "libtspn_mi355x.so not built (run __graft_entry__.build())"
+    raw = ctypes.CDLL(tspn._abi.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), f"library does not export {n}"
+    lib = tspn._abi.lib()
+    assert lib.tspn_version() == 1
+    assert lib.tspn_error_string(-3) == b"workspace too small"
+
+
+def test_abi_argument_validation_without_gpu(tspn):
+    """Argument checks return before any HIP call, so they run on a GPU-less host."""
+    lib = tspn._abi.lib()
+    rc = lib.tspn_predicate_head_f32(None, 4, 8, 8, None, None, 2, None, 1, None, 0, None)
+    assert rc == tspn._abi.TSPN_EINVAL and b"null pointer" in lib.tspn_last_error()
+    with pytest.raises(tspn._abi.TspnError) as e:
+        tspn._abi.check(lib.tspn_heads_f32(0, 1, None, 4, None, None, 1, None, 1, None, 17, 1, 4, 4, 1, None))
+    assert e.value.code == tspn._abi.TSPN_EUNSUPPORTED and "H=17" in str(e.value)
+    assert lib.tspn_conv3_f32(1, 1, -1, 4, 1, 4, None, 0, 1, None) == tspn._abi.TSPN_EINVAL
+    assert lib.tspn_pack_conv3_f32(1, 4, 6, 2, 1, None) == tspn._abi.TSPN_EINVAL  # Cin != 2*split
+    assert lib.tspn_predicate_head_workspace_bytes(56, 11070, 132) >= 56 * 132 * 4
+    d = tspn._abi.FusedDesc()
+    d.B, d.N, d.T, d.D, d.A, d.K, d.P = 1, 32, 150, 2048, 4, 132, 992
+    need = lib.tspn_forward_fused_workspace_bytes(ctypes.byref(d))
+    assert need >= 32 * 8192 * 150 * 4  # the tracklet projections dominate
+    assert tspn.ops.fused_workspace_bytes(1, 32, 150, 2048, 4, 132, 992) == need
+    d.A = 6  # 3A > 16
+    assert lib.tspn_forward_fused_workspace_bytes(ctypes.byref(d)) == 0
+    assert lib.tspn_forward_fused_f32(ctypes.byref(d), None) == tspn._abi.TSPN_EUNSUPPORTED
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the GPU-less behaviour")
+def test_no_cpu_fallback(tspn):
+    model = tspn.BaseModel(cases.baseline_cfg())
+    model.eval()
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        model([tspn.PairList(torch.zeros(2, 11070))], None)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        tspn.ops.predicate_head(torch.zeros(2, 8), torch.zeros(3, 8), None)
+    with pytest.raises(RuntimeError):
+        tspn.ops.pair_index(4, "cpu")
+
+
+def test_product_package_never_imports_the_oracle():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "temporal-span-proposal-network-vidvrd_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text, f
+
+
+def test_hashrng_is_stable(tspn):
+    """Known answers: the fixtures depend on these exact streams."""
+    u = tspn.hashrng.uniform(0, "x", (4,))
+    assert u.dtype == np.float32 and np.all((u >= 0) & (u < 1))
+    np.testing.assert_array_equal(u, tspn.hashrng.uniform(0, "x", (4,)))
+    assert not np.array_equal(u, tspn.hashrng.uniform(1, "x", (4,)))
+    assert not np.array_equal(u, tspn.hashrng.uniform(0, "y", (4,)))
+    n = tspn.hashrng.normal(0, "w", (200000,), std=0.01)
+    assert abs(float(n.std()) - 0.01) < 1e-4 and abs(float(n.mean())) < 1e-4
+    b = tspn.synth.make_video(1, 3, 4, 2)["tracklet_boxes"]
+    assert np.all(b == np.round(b)) and np.all(b[..., 2] > b[..., 0]) and np.all(b[..., 3] > b[..., 1])
+    assert int(tspn.hashrng.bits(0, "x", 1)[0]) == int(tspn.hashrng.bits(0, "x", 3)[0])

@@ -1,0 +1,154 @@
+"""The CPU oracle against the golden vectors produced by the REFERENCE's own modules
+(tests/golden/make_golden.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+import oracle
+
+
+def t(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def sd_t(sd):
+    return {k: t(v) for k, v in sd.items()}
+
+
+PPN_PRE = "relpn.pair_proposal_network.ppn_head."
+DPN_PRE = "relpn.duration_proposal_network.dpn_head."
+
+
+def test_g1_preprocess_and_predicate_head():
+    g = cases.load("g1_baseline_cfg1.npz")
+    c = cases.g1_inputs()
+    feats = oracle.feature_preprocess(t(c["raw"]))
+    # numpy's pairwise L1 sum vs torch's: a few ulp
+    np.testing.assert_allclose(feats[:4, :1200].numpy(), g["preprocessed_rows"], rtol=2e-6, atol=1e-9)
+    assert float(feats[3, 70:1070].abs().max()) == 0.0  # zero-norm block stays zero
+    chk = np.array([feats.double().sum().item(), feats.double().abs().max().item()])
+    np.testing.assert_allclose(chk, g["preprocessed_checksum"], rtol=1e-6)
+    sd = sd_t(c["state_dict"])
+    logits = oracle.predicate_head(feats, sd["classifier.rel_predictor.weight"],
+                                   sd["classifier.rel_predictor.bias"])
+    np.testing.assert_allclose(logits.numpy(), g["rel_logits"], rtol=0, atol=1e-6)
+    loss = torch.nn.functional.binary_cross_entropy(logits, t(c["targets"]))
+    np.testing.assert_allclose(loss.item(), g["loss_rel"], rtol=1e-5)
+
+
+def test_g2_ppn_matrix_and_topk():
+    g = cases.load("g2_ppn_n32.npz")
+    c = cases.g2_inputs(int(g["input_seed"]))
+    sd = sd_t(c["state_dict"])
+    p = {k[len(PPN_PRE):]: v for k, v in sd.items() if k.startswith(PPN_PRE)}
+    mat = oracle.ppn_pair_matrix(t(c["cls"]), p)
+    np.testing.assert_allclose(mat.numpy(), g["pair_matrix"], rtol=0, atol=1e-6)
+    assert float(g["min_gap"]) > 2e-5
+    idx = oracle.ppn_topk(mat, 256)
+    assert idx.dtype == torch.int64
+    np.testing.assert_array_equal(idx.numpy(), g["topk"])  # indices bit-exact
+    assert int(idx.max()) < 32 * 32  # flat N*N incl. diagonal
+
+
+def test_g3_dpn_head():
+    g = cases.load("g3_dpn_head.npz")
+    for tag in cases.G3_SHAPES:
+        c = cases.g3_inputs(tag)
+        sd = sd_t(c["state_dict"])
+        rel, dur, _ = oracle.dpn_head(t(c["x"]), sd[DPN_PRE + "conv.weight"], sd[DPN_PRE + "conv.bias"],
+                                      sd[DPN_PRE + "duration_pred.weight"], sd[DPN_PRE + "duration_pred.bias"],
+                                      sd[DPN_PRE + "relness_pred.weight"], sd[DPN_PRE + "relness_pred.bias"])
+        np.testing.assert_allclose(dur.numpy(), g[f"{tag}_duration"], rtol=0, atol=1e-6)
+        assert rel.shape == (c["x"].shape[0], 4, c["x"].shape[2])
+
+
+def test_g4_cubic_iou_bit_exact():
+    g = cases.load("g4_cubic_iou.npz")
+    b, b2 = cases.g4_inputs()
+    iou = oracle.cubic_iou(b)
+    assert iou.dtype == np.float32
+    np.testing.assert_array_equal(iou, g["iou"])
+    np.testing.assert_array_equal(oracle.cubic_iou(b, b2), g["iou_cross"])
+    np.testing.assert_array_equal(np.diag(iou), np.ones(32, np.float32))
+    np.testing.assert_array_equal(iou, iou.T)
+
+
+def test_g5_anchors():
+    g = cases.load("g5_anchors.npz")
+    for i, (sizes, stride, tw) in enumerate(cases.G5_SPECS):
+        a = oracle.grid_anchors(sizes, stride, tw)
+        np.testing.assert_array_equal(a.numpy(), g[f"anchors_{i}"])
+    a0 = g["anchors_0"]
+    assert a0.shape == (36, 2)
+    np.testing.assert_array_equal(a0[:5], [[-7.5, 7.5], [-15, 15], [-22.5, 22.5], [-30, 30], [0, 15]])
+    np.testing.assert_array_equal(a0[-1], [30, 90])
+
+
+def test_g6_decode():
+    g = cases.load("g6_decode.npz")
+    c = cases.g6_inputs()
+    sc, trip, tids = oracle.decode_topk(t(c["rel_logit"]), t(c["feat70"]), t(c["pairs"]), c["n"])
+    np.testing.assert_array_equal(sc.numpy(), g["scores"])
+    np.testing.assert_array_equal(trip.numpy(), g["triplets"])
+    np.testing.assert_array_equal(tids.numpy(), g["pair_tids"])
+
+
+def test_g7_known_answers():
+    g = cases.load("g7_misc.npz")
+    for a, b in ((0, 30), (0, 45), (0, 150), (0, 29)):
+        got = np.array(oracle.segment_video(a, b), dtype=np.int64).reshape(-1, 2)
+        np.testing.assert_array_equal(got, g[f"segs_{a}_{b}"])
+    assert len(oracle.segment_video(0, 150)) == 9
+    np.testing.assert_array_equal(g["sampler_counts"], [64, 192])
+    np.testing.assert_array_equal(oracle.pair_index(4).numpy(), cases.ref_pairs(4))
+    assert oracle.pair_index(1).shape == (0, 2)
+
+
+def test_pair_gather_layout_and_geometry():
+    v = tspn_video(3, 5, 7, 6)
+    pairs = oracle.pair_index(5)
+    pf, geom = oracle.pair_gather(t(v["tracklet_feats"]), t(v["tracklet_boxes"]), pairs)
+    assert pf.shape == (20, 12, 7) and geom.shape == (20, 8, 7)
+    p = 6  # pair (1, 3)
+    assert tuple(pairs[p].tolist()) == (1, 3)
+    np.testing.assert_array_equal(pf[p, :6].numpy(), v["tracklet_feats"][1].T)
+    np.testing.assert_array_equal(pf[p, 6:].numpy(), v["tracklet_feats"][3].T)
+    # per-frame IoU channel agrees with a T=1 cubic_iou of the same boxes
+    b = v["tracklet_boxes"]
+    for tt in (0, 3):
+        ref = oracle.cubic_iou(b[:, tt:tt + 1], b[:, tt:tt + 1])
+        np.testing.assert_allclose(geom[p, 4, tt].item(), ref[1, 3], rtol=1e-6)
+    assert torch.all(geom[:, 5:7, 0] == 0)
+
+
+def tspn_video(seed, n, tt, d):
+    import tspn_mi355x as tspn
+    return tspn.synth.make_video(seed, n, tt, d)
+
+
+@pytest.mark.parametrize("n,tt,d", [(6, 9, 8), (4, 30, 16)])
+def test_factorised_equals_dense(n, tt, d):
+    """conv(cat(f_s, f_o)) == conv_s(f_s) + conv_o(f_o): the algebra behind the fused HIP path."""
+    import tspn_mi355x as tspn
+    v = tspn_video(11, n, tt, d)
+    sd = sd_t(tspn.synth.make_weights(0, c=2 * d, k=17, bias_std=0.05))
+    w = {"conv_w": sd[DPN_PRE + "conv.weight"], "conv_b": sd[DPN_PRE + "conv.bias"],
+         "dur_w": sd[DPN_PRE + "duration_pred.weight"], "dur_b": sd[DPN_PRE + "duration_pred.bias"],
+         "rel_w": sd[DPN_PRE + "relness_pred.weight"], "rel_b": sd[DPN_PRE + "relness_pred.bias"],
+         "cls_w": sd["classifier.rel_predictor.weight"], "cls_b": sd["classifier.rel_predictor.bias"]}
+    pairs = oracle.pair_index(n)
+    a = oracle.forward_dense(t(v["tracklet_feats"]), t(v["tracklet_boxes"]), pairs, w)
+    b = oracle.forward_factorised(t(v["tracklet_feats"]), t(v["tracklet_boxes"]), pairs, w)
+    for k in ("relness", "duration", "rel_logits"):
+        np.testing.assert_allclose(a[k].numpy(), b[k].numpy(), rtol=0, atol=2e-6)
+
+
+def test_rel_oi_pool_spans():
+    x = torch.arange(2 * 3 * 5, dtype=torch.float32).reshape(2, 3, 5)
+    np.testing.assert_allclose(oracle.rel_oi_pool(x).numpy(), x.mean(2).numpy())
+    spans = torch.tensor([[1, 3], [0, 5]])
+    out = oracle.rel_oi_pool(x, spans)
+    np.testing.assert_allclose(out[0].numpy(), x[0, :, 1:3].mean(1).numpy())
+    np.testing.assert_allclose(out[1].numpy(), x[1].mean(1).numpy())
+    assert oracle.rel_oi_pool(torch.ones(4, 7)).shape == (4, 7)
