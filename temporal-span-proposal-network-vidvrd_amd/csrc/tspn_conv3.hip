@@ -262,13 +262,13 @@ extern "C" int tspn_pack_conv3_f32(const float* W, int64_t M, int64_t Cin, int64
 extern "C" int tspn_conv3_f32(const float* x, int64_t B, int64_t Cin, int64_t T,
                               const float* packed, int64_t M, const float* bias, int relu,
                               float* y, void* stream) {
-  TSPN_REQUIRE(x && packed && y, TSPN_EINVAL, "tspn_conv3_f32: null pointer");
   TSPN_REQUIRE(B >= 0 && Cin > 0 && T > 0 && M > 0, TSPN_EINVAL,
                "tspn_conv3_f32: bad sizes B=%lld Cin=%lld T=%lld M=%lld", (long long)B,
                (long long)Cin, (long long)T, (long long)M);
+  if (B == 0) return TSPN_OK;
+  TSPN_REQUIRE(x && packed && y, TSPN_EINVAL, "tspn_conv3_f32: null pointer");
   TSPN_REQUIRE(Cin < (1 << 24) && T < (1 << 24) && M < (1 << 24), TSPN_EUNSUPPORTED,
                "tspn_conv3_f32: dimension too large");
-  if (B == 0) return TSPN_OK;
   const int64_t ncols = B * T;
   const int64_t tiles_m = tspn::ceil_div(M, BM);
   const int64_t tiles_n = tspn::ceil_div(ncols, BN);

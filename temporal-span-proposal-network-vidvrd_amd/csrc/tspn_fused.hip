@@ -113,6 +113,7 @@ extern "C" int tspn_temporal_encoder_heads_f32(const float* x, int64_t P, int64_
                                                const float* conv_packed, const float* conv_bias,
                                                const float* head_w, const float* head_b, int64_t H,
                                                float* h_ws, float* out_heads, void* stream) {
+  if (P == 0) return TSPN_OK;
   TSPN_REQUIRE(x && conv_packed && head_w && h_ws && out_heads, TSPN_EINVAL,
                "tspn_temporal_encoder_heads_f32: null pointer");
   int rc = tspn_conv3_f32(x, P, C, T, conv_packed, C, conv_bias, 1, h_ws, stream);

@@ -149,8 +149,6 @@ extern "C" int tspn_heads_f32(int mode, const float* a, const float* b, int64_t 
                               const float* bias, const float* Wh, const float* bh, int64_t H, int64_t P, int64_t C,
                               int64_t T, float* out, void* stream) {
   TSPN_REQUIRE(mode == 0 || mode == 1, TSPN_EINVAL, "tspn_heads_f32: mode must be 0 or 1");
-  TSPN_REQUIRE(a && Wh && out, TSPN_EINVAL, "tspn_heads_f32: null pointer");
-  TSPN_REQUIRE(mode == 0 || b, TSPN_EINVAL, "tspn_heads_f32: mode 1 needs operand b");
   TSPN_REQUIRE(H > 0 && H <= 16, TSPN_EUNSUPPORTED, "tspn_heads_f32: H=%lld not in [1,16]",
                (long long)H);
   TSPN_REQUIRE(P >= 0 && C > 0 && T > 0 && lda >= C && idx_stride >= 1, TSPN_EINVAL,
@@ -158,6 +156,8 @@ extern "C" int tspn_heads_f32(int mode, const float* a, const float* b, int64_t 
                (long long)C, (long long)T, (long long)lda);
   TSPN_REQUIRE(C < (1 << 24) && T < (1 << 24), TSPN_EUNSUPPORTED, "tspn_heads_f32: dim too large");
   if (P == 0) return TSPN_OK;
+  TSPN_REQUIRE(a && Wh && out, TSPN_EINVAL, "tspn_heads_f32: null pointer");
+  TSPN_REQUIRE(mode == 0 || b, TSPN_EINVAL, "tspn_heads_f32: mode 1 needs operand b");
   const bool vec2 = (T % 2 == 0) && T >= 2 &&
                     ((reinterpret_cast<uintptr_t>(a) & 7) == 0) &&
                     (mode == 0 || (reinterpret_cast<uintptr_t>(b) & 7) == 0) &&

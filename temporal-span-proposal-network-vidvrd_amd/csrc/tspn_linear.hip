@@ -40,7 +40,7 @@ __global__ __launch_bounds__(THREADS) void linear_splitk_kernel(
   const int64_t row0 = (int64_t)blockIdx.x * TM;
   const int64_t col0 = (int64_t)blockIdx.y * TN;
   const int64_t kbeg = (int64_t)blockIdx.z * k_per_split;
-  const int64_t kend = std::min<int64_t>(F, kbeg + k_per_split);
+  const int64_t kend = (kbeg + k_per_split < F) ? kbeg + k_per_split : F;
 
   f32x4 acc[NBLK];
 #pragma unroll
@@ -125,11 +125,11 @@ extern "C" int tspn_predicate_head_f32(const float* x, int64_t P, int64_t F, int
                                        const float* W, const float* b, int64_t K, float* out,
                                        int apply_sigmoid, void* workspace, size_t workspace_bytes,
                                        void* stream) {
-  TSPN_REQUIRE(x && W && out, TSPN_EINVAL, "tspn_predicate_head_f32: null pointer");
   TSPN_REQUIRE(P >= 0 && F > 0 && K > 0 && ldx >= F, TSPN_EINVAL,
                "tspn_predicate_head_f32: bad sizes P=%lld F=%lld K=%lld ldx=%lld", (long long)P,
                (long long)F, (long long)K, (long long)ldx);
   if (P == 0) return TSPN_OK;
+  TSPN_REQUIRE(x && W && out, TSPN_EINVAL, "tspn_predicate_head_f32: null pointer");
   const int splits = choose_splits(P, F, K);
   const size_t need = (size_t)splits * (size_t)P * (size_t)K * sizeof(float);
   TSPN_REQUIRE(workspace != nullptr && workspace_bytes >= need, TSPN_EWORKSPACE,
