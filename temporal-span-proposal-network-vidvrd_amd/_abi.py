@@ -11,7 +11,8 @@ import threading
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-LIB_PATH = os.path.join(HERE, "libtspn_mi355x.so")
+# TSPN_LIB_PATH selects another build of the same ABI (A/B timing of kernel variants)
+LIB_PATH = os.environ.get("TSPN_LIB_PATH") or os.path.join(HERE, "libtspn_mi355x.so")
 HEADER_PATH = os.path.join(ROOT, "include", "tspn_mi355x.h")
 
 TSPN_OK = 0

@@ -17,11 +17,13 @@
 // Tiling: workgroup 128(m) x 128(n), 4 waves as 2x2, each wave 64x64 = 2x2
 // MFMA blocks of 32x32 (64 accumulator VGPRs); K chunk = 16 channels x 3 taps;
 // LDS double-buffered (66 KB -> 2 workgroups / CU), global->register->LDS
-// staging with the next chunk's loads in flight under the MFMAs.
+// staging through two register sets, loads issued two chunks ahead.
 // fp32 MFMA runs at 64 FLOP/clk/SIMD (= 157 TF/s chip peak): one LDS dword per
 // operand per 4096 FLOP, so LDS/L2 bandwidth is far from limiting; the design
 // goal is simply to keep the matrix pipe issuing back-to-back.
 #include <algorithm>
+#include <cstdlib>
+#include <type_traits>
 
 #include "tspn_common.h"
 
@@ -86,77 +88,114 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_mfma_kernel(
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, kh = lane >> 5;
 
-  // ---- per-thread staging descriptors (constant over the K loop)
+  // ---- per-thread staging descriptors (constant over the K loop).  Source addresses are
+  // clamped into range and the loaded value is masked, so staging is branch-free.
   // B main: slot = 1 + (tid & 127) <-> column n0 + (tid & 127); rows (tid>>7)*8 .. +7
   const int bslot = 1 + (tid & 127);
   const int brow0 = (tid >> 7) * 8;
-  const float* bptr = nullptr;
+  bool bvalid;
+  const float* bptr;
   {
     const int64_t n = n0 + (tid & 127);
-    if (n < ncols) {
-      const int64_t b = n / T;
-      bptr = x + (b * Cin) * (int64_t)T + (n - b * T);
-    }
+    bvalid = n < ncols;
+    const int64_t nc = bvalid ? n : ncols - 1;
+    const int64_t b = nc / T;
+    bptr = x + (b * Cin) * (int64_t)T + (nc - b * T);
   }
   // B halo: threads 0..31: row = tid & 15, side = tid >> 4 (0: column n0-1, 1: column n0+BN)
-  const float* hptr = nullptr;
   const int hrow = tid & 15;
   const int hslot = (tid >> 4) & 1 ? BN + 1 : 0;
-  if (tid < 32) {
-    const int64_t n = (tid >> 4) ? n0 + BN : n0 - 1;
-    if (n >= 0 && n < ncols) {
-      const int64_t b = n / T;
-      hptr = x + (b * Cin) * (int64_t)T + (n - b * T);
-    }
+  bool hvalid;
+  const float* hptr;
+  {
+    const int64_t n = ((tid >> 4) & 1) ? n0 + BN : n0 - 1;
+    hvalid = tid < 32 && n >= 0 && n < ncols;
+    const int64_t nc = hvalid ? n : 0;
+    const int64_t b = nc / T;
+    hptr = x + (b * Cin) * (int64_t)T + (nc - b * T);
   }
+  // A: 6 float4 per thread; row = tap*KC + ci, 4 consecutive m
+  const int am = (tid & 31) * 4;
+  const bool avalid = m0 + am < M;  // M % 4 == 0 on the VEC_A path
+  const int amc = avalid ? m0 + am : 0;
 
-  float4 a_reg[6];
-  float b_reg[8];
-  float h_reg = 0.f;
+  // Two staging register sets: chunk j travels global -> set (j&1) -> LDS buffer (j&1); its loads
+  // are issued two chunks (~5 us of MFMA work) before the ds_write that consumes them, which is
+  // what hides L2-miss latency (one chunk of distance left the matrix pipe ~20 % idle).
+  float4 a_reg[2][6];
+  float b_reg[2][8];
+  float h_reg[2] = {0.f, 0.f};
 
-  auto load_chunk = [&](int c0) {
+  // Loads are unconditional (clamped addresses) and their results are not touched until the
+  // ds_write two chunks later: any use here would make the wave wait for the load at once.
+  auto load_chunk = [&](auto set_tag, int c0) {
+    constexpr int S = decltype(set_tag)::value;
+#if defined(TSPN_ABLATE_NOLOAD)
+    if (c0 > 0) return;  // diagnostic build
+#endif
+#if defined(TSPN_ABLATE_HOTLOAD)
+    c0 = c0 & 16;  // diagnostic build: always re-read chunks 0/1 (cache-hot), same instruction stream
+#endif
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
-      const int idx4 = tid + r * THREADS;  // 0..1535
-      const int row = idx4 >> 5;           // 0..47 = tap*KC + ci
-      const int m = (idx4 & 31) * 4;
-      const int tap = row / KC, ci = row - tap * KC;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c0 + ci < Cin) {
-        const float* src = Wp + ((int64_t)tap * Cin + c0 + ci) * M + m0 + m;
-        if (VEC_A) {
-          if (m0 + m < M) v = *reinterpret_cast<const float4*>(src);
-        } else {
-          if (m0 + m + 0 < M) v.x = src[0];
-          if (m0 + m + 1 < M) v.y = src[1];
-          if (m0 + m + 2 < M) v.z = src[2];
-          if (m0 + m + 3 < M) v.w = src[3];
-        }
+      const int row = (tid >> 5) + r * 8;  // 0..47 = tap*KC + ci
+      const int tap = row / KC, ci = c0 + row - tap * KC;
+      const int cic = ci < Cin ? ci : Cin - 1;
+      const float* src = Wp + ((int64_t)tap * Cin + cic) * M + amc;
+      if (VEC_A) {
+        a_reg[S][r] = *reinterpret_cast<const float4*>(src);
+      } else {
+        a_reg[S][r].x = src[0];
+        a_reg[S][r].y = src[m0 + am + 1 < M ? 1 : 0];
+        a_reg[S][r].z = src[m0 + am + 2 < M ? 2 : 0];
+        a_reg[S][r].w = src[m0 + am + 3 < M ? 3 : 0];
       }
-      a_reg[r] = v;
     }
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const int ci = c0 + brow0 + r;
-      b_reg[r] = (bptr != nullptr && ci < Cin) ? bptr[(int64_t)ci * T] : 0.f;
+      b_reg[S][r] = bptr[(int64_t)(ci < Cin ? ci : Cin - 1) * T];
     }
-    if (tid < 32) {
+    {
       const int ci = c0 + hrow;
-      h_reg = (hptr != nullptr && ci < Cin) ? hptr[(int64_t)ci * T] : 0.f;
+      h_reg[S] = hptr[(int64_t)(ci < Cin ? ci : Cin - 1) * T];
     }
   };
 
-  auto store_chunk = [&](int buf) {
-    float* Ab = As + buf * A_STAGE;
-    float* Bb = Bs + buf * B_STAGE;
+  // Masking happens on the way into LDS.  Channels past Cin are zeroed on the weight side only
+  // (a zero A row kills the product); columns past the tensor are zeroed on the x side.
+  auto store_chunk = [&](auto set_tag, int c0) {  // set S -> LDS buffer S
+    constexpr int S = decltype(set_tag)::value;
+#if defined(TSPN_ABLATE_NOSTORE)
+    if (c0 > 0) {  // diagnostic build: consume the registers, write nothing
+      for (int r = 0; r < 6; ++r) asm volatile("" ::"v"(a_reg[S][r].x), "v"(a_reg[S][r].y), "v"(a_reg[S][r].z), "v"(a_reg[S][r].w));
+      for (int r = 0; r < 8; ++r) asm volatile("" ::"v"(b_reg[S][r]));
+      asm volatile("" ::"v"(h_reg[S]));
+      return;
+    }
+#endif
+    float* Ab = As + S * A_STAGE;
+    float* Bb = Bs + S * B_STAGE;
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
-      const int idx4 = tid + r * THREADS;
-      *reinterpret_cast<float4*>(Ab + idx4 * 4) = a_reg[r];
+      const int row = (tid >> 5) + r * 8;
+      const int tap = row / KC, ci = c0 + row - tap * KC;
+      const bool ok = avalid && ci < Cin;
+      float4 v = a_reg[S][r];
+      if (!VEC_A) {
+        v.y = m0 + am + 1 < M ? v.y : 0.f;
+        v.z = m0 + am + 2 < M ? v.z : 0.f;
+        v.w = m0 + am + 3 < M ? v.w : 0.f;
+      }
+      v.x = ok ? v.x : 0.f;
+      v.y = ok ? v.y : 0.f;
+      v.z = ok ? v.z : 0.f;
+      v.w = ok ? v.w : 0.f;
+      *reinterpret_cast<float4*>(Ab + (tid + r * THREADS) * 4) = v;
     }
 #pragma unroll
-    for (int r = 0; r < 8; ++r) Bb[(brow0 + r) * BNP + bslot] = b_reg[r];
-    if (tid < 32) Bb[hrow * BNP + hslot] = h_reg;
+    for (int r = 0; r < 8; ++r) Bb[(brow0 + r) * BNP + bslot] = bvalid ? b_reg[S][r] : 0.f;
+    if (tid < 32) Bb[hrow * BNP + hslot] = hvalid ? h_reg[S] : 0.f;
   };
 
   // ---- lane-constant sequence-boundary masks for the +-1 taps
@@ -177,26 +216,60 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_mfma_kernel(
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
-  const int nchunks = (Cin + KC - 1) / KC;
-  load_chunk(0);
-  store_chunk(0);
-  __syncthreads();
-
-  for (int c = 0; c < nchunks; ++c) {
-    const int buf = c & 1;
-    if (c + 1 < nchunks) load_chunk((c + 1) * KC);
-
-    const float* Ab = As + buf * A_STAGE + wm * 64 + li;
-    const float* Bb = Bs + buf * B_STAGE + wn * 64 + li;
+  // One k-step = channels (2kk, 2kk+1) x 3 taps: 6 A values + 6 B values feed 12 MFMAs.
+  struct Frag {
+    float a[3][2];
+    float b[2][3];
+  };
+  auto read_frag = [&](const float* Ab, const float* Bb, int kk) {
+    Frag f;
+#if defined(TSPN_ABLATE_NOLDS)
+    for (int tap = 0; tap < 3; ++tap) { f.a[tap][0] = 1.f + kk; f.a[tap][1] = 2.f; }
+    for (int ni = 0; ni < 2; ++ni) for (int j = 0; j < 3; ++j) f.b[ni][j] = 0.5f * kh;
+    asm volatile("" : "+v"(f.a[0][0]), "+v"(f.b[0][0]));
+    return f;
+#endif
+    const int k = 2 * kk + kh;
 #pragma unroll
     for (int tap = 0; tap < 3; ++tap) {
+      f.a[tap][0] = Ab[(tap * KC + k) * BM];
+      f.a[tap][1] = Ab[(tap * KC + k) * BM + 32];
+    }
 #pragma unroll
-      for (int kk = 0; kk < KC / 2; ++kk) {
-        const int k = 2 * kk + kh;
-        const float a0 = Ab[(tap * KC + k) * BM];
-        const float a1 = Ab[(tap * KC + k) * BM + 32];
-        float b0 = Bb[k * BNP + tap];
-        float b1 = Bb[k * BNP + tap + 32];
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) f.b[ni][j] = Bb[k * BNP + ni * 32 + j];
+    return f;
+  };
+
+  using Set0 = std::integral_constant<int, 0>;
+  using Set1 = std::integral_constant<int, 1>;
+  const int nchunks = (Cin + KC - 1) / KC;
+  load_chunk(Set0{}, 0);
+  if (nchunks > 1) load_chunk(Set1{}, KC);
+  store_chunk(Set0{}, 0);
+  if (nchunks > 2) load_chunk(Set0{}, 2 * KC);
+  __syncthreads();
+
+  constexpr int KSTEPS = KC / 2;
+  constexpr int STORE_AT = 1;  // k-step after which chunk c+1 is staged into LDS and c+3 requested
+  // Chunk c is computed from LDS buffer (c&1); set/buffer NEXT = (c+1)&1 holds chunk c+1.
+  auto chunk_body = [&](auto next_tag, int c) {
+    constexpr int NEXT = decltype(next_tag)::value;
+    constexpr int BUF = NEXT ^ 1;
+    const float* Ab = As + BUF * A_STAGE + wm * 64 + li;
+    const float* Bb = Bs + BUF * B_STAGE + wn * 64 + li;
+    Frag cur = read_frag(Ab, Bb, 0);
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; ++kk) {
+      Frag nxt = cur;
+      if (kk + 1 < KSTEPS) nxt = read_frag(Ab, Bb, kk + 1);
+      // Pin the order: the next k-step's LDS reads are issued BEFORE this step's 12 MFMAs, so
+      // their latency is covered by 768 cycles of matrix work.
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int tap = 0; tap < 3; ++tap) {
+        float b0 = cur.b[0][tap], b1 = cur.b[1][tap];
         if (tap == 0) {
           b0 = mask_l[0] ? b0 : 0.f;
           b1 = mask_l[1] ? b1 : 0.f;
@@ -204,20 +277,326 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_mfma_kernel(
           b0 = mask_r[0] ? b0 : 0.f;
           b1 = mask_r[1] ? b1 : 0.f;
         }
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[tap][0], b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[tap][0], b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[tap][1], b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[tap][1], b1, acc[1][1], 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      if (kk == STORE_AT) {
+#if !defined(TSPN_ABLATE_NOGLOBAL)
+        // LDS buffer NEXT has been free since the barrier that ended chunk c-1.
+        if (c + 1 < nchunks) store_chunk(next_tag, (c + 1) * KC);
+        if (c + 3 < nchunks) load_chunk(next_tag, (c + 3) * KC);
+#endif
+      }
+      cur = nxt;
     }
-
-    if (c + 1 < nchunks) store_chunk(buf ^ 1);
+#if !defined(TSPN_ABLATE_NOBARRIER)
     __syncthreads();
+#endif
+  };
+  for (int c = 0; c < nchunks; c += 2) {
+    chunk_body(Set1{}, c);
+    if (c + 1 < nchunks) chunk_body(Set0{}, c + 1);
   }
 
   // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31,
   // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  For a fixed register the 32 lanes
   // of a half-wave write 32 consecutive t -> 128-B contiguous stores.
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int64_t n = n0 + wn * 64 + ni * 32 + li;
+    if (n >= ncols) continue;
+    const int64_t b = n / T;
+    const int64_t t = n - b * T;
+    float* ycol = y + (b * M) * (int64_t)T + t;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        if (m < M) {
+          float v = acc[mi][ni][e];
+          if (bias != nullptr) v += bias[m];
+          if (relu) v = fmaxf(v, 0.f);
+          ycol[(int64_t)m * T] = v;
+        }
+      }
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Fast path: the same tiling with the operand tiles moved HBM/L2 -> LDS by LDS-DMA
+// (global_load_lds): no staging registers, no ds_write pass, a dozen VMEM instructions per wave
+// and chunk.  Ablation on MI355X (profiles/r1/conv3_ablation.md) showed the register-staged
+// kernel losing ~15 % of the matrix pipe to the *instructions* of its staging pass (address
+// arithmetic + 15 loads + 15 ds_writes + masks per lane and chunk), not to memory latency.
+// Requires Cin % KC == 0, M % 4 == 0 and 16-B aligned weights; edge tiles need no masking in
+// flight: out-of-range rows / columns read clamped addresses and are never stored, and the only
+// valid column they could leak into (the last one, through its +1 tap) is already masked as a
+// sequence end.
+__device__ __forceinline__ void glds16(const float* g, float* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+__device__ __forceinline__ void glds4(const float* g, float* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 4, 0, 0);
+}
+
+template <int KCD>
+__global__ __launch_bounds__(THREADS, (KCD == 8 ? 4 : 2)) void conv3_mfma_dma_kernel(
+    const float* __restrict__ x, const float* __restrict__ Wp, const float* __restrict__ bias,
+    float* __restrict__ y, int Cin, int T, int M, int64_t ncols, int tiles_m, int tiles_n,
+    int relu) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int A_ST = 3 * KCD * BM;  // floats per A buffer
+  constexpr int B_ST = KCD * BNP;     // floats per B buffer
+  constexpr int RA = 3 * KCD / 4;     // A rows (tap, ci) per wave and chunk
+  constexpr int RB = KCD / 4;         // x rows per wave and chunk
+  float* As = reinterpret_cast<float*>(smem_raw);  // [2][3][KCD][BM]
+  float* Bs = As + 2 * A_ST;                        // [2][KCD][BNP]
+
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+  constexpr int GM = 8;
+  const int group_sz = GM * tiles_n;
+  const int group = wg / group_sz;
+  const int first_m = group * GM;
+  const int gm = min(GM, tiles_m - first_m);
+  const int in_group = wg - group * group_sz;
+  const int tile_m = first_m + in_group % gm;
+  const int tile_n = in_group / gm;
+  const int m0 = tile_m * BM;
+  const int64_t n0 = (int64_t)tile_n * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, kh = lane >> 5;
+
+  // ---- DMA source pointers (advance by one chunk per iteration)
+  // A: wave w fills LDS rows [RA*w, RA*w+RA) of the chunk's 3*KCD (tap, ci) rows, two rows
+  // (1 KiB) per instruction: lane -> row RA*w + 2i + (lane>>5), 4 consecutive m at (lane&31)*4.
+  const float* asrc[RA / 2];
+  {
+    const int am = (lane & 31) * 4;
+    const int amc = m0 + am < M ? m0 + am : 0;
+#pragma unroll
+    for (int i = 0; i < RA / 2; ++i) {
+      const int row = wave * RA + 2 * i + (lane >> 5);
+      asrc[i] = Wp + ((int64_t)(row / KCD) * Cin + (row % KCD)) * M + amc;
+    }
+  }
+  // B: wave w fills rows [RB*w, RB*w+RB); one instruction = 64 consecutive columns of one row.
+  const float* bsrc[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int64_t n = n0 + 64 * h + lane;
+    const int64_t nc = n < ncols ? n : ncols - 1;
+    const int64_t b = nc / T;
+    bsrc[h] = x + (b * Cin + wave * RB) * (int64_t)T + (nc - b * T);
+  }
+  // halo columns n0-1 and n0+BN: 2*KCD lanes, ordinary load + ds_write
+  const int hrow = tid % KCD;
+  const int hside = (tid / KCD) & 1;
+  const int hslot = hside ? BN + 1 : 0;
+  bool hvalid;
+  const float* hptr;
+  {
+    const int64_t n = hside ? n0 + BN : n0 - 1;
+    hvalid = tid < 2 * KCD && n >= 0 && n < ncols;
+    const int64_t nc = hvalid ? n : 0;
+    const int64_t b = nc / T;
+    hptr = x + (b * Cin + hrow) * (int64_t)T + (nc - b * T);
+  }
+  const int64_t a_step = (int64_t)KCD * M;
+  const int64_t b_step = (int64_t)KCD * T;
+
+  // One DMA instruction of the chunk's NDMA (= RA/2 weight pieces + 2*RB x pieces).  They are
+  // issued one at a time between MFMA groups: a VMEM instruction placed right after an MFMA
+  // issues while that MFMA occupies the matrix pipe, whereas a burst of them at the head of the
+  // chunk kept the wave off the pipe for ~7 % of the time (profiles/r1/conv3_ablation.md).
+  constexpr int NDMA = RA / 2 + 2 * RB;
+  auto stage_one = [&](int buf, auto d_tag) {
+    constexpr int d = decltype(d_tag)::value;
+#if defined(TSPN_ABLATE_NODMA)
+    return;
+#endif
+#if defined(TSPN_ABLATE_NODMA_A)
+    if (d < RA / 2) return;
+#endif
+#if defined(TSPN_ABLATE_NODMA_B)
+    if (d >= RA / 2) return;
+#endif
+    if constexpr (d < RA / 2) {
+      glds16(asrc[d], As + buf * A_ST + (wave * RA + 2 * d) * BM);
+#if !defined(TSPN_ABLATE_HOTDMA)
+      asrc[d] += a_step;
+#endif
+    } else if constexpr (d < NDMA) {
+      constexpr int r = (d - RA / 2) >> 1, h = (d - RA / 2) & 1;
+      glds4(bsrc[h] + (int64_t)r * T, Bs + buf * B_ST + (wave * RB + r) * BNP + 1 + 64 * h);
+      if constexpr (d == NDMA - 1) {
+#if !defined(TSPN_ABLATE_HOTDMA)
+        bsrc[0] += b_step;
+        bsrc[1] += b_step;
+#endif
+      }
+    }
+  };
+  auto stage_all = [&](int buf) {
+    stage_one(buf, std::integral_constant<int, 0>{});
+    stage_one(buf, std::integral_constant<int, 1>{});
+    stage_one(buf, std::integral_constant<int, 2>{});
+    stage_one(buf, std::integral_constant<int, 3>{});
+    stage_one(buf, std::integral_constant<int, 4>{});
+    stage_one(buf, std::integral_constant<int, 5>{});
+    stage_one(buf, std::integral_constant<int, 6>{});
+    stage_one(buf, std::integral_constant<int, 7>{});
+    stage_one(buf, std::integral_constant<int, 8>{});
+    stage_one(buf, std::integral_constant<int, 9>{});
+    stage_one(buf, std::integral_constant<int, 10>{});
+    stage_one(buf, std::integral_constant<int, 11>{});
+    stage_one(buf, std::integral_constant<int, 12>{});
+    stage_one(buf, std::integral_constant<int, 13>{});
+  };
+
+  bool mask_l[2], mask_r[2];
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int64_t n = n0 + wn * 64 + ni * 32 + li;
+    const int t = (int)(n % T);
+    mask_l[ni] = t != 0;
+    mask_r[ni] = t != T - 1;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  struct Frag {
+    float a[3][2];
+    float b[2][3];
+  };
+  auto read_frag = [&](const float* Ab, const float* Bb, int kk) {
+    Frag f;
+#if defined(TSPN_ABLATE_NOLDS)
+    for (int tap = 0; tap < 3; ++tap) { f.a[tap][0] = 1.f + kk; f.a[tap][1] = 2.f; }
+    for (int ni = 0; ni < 2; ++ni) for (int j = 0; j < 3; ++j) f.b[ni][j] = 0.5f * kh;
+    asm volatile("" : "+v"(f.a[0][0]), "+v"(f.b[0][0]));
+    return f;
+#endif
+    const int k = 2 * kk + kh;
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap) {
+      f.a[tap][0] = Ab[(tap * KCD + k) * BM];
+      f.a[tap][1] = Ab[(tap * KCD + k) * BM + 32];
+    }
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) f.b[ni][j] = Bb[k * BNP + ni * 32 + j];
+    return f;
+  };
+
+  const int nchunks = Cin / KCD;
+  stage_all(0);
+  float h_reg = *hptr;
+  hptr += b_step;
+  if (tid < 2 * KCD) Bs[hrow * BNP + hslot] = hvalid ? h_reg : 0.f;
+  __syncthreads();  // (hipcc drains the LDS-DMA with vmcnt(0) here)
+
+  constexpr int KSTEPS = KCD / 2;
+  // The chunk body is instantiated twice: with staging of the next chunk (all chunks but the
+  // last) and without (the last) — a run-time `if` around each DMA would put a branch between
+  // every MFMA group.
+  auto chunk_body = [&](int buf, auto more_tag) {
+    constexpr bool MORE = decltype(more_tag)::value;
+    if (MORE) {  // (buffer buf^1 has been free since the barrier that ended the previous chunk)
+      h_reg = *hptr;
+      hptr += b_step;
+    }
+    const float* Ab = As + buf * A_ST + wm * 64 + li;
+    const float* Bb = Bs + buf * B_ST + wn * 64 + li;
+    Frag cur = read_frag(Ab, Bb, 0);
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; ++kk) {
+      Frag nxt = cur;
+      if (kk + 1 < KSTEPS) nxt = read_frag(Ab, Bb, kk + 1);
+#if defined(TSPN_SCHED_PINNED)
+      // next k-step's LDS reads are issued before this step's 12 MFMAs (768 cycles of cover)
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+      for (int tap = 0; tap < 3; ++tap) {
+        float b0 = cur.b[0][tap], b1 = cur.b[1][tap];
+        if (tap == 0) {
+          b0 = mask_l[0] ? b0 : 0.f;
+          b1 = mask_l[1] ? b1 : 0.f;
+        } else if (tap == 2) {
+          b0 = mask_r[0] ? b0 : 0.f;
+          b1 = mask_r[1] ? b1 : 0.f;
+        }
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[tap][0], b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[tap][0], b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[tap][1], b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[tap][1], b1, acc[1][1], 0, 0, 0);
+        if (MORE) {
+#if defined(TSPN_SCHED_PINNED)
+          __builtin_amdgcn_sched_barrier(0);
+#endif
+          if (kk == 0 && tap == 0) stage_one(buf ^ 1, std::integral_constant<int, 0>{});
+          if (kk == 0 && tap == 1) stage_one(buf ^ 1, std::integral_constant<int, 1>{});
+          if (kk == 0 && tap == 2) stage_one(buf ^ 1, std::integral_constant<int, 2>{});
+          if (kk == 1 && tap == 0) stage_one(buf ^ 1, std::integral_constant<int, 3>{});
+          if (kk == 1 && tap == 1) stage_one(buf ^ 1, std::integral_constant<int, 4>{});
+          if (kk == 1 && tap == 2) stage_one(buf ^ 1, std::integral_constant<int, 5>{});
+          if (kk == 2 && tap == 0) stage_one(buf ^ 1, std::integral_constant<int, 6>{});
+          if (kk == 2 && tap == 1) stage_one(buf ^ 1, std::integral_constant<int, 7>{});
+          if (kk == 2 && tap == 2) stage_one(buf ^ 1, std::integral_constant<int, 8>{});
+          if (kk == 3 && tap == 0) stage_one(buf ^ 1, std::integral_constant<int, 9>{});
+          if (kk == 3 && tap == 1) stage_one(buf ^ 1, std::integral_constant<int, 10>{});
+          if (kk == 3 && tap == 2) stage_one(buf ^ 1, std::integral_constant<int, 11>{});
+          if (KSTEPS > 4 && kk == 4 && tap == 0) stage_one(buf ^ 1, std::integral_constant<int, 12>{});
+          if (KSTEPS > 4 && kk == 4 && tap == 1) stage_one(buf ^ 1, std::integral_constant<int, 13>{});
+        }
+      }
+#if !defined(TSPN_SCHED_PINNED)
+      // Issue pattern for the k-step (measured +2.5 % over issuing the reads as one burst ahead of
+      // the MFMAs): after each MFMA one LDS read of the NEXT k-step, one VALU (mask / address)
+      // and, every fourth group, one LDS-DMA piece issue in the shadow of that MFMA's 64 cycles.
+#define TSPN_G(NV, NVM)                                 \
+  __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);   \
+  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    \
+  __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    \
+  __builtin_amdgcn_sched_group_barrier(0x020, NVM, 0);
+      TSPN_G(4, 0) TSPN_G(1, 0) TSPN_G(1, 0) TSPN_G(1, 1)
+      TSPN_G(1, 0) TSPN_G(1, 0) TSPN_G(1, 0) TSPN_G(1, 1)
+      TSPN_G(1, 0) TSPN_G(1, 0) TSPN_G(1, 0) TSPN_G(1, 1)
+#undef TSPN_G
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      cur = nxt;
+    }
+    if (MORE && tid < 2 * KCD) Bs[(buf ^ 1) * B_ST + hrow * BNP + hslot] = hvalid ? h_reg : 0.f;
+#if !defined(TSPN_ABLATE_NOBARRIER)
+    __syncthreads();
+#endif
+  };
+  for (int c = 0; c + 1 < nchunks; ++c) chunk_body(c & 1, std::true_type{});
+  chunk_body((nchunks - 1) & 1, std::false_type{});
+
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
     const int64_t n = n0 + wn * 64 + ni * 32 + li;
@@ -274,18 +653,25 @@ extern "C" int tspn_conv3_f32(const float* x, int64_t B, int64_t Cin, int64_t T,
   const int64_t tiles_n = tspn::ceil_div(ncols, BN);
   TSPN_REQUIRE(tiles_m * tiles_n < (1LL << 31), TSPN_EUNSUPPORTED, "tspn_conv3_f32: grid too large");
   const bool vec = (M % 4 == 0) && ((reinterpret_cast<uintptr_t>(packed) & 15) == 0);
-  auto kern = vec ? conv3_mfma_kernel<true> : conv3_mfma_kernel<false>;
-  static thread_local bool attr_set[2] = {false, false};
-  if (!attr_set[vec]) {
+  const bool dma = vec && (Cin % 8 == 0) && getenv("TSPN_CONV3_NO_DMA") == nullptr;
+  const char* kc_env = getenv("TSPN_CONV3_KC");
+  const int kcd = (Cin % 16 != 0) ? 8 : (kc_env ? atoi(kc_env) : 16);
+  const bool dma8 = dma && kcd == 8;
+  auto kern = dma ? (dma8 ? conv3_mfma_dma_kernel<8> : conv3_mfma_dma_kernel<16>)
+                  : (vec ? conv3_mfma_kernel<true> : conv3_mfma_kernel<false>);
+  const int which = dma ? (dma8 ? 3 : 2) : (vec ? 1 : 0);
+  const size_t smem = dma8 ? sizeof(float) * 2 * (3 * 8 * BM + 8 * BNP) : SMEM_BYTES;
+  static thread_local bool attr_set[4] = {false, false, false, false};
+  if (!attr_set[which]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)SMEM_BYTES);
+                                       (int)smem);
     if (e != hipSuccess)
       return tspn::fail(TSPN_ELAUNCH, "tspn_conv3_f32: hipFuncSetAttribute: %s",
                         hipGetErrorString(e));
-    attr_set[vec] = true;
+    attr_set[which] = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n)), dim3(THREADS), SMEM_BYTES,
+  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n)), dim3(THREADS), smem,
                      TSPN_STREAM(stream), x, packed, bias, y, (int)Cin, (int)T, (int)M, ncols,
                      (int)tiles_m, (int)tiles_n, relu);
   return tspn::check_launch("tspn_conv3_f32");
