@@ -133,7 +133,7 @@ def main():
     def step(i):
         tspn.ops.forward_fused(feats, pairs, B, N, packed, conv_b, head_w, head_b, cls_w, cls_b,
                                workspace=ws, out_heads=out_heads, out_logits=out_logits,
-                               check_pairs=False, conv_events=events[i])
+                               check_pairs=False, conv_events=events[i], canonical_pairs=True)
         _, idx = tspn.ops.ppn_pair_matrix_topk(cls, ppn_w, 256)
         if world > 1:  # the one collective of the path: final result gather over RCCL
             tspn.dist.gather_results(out_logits.view(B, P_vid, K_PRED), world * B)

@@ -144,6 +144,15 @@ int tspn_heads_f32(int mode, const float* a, const float* b, int64_t lda,
                    const float* Wh, const float* bh, int64_t H,
                    int64_t P, int64_t C, int64_t T, float* out, void* stream);
 
+/* Blocked form of mode 1 for the CANONICAL pair table (all ordered pairs (s,o), s != o, s-major,
+ * per video; lib/modeling/predict.py:133-140): y[B*N, 2C, T] holds the tracklet projections
+ * (channels [0,C) subject part incl. bias, [C,2C) object part);
+ *   out[b*N*(N-1) + s*(N-1) + o - (o>s)][H][T] = bh + Wh @ relu(y[b*N+s, :C] + y[b*N+o, C:])
+ * 8x8 pair blocks share their 16 rows through LDS (6x less traffic than tspn_heads_f32).       */
+int tspn_heads_pairgrid_f32(const float* y, int64_t B, int64_t N, int64_t C, int64_t T,
+                            const float* Wh, const float* bh, int64_t H, float* out,
+                            void* stream);
+
 /* ---- a3: RelOIPool over time --------------------------------------------
  * mean over t of x[R, T, D] -> out[R, D]   (layout_tc = 1, tracklet layout)
  * mean over t of x[R, C, T] -> out[R, C]   (layout_tc = 0, channels-first)  */
@@ -168,6 +177,8 @@ typedef struct tspn_fused_desc {
   const float* feats;          /* [B*N, T, D] */
   const int64_t* pairs;        /* [P,2] global tracklet ids (video b: b*N + local) */
   int64_t P;
+  int64_t canonical_pairs;     /* != 0: `pairs` is the canonical table of tspn_pair_index_i64 for every
+                                  video in order (P == B*N*(N-1)): enables the blocked pair stage */
   const float* conv_packed;    /* tspn_pack_conv3_f32(conv.weight [C,C,3], split=D): [3][D][2C] */
   const float* conv_bias;      /* [C] */
   const float* head_w;         /* [3A, C]: rows [0,A) relness_pred, [A,3A) duration_pred */

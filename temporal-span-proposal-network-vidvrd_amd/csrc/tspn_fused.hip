@@ -99,9 +99,16 @@ extern "C" int tspn_forward_fused_f32(const tspn_fused_desc* d, void* stream) {
   if ((rc = tspn_conv3_f32(xt, NT, D, T, d->conv_packed, 2 * C, bias2, 0, y, stream))) return rc;
   if (d->ev_conv_end) (void)hipEventRecord(static_cast<hipEvent_t>(d->ev_conv_end), s);
   // 3. pair stage + relationness / span heads
-  if ((rc = tspn_heads_f32(1, y, y + C * T, 2 * C, d->pairs, d->pairs + 1, 2, nullptr, d->head_w,
-                           d->head_b, H, d->P, C, T, d->out_heads, stream)))
+  if (d->canonical_pairs) {
+    TSPN_REQUIRE(d->P == d->B * d->N * (d->N - 1), TSPN_EINVAL,
+                 "tspn_forward_fused: canonical_pairs needs P == B*N*(N-1) (P=%lld)", (long long)d->P);
+    if ((rc = tspn_heads_pairgrid_f32(y, d->B, d->N, C, T, d->head_w, d->head_b, H, d->out_heads,
+                                      stream)))
+      return rc;
+  } else if ((rc = tspn_heads_f32(1, y, y + C * T, 2 * C, d->pairs, d->pairs + 1, 2, nullptr,
+                                  d->head_w, d->head_b, H, d->P, C, T, d->out_heads, stream))) {
     return rc;
+  }
   // 4. RelOIPool over the segment on the pair feats (= cat of tracklet means) + predicate head
   if ((rc = tspn_temporal_mean_f32(d->feats, NT, T, D, 1, fbar, stream))) return rc;
   if ((rc = tspn_pair_rows_f32(fbar, NT, D, d->pairs, d->P, pooled, stream))) return rc;

@@ -142,6 +142,161 @@ __global__ __launch_bounds__(WAVES * 64) void heads_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Blocked pair stage for the canonical pair table (all ordered pairs (s,o), s != o, s-major, per
+// video — reference lib/modeling/predict.py:133-140).  A workgroup owns an 8-subject x 8-object
+// block of one video for 32 frames and walks the channels: the 16 tracklet-projection rows it
+// needs are staged through LDS once per 16-channel chunk and reused by all 64 pairs, so HBM /
+// Infinity-Cache traffic is ~6x lower than streaming two rows per pair (the v1 kernel above
+// measured 8.6 GB of fetch per 8 videos, 7x the unique bytes; profiles/r1).  Output slots are
+// computed (p = b*N*(N-1) + s*(N-1) + o - (o>s)), no index table is read.
+// Wave w handles subjects {2w, 2w+1} x 8 objects; lane = (k = lane>>4, column = lane&15); the
+// two 16-column MFMA blocks take the even / odd frames so LDS reads are conflict-free b64.
+constexpr int PG_S = 8, PG_O = 8, PG_CK = 16, PG_T = 32;
+constexpr int PG_ROWS = PG_S + PG_O;
+constexpr int PG_STAGE = PG_ROWS * PG_CK * PG_T;  // floats per LDS buffer (32 KB)
+
+template <bool VEC2>
+__global__ __launch_bounds__(256, 2) void heads_pairgrid_kernel(
+    const float* __restrict__ y, int C, int T, int N, const float* __restrict__ Wh,
+    const float* __restrict__ bh, int H, float* __restrict__ out, int ntb, int nob) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* S = reinterpret_cast<float*>(smem_raw);  // [2][16 rows][16 ch][32 t]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, kq = lane >> 4;
+  const int tb = blockIdx.x % ntb;
+  const int ob = (blockIdx.x / ntb) % nob;
+  const int sb = blockIdx.x / (ntb * nob);
+  const int64_t b = blockIdx.y;
+  const int t0 = tb * PG_T;
+  const int64_t rowlen = 2 * (int64_t)C * T;  // floats per tracklet row of y
+
+  // ---- staging: per chunk every thread moves 16 x 8 bytes: iteration `it` = tile row `it`
+  // (0..7 subject U rows, 8..15 object V rows), channel = tid>>4, frames t0 + 2*(tid&15) (+1).
+  const int st_ch = tid >> 4, st_t2 = tid & 15;
+  int lt = t0 + 2 * st_t2;                 // clamped load frame (tile columns past T are never stored)
+  if (VEC2) lt = min(lt, T - 2); else lt = min(lt, T - 1);
+  const int lt1 = VEC2 ? lt + 1 : min(t0 + 2 * st_t2 + 1, T - 1);
+  const float* src[PG_ROWS];
+#pragma unroll
+  for (int it = 0; it < PG_ROWS; ++it) {
+    const int local = it < PG_S ? sb * PG_S + it : ob * PG_O + (it - PG_S);
+    const int64_t trk = b * N + min(local, N - 1);
+    src[it] = y + trk * rowlen + (it < PG_S ? 0 : (int64_t)C * T);
+  }
+  float2 st[PG_ROWS];
+  float wreg[PG_CK / 4];
+  const int o_a = lane & 15;
+  auto load_chunk = [&](int c0) {
+    const int c = min(c0 + st_ch, C - 1);
+#pragma unroll
+    for (int it = 0; it < PG_ROWS; ++it) {
+      const float* p = src[it] + (int64_t)c * T;
+      if (VEC2) {
+        st[it] = *reinterpret_cast<const float2*>(p + lt);
+      } else {
+        st[it].x = p[lt];
+        st[it].y = p[lt1];
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < PG_CK / 4; ++ks) {
+      const int cw = c0 + ks * 4 + kq;
+      wreg[ks] = Wh[(int64_t)min(o_a, H - 1) * C + min(cw, C - 1)];
+    }
+  };
+  auto store_chunk = [&](int buf) {
+    float* dst = S + buf * PG_STAGE + st_ch * PG_T + 2 * st_t2;
+#pragma unroll
+    for (int it = 0; it < PG_ROWS; ++it)
+      *reinterpret_cast<float2*>(dst + it * PG_CK * PG_T) = st[it];
+  };
+
+  f32x4 acc[2][PG_O][2];
+#pragma unroll
+  for (int si = 0; si < 2; ++si)
+#pragma unroll
+    for (int oj = 0; oj < PG_O; ++oj)
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[si][oj][e][r] = 0.f;
+
+  const int nchunks = (C + PG_CK - 1) / PG_CK;
+  load_chunk(0);
+  store_chunk(0);
+  float wa[PG_CK / 4];
+#pragma unroll
+  for (int ks = 0; ks < PG_CK / 4; ++ks) wa[ks] = wreg[ks];
+  __syncthreads();
+
+  for (int c = 0; c < nchunks; ++c) {
+    const int buf = c & 1;
+    const int c0 = c * PG_CK;
+    if (c + 1 < nchunks) load_chunk(c0 + PG_CK);
+    const float* Sb = S + buf * PG_STAGE + 2 * j;
+#pragma unroll
+    for (int ks = 0; ks < PG_CK / 4; ++ks) {
+      const int ch = ks * 4 + kq;
+      // A operand: head weights; rows >= H and channels >= C contribute zero
+      const float w = (o_a < H && c0 + ch < C) ? wa[ks] : 0.f;
+      float2 u[2], v[PG_O];
+#pragma unroll
+      for (int si = 0; si < 2; ++si)
+        u[si] = *reinterpret_cast<const float2*>(Sb + ((2 * wave + si) * PG_CK + ch) * PG_T);
+#pragma unroll
+      for (int oj = 0; oj < PG_O; ++oj)
+        v[oj] = *reinterpret_cast<const float2*>(Sb + ((PG_S + oj) * PG_CK + ch) * PG_T);
+#pragma unroll
+      for (int si = 0; si < 2; ++si)
+#pragma unroll
+        for (int oj = 0; oj < PG_O; ++oj) {
+          const float h0 = fmaxf(u[si].x + v[oj].x, 0.f);
+          const float h1 = fmaxf(u[si].y + v[oj].y, 0.f);
+          acc[si][oj][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, h0, acc[si][oj][0], 0, 0, 0);
+          acc[si][oj][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, h1, acc[si][oj][1], 0, 0, 0);
+        }
+    }
+    if (c + 1 < nchunks) {
+      store_chunk(buf ^ 1);
+#pragma unroll
+      for (int ks = 0; ks < PG_CK / 4; ++ks) wa[ks] = wreg[ks];
+    }
+    __syncthreads();
+  }
+
+  // C/D layout of the 16x16 MFMA: column = lane&15 -> frames t0+2j (block 0) / t0+2j+1 (block 1),
+  // row = (lane>>4)*4 + reg -> head output
+  const int tA = t0 + 2 * j;
+#pragma unroll
+  for (int si = 0; si < 2; ++si) {
+    const int s = sb * PG_S + 2 * wave + si;
+#pragma unroll
+    for (int oj = 0; oj < PG_O; ++oj) {
+      const int o = ob * PG_O + oj;
+      if (s >= N || o >= N || s == o) continue;
+      const int64_t p = b * N * (int64_t)(N - 1) + (int64_t)s * (N - 1) + o - (o > s ? 1 : 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ho = kq * 4 + r;
+        if (ho >= H) continue;
+        const float bo = bh ? bh[ho] : 0.f;
+        float* dst = out + (p * H + ho) * (int64_t)T;
+        const float v0 = acc[si][oj][0][r] + bo, v1 = acc[si][oj][1][r] + bo;
+        if (VEC2) {
+          if (tA < T) *reinterpret_cast<float2*>(dst + tA) = make_float2(v0, v1);
+        } else {
+          if (tA < T) dst[tA] = v0;
+          if (tA + 1 < T) dst[tA + 1] = v1;
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int tspn_heads_f32(int mode, const float* a, const float* b, int64_t lda,
@@ -178,4 +333,39 @@ extern "C" int tspn_heads_f32(int mode, const float* a, const float* b, int64_t 
   }
 #undef TSPN_HEADS_LAUNCH
   return tspn::check_launch("tspn_heads_f32");
+}
+
+
+extern "C" int tspn_heads_pairgrid_f32(const float* y, int64_t B, int64_t N, int64_t C, int64_t T,
+                                       const float* Wh, const float* bh, int64_t H, float* out,
+                                       void* stream) {
+  TSPN_REQUIRE(B >= 0 && N >= 0 && C > 0 && T > 0, TSPN_EINVAL,
+               "tspn_heads_pairgrid_f32: bad sizes B=%lld N=%lld C=%lld T=%lld", (long long)B,
+               (long long)N, (long long)C, (long long)T);
+  TSPN_REQUIRE(H > 0 && H <= 16, TSPN_EUNSUPPORTED, "tspn_heads_pairgrid_f32: H=%lld not in [1,16]",
+               (long long)H);
+  TSPN_REQUIRE(C < (1 << 24) && T < (1 << 24) && N < (1 << 15), TSPN_EUNSUPPORTED,
+               "tspn_heads_pairgrid_f32: dim too large");
+  if (B == 0 || N < 2) return TSPN_OK;
+  TSPN_REQUIRE(y && Wh && out, TSPN_EINVAL, "tspn_heads_pairgrid_f32: null pointer");
+  TSPN_REQUIRE(B < 65536, TSPN_EUNSUPPORTED, "tspn_heads_pairgrid_f32: B too large");
+  const bool vec2 = (T % 2 == 0) && ((reinterpret_cast<uintptr_t>(y) & 7) == 0) &&
+                    ((reinterpret_cast<uintptr_t>(out) & 7) == 0);
+  const int ntb = (int)tspn::ceil_div(T, PG_T);
+  const int nsb = (int)tspn::ceil_div(N, PG_S), nob = (int)tspn::ceil_div(N, PG_O);
+  const size_t smem = sizeof(float) * 2 * PG_STAGE;
+  auto kern = vec2 ? heads_pairgrid_kernel<true> : heads_pairgrid_kernel<false>;
+  static thread_local bool attr_set[2] = {false, false};
+  if (!attr_set[vec2]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess)
+      return tspn::fail(TSPN_ELAUNCH, "tspn_heads_pairgrid_f32: hipFuncSetAttribute: %s",
+                        hipGetErrorString(e));
+    attr_set[vec2] = true;
+  }
+  dim3 grid((unsigned)(ntb * nob * nsb), (unsigned)B);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, TSPN_STREAM(stream), y, (int)C, (int)T, (int)N, Wh,
+                     bh, (int)H, out, ntb, nob);
+  return tspn::check_launch("tspn_heads_pairgrid_f32");
 }

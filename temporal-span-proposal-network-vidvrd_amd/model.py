@@ -410,8 +410,10 @@ class BaseModel(nn.Module):
             n, t, d = shape
             feats = torch.cat([_f32(pair_list[i].get_field("tracklet_feats"), dev) for i in members])
             pairs = []
+            canonical = True
             for k, i in enumerate(members):
                 p = custom_pairs(pair_list[i])
+                canonical = canonical and p is None
                 if p is None:
                     pairs.append(ops.pair_index(n, dev, base=k * n))
                 else:
@@ -423,7 +425,7 @@ class BaseModel(nn.Module):
             counts = [p.shape[0] for p in pairs]
             allp = torch.cat(pairs).contiguous()
             heads, lg = ops.forward_fused(feats, allp, len(members), n, packed, cbias, hw, hb, cw, cb,
-                                          check_pairs=False)
+                                          check_pairs=False, canonical_pairs=canonical)
             off = 0
             for k, i in enumerate(members):
                 src_dev = pair_list[i].get_field("tracklet_feats").device

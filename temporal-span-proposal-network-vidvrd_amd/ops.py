@@ -13,7 +13,7 @@ from . import _abi
 
 __all__ = [
     "predicate_head", "feature_preprocess_", "ppn_pair_matrix_topk", "traj_iou", "pair_index",
-    "pair_gather", "pack_conv3", "conv3", "heads", "temporal_mean", "pair_rows", "transpose_td",
+    "pair_gather", "pack_conv3", "conv3", "heads", "heads_pairgrid", "temporal_mean", "pair_rows", "transpose_td",
     "forward_fused", "temporal_encoder_heads", "fused_workspace_bytes",
 ]
 
@@ -217,6 +217,19 @@ def heads(a, head_w, head_b, b=None, ia=None, ib=None, bias=None, channels=None,
     return out
 
 
+def heads_pairgrid(y, B, N, head_w, head_b):
+    """Blocked pair stage on tracklet projections y[B*N, 2C, T] for the canonical pair table."""
+    _dev(y, "y"); _dev(head_w, "head_w")
+    NT, C2, T = y.shape
+    C, H = C2 // 2, head_w.shape[0]
+    if NT != B * N or head_w.shape[1] != C:
+        raise ValueError("heads_pairgrid: shape mismatch")
+    out = torch.empty((B * N * max(N - 1, 0), H, T), dtype=torch.float32, device=y.device)
+    _abi.check(_abi.lib().tspn_heads_pairgrid_f32(_p(y), B, N, C, T, _p(head_w), _p(head_b), H, _p(out),
+                                                  _stream()))
+    return out
+
+
 def temporal_mean(x, layout_tc):
     """Mean over frames: x[R,T,D] -> [R,D] (layout_tc=True) or x[R,C,T] -> [R,C]."""
     _dev(x, "x")
@@ -282,10 +295,12 @@ def fused_workspace_bytes(B, N, T, D, A, K, P):
 
 def forward_fused(feats, pairs, B, N, conv_packed, conv_bias, head_w, head_b, cls_w, cls_b,
                   workspace=None, out_heads=None, out_logits=None, check_pairs=True,
-                  conv_events=None):
+                  conv_events=None, canonical_pairs=False):
     """Whole scoring pass on tracklet tensors (tspn_forward_fused_f32).
 
     feats [B*N,T,D]; pairs int64 [P,2] global tracklet ids.
+    `canonical_pairs`: `pairs` is cat_b(pair_index(N, base=b*N)) — the caller built it with
+    pair_index — which lets the pair stage use the blocked kernel with computed output slots.
     `conv_events`: optional (begin, end) torch.cuda.Event pair (enable_timing=True, already
     recorded once so the handles exist) re-recorded around the dominant kernel.
     Returns (heads [P,3A,T], rel_logits [P,K]).
@@ -306,6 +321,9 @@ def forward_fused(feats, pairs, B, N, conv_packed, conv_bias, head_w, head_b, cl
         out_logits = torch.empty((P, d.K), dtype=torch.float32, device=feats.device)
     d.out_heads, d.out_logits = out_heads.data_ptr(), out_logits.data_ptr()
     d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
+    d.canonical_pairs = 1 if canonical_pairs else 0
+    if canonical_pairs and P != B * N * (N - 1):
+        raise ValueError("forward_fused: canonical_pairs needs P == B*N*(N-1)")
     if conv_events is not None:
         d.ev_conv_begin, d.ev_conv_end = conv_events[0].cuda_event, conv_events[1].cuda_event
     _abi.check(l.tspn_forward_fused_f32(ctypes.byref(d), _stream()))

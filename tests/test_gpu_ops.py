@@ -272,23 +272,44 @@ def make_w(tspn, seed, D, A=4, K=132, bias_std=0.05):
                 "cls_w": t(sd["classifier.rel_predictor.weight"]), "cls_b": t(sd["classifier.rel_predictor.bias"])}
 
 
-def run_fused(tspn, device, feats, pairs, B, N, w):
+def run_fused(tspn, device, feats, pairs, B, N, w, canonical=False):
     D = feats.shape[2]
     d = lambda v: v.to(device).contiguous()
     packed = tspn.ops.pack_conv3(d(w["conv_w"]), split=D)
     hw = d(torch.cat([w["rel_w"][:, :, 0], w["dur_w"][:, :, 0]]))
     hb = d(torch.cat([w["rel_b"], w["dur_b"]]))
     return tspn.ops.forward_fused(d(feats), d(pairs), B, N, packed, d(w["conv_b"]), hw, hb,
-                                  d(w["cls_w"]), d(w["cls_b"]))
+                                  d(w["cls_w"]), d(w["cls_b"]), canonical_pairs=canonical)
 
 
-@pytest.mark.parametrize("B,N,T,D", [(1, 2, 1, 2), (1, 8, 30, 32), (3, 5, 33, 18), (2, 6, 150, 64)])
-def test_forward_fused_vs_dense_oracle(tspn, device, B, N, T, D):
+@pytest.mark.parametrize("B,N,C,T,H", [(1, 2, 4, 2, 12), (2, 9, 20, 30, 12), (1, 17, 64, 33, 5), (3, 8, 48, 150, 16)])
+def test_heads_pairgrid_matches_generic(tspn, device, B, N, C, T, H):
+    """Blocked pair stage (canonical pair table) == generic indexed pair stage, and == fp64."""
+    y = tspn.hashrng.uniform(44, "y", (B * N, 2 * C, T), -1, 1)
+    wh = tspn.hashrng.normal(44, "wh", (H, C), std=0.1)
+    bh = tspn.hashrng.normal(44, "bh", (H,), std=0.1)
+    d = lambda v: t(v).to(device)
+    pairs = torch.cat([oracle.pair_index(N) + b * N for b in range(B)])
+    blocked = tspn.ops.heads_pairgrid(d(y), B, N, d(wh), d(bh)).cpu()
+    yd = d(y)
+    generic = tspn.ops.heads(yd[:, :C].contiguous(), d(wh), d(bh), b=yd[:, C:].contiguous(),
+                             ia=pairs[:, 0].contiguous().to(device), ib=pairs[:, 1].contiguous().to(device)).cpu()
+    assert blocked.shape == (B * N * (N - 1), H, T)
+    np.testing.assert_allclose(blocked.numpy(), generic.numpy(), rtol=0, atol=1e-5)
+    yy = t(y).double()
+    h = torch.relu(yy[pairs[:, 0], :C] + yy[pairs[:, 1], C:])
+    ref = torch.einsum("hc,pct->pht", t(wh).double(), h) + t(bh).double().view(1, -1, 1)
+    np.testing.assert_allclose(blocked.numpy(), ref.float().numpy(), rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("canonical", [False, True])
+@pytest.mark.parametrize("B,N,T,D", [(1, 2, 1, 2), (1, 8, 30, 32), (3, 5, 33, 18), (2, 6, 150, 64), (1, 11, 30, 16)])
+def test_forward_fused_vs_dense_oracle(tspn, device, B, N, T, D, canonical):
     _, w = make_w(tspn, 0, D)
     vids = [tspn.synth.make_video(50 + b, N, T, D) for b in range(B)]
     feats = torch.cat([t(v["tracklet_feats"]) for v in vids])
     pairs = torch.cat([oracle.pair_index(N) + b * N for b in range(B)])
-    heads, logits = run_fused(tspn, device, feats, pairs, B, N, w)
+    heads, logits = run_fused(tspn, device, feats, pairs, B, N, w, canonical)
     A = 4
     for b in range(B):
         ref = oracle.forward_dense(t(vids[b]["tracklet_feats"]), t(vids[b]["tracklet_boxes"]),
@@ -324,7 +345,7 @@ def test_forward_fused_full_size_sampled(tspn, device):
     v = tspn.synth.make_video(1, N, T, D)
     feats = t(v["tracklet_feats"])
     pairs = oracle.pair_index(N)
-    heads, logits = run_fused(tspn, device, feats, pairs, B, N, w)
+    heads, logits = run_fused(tspn, device, feats, pairs, B, N, w, canonical=True)
     assert heads.shape == (992, 12, 150) and logits.shape == (992, 132)
     assert bool(torch.isfinite(heads).all()) and bool(torch.isfinite(logits).all())
     sample = torch.tensor([0, 31, 500, 991])
@@ -337,8 +358,11 @@ def test_forward_fused_full_size_sampled(tspn, device):
     # size-independent property: doubling the head weights and zeroing their bias doubles the output
     w2 = dict(w)
     w2["rel_w"], w2["dur_w"] = 2 * w["rel_w"], 2 * w["dur_w"]
-    heads2, _ = run_fused(tspn, device, feats, pairs, B, N, w2)
+    heads2, _ = run_fused(tspn, device, feats, pairs, B, N, w2, canonical=True)
     np.testing.assert_allclose(heads2.cpu().numpy(), 2 * heads.cpu().numpy(), rtol=0, atol=1e-6)
+    # the generic (indexed) pair stage agrees with the blocked one at full size
+    heads3, _ = run_fused(tspn, device, feats, pairs, B, N, w, canonical=False)
+    np.testing.assert_allclose(heads3.cpu().numpy(), heads.cpu().numpy(), rtol=0, atol=2e-5)
 
 
 def test_fused_descriptor_errors(tspn, device):
