@@ -167,6 +167,26 @@ int tspn_pair_rows_f32(const float* src, int64_t NT, int64_t D, const int64_t* p
 int tspn_transpose_td_f32(const float* x, int64_t R, int64_t T, int64_t D, float* out,
                           void* stream);
 
+/* ---- f1: top-k triplet decode -------------------------------------------
+ * Replaces the per-segment decode of lib/modeling/predict.py:66-106 for S segments of P pairs:
+ * per pair the topk_pair best of the K predicate scores, per segment the topk_seg best of those
+ * (both "larger first, lower index first on ties"), then for winner r of segment s:
+ *   out_score[s,r]        the score
+ *   out_pair_tid[s,r,:]   = pairs[s, pair(r), :]                    (local tracklet ids)
+ *   out_triplet[s,r,:]    = (argmax cls_sub[row(tid_s)], predicate id, argmax cls_obj[row(tid_o)])
+ * with row(tid) = s*seg_rows + row_mul*tid in a matrix of row stride `ld`, NO class columns.
+ * predict.py:88-89 reads row (N-1)*tid of the pair-feature matrix (columns 0:35 / 35:70): pass
+ * cls_sub = feats, cls_obj = feats + 35, ld = F, seg_rows = P, row_mul = N-1 to reproduce it, or
+ * the per-tracklet class logits with seg_rows = N, row_mul = 1.
+ * M = min(topk_seg, P*min(topk_pair,K)) <= 1024 rows are written per segment; K <= 256.          */
+size_t tspn_decode_topk_workspace_bytes(int64_t S, int64_t P, int64_t topk_pair);
+int tspn_decode_topk_f32(const float* rel_logit, const int64_t* pairs,
+                         const float* cls_sub, const float* cls_obj, int64_t ld,
+                         int64_t seg_rows, int64_t row_mul, int64_t S, int64_t P, int64_t K,
+                         int64_t NO, int64_t topk_pair, int64_t topk_seg,
+                         float* out_score, int64_t* out_triplet, int64_t* out_pair_tid,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- whole relation-scoring pass on tracklet tensors --------------------
  * The fused/factorised product path for `B` videos of N
  * tracklets each: pair builder + temporal encoder + relationness/span heads

@@ -67,6 +67,9 @@ PROTOTYPES = {
     "tspn_temporal_mean_f32": (_int, [_vp, _i64, _i64, _i64, _int, _vp, _vp]),
     "tspn_pair_rows_f32": (_int, [_vp, _i64, _i64, _vp, _i64, _vp, _vp]),
     "tspn_transpose_td_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
+    "tspn_decode_topk_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "tspn_decode_topk_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
+                                    _vp, _vp, _vp, _vp, _sz, _vp]),
     "tspn_forward_fused_workspace_bytes": (_sz, [ctypes.POINTER(FusedDesc)]),
     "tspn_forward_fused_f32": (_int, [ctypes.POINTER(FusedDesc), _vp]),
     "tspn_temporal_encoder_heads_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64,

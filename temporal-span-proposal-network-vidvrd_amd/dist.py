@@ -25,17 +25,18 @@ def shard_counts(num_items, world_size):
             for r in range(world_size)]
 
 
-def gather_results(local, num_items, group=None):
+def gather_results(local, num_items, group=None, force=False):
     """All-gather per-video result rows back into global video order.
 
     `local` [n_local, ...]: this rank's results for its `shard_range` block.
     Returns [num_items, ...] on every rank.  Ragged shards use the pad-to-max
     scheme (one collective), cf. the unused reference helper lib/utils/comm.py:60-81.
+    `force` issues the collective even for a single rank (used to exercise the RCCL path).
     """
     if not dist.is_available() or not dist.is_initialized():
         return local
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not force:
         return local
     counts = shard_counts(num_items, world)
     rank = dist.get_rank(group)

@@ -435,6 +435,54 @@ class BaseModel(nn.Module):
                 off += counts[k]
         return pair_proposals, durations, logits
 
+    def decode(self, pair_list, rel_logits, topk_per_pair=20, topk_per_seg=200, num_obj=35):
+        """Top-k triplet decode of `forward`'s rel_logits on the GPU (replaces the Python of
+        reference lib/modeling/predict.py:59-117).  Per segment returns
+        (scores [M], triplets int64 [M,3] = (subject class, predicate, object class), pair_tids [M,2]).
+
+        Baseline segments (2-D `features` [P,F>=70]) reproduce predict.py:88-89 as is: class =
+        argmax of feature row (N-1)*tid, columns 0:35 / 35:70.  Tracklet segments use
+        'track_cls_logits' [N,35] directly.  Segments with < 2 tracklets yield empty results
+        (predict.py:61-64 skips them)."""
+        out = [None] * len(pair_list)
+        groups = {}
+        for i, (plist, lg) in enumerate(zip(pair_list, rel_logits)):
+            n = int(plist.get_field("num_tracklets")) if plist.has_field("num_tracklets") else None
+            quirk = plist.features.dim() == 2 and plist.features.shape[1] >= 2 * num_obj
+            if n is None:
+                n = int(plist.get_field("track_cls_logits").shape[0])
+            if n <= 1 or lg.shape[0] == 0:
+                dev = lg.device
+                out[i] = (torch.empty(0, device=dev), torch.empty((0, 3), dtype=torch.int64, device=dev),
+                          torch.empty((0, 2), dtype=torch.int64, device=dev))
+                continue
+            groups.setdefault((n, tuple(lg.shape), quirk, tuple(plist.features.shape) if quirk else None), []).append(i)
+        for (n, _, quirk, _), members in groups.items():
+            dev = _compute_device(*[rel_logits[i] for i in members])
+            lg = torch.stack([_f32(rel_logits[i], dev) for i in members])
+            pairs = []
+            for i in members:
+                plist = pair_list[i]
+                if plist.has_field("tracklet_pairs") and plist.get_field("tracklet_pairs") is not None:
+                    p = plist.get_field("tracklet_pairs")
+                    p = p.detach().long() if isinstance(p, torch.Tensor) else torch.as_tensor(np.asarray(p)).long()
+                    pairs.append(p.to(dev))
+                else:
+                    pairs.append(ops.pair_index(n, dev))
+            pairs = torch.stack(pairs).contiguous()
+            if quirk:
+                cls = torch.stack([_f32(pair_list[i].features, dev) for i in members])
+                res = ops.decode_topk(lg, pairs, cls, row_mul=n - 1, num_obj=num_obj,
+                                      topk_per_pair=topk_per_pair, topk_per_seg=topk_per_seg)
+            else:
+                cls = torch.stack([_f32(pair_list[i].get_field("track_cls_logits"), dev) for i in members])
+                res = ops.decode_topk(lg, pairs, cls, row_mul=1, num_obj=num_obj,
+                                      topk_per_pair=topk_per_pair, topk_per_seg=topk_per_seg)
+            for k, i in enumerate(members):
+                tgt = rel_logits[i].device
+                out[i] = tuple(r[k].to(tgt) for r in res)
+        return out
+
     def pair_geometry(self, pair_list):
         """Relative box geometry [P,8,T] per segment from 'tracklet_boxes' (pair builder side output)."""
         out = []

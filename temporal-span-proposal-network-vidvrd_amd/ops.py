@@ -14,7 +14,7 @@ from . import _abi
 __all__ = [
     "predicate_head", "feature_preprocess_", "ppn_pair_matrix_topk", "traj_iou", "pair_index",
     "pair_gather", "pack_conv3", "conv3", "heads", "heads_pairgrid", "temporal_mean", "pair_rows", "transpose_td",
-    "forward_fused", "temporal_encoder_heads", "fused_workspace_bytes",
+    "forward_fused", "temporal_encoder_heads", "fused_workspace_bytes", "decode_topk",
 ]
 
 
@@ -259,6 +259,53 @@ def transpose_td(x):
     out = torch.empty((R, D, T), dtype=torch.float32, device=x.device)
     _abi.check(_abi.lib().tspn_transpose_td_f32(_p(x), R, T, D, _p(out), _stream()))
     return out
+
+
+def decode_topk(rel_logit, pairs, cls_sub, cls_obj=None, row_mul=1, num_obj=35,
+                topk_per_pair=20, topk_per_seg=200):
+    """Top-k triplet decode (lib/modeling/predict.py:66-106) for a batch of equal-shape segments.
+
+    rel_logit [S,P,K] (or [P,K]); pairs int64 [S,P,2] local tracklet ids; class logits:
+      * reference quirk: cls_sub = feature matrix [S,P,F] with F >= 70 (columns 0:35 subject,
+        35:70 object classeme), row_mul = N-1  (predict.py:88-89 reads row (N-1)*tid);
+      * per-tracklet:    cls_sub = track_cls_logits [S,N,35], row_mul = 1.
+    Returns (scores [S,M], triplets int64 [S,M,3], pair_tids int64 [S,M,2]).
+    """
+    squeeze = rel_logit.dim() == 2
+    if squeeze:
+        rel_logit, pairs, cls_sub = rel_logit.unsqueeze(0), pairs.unsqueeze(0), cls_sub.unsqueeze(0)
+        cls_obj = cls_obj.unsqueeze(0) if cls_obj is not None else None
+    _dev(rel_logit, "rel_logit"); _dev(pairs, "pairs", torch.int64); _dev(cls_sub, "cls_sub")
+    S, P, K = rel_logit.shape
+    if tuple(pairs.shape) != (S, P, 2):
+        raise ValueError("decode_topk: pairs must be [S,P,2]")
+    if cls_sub.dim() != 3 or cls_sub.shape[0] != S:
+        raise ValueError("decode_topk: class logits must be [S,rows,cols]")
+    seg_rows, ld = cls_sub.shape[1], cls_sub.shape[2]
+    if cls_obj is None:
+        if ld >= 2 * num_obj:      # feature matrix: object classeme in columns [NO, 2NO)
+            obj_ptr = cls_sub.data_ptr() + 4 * num_obj
+        else:                      # per-tracklet logits: same table for both roles
+            obj_ptr = cls_sub.data_ptr()
+    else:
+        _dev(cls_obj, "cls_obj")
+        if cls_obj.shape != cls_sub.shape:
+            raise ValueError("decode_topk: cls_obj shape mismatch")
+        obj_ptr = cls_obj.data_ptr()
+    if P and (int(pairs.min()) < 0 or int(pairs.max()) * row_mul >= seg_rows):
+        raise IndexError("decode_topk: row_mul * tracklet id exceeds the class-logit rows")
+    R = min(topk_per_pair, K)
+    M = min(topk_per_seg, P * R)
+    dev = rel_logit.device
+    scores = torch.empty((S, M), dtype=torch.float32, device=dev)
+    trip = torch.empty((S, M, 3), dtype=torch.int64, device=dev)
+    tids = torch.empty((S, M, 2), dtype=torch.int64, device=dev)
+    l = _abi.lib()
+    ws = _ws(l.tspn_decode_topk_workspace_bytes(S, P, R), dev)
+    _abi.check(l.tspn_decode_topk_f32(_p(rel_logit), _p(pairs), _p(cls_sub), ctypes.c_void_p(obj_ptr), ld,
+                                      seg_rows, row_mul, S, P, K, num_obj, topk_per_pair, topk_per_seg,
+                                      _p(scores), _p(trip), _p(tids), _p(ws), ws.numel(), _stream()))
+    return (scores[0], trip[0], tids[0]) if squeeze else (scores, trip, tids)
 
 
 def _fused_desc(feats, pairs, B, N, conv_packed, conv_bias, head_w, head_b, cls_w, cls_b):

@@ -175,3 +175,41 @@ def test_reference_checkpoint_without_relness_loads(tspn, device):
     sd = {("module." + k): v for k, v in model.state_dict().items() if "relness_pred" not in k}
     stripped = {k[len("module."):]: v for k, v in sd.items()}  # lib/utils/serialize.py:13-16
     model.load_state_dict(stripped)  # strict
+
+
+def test_decode_like_predict_py(tspn, device):
+    """predict.py:57-117: forward, then top-20 / top-200 decode — baseline (feature-row quirk) and
+    tracklet segments, batch of two."""
+    g = cases.load("g6_decode.npz")
+    c = cases.g6_inputs()
+    model = tspn.BaseModel(cases.baseline_cfg())
+    feats = torch.zeros(c["rel_logit"].shape[0], 11070)
+    feats[:, :70] = t(c["feat70"])
+    plist = tspn.PairList(feats)
+    plist.add_field("tracklet_pairs", c["pairs"])
+    plist.add_field("num_tracklets", np.int64(c["n"]))
+    single = tspn.PairList(torch.zeros(0, 11070))
+    single.add_field("num_tracklets", np.int64(1))
+    res = model.decode([plist, single, plist], [t(c["rel_logit"]), torch.zeros(0, 132), t(c["rel_logit"])])
+    for k in (0, 2):
+        sc, trip, tids = res[k]
+        assert sc.device.type == "cpu"
+        np.testing.assert_array_equal(sc.numpy(), g["scores"])
+        np.testing.assert_array_equal(trip.numpy(), g["triplets"])
+        np.testing.assert_array_equal(tids.numpy(), g["pair_tids"])
+    assert res[1][0].shape == (0,) and res[1][1].shape == (0, 3)
+    # tracklet segment: class labels come from track_cls_logits
+    D = 8
+    m2 = tspn.BaseModel(temporal_cfg(D, use_ppn=False)).eval()
+    v = tspn.synth.make_video(90, 5, 12, D)
+    pl = tspn.PairList.from_tracklets(t(v["tracklet_feats"]), t(v["tracklet_boxes"]), t(v["track_cls_logits"]))
+    _, _, logits = m2([pl], None)
+    sc, trip, tids = m2.decode([pl], logits)[0]
+    rs, rt, ri = oracle.decode_topk(logits[0], torch.cat([t(v["track_cls_logits"])] * 2, 1)[
+        oracle.pair_index(5)[:, 0] * 0 + torch.arange(20) // 4], oracle.pair_index(5), 5)
+    np.testing.assert_array_equal(sc.numpy(), rs.numpy())
+    np.testing.assert_array_equal(tids.numpy(), ri.numpy())
+    lab = v["track_cls_logits"].argmax(-1)
+    np.testing.assert_array_equal(trip[:, 0].numpy(), lab[tids[:, 0].numpy()])
+    np.testing.assert_array_equal(trip[:, 2].numpy(), lab[tids[:, 1].numpy()])
+    np.testing.assert_array_equal(trip[:, 1].numpy(), rt[:, 1].numpy())

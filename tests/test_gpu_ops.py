@@ -378,3 +378,43 @@ def test_fused_descriptor_errors(tspn, device):
                                d(w["cls_w"]), d(w["cls_b"]))
     with pytest.raises(ValueError):
         run_fused(tspn, device, feats, pairs, 2, 4, w)  # B*N mismatch
+
+
+# ----------------------------------------------------------------- f1: top-k triplet decode
+def test_decode_topk_golden(tspn, device):
+    """Golden G6 = the reference's predict.py:66-106 restated line by line (tie-free input)."""
+    g = cases.load("g6_decode.npz")
+    c = cases.g6_inputs()
+    sc, trip, tids = tspn.ops.decode_topk(t(c["rel_logit"]).to(device), t(c["pairs"]).to(device),
+                                          t(c["feat70"]).to(device), row_mul=c["n"] - 1)
+    np.testing.assert_array_equal(sc.cpu().numpy(), g["scores"])
+    np.testing.assert_array_equal(trip.cpu().numpy(), g["triplets"])
+    np.testing.assert_array_equal(tids.cpu().numpy(), g["pair_tids"])
+
+
+@pytest.mark.parametrize("S,N,K,kp,ks", [(1, 2, 5, 20, 200), (3, 8, 132, 20, 200), (2, 32, 132, 20, 200),
+                                         (1, 12, 70, 7, 33), (1, 40, 132, 20, 1024)])
+def test_decode_topk_vs_oracle_with_ties(tspn, device, S, N, K, kp, ks):
+    """Quantised scores produce many exact ties at both levels: indices must still be bit-exact
+    (lower index first), incl. saturated sigmoids (1.0)."""
+    P = N * (N - 1)
+    logit = np.round(tspn.hashrng.uniform(61, "dec", (S, P, K)) * 16) / 16
+    logit[:, :, 3] = 1.0
+    feat = tspn.hashrng.uniform(61, "feat", (S, P, 75))
+    feat[:, :, 2] = feat[:, :, 9]  # ties in the class argmax too
+    pairs = np.stack([cases.ref_pairs(N)] * S)
+    sc, trip, tids = tspn.ops.decode_topk(t(logit).to(device), t(pairs).to(device), t(feat).to(device),
+                                          row_mul=N - 1, topk_per_pair=kp, topk_per_seg=ks)
+    for s in range(S):
+        rs, rt, ri = oracle.decode_topk(t(logit[s]), t(feat[s, :, :70]), t(pairs[s]), N, kp, ks)
+        np.testing.assert_array_equal(sc[s].cpu().numpy(), rs.numpy())
+        np.testing.assert_array_equal(trip[s].cpu().numpy(), rt.numpy())
+        np.testing.assert_array_equal(tids[s].cpu().numpy(), ri.numpy())
+    # per-tracklet class logits (row_mul = 1)
+    cls = tspn.hashrng.uniform(62, "cls", (S, N, 35))
+    _, trip2, tids2 = tspn.ops.decode_topk(t(logit).to(device), t(pairs).to(device), t(cls).to(device),
+                                           topk_per_pair=kp, topk_per_seg=ks)
+    lab = cls.argmax(-1)
+    for s in range(S):
+        np.testing.assert_array_equal(trip2[s, :, 0].cpu().numpy(), lab[s][tids2[s, :, 0].cpu().numpy()])
+        np.testing.assert_array_equal(trip2[s, :, 2].cpu().numpy(), lab[s][tids2[s, :, 1].cpu().numpy()])
