@@ -71,15 +71,33 @@ def cpu_baseline(weights, target_s):
         return time.perf_counter() - t0
 
     run(2)  # warm-up (thread pool, oneDNN primitive cache)
-    probe = 8
-    run(probe)
-    dt = run(probe)
-    p = int(max(probe, min(N_TRK * (N_TRK - 1), probe * target_s / max(dt, 1e-3))))
-    dt = run(p)
+    p_max = N_TRK * (N_TRK - 1)
+    p, dt = 8, run(8)
+    for _ in range(2):  # two-step calibration towards ~target_s of CPU work (cost is not linear in p)
+        if dt >= 0.6 * target_s or p >= p_max:
+            break
+        p = int(max(p + 1, min(p_max, p * target_s / max(dt, 1e-3))))
+        dt = run(p)
     return {"value": p / dt, "unit": "tracklet-pairs/s", "cores": torch.get_num_threads(),
             "kind": "port",
             "sample": f"{p} of 992 pairs of one cfg2 video, dense reference formulation "
                       f"(oracle.forward_dense), {dt:.1f} s, torch {torch.__version__} CPU"}
+
+
+def pmc_traffic(videos):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/pmc_traffic.json, produced by tools/pmc_summary.py); null if not measured for this
+    batch size.  PMC counters cannot be read from inside the process."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        data = json.load(open(path))
+        k = data["kernels"]["conv3_mfma_cl_kernel"]
+        if data["videos_per_launch"] == videos:
+            return {"traffic": k["hbm_bytes"], "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE)",
+                    "traffic_source": data["source"]}
+    except (OSError, KeyError, ValueError):
+        pass
+    return {"traffic": None}
 
 
 def main():
@@ -185,9 +203,10 @@ def main():
                                + (" + RCCL all-gather of logits/top-k" if use_dist else ""),
                        "dense_equivalent_gflop_per_pair": (2.0 * T * C * (3 * C + 3 * A_ANCH) + 2.0 * C * K_PRED) / 1e9,
                        "executed_gflop_per_pair": (conv_flop + 2.0 * P * T * C * 16 + 2.0 * P * C * K_PRED) / P / 1e9},
-            "roofline": {"bound": "mfma", "kernel": "conv3_mfma_kernel (fp32 32x32x2 MFMA implicit GEMM)",
+            "roofline": {"bound": "mfma", "kernel": "conv3_mfma_cl_kernel (tracklet projections: k=3 conv as "
+                                                    "fp32 32x32x2 MFMA implicit GEMM, M=2C, K=3D)",
                          "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, **pmc_traffic(B),
                          "flop_per_launch": conv_flop, "avg_launch_ms": conv_avg_s * 1e3,
                          "share_of_step": conv_avg_s / (elapsed / args.steps)},
         }

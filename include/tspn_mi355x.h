@@ -128,6 +128,13 @@ int tspn_conv3_f32(const float* x, int64_t B, int64_t Cin, int64_t T,
                    const float* packed, int64_t M, const float* bias, int relu,
                    float* y, void* stream);
 
+/* Same operator on channels-LAST input x[B, T, Cin] (the tracklet layout [N,T,D] itself), output
+ * still y[B, M, T].  Fast path only: needs Cin % 16 == 0, M % 4 == 0, 16-byte aligned x / packed
+ * (otherwise TSPN_EUNSUPPORTED: transpose with tspn_transpose_td_f32 and call tspn_conv3_f32).   */
+int tspn_conv3_tc_f32(const float* x, int64_t B, int64_t T, int64_t Cin,
+                      const float* packed, int64_t M, const float* bias, int relu,
+                      float* y, void* stream);
+
 /* ---- a8/a10: relationness + span-regression heads -----------------------
  * Replaces duration_pred (lib/modeling/relpn/dpn.py:71) and relness_pred
  * (lib/modeling/relpn/dpn_anchor.py:105) as ONE [H, C] 1x1 GEMM:

@@ -61,6 +61,7 @@ PROTOTYPES = {
     "tspn_pair_gather_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp]),
     "tspn_pack_conv3_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "tspn_conv3_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _int, _vp, _vp]),
+    "tspn_conv3_tc_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _int, _vp, _vp]),
     "tspn_heads_f32": (_int, [_int, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64,
                               _i64, _vp, _vp]),
     "tspn_heads_pairgrid_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp]),

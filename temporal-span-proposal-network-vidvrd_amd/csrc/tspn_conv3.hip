@@ -620,6 +620,224 @@ __global__ __launch_bounds__(THREADS, (KCD == 8 ? 4 : 2)) void conv3_mfma_dma_ke
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Channels-last variant: x is [B, T, Cin] — the tracklet layout itself — so the fused path needs
+// no transpose pass, a column's channels are contiguous (16-B aligned DMA pieces: 9 per chunk and
+// workgroup for the x tile instead of 32 four-byte ones), the halo columns are ordinary units of
+// the same DMA, and flat column n is simply row n of x.  LDS image of the x tile:
+// [4 channel groups][132 column slots][4 channels]; a lane reads the two channels it needs for two
+// consecutive MFMA k-steps with one ds_read_b64 (lanes k=0: channels 4g,4g+1; k=1: 4g+2,4g+3 — the
+// weight fragment uses the same channel pairing, any pairing is a valid K order).
+constexpr int CL_KC = 16;
+constexpr int CL_NG = CL_KC / 4;
+constexpr int CL_SLP = 132;                        // padded column slots per channel group (130 used)
+constexpr int CL_A_ST = 3 * CL_KC * BM;            // floats
+constexpr int CL_B_ST = CL_NG * CL_SLP * 4;        // floats
+constexpr int CL_UNITS = CL_NG * CL_SLP;           // 16-B units per x tile (incl. padding)
+constexpr int CL_BPIECES = (CL_UNITS + 63) / 64;   // 9
+constexpr size_t CL_SMEM_BYTES = sizeof(float) * 2 * (CL_A_ST + CL_B_ST);
+
+__global__ __launch_bounds__(THREADS, 2) void conv3_mfma_cl_kernel(
+    const float* __restrict__ x, const float* __restrict__ Wp, const float* __restrict__ bias,
+    float* __restrict__ y, int Cin, int T, int M, int64_t ncols, int tiles_m, int tiles_n,
+    int relu) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* As = reinterpret_cast<float*>(smem_raw);  // [2][3][16][BM]
+  float* Bs = As + 2 * CL_A_ST;                     // [2][4][132][4]
+
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  constexpr int GM = 8;
+  const int group_sz = GM * tiles_n;
+  const int group = wg / group_sz;
+  const int first_m = group * GM;
+  const int gm = min(GM, tiles_m - first_m);
+  const int in_group = wg - group * group_sz;
+  const int tile_m = first_m + in_group % gm;
+  const int tile_n = in_group / gm;
+  const int m0 = tile_m * BM;
+  const int64_t n0 = (int64_t)tile_n * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, kh = lane >> 5;
+
+  // ---- DMA sources.  A: as in the channels-first kernel (6 pieces of 2 rows x 128 m per wave).
+  const float* asrc[6];
+  {
+    const int am = (lane & 31) * 4;
+    const int amc = m0 + am < M ? m0 + am : 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int row = wave * 12 + 2 * i + (lane >> 5);
+      asrc[i] = Wp + ((int64_t)(row >> 4) * Cin + (row & 15)) * M + amc;
+    }
+  }
+  // x: piece p = wave + 4q covers units [64p, 64p+64); unit u = (group g = u/132, slot = u%132),
+  // slot <-> column n0 + slot - 1 (clamped; clamped columns are never stored).
+  const float* bsrc[3];
+  bool bval[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int u = 64 * (wave + 4 * q) + lane;
+    const int g = u / CL_SLP, slot = u - g * CL_SLP;
+    bval[q] = u < CL_UNITS && slot < BN + 2;
+    int64_t n = n0 + slot - 1;
+    n = n < 0 ? 0 : (n < ncols ? n : ncols - 1);
+    bsrc[q] = x + n * Cin + 4 * (g < CL_NG ? g : 0);
+  }
+  const int64_t a_step = (int64_t)CL_KC * M;
+
+  constexpr int NDMA = 6 + 3;
+  auto stage_one = [&](int buf, auto d_tag) {
+    constexpr int d = decltype(d_tag)::value;
+    if constexpr (d < 6) {
+      glds16(asrc[d], As + buf * CL_A_ST + (wave * 12 + 2 * d) * BM);
+      asrc[d] += a_step;
+    } else if constexpr (d < NDMA) {
+      constexpr int q = d - 6;
+      if (bval[q]) glds16(bsrc[q], Bs + buf * CL_B_ST + 64 * (wave + 4 * q) * 4);
+      bsrc[q] += CL_KC;
+    }
+  };
+
+  bool mask_l[2], mask_r[2];
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int64_t n = n0 + wn * 64 + ni * 32 + li;
+    const int t = (int)(n % T);
+    mask_l[ni] = t != 0;
+    mask_r[ni] = t != T - 1;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  // fragments of one channel group (4 channels = 2 MFMA k-steps x 3 taps = 24 MFMAs)
+  struct Frag {
+    float a[3][2][2];  // [tap][mi][row of the lane's channel pair]
+    float2 b[2][3];    // [ni][tap]
+  };
+  auto read_frag = [&](const float* Ab, const float* Bb, int g) {
+    Frag f;
+    const int r0 = 4 * g + 2 * kh;
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        f.a[tap][mi][0] = Ab[(tap * CL_KC + r0) * BM + mi * 32];
+        f.a[tap][mi][1] = Ab[(tap * CL_KC + r0 + 1) * BM + mi * 32];
+      }
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int tap = 0; tap < 3; ++tap)
+        f.b[ni][tap] = *reinterpret_cast<const float2*>(Bb + (g * CL_SLP + ni * 32 + tap) * 4);
+    return f;
+  };
+
+  const int nchunks = Cin / CL_KC;
+  stage_one(0, std::integral_constant<int, 0>{});
+  stage_one(0, std::integral_constant<int, 1>{});
+  stage_one(0, std::integral_constant<int, 2>{});
+  stage_one(0, std::integral_constant<int, 3>{});
+  stage_one(0, std::integral_constant<int, 4>{});
+  stage_one(0, std::integral_constant<int, 5>{});
+  stage_one(0, std::integral_constant<int, 6>{});
+  stage_one(0, std::integral_constant<int, 7>{});
+  stage_one(0, std::integral_constant<int, 8>{});
+  __syncthreads();  // (hipcc drains the LDS-DMA with vmcnt(0) here)
+
+  auto chunk_body = [&](int buf, auto more_tag) {
+    constexpr bool MORE = decltype(more_tag)::value;
+    const float* Ab = As + buf * CL_A_ST + wm * 64 + li;
+    const float* Bb = Bs + buf * CL_B_ST + (wn * 64 + li) * 4 + 2 * kh;
+    Frag cur = read_frag(Ab, Bb, 0);
+#pragma unroll
+    for (int g = 0; g < CL_NG; ++g) {
+      Frag nxt = cur;
+      if (g + 1 < CL_NG) nxt = read_frag(Ab, Bb, g + 1);
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) {
+          float b0 = e ? cur.b[0][tap].y : cur.b[0][tap].x;
+          float b1 = e ? cur.b[1][tap].y : cur.b[1][tap].x;
+          if (tap == 0) {
+            b0 = mask_l[0] ? b0 : 0.f;
+            b1 = mask_l[1] ? b1 : 0.f;
+          } else if (tap == 2) {
+            b0 = mask_r[0] ? b0 : 0.f;
+            b1 = mask_r[1] ? b1 : 0.f;
+          }
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[tap][0][e], b0, acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[tap][0][e], b1, acc[0][1], 0, 0, 0);
+          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[tap][1][e], b0, acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[tap][1][e], b1, acc[1][1], 0, 0, 0);
+          if (MORE) {
+            if (g == 0 && e == 0 && tap == 0) stage_one(buf ^ 1, std::integral_constant<int, 0>{});
+            if (g == 0 && e == 0 && tap == 1) stage_one(buf ^ 1, std::integral_constant<int, 1>{});
+            if (g == 0 && e == 0 && tap == 2) stage_one(buf ^ 1, std::integral_constant<int, 2>{});
+            if (g == 0 && e == 1 && tap == 0) stage_one(buf ^ 1, std::integral_constant<int, 3>{});
+            if (g == 0 && e == 1 && tap == 1) stage_one(buf ^ 1, std::integral_constant<int, 4>{});
+            if (g == 0 && e == 1 && tap == 2) stage_one(buf ^ 1, std::integral_constant<int, 5>{});
+            if (g == 1 && e == 0 && tap == 0) stage_one(buf ^ 1, std::integral_constant<int, 6>{});
+            if (g == 1 && e == 0 && tap == 1) stage_one(buf ^ 1, std::integral_constant<int, 7>{});
+            if (g == 1 && e == 0 && tap == 2) stage_one(buf ^ 1, std::integral_constant<int, 8>{});
+          }
+        }
+      // 24 MFMAs; behind each: one LDS read of the next group, one VALU, every 4th a DMA piece
+#define TSPN_G(NV, NVM)                                 \
+  __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);   \
+  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    \
+  __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    \
+  __builtin_amdgcn_sched_group_barrier(0x020, NVM, 0);
+      TSPN_G(4, 0) TSPN_G(1, 0) TSPN_G(1, 0) TSPN_G(1, 1) TSPN_G(1, 0) TSPN_G(1, 0)
+      TSPN_G(1, 0) TSPN_G(1, 1) TSPN_G(1, 0) TSPN_G(1, 0) TSPN_G(1, 0) TSPN_G(1, 1)
+      TSPN_G(1, 0) TSPN_G(1, 0) TSPN_G(1, 0) TSPN_G(1, 1) TSPN_G(1, 0) TSPN_G(1, 0)
+      TSPN_G(1, 0) TSPN_G(1, 1) TSPN_G(1, 0) TSPN_G(1, 0) TSPN_G(1, 0) TSPN_G(1, 1)
+#undef TSPN_G
+      __builtin_amdgcn_sched_barrier(0);
+      cur = nxt;
+    }
+    __syncthreads();
+  };
+  for (int c = 0; c + 1 < nchunks; ++c) chunk_body(c & 1, std::true_type{});
+  chunk_body((nchunks - 1) & 1, std::false_type{});
+
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int64_t n = n0 + wn * 64 + ni * 32 + li;
+    if (n >= ncols) continue;
+    const int64_t b = n / T;
+    const int64_t t = n - b * T;
+    float* ycol = y + (b * M) * (int64_t)T + t;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        if (m < M) {
+          float v = acc[mi][ni][e];
+          if (bias != nullptr) v += bias[m];
+          if (relu) v = fmaxf(v, 0.f);
+          ycol[(int64_t)m * T] = v;
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int tspn_pack_conv3_f32(const float* W, int64_t M, int64_t Cin, int64_t split,
@@ -675,4 +893,41 @@ extern "C" int tspn_conv3_f32(const float* x, int64_t B, int64_t Cin, int64_t T,
                      TSPN_STREAM(stream), x, packed, bias, y, (int)Cin, (int)T, (int)M, ncols,
                      (int)tiles_m, (int)tiles_n, relu);
   return tspn::check_launch("tspn_conv3_f32");
+}
+
+
+extern "C" int tspn_conv3_tc_f32(const float* x, int64_t B, int64_t T, int64_t Cin,
+                                 const float* packed, int64_t M, const float* bias, int relu,
+                                 float* y, void* stream) {
+  TSPN_REQUIRE(B >= 0 && Cin > 0 && T > 0 && M > 0, TSPN_EINVAL,
+               "tspn_conv3_tc_f32: bad sizes B=%lld T=%lld Cin=%lld M=%lld", (long long)B,
+               (long long)T, (long long)Cin, (long long)M);
+  if (B == 0) return TSPN_OK;
+  TSPN_REQUIRE(x && packed && y, TSPN_EINVAL, "tspn_conv3_tc_f32: null pointer");
+  TSPN_REQUIRE(Cin % CL_KC == 0 && M % 4 == 0, TSPN_EUNSUPPORTED,
+               "tspn_conv3_tc_f32: needs Cin %% 16 == 0 and M %% 4 == 0 (Cin=%lld M=%lld)",
+               (long long)Cin, (long long)M);
+  TSPN_REQUIRE((reinterpret_cast<uintptr_t>(packed) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(x) & 15) == 0,
+               TSPN_EUNSUPPORTED, "tspn_conv3_tc_f32: x and packed must be 16-byte aligned");
+  TSPN_REQUIRE(Cin < (1 << 24) && T < (1 << 24) && M < (1 << 24), TSPN_EUNSUPPORTED,
+               "tspn_conv3_tc_f32: dimension too large");
+  const int64_t ncols = B * T;
+  const int64_t tiles_m = tspn::ceil_div(M, BM);
+  const int64_t tiles_n = tspn::ceil_div(ncols, BN);
+  TSPN_REQUIRE(tiles_m * tiles_n < (1LL << 31), TSPN_EUNSUPPORTED, "tspn_conv3_tc_f32: grid too large");
+  static thread_local bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_mfma_cl_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)CL_SMEM_BYTES);
+    if (e != hipSuccess)
+      return tspn::fail(TSPN_ELAUNCH, "tspn_conv3_tc_f32: hipFuncSetAttribute: %s",
+                        hipGetErrorString(e));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conv3_mfma_cl_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(THREADS),
+                     CL_SMEM_BYTES, TSPN_STREAM(stream), x, packed, bias, y, (int)Cin, (int)T, (int)M,
+                     ncols, (int)tiles_m, (int)tiles_n, relu);
+  return tspn::check_launch("tspn_conv3_tc_f32");
 }

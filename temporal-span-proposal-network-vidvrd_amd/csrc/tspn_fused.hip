@@ -92,11 +92,16 @@ extern "C" int tspn_forward_fused_f32(const tspn_fused_desc* d, void* stream) {
   if (e != hipSuccess)
     return tspn::fail(TSPN_ELAUNCH, "tspn_forward_fused: bias staging: %s", hipGetErrorString(e));
 
-  // 1. tracklet layout [NT,T,D] -> channels-first [NT,D,T]
-  if ((rc = tspn_transpose_td_f32(d->feats, NT, T, D, xt, stream))) return rc;
-  // 2. per-tracklet projections  y[NT, 2C, T]: rows [0,C) = U (+bias), rows [C,2C) = V
+  // 1+2. per-tracklet projections  y[NT, 2C, T]: rows [0,C) = U (+bias), rows [C,2C) = V.
+  // The channels-last kernel consumes the tracklet layout [NT,T,D] directly; ragged shapes go
+  // through a transpose to channels-first [NT,D,T] and the general kernel.
+  const bool tc = (D % 16 == 0) && ((reinterpret_cast<uintptr_t>(d->feats) & 15) == 0) &&
+                  ((reinterpret_cast<uintptr_t>(d->conv_packed) & 15) == 0);
+  if (!tc && (rc = tspn_transpose_td_f32(d->feats, NT, T, D, xt, stream))) return rc;
   if (d->ev_conv_begin) (void)hipEventRecord(static_cast<hipEvent_t>(d->ev_conv_begin), s);
-  if ((rc = tspn_conv3_f32(xt, NT, D, T, d->conv_packed, 2 * C, bias2, 0, y, stream))) return rc;
+  rc = tc ? tspn_conv3_tc_f32(d->feats, NT, T, D, d->conv_packed, 2 * C, bias2, 0, y, stream)
+          : tspn_conv3_f32(xt, NT, D, T, d->conv_packed, 2 * C, bias2, 0, y, stream);
+  if (rc) return rc;
   if (d->ev_conv_end) (void)hipEventRecord(static_cast<hipEvent_t>(d->ev_conv_end), s);
   // 3. pair stage + relationness / span heads
   if (d->canonical_pairs) {

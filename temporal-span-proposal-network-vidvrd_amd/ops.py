@@ -13,7 +13,7 @@ from . import _abi
 
 __all__ = [
     "predicate_head", "feature_preprocess_", "ppn_pair_matrix_topk", "traj_iou", "pair_index",
-    "pair_gather", "pack_conv3", "conv3", "heads", "heads_pairgrid", "temporal_mean", "pair_rows", "transpose_td",
+    "pair_gather", "pack_conv3", "conv3", "conv3_tc", "heads", "heads_pairgrid", "temporal_mean", "pair_rows", "transpose_td",
     "forward_fused", "temporal_encoder_heads", "fused_workspace_bytes", "decode_topk",
 ]
 
@@ -190,6 +190,21 @@ def conv3(x, packed, bias=None, relu=False):
     y = torch.empty((B, M, T), dtype=torch.float32, device=x.device)
     _abi.check(_abi.lib().tspn_conv3_f32(_p(x), B, Cin, T, _p(packed), M, _p(bias), 1 if relu else 0,
                                          _p(y), _stream()))
+    return y
+
+
+def conv3_tc(x, packed, bias=None, relu=False):
+    """conv3 on channels-last x[B,T,Cin] (tracklet layout) -> y[B,M,T]; fast path only."""
+    _dev(x, "x"); _dev(packed, "packed")
+    if bias is not None:
+        _dev(bias, "bias")
+    B, T, Cin = x.shape
+    if packed.dim() != 3 or packed.shape[0] != 3 or packed.shape[1] != Cin:
+        raise ValueError(f"conv3_tc: packed weights {tuple(packed.shape)} do not match Cin={Cin}")
+    M = packed.shape[2]
+    y = torch.empty((B, M, T), dtype=torch.float32, device=x.device)
+    _abi.check(_abi.lib().tspn_conv3_tc_f32(_p(x), B, T, Cin, _p(packed), M, _p(bias), 1 if relu else 0,
+                                            _p(y), _stream()))
     return y
 
 

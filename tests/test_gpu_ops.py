@@ -198,6 +198,29 @@ def test_conv3_vs_fp64(tspn, device, B, Cin, T, M, relu):
     np.testing.assert_allclose(y0.cpu().numpy(), conv_ref(x, w, None, relu), rtol=0, atol=2e-5)
 
 
+@pytest.mark.parametrize("B,Cin,T,M", [(1, 16, 1, 4), (3, 16, 30, 128), (5, 32, 33, 132), (7, 64, 150, 64),
+                                       (2, 144, 257, 260), (40, 32, 30, 36)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_conv3_channels_last_vs_fp64(tspn, device, B, Cin, T, M, relu):
+    """tspn_conv3_tc_f32: x in the tracklet layout [B,T,Cin]; same operator, same output layout."""
+    x = tspn.hashrng.uniform(45, "x", (B, T, Cin), -1, 1)
+    w = tspn.hashrng.normal(45, "w", (M, Cin, 3), std=0.1)
+    b = tspn.hashrng.normal(45, "b", (M,), std=0.1)
+    packed = tspn.ops.pack_conv3(t(w).to(device))
+    y = tspn.ops.conv3_tc(t(x).to(device), packed, t(b).to(device), relu=relu)
+    ref = conv_ref(np.ascontiguousarray(x.transpose(0, 2, 1)), w, b, relu)
+    np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=0, atol=2e-5)
+    # and it agrees with the channels-first kernel on the transposed input
+    y2 = tspn.ops.conv3(tspn.ops.transpose_td(t(x).to(device)), packed, t(b).to(device), relu=relu)
+    np.testing.assert_allclose(y.cpu().numpy(), y2.cpu().numpy(), rtol=0, atol=1e-5)
+
+
+def test_conv3_channels_last_rejects_ragged(tspn, device):
+    with pytest.raises(tspn._abi.TspnError) as e:
+        tspn.ops.conv3_tc(torch.zeros(2, 5, 20, device=device), torch.zeros(3, 20, 8, device=device))
+    assert e.value.code == tspn._abi.TSPN_EUNSUPPORTED
+
+
 def test_conv3_asymmetric_identity(tspn, device):
     """Exact-integer check of the MFMA operand / accumulator lane maps: W = shifted identity,
     asymmetric x (a transposed C-write or a swapped tap would show)."""
@@ -212,6 +235,9 @@ def test_conv3_asymmetric_identity(tspn, device):
     xp = np.pad(x, ((0, 0), (0, 0), (1, 1)))
     ref = (np.roll(xp[:, :, :-2], -1, 1) + 2 * xp[:, :, 1:-1] - 3 * np.roll(xp[:, :, 2:], -5, 1))
     np.testing.assert_array_equal(y, ref)
+    xt = t(np.ascontiguousarray(x.transpose(0, 2, 1))).to(device)
+    y_tc = tspn.ops.conv3_tc(xt, tspn.ops.pack_conv3(t(w).to(device)), None).cpu().numpy()
+    np.testing.assert_array_equal(y_tc, ref)
 
 
 def test_conv3_split_pack(tspn, device):

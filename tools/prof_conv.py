@@ -17,21 +17,27 @@ ap.add_argument("--cin", type=int, default=2048)
 ap.add_argument("--m", type=int, default=8192)
 ap.add_argument("--t", type=int, default=150)
 ap.add_argument("--n", type=int, default=32)
+ap.add_argument("--tc", action="store_true", help="channels-last x (tracklet layout) kernel")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev).manual_seed(0)
 x = torch.rand((args.videos * args.n, args.cin, args.t), device=dev, generator=g)
+conv = tspn.ops.conv3
+if args.tc:
+    x = x.transpose(1, 2).contiguous()
+    conv = tspn.ops.conv3_tc
 w = (torch.rand((3, args.cin, args.m), device=dev, generator=g) - 0.5) * 0.02
 for _ in range(2):
-    y = tspn.ops.conv3(x, w)
+    y = conv(x, w)
 torch.cuda.synchronize()
 evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.iters)]
 for a, b in evs:
     a.record()
-    y = tspn.ops.conv3(x, w)
+    y = conv(x, w)
     b.record()
 torch.cuda.synchronize()
 ms = sorted(a.elapsed_time(b) for a, b in evs)
 flop = 2.0 * args.m * 3 * args.cin * x.shape[0] * args.t
-print(f"conv3 B={x.shape[0]} Cin={args.cin} T={args.t} M={args.m}: median {ms[len(ms)//2]:.3f} ms "
+shape = f"B={x.shape[0]} Cin={args.cin} T={args.t} M={args.m}" + (" [channels-last]" if args.tc else "")
+print(f"conv3 {shape}: median {ms[len(ms)//2]:.3f} ms "
       f"min {ms[0]:.3f} ms -> {flop / ms[len(ms)//2] / 1e9:.1f} TFLOP/s (median)")
