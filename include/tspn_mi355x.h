@@ -194,6 +194,22 @@ int tspn_decode_topk_f32(const float* rel_logit, const int64_t* pairs,
                          float* out_score, int64_t* out_triplet, int64_t* out_pair_tid,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- f3: temporal span decode + 1-D NMS ---------------------------------
+ * Build-defined completion of the reference's stub RelNMS (lib/modeling/relpn/rel_nms.py:5-15;
+ * anchors per lib/modeling/relpn/anchor_generator.py:48-59) — semantics in DESIGN.md §2 and
+ * oracle.decode_spans.  heads[P, 3A, T] as produced by tspn_forward_fused_f32 /
+ * tspn_temporal_encoder_heads_f32 (rows [0,A) relationness logits, [A,3A) (d_c, d_w) per anchor);
+ * `sizes_host` = A anchor widths in frames (HOST pointer, copied into the launch).
+ * Per pair the first `top_k` NMS survivors, best first:
+ *   out_anchor[P,top_k] candidate index t*A+a (-1 = unused)   out_span[P,top_k,2] int64 frames [s,e)
+ *   out_span_f[P,top_k,2] fp32 (start,end)                    out_score[P,top_k] sigmoid(logit)
+ *   out_count[P] number of survivors.
+ * Limits: A <= 8, A*T <= 4096, top_k <= 1024; at most min(pre_nms, 1024) candidates enter the NMS. */
+int tspn_decode_spans_f32(const float* heads, int64_t P, int64_t A, int64_t T,
+                          const float* sizes_host, int64_t top_k, double nms_threshold,
+                          int64_t pre_nms, int64_t* out_anchor, int64_t* out_span,
+                          float* out_span_f, float* out_score, int64_t* out_count, void* stream);
+
 /* ---- whole relation-scoring pass on tracklet tensors --------------------
  * The fused/factorised product path for `B` videos of N
  * tracklets each: pair builder + temporal encoder + relationness/span heads

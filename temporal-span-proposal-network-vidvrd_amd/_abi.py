@@ -71,6 +71,8 @@ PROTOTYPES = {
     "tspn_decode_topk_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "tspn_decode_topk_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                                     _vp, _vp, _vp, _vp, _sz, _vp]),
+    "tspn_decode_spans_f32": (_int, [_vp, _i64, _i64, _i64, ctypes.POINTER(ctypes.c_float), _i64,
+                                     ctypes.c_double, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tspn_forward_fused_workspace_bytes": (_sz, [ctypes.POINTER(FusedDesc)]),
     "tspn_forward_fused_f32": (_int, [ctypes.POINTER(FusedDesc), _vp]),
     "tspn_temporal_encoder_heads_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64,

@@ -319,6 +319,7 @@ class BaseModel(nn.Module):
         self.rel_of_interest_pool = RelOIPool()
         self.classifier = RelationPredictor(in_channels=cfg.PREDICT.FEATURE_DIM,
                                             out_channels=cfg.PREDICT.PREDICATE_NUM)
+        self._anchor_sizes_cfg = getattr(cfg.RELPN.DPN, "ANCHOR_SIZES", None)
 
     def forward(self, pair_list, target_list=None):
         if self.training:
@@ -481,6 +482,31 @@ class BaseModel(nn.Module):
             for k, i in enumerate(members):
                 tgt = rel_logits[i].device
                 out[i] = tuple(r[k].to(tgt) for r in res)
+        return out
+
+    def anchor_sizes(self, num_frames):
+        """Anchor widths (frames) of the A anchors per location.  cfg.RELPN.DPN.ANCHOR_SIZES when it
+        is a sequence of length A; the reference ships a placeholder int there (defaults.py:66), so
+        the default is the proportions of its own example (anchor_generator.py:116-123:
+        sizes (15,30,45,60) on T=60): size_a = (a+1)*T/A."""
+        a = self.relpn.duration_proposal_network.dpn_head.num_windows
+        cfg_sizes = getattr(self, "_anchor_sizes_cfg", None)
+        if isinstance(cfg_sizes, (list, tuple)) and len(cfg_sizes) == a:
+            return [float(v) for v in cfg_sizes]
+        return [(i + 1) * float(num_frames) / a for i in range(a)]
+
+    def decode_spans(self, duration_proposals, sizes=None, top_k=None, nms_threshold=0.5):
+        """Temporal span proposals per pair from `forward`'s duration_proposals (span decode +
+        temporal NMS on the GPU; completes the reference's stub RelNMS, rel_nms.py:5-15).
+        Per segment a dict: anchor [P,k], span int64 [P,k,2] (frames [s,e)), span_f, score, count."""
+        top_k = top_k or self.relpn.duration_proposal_network.top_k_proposals
+        out = []
+        for dp in duration_proposals:
+            heads = dp.heads
+            dev = _compute_device(heads)
+            sz = sizes if sizes is not None else self.anchor_sizes(heads.shape[2])
+            res = ops.decode_spans(_f32(heads, dev), sz, top_k=top_k, nms_threshold=nms_threshold)
+            out.append({k: v.to(heads.device) for k, v in res.items()})
         return out
 
     def pair_geometry(self, pair_list):

@@ -14,7 +14,7 @@ from . import _abi
 __all__ = [
     "predicate_head", "feature_preprocess_", "ppn_pair_matrix_topk", "traj_iou", "pair_index",
     "pair_gather", "pack_conv3", "conv3", "conv3_tc", "heads", "heads_pairgrid", "temporal_mean", "pair_rows", "transpose_td",
-    "forward_fused", "temporal_encoder_heads", "fused_workspace_bytes", "decode_topk",
+    "forward_fused", "temporal_encoder_heads", "fused_workspace_bytes", "decode_topk", "decode_spans",
 ]
 
 
@@ -321,6 +321,29 @@ def decode_topk(rel_logit, pairs, cls_sub, cls_obj=None, row_mul=1, num_obj=35,
                                       seg_rows, row_mul, S, P, K, num_obj, topk_per_pair, topk_per_seg,
                                       _p(scores), _p(trip), _p(tids), _p(ws), ws.numel(), _stream()))
     return (scores[0], trip[0], tids[0]) if squeeze else (scores, trip, tids)
+
+
+def decode_spans(heads, sizes, top_k=64, nms_threshold=0.5, pre_nms=1024):
+    """Temporal span proposals per pair from heads [P,3A,T] (span decode + 1-D NMS).
+
+    Returns dict(anchor int64 [P,top_k], span int64 [P,top_k,2], span_f fp32 [P,top_k,2],
+    score fp32 [P,top_k], count int64 [P])."""
+    _dev(heads, "heads")
+    P, H, T = heads.shape
+    A = len(sizes)
+    if H != 3 * A:
+        raise ValueError(f"decode_spans: heads has {H} channels, expected 3*A = {3 * A}")
+    dev = heads.device
+    out = {"anchor": torch.empty((P, top_k), dtype=torch.int64, device=dev),
+           "span": torch.empty((P, top_k, 2), dtype=torch.int64, device=dev),
+           "span_f": torch.empty((P, top_k, 2), dtype=torch.float32, device=dev),
+           "score": torch.empty((P, top_k), dtype=torch.float32, device=dev),
+           "count": torch.empty((P,), dtype=torch.int64, device=dev)}
+    sz = (ctypes.c_float * A)(*[float(v) for v in sizes])
+    _abi.check(_abi.lib().tspn_decode_spans_f32(_p(heads), P, A, T, sz, top_k, float(nms_threshold), pre_nms,
+                                                _p(out["anchor"]), _p(out["span"]), _p(out["span_f"]),
+                                                _p(out["score"]), _p(out["count"]), _stream()))
+    return out
 
 
 def _fused_desc(feats, pairs, B, N, conv_packed, conv_bias, head_w, head_b, cls_w, cls_b):

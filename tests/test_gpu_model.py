@@ -213,3 +213,23 @@ def test_decode_like_predict_py(tspn, device):
     np.testing.assert_array_equal(trip[:, 0].numpy(), lab[tids[:, 0].numpy()])
     np.testing.assert_array_equal(trip[:, 2].numpy(), lab[tids[:, 1].numpy()])
     np.testing.assert_array_equal(trip[:, 1].numpy(), rt[:, 1].numpy())
+
+
+def test_decode_spans_from_forward(tspn, device):
+    """forward -> decode_spans: integer spans bit-exact vs the oracle run on the same heads."""
+    D, N, T = 16, 6, 30
+    sd = tspn.synth.make_weights(0, c=2 * D, bias_std=0.05)
+    sd = {k: (v * 40 if "relness_pred" in k or "duration_pred" in k else v) for k, v in sd.items()}
+    model = tspn.BaseModel(temporal_cfg(D, use_ppn=False))
+    load(model, sd)
+    model.eval()
+    v = tspn.synth.make_video(91, N, T, D)
+    pl = tspn.PairList.from_tracklets(t(v["tracklet_feats"]), t(v["tracklet_boxes"]))
+    _, dp, _ = model([pl], None)
+    spans = model.decode_spans(dp)[0]
+    sizes = model.anchor_sizes(T)
+    assert sizes == [7.5, 15.0, 22.5, 30.0]
+    ref = oracle.decode_spans(dp[0].relness, dp[0].duration, sizes, top_k=64)
+    for k in ("count", "anchor", "span"):
+        np.testing.assert_array_equal(spans[k].numpy(), ref[k].numpy(), err_msg=k)
+    assert spans["span"].shape == (N * (N - 1), 64, 2) and int(spans["count"].min()) >= 1

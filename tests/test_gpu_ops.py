@@ -444,3 +444,36 @@ def test_decode_topk_vs_oracle_with_ties(tspn, device, S, N, K, kp, ks):
     for s in range(S):
         np.testing.assert_array_equal(trip2[s, :, 0].cpu().numpy(), lab[s][tids2[s, :, 0].cpu().numpy()])
         np.testing.assert_array_equal(trip2[s, :, 2].cpu().numpy(), lab[s][tids2[s, :, 1].cpu().numpy()])
+
+
+# ------------------------------------------------------- f3: span decode + temporal NMS
+@pytest.mark.parametrize("P,A,T,top_k,thr", [(1, 1, 1, 4, 0.5), (5, 4, 30, 64, 0.5), (7, 4, 150, 64, 0.5),
+                                             (3, 3, 33, 10, 0.7), (2, 4, 900, 64, 0.5), (4, 2, 150, 1024, 0.3)])
+def test_decode_spans_bit_exact(tspn, device, P, A, T, top_k, thr):
+    """Span indices (anchor ids, integer frames, counts) bit-exact vs the oracle, incl. tied logits."""
+    sizes = [4.0, 8.0, 16.0, 32.0, 64.0][:A]
+    heads = tspn.hashrng.normal(71, "spans", (P, 3 * A, T), std=1.0)
+    heads[:, :A] = np.round(heads[:, :A] * 8) / 8          # quantised logits -> exact ties
+    heads[:, A:] *= 0.4
+    if T > 4:
+        heads[0, A + 1, 3] = 9.0                            # d_w above the clamp
+    hd = t(heads).to(device)
+    got = tspn.ops.decode_spans(hd, sizes, top_k=top_k, nms_threshold=thr)
+    ref = oracle.decode_spans(t(heads[:, :A]), t(heads[:, A:]), sizes, top_k=top_k, nms_threshold=thr)
+    for k in ("count", "anchor", "span"):
+        np.testing.assert_array_equal(got[k].cpu().numpy(), ref[k].numpy(), err_msg=k)
+    np.testing.assert_array_equal(got["span_f"].cpu().numpy(), ref["span_f"].numpy())
+    np.testing.assert_allclose(got["score"].cpu().numpy(), ref["score"].numpy(), rtol=0, atol=1e-7)
+    sp, cnt = got["span"].cpu().numpy(), got["count"].cpu().numpy()
+    for p in range(P):                                      # invariants
+        v = sp[p, :cnt[p]]
+        assert np.all(v[:, 0] >= 0) and np.all(v[:, 1] <= T) and np.all(v[:, 1] > v[:, 0])
+        assert np.all(sp[p, cnt[p]:] == -1)
+
+
+def test_decode_spans_limits(tspn, device):
+    with pytest.raises(tspn._abi.TspnError) as e:
+        tspn.ops.decode_spans(torch.zeros(1, 12, 2000, device=device), [1.0, 2.0, 3.0, 4.0])
+    assert e.value.code == tspn._abi.TSPN_EUNSUPPORTED
+    with pytest.raises(ValueError):
+        tspn.ops.decode_spans(torch.zeros(1, 11, 20, device=device), [1.0, 2.0, 3.0, 4.0])
