@@ -477,3 +477,44 @@ def test_decode_spans_limits(tspn, device):
     assert e.value.code == tspn._abi.TSPN_EUNSUPPORTED
     with pytest.raises(ValueError):
         tspn.ops.decode_spans(torch.zeros(1, 11, 20, device=device), [1.0, 2.0, 3.0, 4.0])
+
+
+# --------------------------------------------- other BASELINE configs as parity cases
+def test_cfg3_shape_fp32_sampled(tspn, device):
+    """BASELINE cfg3 shape (VidOR long clip: N=64, T=900, D=1024 -> C=2048, P=4032) through the
+    fp32 path (the bf16 path is a later round): sampled pairs vs the dense oracle."""
+    N, T, D = 64, 900, 1024
+    _, w = make_w(tspn, 0, D, bias_std=0.0)
+    v = tspn.synth.make_video(3, N, T, D)
+    feats = t(v["tracklet_feats"])
+    pairs = oracle.pair_index(N)
+    heads, logits = run_fused(tspn, device, feats, pairs, 1, N, w, canonical=True)
+    assert heads.shape == (4032, 12, 900) and logits.shape == (4032, 132)
+    sample = torch.tensor([0, 63, 2017, 4031])
+    ref = oracle.forward_dense(feats, t(v["tracklet_boxes"]), pairs[sample], w)
+    np.testing.assert_allclose(heads[sample, :4].cpu().numpy(), ref["relness"].numpy(), rtol=0, atol=ATOL)
+    np.testing.assert_allclose(heads[sample, 4:].cpu().numpy(), ref["duration"].numpy(), rtol=0, atol=ATOL)
+    np.testing.assert_allclose(logits[sample].cpu().numpy(), ref["rel_logits"].numpy(), rtol=0, atol=ATOL)
+
+
+def test_cfg4_batch_independence(tspn, device):
+    """BASELINE cfg4 (many videos sharded / batched): a video's results do not depend on what it is
+    batched with — bitwise, since each video's tiles see identical operands in the same order...
+    except that tile boundaries move with the batch offset, so compare to a tight tolerance and
+    check bitwise equality for the slot-aligned case (same position in the batch)."""
+    N, T, D, B = 12, 30, 32, 5
+    _, w = make_w(tspn, 2, D)
+    vids = [tspn.synth.make_video(200 + b, N, T, D) for b in range(B)]
+    feats = torch.cat([t(v["tracklet_feats"]) for v in vids])
+    pairs = torch.cat([oracle.pair_index(N) + b * N for b in range(B)])
+    hb, lb = run_fused(tspn, device, feats, pairs, B, N, w, canonical=True)
+    P = N * (N - 1)
+    for b in (0, 3):
+        h1, l1 = run_fused(tspn, device, t(vids[b]["tracklet_feats"]), oracle.pair_index(N), 1, N, w, canonical=True)
+        np.testing.assert_allclose(hb[b * P:(b + 1) * P].cpu().numpy(), h1.cpu().numpy(), rtol=0, atol=2e-6)
+        np.testing.assert_allclose(lb[b * P:(b + 1) * P].cpu().numpy(), l1.cpu().numpy(), rtol=0, atol=2e-6)
+    h0, l0 = run_fused(tspn, device, t(vids[0]["tracklet_feats"]), oracle.pair_index(N), 1, N, w, canonical=True)
+    np.testing.assert_array_equal(hb[:P].cpu().numpy(), h0.cpu().numpy())  # video 0: same tiles -> bitwise
+    # determinism: two runs of the same launch are bitwise identical (no atomics anywhere)
+    hb2, lb2 = run_fused(tspn, device, feats, pairs, B, N, w, canonical=True)
+    assert torch.equal(hb, hb2) and torch.equal(lb, lb2)
