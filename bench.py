@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--videos", type=int, default=8, help="videos per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time")
+    ap.add_argument("--conv", choices=["winograd", "direct"], default="winograd",
+                    help="temporal-conv algorithm of the tracklet projections (both exact fp32 MFMA)")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the RCCL result gather even with one rank (exercises the N>1 code path)")
     return ap.parse_args()
@@ -84,14 +86,14 @@ def cpu_baseline(weights, target_s):
                       f"(oracle.forward_dense), {dt:.1f} s, torch {torch.__version__} CPU"}
 
 
-def pmc_traffic(videos):
+def pmc_traffic(videos, conv):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/pmc_traffic.json, produced by tools/pmc_summary.py); null if not measured for this
     batch size.  PMC counters cannot be read from inside the process."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         data = json.load(open(path))
-        k = data["kernels"]["conv3_mfma_cl_kernel"]
+        k = data["kernels"]["conv3_wino_cl_kernel" if conv == "winograd" else "conv3_mfma_cl_kernel"]
         if data["videos_per_launch"] == videos:
             return {"traffic": k["hbm_bytes"], "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE)",
                     "traffic_source": data["source"]}
@@ -128,7 +130,8 @@ def main():
            "cls_w": sd["classifier.rel_predictor.weight"], "cls_b": sd["classifier.rel_predictor.bias"]}
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
     conv_w = d(wnp["conv_w"])
-    packed = tspn.ops.pack_conv3(conv_w, split=D)
+    packed = (tspn.ops.pack_conv3(conv_w, split=D) if args.conv == "direct"
+              else tspn.ops.pack_conv3_wino(conv_w, split=D))
     del conv_w
     conv_b = d(wnp["conv_b"])
     head_w = d(np.concatenate([wnp["rel_w"][:, :, 0], wnp["dur_w"][:, :, 0]]))
@@ -183,7 +186,9 @@ def main():
     # dominant kernel: conv3_mfma (tracklet projections), HIP events inside the timed steps
     conv_ms = [a.elapsed_time(b) for a, b in events[args.warmup:]]
     conv_avg_s = float(np.mean(conv_ms)) * 1e-3
-    conv_flop = 2.0 * (2 * C) * (3 * D) * (B * N * T)  # executed: M=2C, K=3D, columns=B*N*T
+    conv_flop_direct = 2.0 * (2 * C) * (3 * D) * (B * N * T)  # M=2C, K=3D, columns=B*N*T
+    # Winograd F(2,3) issues 4 channel-GEMMs on half the columns: 2/3 of the direct MFMA work
+    conv_flop = conv_flop_direct * (2.0 / 3.0 if args.conv == "winograd" else 1.0)
     achieved = conv_flop / conv_avg_s / 1e12
 
     if rank == 0:
@@ -202,11 +207,17 @@ def main():
                        "path": "fused/factorised (tspn_forward_fused_f32) + PPN top-k"
                                + (" + RCCL all-gather of logits/top-k" if use_dist else ""),
                        "dense_equivalent_gflop_per_pair": (2.0 * T * C * (3 * C + 3 * A_ANCH) + 2.0 * C * K_PRED) / 1e9,
+                       "conv_algo": args.conv,
                        "executed_gflop_per_pair": (conv_flop + 2.0 * P * T * C * 16 + 2.0 * P * C * K_PRED) / P / 1e9},
-            "roofline": {"bound": "mfma", "kernel": "conv3_mfma_cl_kernel (tracklet projections: k=3 conv as "
-                                                    "fp32 32x32x2 MFMA implicit GEMM, M=2C, K=3D)",
+            "roofline": {"bound": "mfma",
+                         "kernel": ("conv3_wino_cl_kernel (tracklet projections: k=3 conv, Winograd F(2,3), "
+                                    "fp32 32x32x2 MFMA, M=2C, 4 channel-GEMMs of K=D on half the columns)"
+                                    if args.conv == "winograd" else
+                                    "conv3_mfma_cl_kernel (tracklet projections: k=3 conv as fp32 32x32x2 "
+                                    "MFMA implicit GEMM, M=2C, K=3D)"),
                          "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, **pmc_traffic(B),
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, **pmc_traffic(B, args.conv),
+                         "direct_equivalent_tflops": conv_flop_direct / conv_avg_s / 1e12,
                          "flop_per_launch": conv_flop, "avg_launch_ms": conv_avg_s * 1e3,
                          "share_of_step": conv_avg_s / (elapsed / args.steps)},
         }

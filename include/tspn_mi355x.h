@@ -135,6 +135,17 @@ int tspn_conv3_tc_f32(const float* x, int64_t B, int64_t T, int64_t Cin,
                       const float* packed, int64_t M, const float* bias, int relu,
                       float* y, void* stream);
 
+/* Winograd F(2,3) form of tspn_conv3_tc_f32 (two output frames from four inputs: 2/3 of the MFMA
+ * work, same result up to fp32 rounding, |diff| ~ 1e-6).  `packed4`[4][Cin'][M'] comes from
+ * tspn_pack_conv3_wino_f32 (same `split` rule as tspn_pack_conv3_f32; 4*M*Cin floats):
+ *   U0 = g0, U1 = (g0+g1+g2)/2, U2 = (g0-g1+g2)/2, U3 = g2   (g_tap = W[:, :, tap], rounded from fp64).
+ * Needs T even, Cin % 8 == 0, M % 4 == 0, 16-byte aligned x / packed4 (else TSPN_EUNSUPPORTED).   */
+int tspn_pack_conv3_wino_f32(const float* W, int64_t M, int64_t Cin, int64_t split,
+                             float* packed4, void* stream);
+int tspn_conv3_tc_wino_f32(const float* x, int64_t B, int64_t T, int64_t Cin,
+                           const float* packed4, int64_t M, const float* bias, int relu,
+                           float* y, void* stream);
+
 /* ---- a8/a10: relationness + span-regression heads -----------------------
  * Replaces duration_pred (lib/modeling/relpn/dpn.py:71) and relness_pred
  * (lib/modeling/relpn/dpn_anchor.py:105) as ONE [H, C] 1x1 GEMM:
@@ -222,7 +233,9 @@ typedef struct tspn_fused_desc {
   int64_t P;
   int64_t canonical_pairs;     /* != 0: `pairs` is the canonical table of tspn_pair_index_i64 for every
                                   video in order (P == B*N*(N-1)): enables the blocked pair stage */
-  const float* conv_packed;    /* tspn_pack_conv3_f32(conv.weight [C,C,3], split=D): [3][D][2C] */
+  const float* conv_packed;    /* conv_algo 0: tspn_pack_conv3_f32(conv.weight [C,C,3], split=D): [3][D][2C]
+                                  conv_algo 1: tspn_pack_conv3_wino_f32(..., split=D):          [4][D][2C] */
+  int64_t conv_algo;           /* 0 = direct k=3 taps; 1 = Winograd F(2,3) (needs T even, D % 16 == 0) */
   const float* conv_bias;      /* [C] */
   const float* head_w;         /* [3A, C]: rows [0,A) relness_pred, [A,3A) duration_pred */
   const float* head_b;         /* [3A] */

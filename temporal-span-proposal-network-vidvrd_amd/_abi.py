@@ -36,7 +36,7 @@ class FusedDesc(ctypes.Structure):
         ("B", _i64), ("N", _i64), ("T", _i64), ("D", _i64),
         ("A", _i64), ("K", _i64),
         ("feats", _vp), ("pairs", _vp), ("P", _i64), ("canonical_pairs", _i64),
-        ("conv_packed", _vp), ("conv_bias", _vp),
+        ("conv_packed", _vp), ("conv_algo", _i64), ("conv_bias", _vp),
         ("head_w", _vp), ("head_b", _vp),
         ("cls_w", _vp), ("cls_b", _vp),
         ("out_heads", _vp), ("out_logits", _vp),
@@ -62,6 +62,8 @@ PROTOTYPES = {
     "tspn_pack_conv3_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "tspn_conv3_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _int, _vp, _vp]),
     "tspn_conv3_tc_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _int, _vp, _vp]),
+    "tspn_pack_conv3_wino_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
+    "tspn_conv3_tc_wino_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _int, _vp, _vp]),
     "tspn_heads_f32": (_int, [_int, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64,
                               _i64, _vp, _vp]),
     "tspn_heads_pairgrid_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp]),

@@ -838,6 +838,243 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_mfma_cl_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Winograd F(2,3) variant of the channels-last kernel: the k=3 temporal conv of two adjacent
+// output frames (t, t+1) from the four inputs d = x[t-1..t+2]
+//     y_t   = M0 + M1 + M2          M_j = U_j . V_j   (contraction over input channels only)
+//     y_t+1 = M1 - M2 - M3          U = (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2)   (packed once, fp64->fp32)
+//                                   V = (d0-d2, d1+d2, d2-d1, d1-d3)           (formed in registers)
+// needs 4 channel-GEMMs on half the columns instead of 3 on all of them: 2/3 of the MFMA work of
+// the direct form, exact in real arithmetic and within a few 1e-6 of it in fp32 (tests).
+// Tile: 128 output channels x 128 frames (64 frame pairs); wave w = rows [32w, 32w+32) x 64 pairs x
+// 4 positions j (8 accumulator blocks, the output transform stays inside the wave's registers).
+// K chunk = 8 input channels: lanes k=0 / k=1 take channel group 0 / 1 (4 channels each = 4 MFMA
+// k-steps), so every x value a lane reads from LDS (b128 = 4 channels of one column) is used.
+// Requires T even (frame pairs never straddle sequences), Cin % 8 == 0, M % 4 == 0.
+constexpr int WN_KC = 8;
+constexpr int WN_SLP = 132;
+constexpr int WN_A_ST = 4 * WN_KC * BM;        // floats: [4 j][8 ch][128 m]
+constexpr int WN_B_ST = 2 * WN_SLP * 4;        // floats: [2 groups][132 slots][4 ch]
+constexpr int WN_UNITS = 2 * WN_SLP;
+constexpr int WN_BPIECES = (WN_UNITS + 63) / 64;  // 5
+constexpr size_t WN_SMEM_BYTES = sizeof(float) * 2 * (WN_A_ST + WN_B_ST);
+
+__global__ void pack_conv3_wino_kernel(const float* __restrict__ W, int64_t M, int64_t Cin,
+                                       int64_t split, float* __restrict__ packed) {
+  const int64_t Mp = split > 0 ? 2 * M : M;
+  const int64_t Cp = split > 0 ? split : Cin;
+  const int64_t total = Cp * Mp;
+  for (int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; o < total;
+       o += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = o % Mp;
+    const int64_t ci = o / Mp;
+    const int64_t m = r < M ? r : r - M;
+    const int64_t c = r < M ? ci : ci + split;
+    const float* g = W + (m * Cin + c) * 3;
+    const double g0 = g[0], g1 = g[1], g2 = g[2];
+    packed[0 * total + o] = (float)g0;
+    packed[1 * total + o] = (float)(0.5 * (g0 + g1 + g2));
+    packed[2 * total + o] = (float)(0.5 * (g0 - g1 + g2));
+    packed[3 * total + o] = (float)g2;
+  }
+}
+
+__global__ __launch_bounds__(THREADS, 2) void conv3_wino_cl_kernel(
+    const float* __restrict__ x, const float* __restrict__ Wp, const float* __restrict__ bias,
+    float* __restrict__ y, int Cin, int T, int M, int64_t ncols, int tiles_m, int tiles_n,
+    int relu) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* As = reinterpret_cast<float*>(smem_raw);  // [2][4][8][BM]
+  float* Bs = As + 2 * WN_A_ST;                     // [2][2][132][4]
+
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  constexpr int GM = 8;
+  const int group_sz = GM * tiles_n;
+  const int group = wg / group_sz;
+  const int first_m = group * GM;
+  const int gm = min(GM, tiles_m - first_m);
+  const int in_group = wg - group * group_sz;
+  const int tile_m = first_m + in_group % gm;
+  const int tile_n = in_group / gm;
+  const int m0 = tile_m * BM;
+  const int64_t n0 = (int64_t)tile_n * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kh = lane >> 5;
+
+  // ---- DMA sources.  A: wave w stages U_w (8 channel rows x 128 m = 4 pieces of 2 rows).
+  const float* asrc[4];
+  {
+    const int am = (lane & 31) * 4;
+    const int amc = m0 + am < M ? m0 + am : 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ch = 2 * i + (lane >> 5);
+      asrc[i] = Wp + ((int64_t)wave * Cin + ch) * M + amc;
+    }
+  }
+  const float* bsrc[2];
+  bool bval[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int u = 64 * (wave + 4 * q) + lane;
+    const int g = u / WN_SLP, slot = u - g * WN_SLP;
+    bval[q] = u < WN_UNITS && slot < BN + 2;
+    int64_t n = n0 + slot - 1;
+    n = n < 0 ? 0 : (n < ncols ? n : ncols - 1);
+    bsrc[q] = x + n * Cin + 4 * (g < 2 ? g : 0);
+  }
+  const int64_t a_step = (int64_t)WN_KC * M;
+
+  auto stage_one = [&](int buf, auto d_tag) {
+    constexpr int d = decltype(d_tag)::value;
+#if defined(TSPN_ABLATE_NODMA)
+    return;
+#endif
+    if constexpr (d < 4) {
+      glds16(asrc[d], As + buf * WN_A_ST + (wave * WN_KC + 2 * d) * BM);
+#if !defined(TSPN_ABLATE_HOTDMA)
+      asrc[d] += a_step;
+#endif
+    } else {
+      constexpr int q = d - 4;
+      if (bval[q]) glds16(bsrc[q], Bs + buf * WN_B_ST + 64 * (wave + 4 * q) * 4);
+#if !defined(TSPN_ABLATE_HOTDMA)
+      bsrc[q] += WN_KC;
+#endif
+    }
+  };
+
+  // frame pair q of the tile <-> frames (2q, 2q+1): d0 = x[2q-1] is outside the sequence when the
+  // first frame is t = 0, d3 = x[2q+2] when the second frame is t = T-1.
+  bool mask0[2], mask3[2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int64_t n = n0 + 2 * (qb * 32 + li);
+    const int t = (int)(n % T);
+    mask0[qb] = t != 0;
+    mask3[qb] = t != T - 2;
+  }
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][qb][e] = 0.f;
+
+  const int nchunks = Cin / WN_KC;
+  stage_one(0, std::integral_constant<int, 0>{});
+  stage_one(0, std::integral_constant<int, 1>{});
+  stage_one(0, std::integral_constant<int, 2>{});
+  stage_one(0, std::integral_constant<int, 3>{});
+  stage_one(0, std::integral_constant<int, 4>{});
+  stage_one(0, std::integral_constant<int, 5>{});
+  __syncthreads();
+
+  auto chunk_body = [&](int buf, auto more_tag) {
+    constexpr bool MORE = decltype(more_tag)::value;
+    const float* Ab = As + buf * WN_A_ST + (4 * kh) * BM + wave * 32 + li;
+    const float* Bb = Bs + buf * WN_B_ST + (kh * WN_SLP + 2 * li) * 4;
+    float4 d[2][4];
+    float a[4][4];
+#if defined(TSPN_ABLATE_NOLDS)
+    for (int qb = 0; qb < 2; ++qb) for (int pos = 0; pos < 4; ++pos) d[qb][pos] = make_float4(1.f + pos, 2.f, 3.f * kh, 4.f);
+    for (int j = 0; j < 4; ++j) for (int e = 0; e < 4; ++e) a[j][e] = 0.25f * (j + e);
+    asm volatile("" : "+v"(d[0][0].x), "+v"(a[0][0]));
+#else
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+      for (int pos = 0; pos < 4; ++pos)
+        d[qb][pos] = *reinterpret_cast<const float4*>(Bb + (qb * 64 + pos) * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[j][e] = Ab[(j * WN_KC + e) * BM];
+#endif
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        const float* d0p = reinterpret_cast<const float*>(&d[qb][0]);
+        const float* d1p = reinterpret_cast<const float*>(&d[qb][1]);
+        const float* d2p = reinterpret_cast<const float*>(&d[qb][2]);
+        const float* d3p = reinterpret_cast<const float*>(&d[qb][3]);
+        const float d0 = mask0[qb] ? d0p[e] : 0.f;
+        const float d1 = d1p[e], d2 = d2p[e];
+        const float d3 = mask3[qb] ? d3p[e] : 0.f;
+        const float v0 = d0 - d2, v1 = d1 + d2, v2 = d2 - d1, v3 = d1 - d3;
+        acc[0][qb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][e], v0, acc[0][qb], 0, 0, 0);
+        acc[1][qb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][e], v1, acc[1][qb], 0, 0, 0);
+        acc[2][qb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2][e], v2, acc[2][qb], 0, 0, 0);
+        acc[3][qb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3][e], v3, acc[3][qb], 0, 0, 0);
+        if (MORE) {
+          if (e == 0 && qb == 0) stage_one(buf ^ 1, std::integral_constant<int, 0>{});
+          if (e == 0 && qb == 1) stage_one(buf ^ 1, std::integral_constant<int, 1>{});
+          if (e == 1 && qb == 0) stage_one(buf ^ 1, std::integral_constant<int, 2>{});
+          if (e == 1 && qb == 1) stage_one(buf ^ 1, std::integral_constant<int, 3>{});
+          if (e == 2 && qb == 0) stage_one(buf ^ 1, std::integral_constant<int, 4>{});
+          if (e == 2 && qb == 1) stage_one(buf ^ 1, std::integral_constant<int, 5>{});
+        }
+      }
+    }
+#if !defined(TSPN_WINO_NOSCHED)
+    // Issue pattern: the fragments of (e = 0, first pair block) up front, then behind every MFMA
+    // one LDS read, two VALU (Winograd input transform / masks) and, every fourth, a DMA piece.
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#define TSPN_G(NVM)                                     \
+  __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);    \
+  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    \
+  __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    \
+  __builtin_amdgcn_sched_group_barrier(0x020, NVM, 0);
+    TSPN_G(0) TSPN_G(0) TSPN_G(0) TSPN_G(1) TSPN_G(0) TSPN_G(0) TSPN_G(0) TSPN_G(1)
+    TSPN_G(0) TSPN_G(0) TSPN_G(0) TSPN_G(1) TSPN_G(0) TSPN_G(0) TSPN_G(0) TSPN_G(1)
+    TSPN_G(0) TSPN_G(0) TSPN_G(0) TSPN_G(1) TSPN_G(0) TSPN_G(0) TSPN_G(0) TSPN_G(1)
+    TSPN_G(0) TSPN_G(0) TSPN_G(0) TSPN_G(0) TSPN_G(0) TSPN_G(0) TSPN_G(0) TSPN_G(0)
+#undef TSPN_G
+#endif
+    __syncthreads();
+  };
+  for (int c = 0; c + 1 < nchunks; ++c) chunk_body(c & 1, std::true_type{});
+  chunk_body((nchunks - 1) & 1, std::false_type{});
+
+  // ---- output transform + store: lane column = frame pair q -> frames (t, t+1), float2 per row
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int64_t n = n0 + 2 * (qb * 32 + li);
+    if (n >= ncols) continue;
+    const int64_t b = n / T;
+    const int64_t t = n - b * T;
+    float* ycol = y + (b * M) * (int64_t)T + t;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = m0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+      if (m < M) {
+        float v0 = acc[0][qb][e] + acc[1][qb][e] + acc[2][qb][e];
+        float v1 = acc[1][qb][e] - acc[2][qb][e] - acc[3][qb][e];
+        if (bias != nullptr) {
+          const float bb = bias[m];
+          v0 += bb;
+          v1 += bb;
+        }
+        if (relu) {
+          v0 = fmaxf(v0, 0.f);
+          v1 = fmaxf(v1, 0.f);
+        }
+        *reinterpret_cast<float2*>(ycol + (int64_t)m * T) = make_float2(v0, v1);
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int tspn_pack_conv3_f32(const float* W, int64_t M, int64_t Cin, int64_t split,
@@ -930,4 +1167,47 @@ extern "C" int tspn_conv3_tc_f32(const float* x, int64_t B, int64_t T, int64_t C
                      CL_SMEM_BYTES, TSPN_STREAM(stream), x, packed, bias, y, (int)Cin, (int)T, (int)M,
                      ncols, (int)tiles_m, (int)tiles_n, relu);
   return tspn::check_launch("tspn_conv3_tc_f32");
+}
+
+
+extern "C" int tspn_pack_conv3_wino_f32(const float* W, int64_t M, int64_t Cin, int64_t split,
+                                        float* packed, void* stream) {
+  TSPN_REQUIRE(W && packed, TSPN_EINVAL, "tspn_pack_conv3_wino_f32: null pointer");
+  TSPN_REQUIRE(M > 0 && Cin > 0 && split >= 0, TSPN_EINVAL, "tspn_pack_conv3_wino_f32: bad sizes");
+  TSPN_REQUIRE(split == 0 || Cin == 2 * split, TSPN_EINVAL,
+               "tspn_pack_conv3_wino_f32: split=%lld requires Cin == 2*split (Cin=%lld)",
+               (long long)split, (long long)Cin);
+  const int64_t total = M * Cin;
+  const int blocks = (int)std::min<int64_t>(tspn::ceil_div(total, 256), 8192);
+  hipLaunchKernelGGL(pack_conv3_wino_kernel, dim3(blocks), dim3(256), 0, TSPN_STREAM(stream), W, M,
+                     Cin, split, packed);
+  return tspn::check_launch("tspn_pack_conv3_wino_f32");
+}
+
+extern "C" int tspn_conv3_tc_wino_f32(const float* x, int64_t B, int64_t T, int64_t Cin,
+                                      const float* packed4, int64_t M, const float* bias, int relu,
+                                      float* y, void* stream) {
+  TSPN_REQUIRE(B >= 0 && Cin > 0 && T > 0 && M > 0, TSPN_EINVAL,
+               "tspn_conv3_tc_wino_f32: bad sizes B=%lld T=%lld Cin=%lld M=%lld", (long long)B,
+               (long long)T, (long long)Cin, (long long)M);
+  if (B == 0) return TSPN_OK;
+  TSPN_REQUIRE(x && packed4 && y, TSPN_EINVAL, "tspn_conv3_tc_wino_f32: null pointer");
+  TSPN_REQUIRE(Cin % WN_KC == 0 && M % 4 == 0 && T % 2 == 0, TSPN_EUNSUPPORTED,
+               "tspn_conv3_tc_wino_f32: needs Cin %% 8 == 0, M %% 4 == 0, T even (Cin=%lld M=%lld T=%lld)",
+               (long long)Cin, (long long)M, (long long)T);
+  TSPN_REQUIRE((reinterpret_cast<uintptr_t>(packed4) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(y) & 7) == 0,
+               TSPN_EUNSUPPORTED, "tspn_conv3_tc_wino_f32: x/packed must be 16-byte, y 8-byte aligned");
+  TSPN_REQUIRE(Cin < (1 << 24) && T < (1 << 24) && M < (1 << 24), TSPN_EUNSUPPORTED,
+               "tspn_conv3_tc_wino_f32: dimension too large");
+  const int64_t ncols = B * T;
+  const int64_t tiles_m = tspn::ceil_div(M, BM);
+  const int64_t tiles_n = tspn::ceil_div(ncols, BN);
+  TSPN_REQUIRE(tiles_m * tiles_n < (1LL << 31), TSPN_EUNSUPPORTED,
+               "tspn_conv3_tc_wino_f32: grid too large");
+  hipLaunchKernelGGL(conv3_wino_cl_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(THREADS),
+                     WN_SMEM_BYTES, TSPN_STREAM(stream), x, packed4, bias, y, (int)Cin, (int)T, (int)M,
+                     ncols, (int)tiles_m, (int)tiles_n, relu);
+  return tspn::check_launch("tspn_conv3_tc_wino_f32");
 }

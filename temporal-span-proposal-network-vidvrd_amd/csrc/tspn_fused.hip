@@ -97,10 +97,17 @@ extern "C" int tspn_forward_fused_f32(const tspn_fused_desc* d, void* stream) {
   // through a transpose to channels-first [NT,D,T] and the general kernel.
   const bool tc = (D % 16 == 0) && ((reinterpret_cast<uintptr_t>(d->feats) & 15) == 0) &&
                   ((reinterpret_cast<uintptr_t>(d->conv_packed) & 15) == 0);
+  TSPN_REQUIRE(d->conv_algo == 0 || d->conv_algo == 1, TSPN_EINVAL,
+               "tspn_forward_fused: conv_algo must be 0 or 1");
+  TSPN_REQUIRE(d->conv_algo == 0 || (tc && T % 2 == 0), TSPN_EUNSUPPORTED,
+               "tspn_forward_fused: conv_algo 1 (Winograd) needs T even, D %% 16 == 0, aligned operands");
   if (!tc && (rc = tspn_transpose_td_f32(d->feats, NT, T, D, xt, stream))) return rc;
   if (d->ev_conv_begin) (void)hipEventRecord(static_cast<hipEvent_t>(d->ev_conv_begin), s);
-  rc = tc ? tspn_conv3_tc_f32(d->feats, NT, T, D, d->conv_packed, 2 * C, bias2, 0, y, stream)
-          : tspn_conv3_f32(xt, NT, D, T, d->conv_packed, 2 * C, bias2, 0, y, stream);
+  if (d->conv_algo == 1)
+    rc = tspn_conv3_tc_wino_f32(d->feats, NT, T, D, d->conv_packed, 2 * C, bias2, 0, y, stream);
+  else
+    rc = tc ? tspn_conv3_tc_f32(d->feats, NT, T, D, d->conv_packed, 2 * C, bias2, 0, y, stream)
+            : tspn_conv3_f32(xt, NT, D, T, d->conv_packed, 2 * C, bias2, 0, y, stream);
   if (rc) return rc;
   if (d->ev_conv_end) (void)hipEventRecord(static_cast<hipEvent_t>(d->ev_conv_end), s);
   // 3. pair stage + relationness / span heads

@@ -254,9 +254,14 @@ class DPN(nn.Module):
         return self._cache.get("conv_dense", (c.weight, c.bias), dev,
                                lambda ts: (ops.pack_conv3(ts[0]), ts[1]))
 
-    def _conv_split(self, dev):
+    def _conv_split(self, dev, winograd=False):
+        """Packed weights of the factorised pair form (subject / object halves stacked along M);
+        `winograd` selects the F(2,3) packing used when T is even and D % 16 == 0."""
         c = self.dpn_head.conv
         half = self.dpn_head.in_channels // 2
+        if winograd:
+            return self._cache.get("conv_split_wino", (c.weight, c.bias), dev,
+                                   lambda ts: (ops.pack_conv3_wino(ts[0], split=half), ts[1]))
         return self._cache.get("conv_split", (c.weight, c.bias), dev,
                                lambda ts: (ops.pack_conv3(ts[0], split=half), ts[1]))
 
@@ -381,7 +386,6 @@ class BaseModel(nn.Module):
         if cls.in_features != 2 * d_feat:
             raise ValueError(f"PREDICT.FEATURE_DIM must equal 2*D = {2 * d_feat} on the temporal path "
                              f"(got {cls.in_features})")
-        packed, cbias = dpn._conv_split(dev)
         hw, hb = dpn._head_weights(dev)
         cw, cb = self.classifier._cache.get("cls", (cls.weight, cls.bias), dev, lambda ts: ts)
 
@@ -425,6 +429,7 @@ class BaseModel(nn.Module):
                     pairs.append(p.to(dev) + k * n)
             counts = [p.shape[0] for p in pairs]
             allp = torch.cat(pairs).contiguous()
+            packed, cbias = dpn._conv_split(dev, winograd=(t % 2 == 0 and d % 16 == 0))
             heads, lg = ops.forward_fused(feats, allp, len(members), n, packed, cbias, hw, hb, cw, cb,
                                           check_pairs=False, canonical_pairs=canonical)
             off = 0

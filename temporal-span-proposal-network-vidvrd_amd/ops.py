@@ -13,7 +13,7 @@ from . import _abi
 
 __all__ = [
     "predicate_head", "feature_preprocess_", "ppn_pair_matrix_topk", "traj_iou", "pair_index",
-    "pair_gather", "pack_conv3", "conv3", "conv3_tc", "heads", "heads_pairgrid", "temporal_mean", "pair_rows", "transpose_td",
+    "pair_gather", "pack_conv3", "conv3", "conv3_tc", "pack_conv3_wino", "conv3_tc_wino", "heads", "heads_pairgrid", "temporal_mean", "pair_rows", "transpose_td",
     "forward_fused", "temporal_encoder_heads", "fused_workspace_bytes", "decode_topk", "decode_spans",
 ]
 
@@ -208,6 +208,33 @@ def conv3_tc(x, packed, bias=None, relu=False):
     return y
 
 
+def pack_conv3_wino(weight, split=0):
+    """nn.Conv1d weight [M,Cin,3] -> Winograd F(2,3) layout [4][Cin'][M'] (tspn_pack_conv3_wino_f32)."""
+    _dev(weight, "conv weight")
+    if weight.dim() != 3 or weight.shape[2] != 3:
+        raise ValueError("pack_conv3_wino: weight must be [M,Cin,3]")
+    M, Cin, _ = weight.shape
+    shape = (4, split, 2 * M) if split else (4, Cin, M)
+    packed = torch.empty(shape, dtype=torch.float32, device=weight.device)
+    _abi.check(_abi.lib().tspn_pack_conv3_wino_f32(_p(weight), M, Cin, split, _p(packed), _stream()))
+    return packed
+
+
+def conv3_tc_wino(x, packed4, bias=None, relu=False):
+    """Winograd F(2,3) conv3 on channels-last x[B,T,Cin] -> y[B,M,T]; needs T even, Cin % 8 == 0."""
+    _dev(x, "x"); _dev(packed4, "packed4")
+    if bias is not None:
+        _dev(bias, "bias")
+    B, T, Cin = x.shape
+    if packed4.dim() != 3 or packed4.shape[0] != 4 or packed4.shape[1] != Cin:
+        raise ValueError(f"conv3_tc_wino: packed weights {tuple(packed4.shape)} do not match Cin={Cin}")
+    M = packed4.shape[2]
+    y = torch.empty((B, M, T), dtype=torch.float32, device=x.device)
+    _abi.check(_abi.lib().tspn_conv3_tc_wino_f32(_p(x), B, T, Cin, _p(packed4), M, _p(bias),
+                                                 1 if relu else 0, _p(y), _stream()))
+    return y
+
+
 def heads(a, head_w, head_b, b=None, ia=None, ib=None, bias=None, channels=None, num_pairs=None):
     """out[P,H,T] = head_b + head_w @ h_p; h_p = a[ia[p]] (dense) or relu(a[ia[p]] + b[ib[p]] + bias)."""
     _dev(a, "a"); _dev(head_w, "head_w")
@@ -358,8 +385,9 @@ def _fused_desc(feats, pairs, B, N, conv_packed, conv_bias, head_w, head_b, cls_
     H = head_w.shape[0]
     if H % 3 or head_w.shape[1] != C or head_b.shape != (H,):
         raise ValueError("forward_fused: head_w must be [3A, 2D]")
-    if tuple(conv_packed.shape) != (3, D, 2 * C) or conv_bias.shape != (C,):
-        raise ValueError(f"forward_fused: conv_packed must be [3, D={D}, 4D={2 * C}] (pack_conv3(w, split=D))")
+    if tuple(conv_packed.shape) not in ((3, D, 2 * C), (4, D, 2 * C)) or conv_bias.shape != (C,):
+        raise ValueError(f"forward_fused: conv_packed must be [3 or 4, D={D}, 4D={2 * C}] "
+                         "(pack_conv3(w, split=D) or pack_conv3_wino(w, split=D))")
     if cls_w.dim() != 2 or cls_w.shape[1] != C or cls_b.shape != (cls_w.shape[0],):
         raise ValueError("forward_fused: cls_w must be [K, 2D]")
     d = _abi.FusedDesc()
@@ -367,6 +395,7 @@ def _fused_desc(feats, pairs, B, N, conv_packed, conv_bias, head_w, head_b, cls_
     d.A, d.K = H // 3, cls_w.shape[0]
     d.feats, d.pairs, d.P = feats.data_ptr(), pairs.data_ptr(), pairs.shape[0]
     d.conv_packed, d.conv_bias = conv_packed.data_ptr(), conv_bias.data_ptr()
+    d.conv_algo = 1 if conv_packed.shape[0] == 4 else 0  # Winograd F(2,3) packing has 4 matrices
     d.head_w, d.head_b = head_w.data_ptr(), head_b.data_ptr()
     d.cls_w, d.cls_b = cls_w.data_ptr(), cls_b.data_ptr()
     return d

@@ -215,6 +215,40 @@ def test_conv3_channels_last_vs_fp64(tspn, device, B, Cin, T, M, relu):
     np.testing.assert_allclose(y.cpu().numpy(), y2.cpu().numpy(), rtol=0, atol=1e-5)
 
 
+@pytest.mark.parametrize("B,Cin,T,M", [(1, 8, 2, 4), (3, 16, 30, 128), (5, 24, 34, 132), (7, 64, 150, 64),
+                                       (2, 144, 258, 260), (40, 32, 30, 36)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_conv3_winograd_vs_fp64(tspn, device, B, Cin, T, M, relu):
+    """Winograd F(2,3) kernel == the conv (fp64 reference); error stays within a few 1e-6."""
+    x = tspn.hashrng.uniform(46, "x", (B, T, Cin), -1, 1)
+    w = tspn.hashrng.normal(46, "w", (M, Cin, 3), std=0.1)
+    b = tspn.hashrng.normal(46, "b", (M,), std=0.1)
+    p4 = tspn.ops.pack_conv3_wino(t(w).to(device))
+    g = w.astype(np.float64).transpose(2, 1, 0)  # [3][Cin][M]
+    u = np.stack([g[0], 0.5 * (g[0] + g[1] + g[2]), 0.5 * (g[0] - g[1] + g[2]), g[2]]).astype(np.float32)
+    np.testing.assert_array_equal(p4.cpu().numpy(), u)
+    y = tspn.ops.conv3_tc_wino(t(x).to(device), p4, t(b).to(device), relu=relu)
+    ref = conv_ref(np.ascontiguousarray(x.transpose(0, 2, 1)), w, b, relu)
+    np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=0, atol=3e-5)
+    if Cin % 16 == 0:
+        y2 = tspn.ops.conv3_tc(t(x).to(device), tspn.ops.pack_conv3(t(w).to(device)), t(b).to(device), relu=relu)
+        np.testing.assert_allclose(y.cpu().numpy(), y2.cpu().numpy(), rtol=0, atol=2e-5)
+
+
+def test_conv3_winograd_exact_integers_and_limits(tspn, device):
+    """Exact-integer operands: the F(2,3) transforms (incl. the 1/2 factors) are exact, so the
+    result must equal the direct conv bit for bit; odd T is rejected."""
+    B, C, T = 2, 32, 70
+    x = ((np.arange(B * T * C, dtype=np.float32).reshape(B, T, C) * 7) % 23) - 11.0
+    w = (((np.arange(C * C * 3, dtype=np.float32).reshape(C, C, 3) * 5) % 9) - 4.0) * 2.0
+    y = tspn.ops.conv3_tc_wino(t(x).to(device), tspn.ops.pack_conv3_wino(t(w).to(device)), None).cpu().numpy()
+    ref = conv_ref(np.ascontiguousarray(x.transpose(0, 2, 1)), w, None, False)
+    np.testing.assert_array_equal(y, ref)
+    with pytest.raises(tspn._abi.TspnError) as e:
+        tspn.ops.conv3_tc_wino(torch.zeros(2, 31, 16, device=device), torch.zeros(4, 16, 8, device=device))
+    assert e.value.code == tspn._abi.TSPN_EUNSUPPORTED
+
+
 def test_conv3_channels_last_rejects_ragged(tspn, device):
     with pytest.raises(tspn._abi.TspnError) as e:
         tspn.ops.conv3_tc(torch.zeros(2, 5, 20, device=device), torch.zeros(3, 20, 8, device=device))
