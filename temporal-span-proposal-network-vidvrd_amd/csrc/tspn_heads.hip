@@ -160,17 +160,27 @@ constexpr int PG_STAGE = PG_ROWS * PG_CK * PG_T;  // floats per LDS buffer (32 K
 template <bool VEC2>
 __global__ __launch_bounds__(256, 2) void heads_pairgrid_kernel(
     const float* __restrict__ y, int C, int T, int N, const float* __restrict__ Wh,
-    const float* __restrict__ bh, int H, float* __restrict__ out, int ntb, int nob) {
+    const float* __restrict__ bh, int H, float* __restrict__ out, int ntb, int nob, int nsb,
+    int64_t ngroups) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* S = reinterpret_cast<float*>(smem_raw);  // [2][16 rows][16 ch][32 t]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, kq = lane >> 4;
-  const int tb = blockIdx.x % ntb;
-  const int ob = (blockIdx.x / ntb) % nob;
-  const int sb = blockIdx.x / (ntb * nob);
-  const int64_t b = blockIdx.y;
+  // Workgroup -> (video, frame block, subject block, object block).  The nsb*nob workgroups of
+  // one (video, frame block) group read the same tracklet rows and walk the channels in step, so
+  // they are placed on ONE XCD (ids congruent mod 8 share an XCD) and dispatched back to back:
+  // each row chunk then comes from HBM once and from that XCD's L2 for the other blocks.
+  const int per_group = nsb * nob;
+  const int id = blockIdx.x;
+  const int xcd = id & 7, k = id >> 3;
+  const int64_t G = (int64_t)(k / per_group) * 8 + xcd;
+  if (G >= ngroups) return;  // uniform per workgroup, before any barrier
+  const int member = k % per_group;
+  const int sb = member / nob, ob = member - sb * nob;
+  const int64_t b = G / ntb;
+  const int tb = (int)(G - b * ntb);
   const int t0 = tb * PG_T;
   const int64_t rowlen = 2 * (int64_t)C * T;  // floats per tracklet row of y
 
@@ -236,7 +246,9 @@ __global__ __launch_bounds__(256, 2) void heads_pairgrid_kernel(
   for (int c = 0; c < nchunks; ++c) {
     const int buf = c & 1;
     const int c0 = c * PG_CK;
+#if !defined(TSPN_ABLATE_NOSTAGE)
     if (c + 1 < nchunks) load_chunk(c0 + PG_CK);
+#endif
     const float* Sb = S + buf * PG_STAGE + 2 * j;
 #pragma unroll
     for (int ks = 0; ks < PG_CK / 4; ++ks) {
@@ -254,17 +266,23 @@ __global__ __launch_bounds__(256, 2) void heads_pairgrid_kernel(
       for (int si = 0; si < 2; ++si)
 #pragma unroll
         for (int oj = 0; oj < PG_O; ++oj) {
+#if defined(TSPN_ABLATE_NOVALU)
+          const float h0 = v[oj].x, h1 = u[si].y;
+#else
           const float h0 = fmaxf(u[si].x + v[oj].x, 0.f);
           const float h1 = fmaxf(u[si].y + v[oj].y, 0.f);
+#endif
           acc[si][oj][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, h0, acc[si][oj][0], 0, 0, 0);
           acc[si][oj][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, h1, acc[si][oj][1], 0, 0, 0);
         }
     }
+#if !defined(TSPN_ABLATE_NOSTAGE)
     if (c + 1 < nchunks) {
       store_chunk(buf ^ 1);
 #pragma unroll
       for (int ks = 0; ks < PG_CK / 4; ++ks) wa[ks] = wreg[ks];
     }
+#endif
     __syncthreads();
   }
 
@@ -348,7 +366,6 @@ extern "C" int tspn_heads_pairgrid_f32(const float* y, int64_t B, int64_t N, int
                "tspn_heads_pairgrid_f32: dim too large");
   if (B == 0 || N < 2) return TSPN_OK;
   TSPN_REQUIRE(y && Wh && out, TSPN_EINVAL, "tspn_heads_pairgrid_f32: null pointer");
-  TSPN_REQUIRE(B < 65536, TSPN_EUNSUPPORTED, "tspn_heads_pairgrid_f32: B too large");
   const bool vec2 = (T % 2 == 0) && ((reinterpret_cast<uintptr_t>(y) & 7) == 0) &&
                     ((reinterpret_cast<uintptr_t>(out) & 7) == 0);
   const int ntb = (int)tspn::ceil_div(T, PG_T);
@@ -364,8 +381,10 @@ extern "C" int tspn_heads_pairgrid_f32(const float* y, int64_t B, int64_t N, int
                         hipGetErrorString(e));
     attr_set[vec2] = true;
   }
-  dim3 grid((unsigned)(ntb * nob * nsb), (unsigned)B);
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, TSPN_STREAM(stream), y, (int)C, (int)T, (int)N, Wh,
-                     bh, (int)H, out, ntb, nob);
+  const int64_t ngroups = B * ntb;
+  const int64_t nwg = tspn::ceil_div(ngroups, 8) * 8 * nsb * nob;
+  TSPN_REQUIRE(nwg < (1LL << 31), TSPN_EUNSUPPORTED, "tspn_heads_pairgrid_f32: grid too large");
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), smem, TSPN_STREAM(stream), y, (int)C, (int)T,
+                     (int)N, Wh, bh, (int)H, out, ntb, nob, nsb, ngroups);
   return tspn::check_launch("tspn_heads_pairgrid_f32");
 }
