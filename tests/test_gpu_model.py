@@ -233,3 +233,29 @@ def test_decode_spans_from_forward(tspn, device):
     for k in ("count", "anchor", "span"):
         np.testing.assert_array_equal(spans[k].numpy(), ref[k].numpy(), err_msg=k)
     assert spans["span"].shape == (N * (N - 1), 64, 2) and int(spans["count"].min()) >= 1
+
+
+@pytest.mark.parametrize("n,tt,d", [(1, 30, 16), (2, 1, 16), (3, 7, 10), (2, 30, 16), (9, 31, 32), (9, 30, 24)])
+def test_temporal_forward_edge_shapes(tspn, device, n, tt, d):
+    """Ragged / degenerate segments through every dispatch of the fused path: a single tracklet (no
+    pairs), one frame, odd T (direct conv instead of Winograd), D not a multiple of 16 (transpose +
+    general conv kernel), D % 16 == 8."""
+    sd = tspn.synth.make_weights(0, c=2 * d, bias_std=0.05)
+    model = tspn.BaseModel(temporal_cfg(d))
+    load(model, sd)
+    model.eval()
+    v = tspn.synth.make_video(95, n, tt, d)
+    pl = tspn.PairList.from_tracklets(t(v["tracklet_feats"]), t(v["tracklet_boxes"]), t(v["track_cls_logits"]))
+    pp, dp, logits = model([pl], None)
+    p = n * (n - 1)
+    assert logits[0].shape == (p, 132) and dp[0].relness.shape == (p, 4, tt) and pp[0].shape == (min(256, n * n),)
+    if p:
+        ref = oracle.forward_dense(t(v["tracklet_feats"]), t(v["tracklet_boxes"]), oracle.pair_index(n),
+                                   oracle_weights(sd))
+        np.testing.assert_allclose(dp[0].relness.numpy(), ref["relness"].numpy(), rtol=0, atol=1e-5)
+        np.testing.assert_allclose(dp[0].duration.numpy(), ref["duration"].numpy(), rtol=0, atol=1e-5)
+        np.testing.assert_allclose(logits[0].numpy(), ref["rel_logits"].numpy(), rtol=0, atol=1e-5)
+        spans = model.decode_spans(dp)[0]
+        assert spans["span"].shape[0] == p
+    dec = model.decode([pl], logits)[0]
+    assert dec[0].shape[0] == (min(200, p * 20) if n > 1 else 0)
