@@ -62,6 +62,19 @@ int tspn_predicate_head_f32(const float* x, int64_t P, int64_t F, int64_t ldx,
                             float* out, int apply_sigmoid,
                             void* workspace, size_t workspace_bytes, void* stream);
 
+/* f2 — a15 folded into a2: same as tspn_predicate_head_f32 on RAW features, with the block-L1
+ * normalisation of VRDataset._feature_preprocess (lib/dataset/vrdataset.py:219-243) applied on the
+ * fly: columns [first + k*block, first + (k+1)*block), k < nblocks, of every row are divided by their
+ * L1 norm (0 -> 1).  Split-K slices never straddle a block, each returns sum|x| per row, and the
+ * ordered reduce divides — x is read once and never rewritten.                                    */
+size_t tspn_predicate_head_norm_workspace_bytes(int64_t P, int64_t F, int64_t K, int64_t first,
+                                                int64_t block, int64_t nblocks);
+int tspn_predicate_head_norm_f32(const float* x, int64_t P, int64_t F, int64_t ldx,
+                                 const float* W, const float* b, int64_t K,
+                                 int64_t first, int64_t block, int64_t nblocks,
+                                 float* out, int apply_sigmoid,
+                                 void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- a15: block-L1 feature preprocessing --------------------------------
  * Replaces VRDataset._feature_preprocess (lib/dataset/vrdataset.py:219-243,
  * lib/utils/miscellaneous.py:32-35), in place on feats[P, ld>=F].           */

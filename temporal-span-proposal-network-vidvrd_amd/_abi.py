@@ -52,6 +52,9 @@ PROTOTYPES = {
     "tspn_error_string": (ctypes.c_char_p, [_int]),
     "tspn_predicate_head_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "tspn_predicate_head_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _int, _vp, _sz, _vp]),
+    "tspn_predicate_head_norm_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _i64, _i64]),
+    "tspn_predicate_head_norm_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _int,
+                                            _vp, _sz, _vp]),
     "tspn_feature_preprocess_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp]),
     "tspn_ppn_pair_matrix_topk_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _i64,
                                              _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,

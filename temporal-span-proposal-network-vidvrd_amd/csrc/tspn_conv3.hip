@@ -635,7 +635,6 @@ constexpr int CL_SLP = 132;                        // padded column slots per ch
 constexpr int CL_A_ST = 3 * CL_KC * BM;            // floats
 constexpr int CL_B_ST = CL_NG * CL_SLP * 4;        // floats
 constexpr int CL_UNITS = CL_NG * CL_SLP;           // 16-B units per x tile (incl. padding)
-constexpr int CL_BPIECES = (CL_UNITS + 63) / 64;   // 9
 constexpr size_t CL_SMEM_BYTES = sizeof(float) * 2 * (CL_A_ST + CL_B_ST);
 
 __global__ __launch_bounds__(THREADS, 2) void conv3_mfma_cl_kernel(
@@ -857,7 +856,6 @@ constexpr int WN_SLP = 132;
 constexpr int WN_A_ST = 4 * WN_KC * BM;        // floats: [4 j][8 ch][128 m]
 constexpr int WN_B_ST = 2 * WN_SLP * 4;        // floats: [2 groups][132 slots][4 ch]
 constexpr int WN_UNITS = 2 * WN_SLP;
-constexpr int WN_BPIECES = (WN_UNITS + 63) / 64;  // 5
 constexpr size_t WN_SMEM_BYTES = sizeof(float) * 2 * (WN_A_ST + WN_B_ST);
 
 __global__ void pack_conv3_wino_kernel(const float* __restrict__ W, int64_t M, int64_t Cin,

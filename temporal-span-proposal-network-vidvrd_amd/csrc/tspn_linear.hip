@@ -28,9 +28,23 @@ constexpr int LDS_STRIDE = KC + 2;  // 34: (2*row + k) % 32 -> conflict-free fra
 constexpr int THREADS = 256;
 constexpr int MAX_SPLIT = 64;
 
+// f2 (fused a15): K-ranges of the split-K slices when the block-L1 preprocessing of
+// VRDataset._feature_preprocess (reference lib/dataset/vrdataset.py:219-243) is folded into the GEMM:
+// slices never straddle a normalisation block, each slice also returns sum|x| per row, and the
+// reduce kernel divides the slices of a block by that block's L1 norm — x is read exactly once.
+constexpr int MAX_NORM_SPLITS = 128;
+struct SplitTable {
+  int n;
+  int kbeg[MAX_NORM_SPLITS];
+  int kend[MAX_NORM_SPLITS];
+  short blk[MAX_NORM_SPLITS];  // normalisation block id, -1 = not normalised
+};
+
+template <bool NORM>
 __global__ __launch_bounds__(THREADS) void linear_splitk_kernel(
     const float* __restrict__ x, int64_t P, int64_t F, int64_t ldx, const float* __restrict__ W,
-    int64_t K, int64_t k_per_split, float* __restrict__ partial) {
+    int64_t K, int64_t k_per_split, float* __restrict__ partial, SplitTable tab,
+    float* __restrict__ norm_partial) {
   __shared__ float xs[TM * LDS_STRIDE];
   __shared__ float wsm[TN * LDS_STRIDE];
 
@@ -39,8 +53,17 @@ __global__ __launch_bounds__(THREADS) void linear_splitk_kernel(
   const int li = lane & 15, kq = lane >> 4;
   const int64_t row0 = (int64_t)blockIdx.x * TM;
   const int64_t col0 = (int64_t)blockIdx.y * TN;
-  const int64_t kbeg = (int64_t)blockIdx.z * k_per_split;
-  const int64_t kend = (kbeg + k_per_split < F) ? kbeg + k_per_split : F;
+  int64_t kbeg, kend;
+  if (NORM) {
+    kbeg = tab.kbeg[blockIdx.z];
+    kend = tab.kend[blockIdx.z];
+  } else {
+    kbeg = (int64_t)blockIdx.z * k_per_split;
+    kend = (kbeg + k_per_split < F) ? kbeg + k_per_split : F;
+  }
+  float asum[TM / 8];
+#pragma unroll
+  for (int r = 0; r < TM / 8; ++r) asum[r] = 0.f;
 
   f32x4 acc[NBLK];
 #pragma unroll
@@ -58,7 +81,9 @@ __global__ __launch_bounds__(THREADS) void linear_splitk_kernel(
     for (int r = 0; r < TM / 8; ++r) {
       const int row = lr + 8 * r;
       const int64_t gr = row0 + row;
-      xs[row * LDS_STRIDE + lk] = (kv && gr < P) ? x[gr * ldx + k] : 0.f;
+      const float xv = (kv && gr < P) ? x[gr * ldx + k] : 0.f;
+      xs[row * LDS_STRIDE + lk] = xv;
+      if (NORM) asum[r] += fabsf(xv);
     }
 #pragma unroll
     for (int r = 0; r < TN / 8; ++r) {
@@ -79,6 +104,16 @@ __global__ __launch_bounds__(THREADS) void linear_splitk_kernel(
     __syncthreads();
   }
 
+  if (NORM && blockIdx.y == 0) {  // sum|x| of this slice per row: 32 lanes share a row
+#pragma unroll
+    for (int r = 0; r < TM / 8; ++r) {
+      float a = asum[r];
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) a += __shfl_xor(a, off);
+      const int64_t gr = row0 + lr + 8 * r;
+      if (lk == 0 && gr < P) norm_partial[(int64_t)blockIdx.z * P + gr] = a;
+    }
+  }
   // C/D layout: column = lane&15, row = (lane>>4)*4 + reg
   float* dst = partial + (int64_t)blockIdx.z * P * K;
 #pragma unroll
@@ -104,6 +139,64 @@ __global__ void linear_reduce_kernel(const float* __restrict__ partial, int64_t 
     if (apply_sigmoid) s = 1.f / (1.f + expf(-s));
     out[i] = s;
   }
+}
+
+__global__ void linear_reduce_norm_kernel(const float* __restrict__ partial,
+                                          const float* __restrict__ norm_partial, int64_t P,
+                                          int64_t K, SplitTable tab, const float* __restrict__ b,
+                                          int apply_sigmoid, float* __restrict__ out) {
+  const int64_t PK = P * K;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < PK;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / K;
+    float s = 0.f;
+    int z = 0;
+    while (z < tab.n) {  // slices of one block are contiguous in the table
+      const int blk = tab.blk[z];
+      float acc = 0.f, l1 = 0.f;
+      int z2 = z;
+      for (; z2 < tab.n && tab.blk[z2] == blk; ++z2) {
+        acc += partial[(int64_t)z2 * PK + i];
+        if (blk >= 0) l1 += norm_partial[(int64_t)z2 * P + row];
+      }
+      if (blk >= 0) acc = acc / (l1 == 0.f ? 1.f : l1);
+      s += acc;
+      z = z2;
+    }
+    if (b != nullptr) s += b[i % K];
+    if (apply_sigmoid) s = 1.f / (1.f + expf(-s));
+    out[i] = s;
+  }
+}
+
+// host: slice table for the fused-normalisation form
+int build_split_table(int64_t P, int64_t F, int64_t K, int64_t first, int64_t block, int64_t nblocks,
+                      SplitTable* tab) {
+  const int64_t tiles = tspn::ceil_div(P, TM) * tspn::ceil_div(K, TN);
+  int64_t target = std::min<int64_t>(std::max<int64_t>(tspn::ceil_div(512, tiles), 1), 64);
+  const int64_t len = std::max<int64_t>(tspn::ceil_div(tspn::ceil_div(F, target), KC) * KC, 2 * KC);
+  int n = 0;
+  auto add_region = [&](int64_t lo, int64_t hi, int blk) {
+    if (hi <= lo) return true;
+    const int64_t pieces = tspn::ceil_div(hi - lo, len);
+    const int64_t step = tspn::ceil_div(tspn::ceil_div(hi - lo, pieces), KC) * KC;
+    for (int64_t k = lo; k < hi; k += step) {
+      if (n >= MAX_NORM_SPLITS) return false;
+      tab->kbeg[n] = (int)k;
+      tab->kend[n] = (int)std::min<int64_t>(k + step, hi);
+      tab->blk[n] = (short)blk;
+      ++n;
+    }
+    return true;
+  };
+  bool ok = add_region(0, first, -1);
+  for (int64_t bl = 0; ok && bl < nblocks; ++bl)
+    ok = add_region(first + bl * block, first + (bl + 1) * block, (int)bl);
+  // the unnormalised tail must not be merged with the head region (-1) by the reduce loop: it is not
+  // adjacent to it in the table, and runs of equal ids are only merged when contiguous, which is fine
+  ok = ok && add_region(first + nblocks * block, F, -1);
+  tab->n = n;
+  return ok ? n : -1;
 }
 
 int choose_splits(int64_t P, int64_t F, int64_t K) {
@@ -141,8 +234,9 @@ extern "C" int tspn_predicate_head_f32(const float* x, int64_t P, int64_t F, int
                "tspn_predicate_head_f32: grid too large");
   hipStream_t s = TSPN_STREAM(stream);
   float* partial = static_cast<float*>(workspace);
-  hipLaunchKernelGGL(linear_splitk_kernel, dim3((unsigned)gx, (unsigned)gy, (unsigned)splits),
-                     dim3(THREADS), 0, s, x, P, F, ldx, W, K, kps, partial);
+  hipLaunchKernelGGL(linear_splitk_kernel<false>, dim3((unsigned)gx, (unsigned)gy, (unsigned)splits),
+                     dim3(THREADS), 0, s, x, P, F, ldx, W, K, kps, partial, SplitTable{},
+                     (float*)nullptr);
   int rc = tspn::check_launch("tspn_predicate_head_f32(splitk)");
   if (rc) return rc;
   const int64_t PK = P * K;
@@ -150,4 +244,55 @@ extern "C" int tspn_predicate_head_f32(const float* x, int64_t P, int64_t F, int
   hipLaunchKernelGGL(linear_reduce_kernel, dim3(blocks), dim3(256), 0, s, partial, PK, K, splits,
                      b, apply_sigmoid, out);
   return tspn::check_launch("tspn_predicate_head_f32(reduce)");
+}
+
+
+extern "C" size_t tspn_predicate_head_norm_workspace_bytes(int64_t P, int64_t F, int64_t K,
+                                                           int64_t first, int64_t block,
+                                                           int64_t nblocks) {
+  if (P <= 0 || F <= 0 || K <= 0 || first < 0 || block <= 0 || nblocks < 0 ||
+      first + block * nblocks > F)
+    return 0;
+  SplitTable tab;
+  const int n = build_split_table(P, F, K, first, block, nblocks, &tab);
+  if (n < 0) return 0;
+  return (size_t)n * (size_t)P * (size_t)(K + 1) * sizeof(float);
+}
+
+extern "C" int tspn_predicate_head_norm_f32(const float* x, int64_t P, int64_t F, int64_t ldx,
+                                            const float* W, const float* b, int64_t K,
+                                            int64_t first, int64_t block, int64_t nblocks,
+                                            float* out, int apply_sigmoid, void* workspace,
+                                            size_t workspace_bytes, void* stream) {
+  TSPN_REQUIRE(P >= 0 && F > 0 && K > 0 && ldx >= F, TSPN_EINVAL,
+               "tspn_predicate_head_norm_f32: bad sizes P=%lld F=%lld K=%lld ldx=%lld", (long long)P,
+               (long long)F, (long long)K, (long long)ldx);
+  TSPN_REQUIRE(first >= 0 && block > 0 && nblocks >= 0 && first + block * nblocks <= F, TSPN_EINVAL,
+               "tspn_predicate_head_norm_f32: blocks [%lld, %lld) exceed F=%lld", (long long)first,
+               (long long)(first + block * nblocks), (long long)F);
+  TSPN_REQUIRE(F < (1LL << 31) && nblocks < 32768, TSPN_EUNSUPPORTED,
+               "tspn_predicate_head_norm_f32: F or nblocks too large");
+  if (P == 0) return TSPN_OK;
+  TSPN_REQUIRE(x && W && out, TSPN_EINVAL, "tspn_predicate_head_norm_f32: null pointer");
+  SplitTable tab;
+  const int n = build_split_table(P, F, K, first, block, nblocks, &tab);
+  TSPN_REQUIRE(n > 0, TSPN_EUNSUPPORTED, "tspn_predicate_head_norm_f32: more than %d K-slices needed",
+               MAX_NORM_SPLITS);
+  const size_t need = (size_t)n * (size_t)P * (size_t)(K + 1) * sizeof(float);
+  TSPN_REQUIRE(workspace != nullptr && workspace_bytes >= need, TSPN_EWORKSPACE,
+               "tspn_predicate_head_norm_f32: workspace %zu < %zu bytes", workspace_bytes, need);
+  const int64_t gx = tspn::ceil_div(P, TM), gy = tspn::ceil_div(K, TN);
+  TSPN_REQUIRE(gx < (1LL << 31) && gy < 65536, TSPN_EUNSUPPORTED,
+               "tspn_predicate_head_norm_f32: grid too large");
+  hipStream_t s = TSPN_STREAM(stream);
+  float* partial = static_cast<float*>(workspace);
+  float* norm_partial = partial + (size_t)n * P * K;
+  hipLaunchKernelGGL(linear_splitk_kernel<true>, dim3((unsigned)gx, (unsigned)gy, (unsigned)n),
+                     dim3(THREADS), 0, s, x, P, F, ldx, W, K, (int64_t)0, partial, tab, norm_partial);
+  int rc = tspn::check_launch("tspn_predicate_head_norm_f32(splitk)");
+  if (rc) return rc;
+  const int blocks = (int)std::min<int64_t>(tspn::ceil_div(P * K, 256), 4096);
+  hipLaunchKernelGGL(linear_reduce_norm_kernel, dim3(blocks), dim3(256), 0, s, partial, norm_partial,
+                     P, K, tab, b, apply_sigmoid, out);
+  return tspn::check_launch("tspn_predicate_head_norm_f32(reduce)");
 }

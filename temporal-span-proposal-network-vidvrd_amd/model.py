@@ -88,11 +88,17 @@ class _PredicateHeadFn(torch.autograd.Function):
 class RelationPredictor(nn.Module):
     """Predicate-classification head (reference lib/modeling/model.py:76-88)."""
 
-    def __init__(self, in_channels, out_channels):
+    # block-L1 layout of the 11070-d baseline feature (lib/dataset/vrdataset.py:227-236)
+    PREPROCESS_BLOCKS = (70, 1000, 8)
+
+    def __init__(self, in_channels, out_channels, fuse_preprocess=False):
         super().__init__()
         self.rel_predictor = nn.Linear(in_channels, out_channels)
         nn.init.normal_(self.rel_predictor.weight, std=0.01)
         nn.init.constant_(self.rel_predictor.bias, 0)
+        # PREDICT.FUSE_PREPROCESS: features arrive RAW (the DataLoader skips _feature_preprocess) and
+        # the normalisation is folded into the predicate GEMM (SURVEY.md §8 f2); eval only
+        self.fuse_preprocess = bool(fuse_preprocess)
         self._cache = _DeviceCache()
 
     def forward(self, reloi_feats):
@@ -105,7 +111,10 @@ class RelationPredictor(nn.Module):
             out = _PredicateHeadFn.apply(x, w.contiguous(), b.contiguous())
         else:
             wd, bd = self._cache.get("cls", (w, b), dev, lambda ts: ts)
-            out = ops.predicate_head(x, wd, bd, apply_sigmoid=True)
+            first, block, nblocks = self.PREPROCESS_BLOCKS
+            norm = self.PREPROCESS_BLOCKS if (self.fuse_preprocess and x.dim() == 2
+                                              and x.shape[1] >= first + block * nblocks) else None
+            out = ops.predicate_head(x, wd, bd, apply_sigmoid=True, norm=norm)
         return out.to(reloi_feats.device)
 
 
@@ -323,7 +332,8 @@ class BaseModel(nn.Module):
         self.relpn = make_relpn(cfg)
         self.rel_of_interest_pool = RelOIPool()
         self.classifier = RelationPredictor(in_channels=cfg.PREDICT.FEATURE_DIM,
-                                            out_channels=cfg.PREDICT.PREDICATE_NUM)
+                                            out_channels=cfg.PREDICT.PREDICATE_NUM,
+                                            fuse_preprocess=getattr(cfg.PREDICT, "FUSE_PREPROCESS", False))
         self._anchor_sizes_cfg = getattr(cfg.RELPN.DPN, "ANCHOR_SIZES", None)
 
     def forward(self, pair_list, target_list=None):

@@ -44,8 +44,11 @@ def _ws(nbytes, device):
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
-def predicate_head(x, weight, bias, apply_sigmoid=True):
-    """sigmoid(x @ W.T + b) — RelationPredictor.forward (reference lib/modeling/model.py:85-88)."""
+def predicate_head(x, weight, bias, apply_sigmoid=True, norm=None):
+    """sigmoid(x @ W.T + b) — RelationPredictor.forward (reference lib/modeling/model.py:85-88).
+
+    `norm=(first, block, nblocks)`: x holds RAW features and the block-L1 normalisation of
+    VRDataset._feature_preprocess (lib/dataset/vrdataset.py:219-243) is folded into the GEMM."""
     _dev(x, "x"); _dev(weight, "weight")
     if bias is not None:
         _dev(bias, "bias")
@@ -57,6 +60,15 @@ def predicate_head(x, weight, bias, apply_sigmoid=True):
     K = weight.shape[0]
     out = torch.empty((P, K), dtype=torch.float32, device=x.device)
     l = _abi.lib()
+    if norm is not None:
+        first, block, nblocks = (int(v) for v in norm)
+        if first < 0 or block <= 0 or nblocks < 0 or first + block * nblocks > F:
+            raise ValueError(f"predicate_head: normalisation blocks {norm} exceed F={F}")
+        ws = _ws(l.tspn_predicate_head_norm_workspace_bytes(P, F, K, first, block, nblocks), x.device)
+        _abi.check(l.tspn_predicate_head_norm_f32(_p(x), P, F, F, _p(weight), _p(bias), K, first, block,
+                                                  nblocks, _p(out), 1 if apply_sigmoid else 0, _p(ws),
+                                                  ws.numel(), _stream()))
+        return out
     nbytes = l.tspn_predicate_head_workspace_bytes(P, F, K)
     ws = _ws(nbytes, x.device)
     _abi.check(l.tspn_predicate_head_f32(_p(x), P, F, F, _p(weight), _p(bias), K, _p(out),

@@ -259,3 +259,14 @@ def test_temporal_forward_edge_shapes(tspn, device, n, tt, d):
         assert spans["span"].shape[0] == p
     dec = model.decode([pl], logits)[0]
     assert dec[0].shape[0] == (min(200, p * 20) if n > 1 else 0)
+
+
+def test_baseline_forward_fused_preprocess_flag(tspn, device):
+    """PREDICT.FUSE_PREPROCESS: raw features in, same logits as reference preprocess + forward (G1)."""
+    g = cases.load("g1_baseline_cfg1.npz")
+    c = cases.g1_inputs()
+    model = tspn.BaseModel(cases.baseline_cfg(**{"PREDICT.FUSE_PREPROCESS": True}))
+    load(model, c["state_dict"])
+    model.eval()
+    _, _, logits = model([tspn.PairList(t(c["raw"]))], None)
+    np.testing.assert_allclose(logits[0].numpy(), g["rel_logits"], rtol=0, atol=2e-6)

@@ -58,6 +58,31 @@ def test_predicate_head_shapes(tspn, device, P, F, K):
     np.testing.assert_allclose(raw.cpu().numpy(), ref_raw, rtol=0, atol=2e-5)
 
 
+def test_predicate_head_fused_preprocess_golden_cfg1(tspn, device):
+    """f2: raw 11070-d features in, block-L1 normalisation folded into the GEMM == reference
+    `_feature_preprocess` + `RelationPredictor` (golden G1), incl. the zero-norm block."""
+    g = cases.load("g1_baseline_cfg1.npz")
+    c = cases.g1_inputs()
+    sd = dev_sd(c["state_dict"], device)
+    raw = t(c["raw"]).to(device)
+    out = tspn.ops.predicate_head(raw, sd["classifier.rel_predictor.weight"],
+                                  sd["classifier.rel_predictor.bias"], norm=(70, 1000, 8))
+    np.testing.assert_allclose(out.cpu().numpy(), g["rel_logits"], rtol=0, atol=2e-6)
+    np.testing.assert_array_equal(raw.cpu().numpy(), c["raw"])  # input untouched
+
+
+@pytest.mark.parametrize("P,F,K,norm", [(3, 40, 5, (4, 6, 5)), (70, 300, 132, (0, 100, 3)), (200, 1001, 17, (1, 250, 4)),
+                                        (992, 11070, 132, (70, 1000, 8)), (9, 64, 4, (0, 64, 0))])
+def test_predicate_head_fused_preprocess_vs_oracle(tspn, device, P, F, K, norm):
+    x = tspn.hashrng.uniform(25, "x", (P, F), -1.0, 1.0)
+    x[min(2, P - 1), norm[0]:norm[0] + norm[1]] = 0
+    w = tspn.hashrng.normal(25, "w", (K, F), std=0.05)
+    b = tspn.hashrng.normal(25, "b", (K,), std=0.1)
+    ref = oracle.predicate_head(oracle.feature_preprocess(t(x).double(), *norm), t(w).double(), t(b).double())
+    out = tspn.ops.predicate_head(t(x).to(device), t(w).to(device), t(b).to(device), norm=norm)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.float().numpy(), rtol=0, atol=5e-6)
+
+
 def test_predicate_head_empty_and_errors(tspn, device):
     w = torch.zeros(4, 8, device=device)
     out = tspn.ops.predicate_head(torch.zeros(0, 8, device=device), w, None)
