@@ -5,7 +5,7 @@
     python bench.py --gpus N --steps K --warmup W
     (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" = one pass of the hot path over one batch of `--videos` synthetic videos per GPU
+A "step" = one pass of the hot path over one batch of `--videos` (default 16) synthetic videos per GPU
 (inputs resident in HBM): tracklet tensors -> [pair builder + temporal encoder +
 relationness/span heads + RelOIPool + predicate head] (tspn_forward_fused_f32) + PPN
 pair-matrix/top-k.  Videos shard across ranks (weak scaling, no collective in the forward);
@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--videos", type=int, default=8, help="videos per GPU per step")
+    ap.add_argument("--videos", type=int, default=16, help="videos per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time")
     ap.add_argument("--conv", choices=["winograd", "direct"], default="winograd",
@@ -75,7 +75,7 @@ def cpu_baseline(weights, target_s):
     run(2)  # warm-up (thread pool, oneDNN primitive cache)
     p_max = N_TRK * (N_TRK - 1)
     p, dt = 8, run(8)
-    for _ in range(2):  # two-step calibration towards ~target_s of CPU work (cost is not linear in p)
+    for _ in range(3):  # stepwise calibration towards ~target_s of CPU work (cost is not linear in p)
         if dt >= 0.6 * target_s or p >= p_max:
             break
         p = int(max(p + 1, min(p_max, p * target_s / max(dt, 1e-3))))
@@ -93,7 +93,7 @@ def pmc_traffic(videos, conv):
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         data = json.load(open(path))
-        k = data["kernels"]["conv3_wino_cl_kernel" if conv == "winograd" else "conv3_mfma_cl_kernel"]
+        k = data["kernels"]["conv3_wino2_cl_kernel" if conv == "winograd" else "conv3_mfma_cl_kernel"]
         if data["videos_per_launch"] == videos:
             return {"traffic": k["hbm_bytes"], "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE)",
                     "traffic_source": data["source"]}
@@ -210,7 +210,7 @@ def main():
                        "conv_algo": args.conv,
                        "executed_gflop_per_pair": (conv_flop + 2.0 * P * T * C * 16 + 2.0 * P * C * K_PRED) / P / 1e9},
             "roofline": {"bound": "mfma",
-                         "kernel": ("conv3_wino_cl_kernel (tracklet projections: k=3 conv, Winograd F(2,3), "
+                         "kernel": ("conv3_wino2_cl_kernel (tracklet projections: k=3 conv, Winograd F(2,3), "
                                     "fp32 32x32x2 MFMA, M=2C, 4 channel-GEMMs of K=D on half the columns)"
                                     if args.conv == "winograd" else
                                     "conv3_mfma_cl_kernel (tracklet projections: k=3 conv as fp32 32x32x2 "
