@@ -29,6 +29,16 @@ inline int check_launch(const char* what) {
 }
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Internal (not exported) forms with explicit row strides, shared between translation units.
+// y[b][m][ldy]: the fused driver pads rows of the tracklet projections to a multiple of 4 frames so
+// that the pair stage can stage them with 16-byte LDS-DMA pieces.
+int conv3_tc_direct(const float* x, int64_t B, int64_t T, int64_t Cin, const float* packed, int64_t M,
+                    const float* bias, int relu, float* y, int64_t ldy, void* stream);
+int conv3_tc_wino(const float* x, int64_t B, int64_t T, int64_t Cin, const float* packed4, int64_t M,
+                  const float* bias, int relu, float* y, int64_t ldy, void* stream);
+int heads_pairgrid(const float* y, int64_t ldt, int64_t B, int64_t N, int64_t C, int64_t T,
+                   const float* Wh, const float* bh, int64_t H, float* out, void* stream);
 inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 
 }  // namespace tspn

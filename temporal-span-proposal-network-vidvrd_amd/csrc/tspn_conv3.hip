@@ -60,7 +60,7 @@ template <bool VEC_A>
 __global__ __launch_bounds__(THREADS, 2) void conv3_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ Wp, const float* __restrict__ bias,
     float* __restrict__ y, int Cin, int T, int M, int64_t ncols, int tiles_m, int tiles_n,
-    int relu) {
+    int relu, int ldy) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* As = reinterpret_cast<float*>(smem_raw);  // [2][3][KC][BM]
   float* Bs = As + 2 * A_STAGE;                     // [2][KC][BNP]
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_mfma_kernel(
     if (n >= ncols) continue;
     const int64_t b = n / T;
     const int64_t t = n - b * T;
-    float* ycol = y + (b * M) * (int64_t)T + t;
+    float* ycol = y + (b * M) * (int64_t)ldy + t;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_mfma_kernel(
           float v = acc[mi][ni][e];
           if (bias != nullptr) v += bias[m];
           if (relu) v = fmaxf(v, 0.f);
-          ycol[(int64_t)m * T] = v;
+          ycol[(int64_t)m * ldy] = v;
         }
       }
     }
@@ -351,7 +351,7 @@ template <int KCD>
 __global__ __launch_bounds__(THREADS, (KCD == 8 ? 4 : 2)) void conv3_mfma_dma_kernel(
     const float* __restrict__ x, const float* __restrict__ Wp, const float* __restrict__ bias,
     float* __restrict__ y, int Cin, int T, int M, int64_t ncols, int tiles_m, int tiles_n,
-    int relu) {
+    int relu, int ldy) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int A_ST = 3 * KCD * BM;  // floats per A buffer
   constexpr int B_ST = KCD * BNP;     // floats per B buffer
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(THREADS, (KCD == 8 ? 4 : 2)) void conv3_mfma_dma_ke
     if (n >= ncols) continue;
     const int64_t b = n / T;
     const int64_t t = n - b * T;
-    float* ycol = y + (b * M) * (int64_t)T + t;
+    float* ycol = y + (b * M) * (int64_t)ldy + t;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
@@ -613,7 +613,7 @@ __global__ __launch_bounds__(THREADS, (KCD == 8 ? 4 : 2)) void conv3_mfma_dma_ke
           float v = acc[mi][ni][e];
           if (bias != nullptr) v += bias[m];
           if (relu) v = fmaxf(v, 0.f);
-          ycol[(int64_t)m * T] = v;
+          ycol[(int64_t)m * ldy] = v;
         }
       }
     }
@@ -640,7 +640,7 @@ constexpr size_t CL_SMEM_BYTES = sizeof(float) * 2 * (CL_A_ST + CL_B_ST);
 __global__ __launch_bounds__(THREADS, 2) void conv3_mfma_cl_kernel(
     const float* __restrict__ x, const float* __restrict__ Wp, const float* __restrict__ bias,
     float* __restrict__ y, int Cin, int T, int M, int64_t ncols, int tiles_m, int tiles_n,
-    int relu) {
+    int relu, int ldy) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* As = reinterpret_cast<float*>(smem_raw);  // [2][3][16][BM]
   float* Bs = As + 2 * CL_A_ST;                     // [2][4][132][4]
@@ -820,7 +820,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_mfma_cl_kernel(
     if (n >= ncols) continue;
     const int64_t b = n / T;
     const int64_t t = n - b * T;
-    float* ycol = y + (b * M) * (int64_t)T + t;
+    float* ycol = y + (b * M) * (int64_t)ldy + t;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
@@ -830,7 +830,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_mfma_cl_kernel(
           float v = acc[mi][ni][e];
           if (bias != nullptr) v += bias[m];
           if (relu) v = fmaxf(v, 0.f);
-          ycol[(int64_t)m * T] = v;
+          ycol[(int64_t)m * ldy] = v;
         }
       }
     }
@@ -881,7 +881,7 @@ __global__ void pack_conv3_wino_kernel(const float* __restrict__ W, int64_t M, i
 __global__ __launch_bounds__(THREADS, 2) void conv3_wino_cl_kernel(
     const float* __restrict__ x, const float* __restrict__ Wp, const float* __restrict__ bias,
     float* __restrict__ y, int Cin, int T, int M, int64_t ncols, int tiles_m, int tiles_n,
-    int relu) {
+    int relu, int ldy) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* As = reinterpret_cast<float*>(smem_raw);  // [2][4][8][BM]
   float* Bs = As + 2 * WN_A_ST;                     // [2][2][132][4]
@@ -1051,7 +1051,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_wino_cl_kernel(
     if (n >= ncols) continue;
     const int64_t b = n / T;
     const int64_t t = n - b * T;
-    float* ycol = y + (b * M) * (int64_t)T + t;
+    float* ycol = y + (b * M) * (int64_t)ldy + t;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int m = m0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
@@ -1067,7 +1067,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_wino_cl_kernel(
           v0 = fmaxf(v0, 0.f);
           v1 = fmaxf(v1, 0.f);
         }
-        *reinterpret_cast<float2*>(ycol + (int64_t)m * T) = make_float2(v0, v1);
+        *reinterpret_cast<float2*>(ycol + (int64_t)m * ldy) = make_float2(v0, v1);
       }
     }
   }
@@ -1089,7 +1089,7 @@ constexpr size_t W2_SMEM_BYTES = sizeof(float) * 2 * (W2_A_ST + W2_X_ST + W2_V_S
 __global__ __launch_bounds__(THREADS, 2) void conv3_wino2_cl_kernel(
     const float* __restrict__ x, const float* __restrict__ Wp, const float* __restrict__ bias,
     float* __restrict__ y, int Cin, int T, int M, int64_t ncols, int tiles_m, int tiles_n,
-    int relu) {
+    int relu, int ldy) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* As = reinterpret_cast<float*>(smem_raw);
   float* Xs = As + 2 * W2_A_ST;
@@ -1263,7 +1263,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_wino2_cl_kernel(
     if (n >= ncols) continue;
     const int64_t b = n / T;
     const int64_t t = n - b * T;
-    float* ycol = y + (b * M) * (int64_t)T + t;
+    float* ycol = y + (b * M) * (int64_t)ldy + t;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int m = m0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
@@ -1279,7 +1279,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_wino2_cl_kernel(
           v0 = fmaxf(v0, 0.f);
           v1 = fmaxf(v1, 0.f);
         }
-        *reinterpret_cast<float2*>(ycol + (int64_t)m * T) = make_float2(v0, v1);
+        *reinterpret_cast<float2*>(ycol + (int64_t)m * ldy) = make_float2(v0, v1);
       }
     }
   }
@@ -1338,7 +1338,7 @@ extern "C" int tspn_conv3_f32(const float* x, int64_t B, int64_t Cin, int64_t T,
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n)), dim3(THREADS), smem,
                      TSPN_STREAM(stream), x, packed, bias, y, (int)Cin, (int)T, (int)M, ncols,
-                     (int)tiles_m, (int)tiles_n, relu);
+                     (int)tiles_m, (int)tiles_n, relu, (int)T);
   return tspn::check_launch("tspn_conv3_f32");
 }
 
@@ -1346,6 +1346,14 @@ extern "C" int tspn_conv3_f32(const float* x, int64_t B, int64_t Cin, int64_t T,
 extern "C" int tspn_conv3_tc_f32(const float* x, int64_t B, int64_t T, int64_t Cin,
                                  const float* packed, int64_t M, const float* bias, int relu,
                                  float* y, void* stream) {
+  return tspn::conv3_tc_direct(x, B, T, Cin, packed, M, bias, relu, y, T, stream);
+}
+
+// internal form with an output row stride ldy >= T (y[b][m][ldy]); used by the fused driver
+int tspn::conv3_tc_direct(const float* x, int64_t B, int64_t T, int64_t Cin, const float* packed,
+                          int64_t M, const float* bias, int relu, float* y, int64_t ldy,
+                          void* stream) {
+  TSPN_REQUIRE(ldy >= T && ldy < (1 << 24), TSPN_EINVAL, "tspn_conv3_tc_f32: bad ldy");
   TSPN_REQUIRE(B >= 0 && Cin > 0 && T > 0 && M > 0, TSPN_EINVAL,
                "tspn_conv3_tc_f32: bad sizes B=%lld T=%lld Cin=%lld M=%lld", (long long)B,
                (long long)T, (long long)Cin, (long long)M);
@@ -1375,7 +1383,7 @@ extern "C" int tspn_conv3_tc_f32(const float* x, int64_t B, int64_t T, int64_t C
   }
   hipLaunchKernelGGL(conv3_mfma_cl_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(THREADS),
                      CL_SMEM_BYTES, TSPN_STREAM(stream), x, packed, bias, y, (int)Cin, (int)T, (int)M,
-                     ncols, (int)tiles_m, (int)tiles_n, relu);
+                     ncols, (int)tiles_m, (int)tiles_n, relu, (int)ldy);
   return tspn::check_launch("tspn_conv3_tc_f32");
 }
 
@@ -1397,6 +1405,13 @@ extern "C" int tspn_pack_conv3_wino_f32(const float* W, int64_t M, int64_t Cin, 
 extern "C" int tspn_conv3_tc_wino_f32(const float* x, int64_t B, int64_t T, int64_t Cin,
                                       const float* packed4, int64_t M, const float* bias, int relu,
                                       float* y, void* stream) {
+  return tspn::conv3_tc_wino(x, B, T, Cin, packed4, M, bias, relu, y, T, stream);
+}
+
+int tspn::conv3_tc_wino(const float* x, int64_t B, int64_t T, int64_t Cin, const float* packed4,
+                        int64_t M, const float* bias, int relu, float* y, int64_t ldy, void* stream) {
+  TSPN_REQUIRE(ldy >= T && (ldy % 2 == 0 || T % 2 != 0) && ldy < (1 << 24), TSPN_EINVAL,
+               "tspn_conv3_tc_wino_f32: bad ldy");
   TSPN_REQUIRE(B >= 0 && Cin > 0 && T > 0 && M > 0, TSPN_EINVAL,
                "tspn_conv3_tc_wino_f32: bad sizes B=%lld T=%lld Cin=%lld M=%lld", (long long)B,
                (long long)T, (long long)Cin, (long long)M);
@@ -1419,11 +1434,11 @@ extern "C" int tspn_conv3_tc_wino_f32(const float* x, int64_t B, int64_t T, int6
   if (getenv("TSPN_WINO_V1") != nullptr) {
     hipLaunchKernelGGL(conv3_wino_cl_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(THREADS),
                        WN_SMEM_BYTES, TSPN_STREAM(stream), x, packed4, bias, y, (int)Cin, (int)T, (int)M,
-                       ncols, (int)tiles_m, (int)tiles_n, relu);
+                       ncols, (int)tiles_m, (int)tiles_n, relu, (int)ldy);
   } else {
     hipLaunchKernelGGL(conv3_wino2_cl_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(THREADS),
                        W2_SMEM_BYTES, TSPN_STREAM(stream), x, packed4, bias, y, (int)Cin, (int)T, (int)M,
-                       ncols, (int)tiles_m, (int)tiles_n, relu);
+                       ncols, (int)tiles_m, (int)tiles_n, relu, (int)ldy);
   }
   return tspn::check_launch("tspn_conv3_tc_wino_f32");
 }

@@ -34,7 +34,8 @@ FusedLayout layout_of(const tspn_fused_desc* d) {
     return o;
   };
   L.xt = take(NT * D * T * sizeof(float));
-  L.y = take(NT * 2 * C * T * sizeof(float));
+  // rows of y may be padded to a multiple of 4 frames (ldy), see tspn_forward_fused_f32
+  L.y = take(NT * 2 * C * tspn::align_up(T, 4) * sizeof(float));
   L.bias2 = take(2 * C * sizeof(float));
   L.fbar = take(NT * D * sizeof(float));
   L.pooled = take((size_t)d->P * C * sizeof(float));
@@ -101,12 +102,17 @@ extern "C" int tspn_forward_fused_f32(const tspn_fused_desc* d, void* stream) {
                "tspn_forward_fused: conv_algo must be 0 or 1");
   TSPN_REQUIRE(d->conv_algo == 0 || (tc && T % 2 == 0), TSPN_EUNSUPPORTED,
                "tspn_forward_fused: conv_algo 1 (Winograd) needs T even, D %% 16 == 0, aligned operands");
+  // On the fast path the rows of y are padded to ldy = ceil4(T) frames so that the blocked pair stage
+  // can stage them with 16-byte LDS-DMA pieces that never leave a row (pad frames are never read out).
+  // (needs what the DMA pair-stage kernel needs: even T, C % 16 == 0 — implied by tc)
+  const int64_t ldy =
+      (tc && d->canonical_pairs && T % 2 == 0) ? (int64_t)tspn::align_up((size_t)T, 4) : T;
   if (!tc && (rc = tspn_transpose_td_f32(d->feats, NT, T, D, xt, stream))) return rc;
   if (d->ev_conv_begin) (void)hipEventRecord(static_cast<hipEvent_t>(d->ev_conv_begin), s);
   if (d->conv_algo == 1)
-    rc = tspn_conv3_tc_wino_f32(d->feats, NT, T, D, d->conv_packed, 2 * C, bias2, 0, y, stream);
+    rc = tspn::conv3_tc_wino(d->feats, NT, T, D, d->conv_packed, 2 * C, bias2, 0, y, ldy, stream);
   else
-    rc = tc ? tspn_conv3_tc_f32(d->feats, NT, T, D, d->conv_packed, 2 * C, bias2, 0, y, stream)
+    rc = tc ? tspn::conv3_tc_direct(d->feats, NT, T, D, d->conv_packed, 2 * C, bias2, 0, y, ldy, stream)
             : tspn_conv3_f32(xt, NT, D, T, d->conv_packed, 2 * C, bias2, 0, y, stream);
   if (rc) return rc;
   if (d->ev_conv_end) (void)hipEventRecord(static_cast<hipEvent_t>(d->ev_conv_end), s);
@@ -114,8 +120,8 @@ extern "C" int tspn_forward_fused_f32(const tspn_fused_desc* d, void* stream) {
   if (d->canonical_pairs) {
     TSPN_REQUIRE(d->P == d->B * d->N * (d->N - 1), TSPN_EINVAL,
                  "tspn_forward_fused: canonical_pairs needs P == B*N*(N-1) (P=%lld)", (long long)d->P);
-    if ((rc = tspn_heads_pairgrid_f32(y, d->B, d->N, C, T, d->head_w, d->head_b, H, d->out_heads,
-                                      stream)))
+    if ((rc = tspn::heads_pairgrid(y, ldy, d->B, d->N, C, T, d->head_w, d->head_b, H, d->out_heads,
+                                   stream)))
       return rc;
   } else if ((rc = tspn_heads_f32(1, y, y + C * T, 2 * C, d->pairs, d->pairs + 1, 2, nullptr,
                                   d->head_w, d->head_b, H, d->P, C, T, d->out_heads, stream))) {

@@ -15,6 +15,9 @@
 // adds, applies ReLU and feeds the matrix pipe.  One wave = NP consecutive pairs
 // x 32 frames; the two 16-column MFMA blocks take the even / odd frames of the
 // float2 a lane loads, so a half-wave row reads one full 128-B line.
+#include <cstdlib>
+#include <type_traits>
+
 #include "tspn_common.h"
 
 namespace {
@@ -315,6 +318,202 @@ __global__ __launch_bounds__(256, 2) void heads_pairgrid_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Third structure of the blocked pair stage (same tiling: 8 subjects x 8 objects x 32 frames per
+// workgroup, 16-channel chunks).  Ablation of the kernel above (profiles/r1) put 0.55 ms of 2.55
+// on register staging (16 loads + 16 ds_writes per lane and chunk) and 0.54 ms on the add+ReLU
+// that hipcc chains through one temporary in front of every MFMA.  Here
+//   * the projection rows are staged by LDS-DMA: rows of y are padded to a multiple of 4 frames
+//     (ldt) so a 16-byte piece never leaves its row; a piece = 8 channels x 32 frames of one row;
+//   * the activations of the NEXT (k-step, subject) phase are computed under the 16 MFMAs of the
+//     current one (explicit software pipeline, issue pattern 2 VALU : 1 MFMA).
+__device__ __forceinline__ void hglds16(const float* g, float* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 2) void heads_pairgrid3_kernel(
+    const float* __restrict__ y, int64_t ldt, int C, int T, int N, const float* __restrict__ Wh,
+    const float* __restrict__ bh, int H, float* __restrict__ out, int ntb, int nob, int nsb,
+    int64_t ngroups) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* S = reinterpret_cast<float*>(smem_raw);  // [2][16 rows][16 ch][32 t]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, kq = lane >> 4;
+  const int per_group = nsb * nob;
+  const int id = blockIdx.x;
+  const int xcd = id & 7, k = id >> 3;
+  const int64_t G = (int64_t)(k / per_group) * 8 + xcd;
+  if (G >= ngroups) return;
+  const int member = k % per_group;
+  const int sb = member / nob, ob = member - sb * nob;
+  const int64_t b = G / ntb;
+  const int tb = (int)(G - b * ntb);
+  const int t0 = tb * PG_T;
+  const int64_t rowlen = 2 * (int64_t)C * ldt;
+
+  // ---- DMA sources: wave w stages tile rows 4w..4w+3; lane -> (channel line lane>>3, 4 frames)
+  const float* src[4];
+  {
+    const int64_t tsrc = min((int64_t)t0 + (lane & 7) * 4, ldt - 4);  // groups past the row end are never stored
+    const int line = lane >> 3;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * wave + r;
+      const int local = row < PG_S ? sb * PG_S + row : ob * PG_O + (row - PG_S);
+      const int64_t trk = b * N + min(local, N - 1);
+      src[r] = y + trk * rowlen + (row < PG_S ? 0 : (int64_t)C * ldt) + line * ldt + tsrc;
+    }
+  }
+  const int64_t half_step = 8 * ldt, chunk_step = 16 * ldt;
+  auto stage_piece = [&](int buf, auto p_tag) {  // piece p = 2*r + hh of this wave
+    constexpr int p = decltype(p_tag)::value;
+    constexpr int r = p >> 1, hh = p & 1;
+    hglds16(src[r] + hh * half_step, S + buf * PG_STAGE + ((4 * wave + r) * PG_CK + 8 * hh) * PG_T);
+    if (hh == 1) src[r] += chunk_step;
+  };
+  const int o_a = lane & 15;
+  const float* wsrc = Wh + (int64_t)min(o_a, H - 1) * C + kq;
+  float wreg[PG_CK / 4], wa[PG_CK / 4];
+  auto load_w = [&](int c0) {
+#pragma unroll
+    for (int ks = 0; ks < PG_CK / 4; ++ks) wreg[ks] = wsrc[c0 + ks * 4];
+  };
+
+  f32x4 acc[2][PG_O][2];
+#pragma unroll
+  for (int si = 0; si < 2; ++si)
+#pragma unroll
+    for (int oj = 0; oj < PG_O; ++oj)
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[si][oj][e][r] = 0.f;
+
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  using P2 = std::integral_constant<int, 2>;
+  using P3 = std::integral_constant<int, 3>;
+  using P4 = std::integral_constant<int, 4>;
+  using P5 = std::integral_constant<int, 5>;
+  using P6 = std::integral_constant<int, 6>;
+  using P7 = std::integral_constant<int, 7>;
+
+  const int nchunks = C / PG_CK;
+  stage_piece(0, P0{}); stage_piece(0, P1{}); stage_piece(0, P2{}); stage_piece(0, P3{});
+  stage_piece(0, P4{}); stage_piece(0, P5{}); stage_piece(0, P6{}); stage_piece(0, P7{});
+  load_w(0);
+#pragma unroll
+  for (int ks = 0; ks < PG_CK / 4; ++ks) wa[ks] = (o_a < H) ? wreg[ks] : 0.f;
+  __syncthreads();
+
+  struct UV {
+    float2 u[2];
+    float2 v[PG_O];
+  };
+  auto read_uv = [&](const float* Sb, int ks) {
+    UV f;
+    const int ch = ks * 4 + kq;
+#pragma unroll
+    for (int si = 0; si < 2; ++si)
+      f.u[si] = *reinterpret_cast<const float2*>(Sb + ((2 * wave + si) * PG_CK + ch) * PG_T);
+#pragma unroll
+    for (int oj = 0; oj < PG_O; ++oj)
+      f.v[oj] = *reinterpret_cast<const float2*>(Sb + ((PG_S + oj) * PG_CK + ch) * PG_T);
+    return f;
+  };
+  struct HB {
+    float h[PG_O][2];
+  };
+  auto compute_h = [&](const UV& f, int si) {
+    HB r;
+#pragma unroll
+    for (int oj = 0; oj < PG_O; ++oj) {
+      r.h[oj][0] = fmaxf(f.u[si].x + f.v[oj].x, 0.f);
+      r.h[oj][1] = fmaxf(f.u[si].y + f.v[oj].y, 0.f);
+    }
+    return r;
+  };
+
+  auto chunk_body = [&](int c, auto more_tag) {
+    constexpr bool MORE = decltype(more_tag)::value;
+    const int buf = c & 1;
+    const float* Sb = S + buf * PG_STAGE + 2 * j;
+    if (MORE) load_w((c + 1) * PG_CK);
+    UV uv = read_uv(Sb, 0);
+    UV uvn = uv;
+    HB hc = compute_h(uv, 0);
+#pragma unroll
+    for (int ph = 0; ph < 8; ++ph) {
+      const int ks = ph >> 1, si = ph & 1;
+      if (si == 0 && ks < 3) uvn = read_uv(Sb, ks + 1);
+      HB hn = hc;
+      if (ph < 7) hn = (si == 0) ? compute_h(uv, 1) : compute_h(uvn, 0);
+#pragma unroll
+      for (int oj = 0; oj < PG_O; ++oj) {
+        acc[si][oj][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[ks], hc.h[oj][0], acc[si][oj][0], 0, 0, 0);
+        acc[si][oj][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[ks], hc.h[oj][1], acc[si][oj][1], 0, 0, 0);
+      }
+      if (MORE) {
+        if (ph == 0) stage_piece(buf ^ 1, P0{});
+        if (ph == 1) stage_piece(buf ^ 1, P1{});
+        if (ph == 2) stage_piece(buf ^ 1, P2{});
+        if (ph == 3) stage_piece(buf ^ 1, P3{});
+        if (ph == 4) stage_piece(buf ^ 1, P4{});
+        if (ph == 5) stage_piece(buf ^ 1, P5{});
+        if (ph == 6) stage_piece(buf ^ 1, P6{});
+        if (ph == 7) stage_piece(buf ^ 1, P7{});
+      }
+#define TSPN_G                                           \
+  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     \
+  __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);     \
+  __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      TSPN_G TSPN_G TSPN_G TSPN_G TSPN_G TSPN_G TSPN_G TSPN_G
+      TSPN_G TSPN_G TSPN_G TSPN_G TSPN_G TSPN_G TSPN_G TSPN_G
+#undef TSPN_G
+      __builtin_amdgcn_sched_barrier(0);
+      hc = hn;
+      if (si == 1) uv = uvn;
+    }
+    if (MORE) {
+#pragma unroll
+      for (int ks = 0; ks < PG_CK / 4; ++ks) wa[ks] = (o_a < H) ? wreg[ks] : 0.f;
+    }
+    __syncthreads();
+  };
+  for (int c = 0; c + 1 < nchunks; ++c) chunk_body(c, std::true_type{});
+  chunk_body(nchunks - 1, std::false_type{});
+
+  const int tA = t0 + 2 * j;
+#pragma unroll
+  for (int si = 0; si < 2; ++si) {
+    const int s = sb * PG_S + 2 * wave + si;
+#pragma unroll
+    for (int oj = 0; oj < PG_O; ++oj) {
+      const int o = ob * PG_O + oj;
+      if (s >= N || o >= N || s == o) continue;
+      const int64_t p = b * N * (int64_t)(N - 1) + (int64_t)s * (N - 1) + o - (o > s ? 1 : 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ho = kq * 4 + r;
+        if (ho >= H) continue;
+        const float bo = bh ? bh[ho] : 0.f;
+        float* dst = out + (p * H + ho) * (int64_t)T;
+        const float v0 = acc[si][oj][0][r] + bo, v1 = acc[si][oj][1][r] + bo;
+        if (tA + 1 < T) {
+          *reinterpret_cast<float2*>(dst + tA) = make_float2(v0, v1);
+        } else if (tA < T) {
+          dst[tA] = v0;
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int tspn_heads_f32(int mode, const float* a, const float* b, int64_t lda,
@@ -357,34 +556,58 @@ extern "C" int tspn_heads_f32(int mode, const float* a, const float* b, int64_t 
 extern "C" int tspn_heads_pairgrid_f32(const float* y, int64_t B, int64_t N, int64_t C, int64_t T,
                                        const float* Wh, const float* bh, int64_t H, float* out,
                                        void* stream) {
-  TSPN_REQUIRE(B >= 0 && N >= 0 && C > 0 && T > 0, TSPN_EINVAL,
-               "tspn_heads_pairgrid_f32: bad sizes B=%lld N=%lld C=%lld T=%lld", (long long)B,
-               (long long)N, (long long)C, (long long)T);
+  return tspn::heads_pairgrid(y, T, B, N, C, T, Wh, bh, H, out, stream);
+}
+
+// y[B*N][2C][ldt] (ldt >= T frames per row)
+int tspn::heads_pairgrid(const float* y, int64_t ldt, int64_t B, int64_t N, int64_t C, int64_t T,
+                         const float* Wh, const float* bh, int64_t H, float* out, void* stream) {
+  TSPN_REQUIRE(B >= 0 && N >= 0 && C > 0 && T > 0 && ldt >= T, TSPN_EINVAL,
+               "tspn_heads_pairgrid_f32: bad sizes B=%lld N=%lld C=%lld T=%lld ldt=%lld", (long long)B,
+               (long long)N, (long long)C, (long long)T, (long long)ldt);
   TSPN_REQUIRE(H > 0 && H <= 16, TSPN_EUNSUPPORTED, "tspn_heads_pairgrid_f32: H=%lld not in [1,16]",
                (long long)H);
-  TSPN_REQUIRE(C < (1 << 24) && T < (1 << 24) && N < (1 << 15), TSPN_EUNSUPPORTED,
+  TSPN_REQUIRE(C < (1 << 24) && ldt < (1 << 24) && N < (1 << 15), TSPN_EUNSUPPORTED,
                "tspn_heads_pairgrid_f32: dim too large");
   if (B == 0 || N < 2) return TSPN_OK;
   TSPN_REQUIRE(y && Wh && out, TSPN_EINVAL, "tspn_heads_pairgrid_f32: null pointer");
-  const bool vec2 = (T % 2 == 0) && ((reinterpret_cast<uintptr_t>(y) & 7) == 0) &&
-                    ((reinterpret_cast<uintptr_t>(out) & 7) == 0);
   const int ntb = (int)tspn::ceil_div(T, PG_T);
   const int nsb = (int)tspn::ceil_div(N, PG_S), nob = (int)tspn::ceil_div(N, PG_O);
   const size_t smem = sizeof(float) * 2 * PG_STAGE;
-  auto kern = vec2 ? heads_pairgrid_kernel<true> : heads_pairgrid_kernel<false>;
-  static thread_local bool attr_set[2] = {false, false};
-  if (!attr_set[vec2]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess)
-      return tspn::fail(TSPN_ELAUNCH, "tspn_heads_pairgrid_f32: hipFuncSetAttribute: %s",
-                        hipGetErrorString(e));
-    attr_set[vec2] = true;
-  }
   const int64_t ngroups = B * ntb;
   const int64_t nwg = tspn::ceil_div(ngroups, 8) * 8 * nsb * nob;
   TSPN_REQUIRE(nwg < (1LL << 31), TSPN_EUNSUPPORTED, "tspn_heads_pairgrid_f32: grid too large");
-  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), smem, TSPN_STREAM(stream), y, (int)C, (int)T,
-                     (int)N, Wh, bh, (int)H, out, ntb, nob, nsb, ngroups);
+  // v3 (LDS-DMA staging + pipelined activations) needs 16-byte pieces inside a row and even frame
+  // pairs in the output; anything else runs the register-staged kernel
+  const bool v3 = (ldt % 4 == 0) && ldt >= 4 && (C % PG_CK == 0) && (T % 2 == 0) &&
+                  ((reinterpret_cast<uintptr_t>(y) & 15) == 0) &&
+                  ((reinterpret_cast<uintptr_t>(out) & 7) == 0) && getenv("TSPN_HEADS_V2") == nullptr;
+  const bool vec2 = (T % 2 == 0) && (ldt % 2 == 0) && ((reinterpret_cast<uintptr_t>(y) & 7) == 0) &&
+                    ((reinterpret_cast<uintptr_t>(out) & 7) == 0);
+  TSPN_REQUIRE(v3 || ldt == T, TSPN_EUNSUPPORTED,
+               "tspn_heads_pairgrid_f32: padded rows (ldt != T) need the DMA kernel's preconditions");
+  const void* fn = v3 ? reinterpret_cast<const void*>(heads_pairgrid3_kernel)
+                      : (vec2 ? reinterpret_cast<const void*>(heads_pairgrid_kernel<true>)
+                              : reinterpret_cast<const void*>(heads_pairgrid_kernel<false>));
+  const int which = v3 ? 2 : (vec2 ? 1 : 0);
+  static thread_local bool attr_set[3] = {false, false, false};
+  if (!attr_set[which]) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess)
+      return tspn::fail(TSPN_ELAUNCH, "tspn_heads_pairgrid_f32: hipFuncSetAttribute: %s",
+                        hipGetErrorString(e));
+    attr_set[which] = true;
+  }
+  hipStream_t st = TSPN_STREAM(stream);
+  if (v3) {
+    hipLaunchKernelGGL(heads_pairgrid3_kernel, dim3((unsigned)nwg), dim3(256), smem, st, y, ldt, (int)C,
+                       (int)T, (int)N, Wh, bh, (int)H, out, ntb, nob, nsb, ngroups);
+  } else if (vec2) {
+    hipLaunchKernelGGL(heads_pairgrid_kernel<true>, dim3((unsigned)nwg), dim3(256), smem, st, y, (int)C,
+                       (int)T, (int)N, Wh, bh, (int)H, out, ntb, nob, nsb, ngroups);
+  } else {
+    hipLaunchKernelGGL(heads_pairgrid_kernel<false>, dim3((unsigned)nwg), dim3(256), smem, st, y,
+                       (int)C, (int)T, (int)N, Wh, bh, (int)H, out, ntb, nob, nsb, ngroups);
+  }
   return tspn::check_launch("tspn_heads_pairgrid_f32");
 }
