@@ -40,6 +40,13 @@ int conv3_tc_wino(const float* x, int64_t B, int64_t T, int64_t Cin, const float
 int heads_pairgrid(const float* y, int64_t ldt, int64_t B, int64_t N, int64_t C, int64_t T,
                    const float* Wh, const float* bh, int64_t H, float* out, void* stream);
 inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
+int linear(const float* x, int64_t P, int64_t F, int64_t ldx, const float* W, int64_t ldw,
+           const float* b, int64_t K, float* out, int apply_sigmoid, void* workspace,
+           size_t workspace_bytes, void* stream);
+size_t pair_predicate_workspace_bytes(int64_t NT, int64_t D, int64_t K);
+int pair_predicate(const float* fbar, int64_t NT, int64_t D, const int64_t* pairs, int64_t P,
+                   const float* cls_w, const float* cls_b, int64_t K, float* out, void* workspace,
+                   size_t workspace_bytes, void* stream);
 
 }  // namespace tspn
 

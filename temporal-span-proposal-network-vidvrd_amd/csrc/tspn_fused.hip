@@ -38,8 +38,8 @@ FusedLayout layout_of(const tspn_fused_desc* d) {
   L.y = take(NT * 2 * C * tspn::align_up(T, 4) * sizeof(float));
   L.bias2 = take(2 * C * sizeof(float));
   L.fbar = take(NT * D * sizeof(float));
-  L.pooled = take((size_t)d->P * C * sizeof(float));
-  L.lin_bytes = tspn_predicate_head_workspace_bytes(d->P, (int64_t)C, d->K);
+  L.pooled = take(256);  // (unused since the predicate head is evaluated per tracklet)
+  L.lin_bytes = tspn::pair_predicate_workspace_bytes((int64_t)NT, (int64_t)D, d->K);
   L.lin = take(L.lin_bytes);
   L.total = off;
   return L;
@@ -127,11 +127,12 @@ extern "C" int tspn_forward_fused_f32(const tspn_fused_desc* d, void* stream) {
                                   d->head_w, d->head_b, H, d->P, C, T, d->out_heads, stream))) {
     return rc;
   }
-  // 4. RelOIPool over the segment on the pair feats (= cat of tracklet means) + predicate head
+  // 4. RelOIPool over the segment on the pair feats (= cat of the two tracklet means) + predicate
+  // head; linear in the two halves, so evaluated per tracklet and combined per pair
   if ((rc = tspn_temporal_mean_f32(d->feats, NT, T, D, 1, fbar, stream))) return rc;
-  if ((rc = tspn_pair_rows_f32(fbar, NT, D, d->pairs, d->P, pooled, stream))) return rc;
-  return tspn_predicate_head_f32(pooled, d->P, C, C, d->cls_w, d->cls_b, d->K, d->out_logits, 1,
-                                 lin, L.lin_bytes, stream);
+  (void)pooled;
+  return tspn::pair_predicate(fbar, NT, D, d->pairs, d->P, d->cls_w, d->cls_b, d->K, d->out_logits, lin,
+                              L.lin_bytes, stream);
 }
 
 extern "C" int tspn_temporal_encoder_heads_f32(const float* x, int64_t P, int64_t C, int64_t T,

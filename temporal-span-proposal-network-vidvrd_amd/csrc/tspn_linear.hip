@@ -43,7 +43,7 @@ struct SplitTable {
 template <bool NORM>
 __global__ __launch_bounds__(THREADS) void linear_splitk_kernel(
     const float* __restrict__ x, int64_t P, int64_t F, int64_t ldx, const float* __restrict__ W,
-    int64_t K, int64_t k_per_split, float* __restrict__ partial, SplitTable tab,
+    int64_t ldw, int64_t K, int64_t k_per_split, float* __restrict__ partial, SplitTable tab,
     float* __restrict__ norm_partial) {
   __shared__ float xs[TM * LDS_STRIDE];
   __shared__ float wsm[TN * LDS_STRIDE];
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(THREADS) void linear_splitk_kernel(
     for (int r = 0; r < TN / 8; ++r) {
       const int row = lr + 8 * r;
       const int64_t gc = col0 + row;
-      wsm[row * LDS_STRIDE + lk] = (kv && gc < K) ? W[gc * F + k] : 0.f;
+      wsm[row * LDS_STRIDE + lk] = (kv && gc < K) ? W[gc * ldw + k] : 0.f;
     }
     __syncthreads();
 #pragma unroll
@@ -199,6 +199,21 @@ int build_split_table(int64_t P, int64_t F, int64_t K, int64_t first, int64_t bl
   return ok ? n : -1;
 }
 
+// logits[p,k] = sigmoid(rs[s(p),k] + ro[o(p),k] + b[k]): the predicate head on cat(f_s, f_o) is linear
+// in the two halves, so it is evaluated per tracklet (rs = f W_s^T, ro = f W_o^T) and combined per pair.
+__global__ void pair_combine_kernel(const float* __restrict__ rs, const float* __restrict__ ro,
+                                    const int64_t* __restrict__ pairs, int64_t P, int64_t K,
+                                    const float* __restrict__ b, float* __restrict__ out) {
+  const int64_t total = P * K;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = i / K, k = i - p * K;
+    float v = rs[pairs[2 * p] * K + k] + ro[pairs[2 * p + 1] * K + k];
+    if (b != nullptr) v += b[k];
+    out[i] = 1.f / (1.f + expf(-v));
+  }
+}
+
 int choose_splits(int64_t P, int64_t F, int64_t K) {
   const int64_t tiles = tspn::ceil_div(P, TM) * tspn::ceil_div(K, TN);
   int64_t s = tspn::ceil_div(512, tiles);
@@ -218,6 +233,14 @@ extern "C" int tspn_predicate_head_f32(const float* x, int64_t P, int64_t F, int
                                        const float* W, const float* b, int64_t K, float* out,
                                        int apply_sigmoid, void* workspace, size_t workspace_bytes,
                                        void* stream) {
+  return tspn::linear(x, P, F, ldx, W, F, b, K, out, apply_sigmoid, workspace, workspace_bytes, stream);
+}
+
+// out[P,K] = act(x[P,F] @ W[K, :F]^T + b) with row strides ldx / ldw (a column slice of a wider W)
+int tspn::linear(const float* x, int64_t P, int64_t F, int64_t ldx, const float* W, int64_t ldw,
+                 const float* b, int64_t K, float* out, int apply_sigmoid, void* workspace,
+                 size_t workspace_bytes, void* stream) {
+  TSPN_REQUIRE(ldw >= F, TSPN_EINVAL, "tspn_predicate_head_f32: bad ldw");
   TSPN_REQUIRE(P >= 0 && F > 0 && K > 0 && ldx >= F, TSPN_EINVAL,
                "tspn_predicate_head_f32: bad sizes P=%lld F=%lld K=%lld ldx=%lld", (long long)P,
                (long long)F, (long long)K, (long long)ldx);
@@ -235,7 +258,7 @@ extern "C" int tspn_predicate_head_f32(const float* x, int64_t P, int64_t F, int
   hipStream_t s = TSPN_STREAM(stream);
   float* partial = static_cast<float*>(workspace);
   hipLaunchKernelGGL(linear_splitk_kernel<false>, dim3((unsigned)gx, (unsigned)gy, (unsigned)splits),
-                     dim3(THREADS), 0, s, x, P, F, ldx, W, K, kps, partial, SplitTable{},
+                     dim3(THREADS), 0, s, x, P, F, ldx, W, ldw, K, kps, partial, SplitTable{},
                      (float*)nullptr);
   int rc = tspn::check_launch("tspn_predicate_head_f32(splitk)");
   if (rc) return rc;
@@ -288,11 +311,39 @@ extern "C" int tspn_predicate_head_norm_f32(const float* x, int64_t P, int64_t F
   float* partial = static_cast<float*>(workspace);
   float* norm_partial = partial + (size_t)n * P * K;
   hipLaunchKernelGGL(linear_splitk_kernel<true>, dim3((unsigned)gx, (unsigned)gy, (unsigned)n),
-                     dim3(THREADS), 0, s, x, P, F, ldx, W, K, (int64_t)0, partial, tab, norm_partial);
+                     dim3(THREADS), 0, s, x, P, F, ldx, W, F, K, (int64_t)0, partial, tab, norm_partial);
   int rc = tspn::check_launch("tspn_predicate_head_norm_f32(splitk)");
   if (rc) return rc;
   const int blocks = (int)std::min<int64_t>(tspn::ceil_div(P * K, 256), 4096);
   hipLaunchKernelGGL(linear_reduce_norm_kernel, dim3(blocks), dim3(256), 0, s, partial, norm_partial,
                      P, K, tab, b, apply_sigmoid, out);
   return tspn::check_launch("tspn_predicate_head_norm_f32(reduce)");
+}
+
+
+size_t tspn::pair_predicate_workspace_bytes(int64_t NT, int64_t D, int64_t K) {
+  return tspn::align_up(tspn_predicate_head_workspace_bytes(NT, D, K), 256) +
+         2 * tspn::align_up((size_t)NT * K * sizeof(float), 256);
+}
+
+// rel_logits[P,K] = sigmoid(cat(fbar[s], fbar[o]) @ cls_w[K,2D]^T + b), factorised per tracklet
+int tspn::pair_predicate(const float* fbar, int64_t NT, int64_t D, const int64_t* pairs, int64_t P,
+                         const float* cls_w, const float* cls_b, int64_t K, float* out,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+  if (P == 0 || NT == 0) return TSPN_OK;
+  const size_t lin = tspn::align_up(tspn_predicate_head_workspace_bytes(NT, D, K), 256);
+  const size_t rbytes = tspn::align_up((size_t)NT * K * sizeof(float), 256);
+  TSPN_REQUIRE(workspace && workspace_bytes >= lin + 2 * rbytes, TSPN_EWORKSPACE,
+               "pair_predicate: workspace too small");
+  char* ws = static_cast<char*>(workspace);
+  float* rs = reinterpret_cast<float*>(ws + lin);
+  float* ro = reinterpret_cast<float*>(ws + lin + rbytes);
+  int rc = tspn::linear(fbar, NT, D, D, cls_w, 2 * D, nullptr, K, rs, 0, ws, lin, stream);
+  if (rc) return rc;
+  rc = tspn::linear(fbar, NT, D, D, cls_w + D, 2 * D, nullptr, K, ro, 0, ws, lin, stream);
+  if (rc) return rc;
+  const int blocks = (int)std::min<int64_t>(tspn::ceil_div(P * K, 256), 4096);
+  hipLaunchKernelGGL(pair_combine_kernel, dim3(blocks), dim3(256), 0, TSPN_STREAM(stream), rs, ro, pairs,
+                     P, K, cls_b, out);
+  return tspn::check_launch("pair_predicate(combine)");
 }
