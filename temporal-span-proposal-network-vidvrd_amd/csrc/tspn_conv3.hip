@@ -1089,17 +1089,21 @@ constexpr size_t W2_SMEM_BYTES = sizeof(float) * 2 * (W2_A_ST + W2_X_ST + W2_V_S
 __global__ __launch_bounds__(THREADS, 2) void conv3_wino2_cl_kernel(
     const float* __restrict__ x, const float* __restrict__ Wp, const float* __restrict__ bias,
     float* __restrict__ y, int Cin, int T, int M, int64_t ncols, int tiles_m, int tiles_n,
-    int relu, int ldy) {
+    int relu, int ldy, int GM) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* As = reinterpret_cast<float*>(smem_raw);
   float* Xs = As + 2 * W2_A_ST;
   float* Vs = Xs + 2 * W2_X_ST;
 
+  // ---- workgroup -> tile: bijective XCD remap (XCD = bid % 8 gets a contiguous range), then groups of
+  // GM weight panels x all frame tiles with the panel index fastest, so the 64 workgroups resident on
+  // one XCD share panels (4 MB each) and x tiles (1 MB each) in its L2.  GM = 2 (launcher) measured the
+  // least L2-miss traffic (FETCH_SIZE, 8 videos: 25 GB against 36 GB at GM = 8, 67 GB at 16); cutting
+  // the dispatch order into frame superblocks changed neither traffic nor time (MFMA-bound; r1 notes).
   const int nwg = gridDim.x;
   const int bid = blockIdx.x;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
   const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  constexpr int GM = 8;
   const int group_sz = GM * tiles_n;
   const int group = wg / group_sz;
   const int first_m = group * GM;
@@ -1436,9 +1440,14 @@ int tspn::conv3_tc_wino(const float* x, int64_t B, int64_t T, int64_t Cin, const
                        WN_SMEM_BYTES, TSPN_STREAM(stream), x, packed4, bias, y, (int)Cin, (int)T, (int)M,
                        ncols, (int)tiles_m, (int)tiles_n, relu, (int)ldy);
   } else {
+    static const int gm_tiles = [] {
+      const char* e = getenv("TSPN_WINO_GM");
+      const int v = e ? atoi(e) : 2;
+      return v > 0 ? v : 2;
+    }();
     hipLaunchKernelGGL(conv3_wino2_cl_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(THREADS),
                        W2_SMEM_BYTES, TSPN_STREAM(stream), x, packed4, bias, y, (int)Cin, (int)T, (int)M,
-                       ncols, (int)tiles_m, (int)tiles_n, relu, (int)ldy);
+                       ncols, (int)tiles_m, (int)tiles_n, relu, (int)ldy, gm_tiles);
   }
   return tspn::check_launch("tspn_conv3_tc_wino_f32");
 }

@@ -37,7 +37,7 @@ def main():
         if not files:
             raise SystemExit(f"no counter_collection.csv under {args.src}/{sub}")
         agg = collections.defaultdict(list)
-        for r in csv.DictReader(open(files[0])):
+        for r in csv.DictReader(open(max(files, key=os.path.getmtime))):  # newest pass
             if r["Counter_Name"] != ctr:
                 continue
             agg[short(r["Kernel_Name"])].append(
