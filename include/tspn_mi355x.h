@@ -267,6 +267,55 @@ typedef struct tspn_fused_desc {
 size_t tspn_forward_fused_workspace_bytes(const tspn_fused_desc* d);
 int tspn_forward_fused_f32(const tspn_fused_desc* d, void* stream);
 
+/* ---- bf16-operand path (BASELINE config 3: N=64, T=900, D=1024, bf16) ----
+ * Semantics (build-defined; pinned by tests/golden/g8 against the reference's own DPNHead /
+ * RelationPredictor modules cast with .bfloat16(), lib/modeling/relpn/dpn.py:55-73, model.py:76-88):
+ * operands bf16 (stored as uint16_t bit patterns), products exact, accumulation and biases fp32; the
+ * encoder activation relu(conv + b) is rounded to bf16 once, the span-pooled feature is rounded to
+ * bf16, head outputs and logits are fp32.                                                          */
+int tspn_cast_bf16(const float* src, int64_t n, uint16_t* dst, void* stream); /* round-to-nearest-even */
+/* conv.weight [M, Cin, 3] fp32 -> [3][Cp/8][Mp][8] bf16; `split` as in tspn_pack_conv3_f32 */
+int tspn_pack_conv3_bf16(const float* W, int64_t M, int64_t Cin, int64_t split, uint16_t* packed,
+                         void* stream);
+/* 1x1 head weights [H <= 16, C] fp32 -> [C/8][16][8] bf16 (rows H..15 zero) */
+int tspn_pack_heads_bf16(const float* W, int64_t H, int64_t C, uint16_t* packed, void* stream);
+/* k=3, pad=1 conv over time; x bf16 channels-last [B, T, Cin]; y fp32 channels-last [B*T, ldm]
+ * (y[n][m], n = b*T + t), + bias[m] if given.  Needs Cin % 32 == 0, M % 4 == 0, ldm % 4 == 0. */
+int tspn_conv3_tc_bf16(const uint16_t* x, int64_t B, int64_t T, int64_t Cin, const uint16_t* packed,
+                       int64_t M, const float* bias, float* y, int64_t ldm, void* stream);
+/* pair stage on the canonical pair table: y fp32 [B*N*T, ldm] with U = channels [0,C), V = [C,2C);
+ * out[p][h][t] = head_b[h] + sum_c Wh[h][c] * bf16(relu(U[s][t][c] + V[o][t][c])), out [B*N*(N-1), H, T] */
+int tspn_heads_pairgrid_bf16(const float* y, int64_t ldm, int64_t B, int64_t N, int64_t C, int64_t T,
+                             const uint16_t* head_packed, const float* head_b, int64_t H, float* out,
+                             void* stream);
+/* mean over frames of bf16 [R, T, D] -> fp32 [R, D] holding bf16-rounded values (RelOIPool over the
+ * whole segment, model.py:59-60) */
+int tspn_temporal_mean_bf16(const uint16_t* x, int64_t R, int64_t T, int64_t D, float* out, void* stream);
+
+typedef struct tspn_fused_bf16_desc {
+  int64_t B, N, T, D;            /* C = 2D; D % 32 == 0 */
+  int64_t A, K;
+  const uint16_t* feats;         /* bf16 [B*N, T, D] */
+  const int64_t* pairs;          /* canonical table of tspn_pair_index_i64 for every video, global ids */
+  int64_t P;                     /* == B*N*(N-1) */
+  const uint16_t* conv_packed;   /* tspn_pack_conv3_bf16(conv.weight [C,C,3], split=D): [3][D/8][2C][8] */
+  const float* conv_bias;        /* [C] fp32 */
+  const uint16_t* head_packed;   /* tspn_pack_heads_bf16([3A, C]) */
+  const float* head_b;           /* [3A] fp32 */
+  const float* cls_w;            /* [K, C] fp32 storage of bf16-rounded weights (products of bf16 values are
+                                    exact in fp32, so the fp32 predicate kernels give the bf16-MFMA result) */
+  const float* cls_b;            /* [K] */
+  float* out_heads;              /* [P, 3A, T] fp32 */
+  float* out_logits;             /* [P, K] fp32 */
+  void* workspace;
+  size_t workspace_bytes;
+  void* ev_conv_begin;           /* optional hipEvent_t around the conv kernel, as in tspn_fused_desc */
+  void* ev_conv_end;
+} tspn_fused_bf16_desc;
+
+size_t tspn_forward_fused_bf16_workspace_bytes(const tspn_fused_bf16_desc* d);
+int tspn_forward_fused_bf16(const tspn_fused_bf16_desc* d, void* stream);
+
 /* ---- dense reference-faithful encoder + heads on a materialised [P,C,T] --
  * DPNHead.forward (lib/modeling/relpn/dpn.py:69-73) on arbitrary pair feats:
  * conv3+ReLU into `h_ws` [P,C,T] (caller scratch), then tspn_heads_f32 mode 0. */

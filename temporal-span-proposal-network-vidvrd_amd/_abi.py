@@ -45,6 +45,21 @@ class FusedDesc(ctypes.Structure):
     ]
 
 
+class FusedBf16Desc(ctypes.Structure):
+    """struct tspn_fused_bf16_desc (include/tspn_mi355x.h)."""
+    _fields_ = [
+        ("B", _i64), ("N", _i64), ("T", _i64), ("D", _i64),
+        ("A", _i64), ("K", _i64),
+        ("feats", _vp), ("pairs", _vp), ("P", _i64),
+        ("conv_packed", _vp), ("conv_bias", _vp),
+        ("head_packed", _vp), ("head_b", _vp),
+        ("cls_w", _vp), ("cls_b", _vp),
+        ("out_heads", _vp), ("out_logits", _vp),
+        ("workspace", _vp), ("workspace_bytes", _sz),
+        ("ev_conv_begin", _vp), ("ev_conv_end", _vp),
+    ]
+
+
 # name -> (restype, argtypes); mirrors the header one-to-one
 PROTOTYPES = {
     "tspn_version": (_int, []),
@@ -82,6 +97,14 @@ PROTOTYPES = {
     "tspn_forward_fused_f32": (_int, [ctypes.POINTER(FusedDesc), _vp]),
     "tspn_temporal_encoder_heads_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64,
                                                _vp, _vp, _vp]),
+    "tspn_cast_bf16": (_int, [_vp, _i64, _vp, _vp]),
+    "tspn_pack_conv3_bf16": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
+    "tspn_pack_heads_bf16": (_int, [_vp, _i64, _i64, _vp, _vp]),
+    "tspn_conv3_tc_bf16": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _vp]),
+    "tspn_heads_pairgrid_bf16": (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp]),
+    "tspn_temporal_mean_bf16": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
+    "tspn_forward_fused_bf16_workspace_bytes": (_sz, [ctypes.POINTER(FusedBf16Desc)]),
+    "tspn_forward_fused_bf16": (_int, [ctypes.POINTER(FusedBf16Desc), _vp]),
 }
 
 _lib = None

@@ -1,0 +1,606 @@
+// bf16-operand relation-scoring path (BASELINE config 3: N=64, T=900, D=1024, bf16) for gfx950.
+//
+// Semantics (build-defined; the reference has no reduced-precision path — the closest statement is
+// its own modules cast with `.bfloat16()`, lib/modeling/relpn/dpn.py:55-73 and model.py:76-88, which
+// tests/golden/g8 pins): operands (tracklet features, conv / head / classifier weights) are bf16,
+// every product is exact and accumulated in fp32, biases are fp32, the encoder activation
+// relu(conv + b) is rounded to bf16 ONCE (what a bf16 Conv1d + ReLU hands to the 1x1 heads), the
+// span-pooled feature (mean over frames) is rounded to bf16, head outputs and logits stay fp32.
+// With the factorised encoder that means the tracklet projections U, V stay fp32
+// and only relu(U[s] + V[o]) is rounded.
+//
+// Kernels:
+//   conv3_bf16_cl_kernel        k=3 temporal conv of the tracklet projections as implicit GEMM on
+//                               v_mfma_f32_32x32x16_bf16; channels-last x AND channels-last fp32 y
+//                               ([tracklet*frame][2C]) so that the pair stage finds the 8 channels a
+//                               lane needs contiguous;
+//   heads_pairgrid_bf16_kernel  pair stage: relu(U[s]+V[o]) -> bf16 in registers (v_pk_add_f32,
+//                               v_cvt_pk_bf16_f32, v_pk_max_i16) as B operand of the [3A,C] head GEMM
+//                               on v_mfma_f32_16x16x32_bf16;
+//   helpers                     fp32->bf16 cast, weight packing, temporal mean.
+#include <algorithm>
+#include <type_traits>
+
+#include "tspn_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int THREADS = 256;
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void cast_bf16_kernel(const float* __restrict__ src, int64_t n, __bf16* __restrict__ dst) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] = (__bf16)src[i];  // round to nearest even (v_cvt_pk_bf16_f32)
+}
+
+// conv.weight [M, Cin, 3] fp32 -> [3 taps][Cp/8][Mp][8] bf16 (split > 0: rows [0,M) take input
+// channels [0,split) = subject half, rows [M,2M) take [split, 2 split) = object half; Cp = split)
+__global__ void pack_conv3_bf16_kernel(const float* __restrict__ W, int64_t M, int64_t Cin,
+                                       int64_t split, __bf16* __restrict__ packed) {
+  const int64_t Mp = split > 0 ? 2 * M : M;
+  const int64_t Cp = split > 0 ? split : Cin;
+  const int64_t total = 3 * Cp * Mp;
+  for (int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; o < total;
+       o += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t j = o & 7;
+    const int64_t r = (o >> 3) % Mp;
+    const int64_t cg = (o >> 3) / Mp % (Cp >> 3);
+    const int64_t tap = o / (Mp * Cp);
+    const int64_t ci = cg * 8 + j;
+    const int64_t m = r < M ? r : r - M;
+    const int64_t c = r < M ? ci : ci + split;
+    packed[o] = (__bf16)W[(m * Cin + c) * 3 + tap];
+  }
+}
+
+// head weights [H, C] fp32 -> [C/8][16][8] bf16, rows H..15 zero
+__global__ void pack_heads_bf16_kernel(const float* __restrict__ W, int64_t H, int64_t C,
+                                       __bf16* __restrict__ packed) {
+  const int64_t total = C * 16;
+  for (int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; o < total;
+       o += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t j = o & 7, h = (o >> 3) & 15, cg = o >> 7;
+    packed[o] = h < H ? (__bf16)W[h * C + cg * 8 + j] : (__bf16)0.f;
+  }
+}
+
+// mean over frames of bf16 features [R, T, D] -> fp32 [R, D] holding bf16-rounded values
+__global__ __launch_bounds__(256) void temporal_mean_bf16_kernel(const __bf16* __restrict__ x,
+                                                                 int64_t R, int T, int D,
+                                                                 float* __restrict__ out) {
+  __shared__ float part[4][64][8];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int64_t groups = D >> 3;
+  const int64_t item = blockIdx.x * 64LL + tx;  // (row, channel group)
+  const bool ok = item < R * groups;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (ok) {
+    const int64_t r = item / groups, g = item - r * groups;
+    const __bf16* p = x + (r * T) * (int64_t)D + g * 8;
+    for (int t = ty; t < T; t += 4) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(p + (int64_t)t * D);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) part[ty][tx][j] = acc[j];
+  __syncthreads();
+  if (ty == 0 && ok) {
+    const int64_t r = item / groups, g = item - r * groups;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float s = (part[0][tx][j] + part[1][tx][j]) + (part[2][tx][j] + part[3][tx][j]);
+      out[r * D + g * 8 + j] = (float)(__bf16)(s / (float)T);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv3, bf16 operands.  Workgroup tile 128 output channels x 128 flat (tracklet, frame) columns,
+// 4 waves x (2 x 2 blocks of 32 x 32), K chunk = 32 input channels x 3 taps = 24 MFMAs per wave.
+// LDS images (both filled by 16-byte LDS-DMA pieces, double-buffered, 64.5 KB -> 2 workgroups/CU):
+//   weights [3 taps][4 channel groups][128 m][8 ch]   a lane's A fragment = one ds_read_b128
+//   x       [4 channel groups][132 column slots][8 ch] read at 3 shifts (halo columns are ordinary
+//                                                      units of the same DMA; no im2col)
+// Lanes k = 0 / 1 of the 32x32x16 MFMA take channel groups 2s / 2s+1 of k-step s.
+constexpr int BM = 128, BN = 128;
+constexpr int KC = 32, KG = KC / 8;
+constexpr int SLP = 132;
+constexpr int A_ST = 3 * KG * BM * 16;   // bytes per stage
+constexpr int X_ST = KG * SLP * 16;
+constexpr int X_UNITS = KG * SLP;
+constexpr size_t CONV_SMEM = 2 * (size_t)(A_ST + X_ST);
+
+__global__ __launch_bounds__(THREADS, 2) void conv3_bf16_cl_kernel(
+    const __bf16* __restrict__ x, const __bf16* __restrict__ Wp, const float* __restrict__ bias,
+    float* __restrict__ y, int Cin, int T, int M, int64_t ncols, int tiles_m, int tiles_n, int ldm) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* As = smem;
+  char* Xs = smem + 2 * A_ST;
+
+  // workgroup -> tile: bijective XCD remap, then groups of 2 weight panels x all column tiles
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  constexpr int GM = 2;
+  const int group_sz = GM * tiles_n;
+  const int group = wg / group_sz;
+  const int first_m = group * GM;
+  const int gm = min(GM, tiles_m - first_m);
+  const int in_group = wg - group * group_sz;
+  const int tile_m = first_m + in_group % gm;
+  const int tile_n = in_group / gm;
+  const int m0 = tile_m * BM;
+  const int64_t n0 = (int64_t)tile_n * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, kh = lane >> 5;
+
+  // weight pieces: piece pa = (tap*4 + group)*2 + half covers 64 rows m; wave w stages pa = 6w .. 6w+5
+  const __bf16* asrc[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int pa = wave * 6 + i;
+    const int tap = pa >> 3, kg = (pa >> 1) & 3, half = pa & 1;
+    int m = m0 + 64 * half + lane;
+    m = m < M ? m : 0;
+    asrc[i] = Wp + (((int64_t)tap * (Cin >> 3) + kg) * M + m) * 8;
+  }
+  const int64_t a_step = (int64_t)KG * M * 8;
+  // x pieces: piece p = wave + 4q covers units [64p, 64p+64); unit u = (group u/132, slot u%132),
+  // slot <-> column n0 + slot - 1 (clamped; clamped columns are masked or never stored)
+  const __bf16* bsrc[3];
+  bool bval[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int u = 64 * (wave + 4 * q) + lane;
+    const int g = u / SLP, slot = u - g * SLP;
+    bval[q] = u < X_UNITS && slot < BN + 2;
+    int64_t n = n0 + slot - 1;
+    n = n < 0 ? 0 : (n < ncols ? n : ncols - 1);
+    bsrc[q] = x + n * Cin + 8 * (g < KG ? g : 0);
+  }
+  auto stage_one = [&](int buf, auto d_tag) {
+    constexpr int d = decltype(d_tag)::value;
+    if constexpr (d < 6) {
+      glds16(asrc[d], As + buf * A_ST + (wave * 6 + d) * 1024);
+      asrc[d] += a_step;
+    } else {
+      constexpr int q = d - 6;
+      if (bval[q]) glds16(bsrc[q], Xs + buf * X_ST + 64 * (wave + 4 * q) * 16);
+      bsrc[q] += KC;
+    }
+  };
+#define TSPN_STAGE(buf, d) stage_one(buf, std::integral_constant<int, d>{})
+
+  bool mask_l[2], mask_r[2];
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int64_t n = n0 + wn * 64 + ni * 32 + li;
+    const int t = (int)(n % T);
+    mask_l[ni] = t != 0;
+    mask_r[ni] = t != T - 1;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  const int nchunks = Cin / KC;
+  TSPN_STAGE(0, 0); TSPN_STAGE(0, 1); TSPN_STAGE(0, 2); TSPN_STAGE(0, 3); TSPN_STAGE(0, 4);
+  TSPN_STAGE(0, 5); TSPN_STAGE(0, 6); TSPN_STAGE(0, 7); TSPN_STAGE(0, 8);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto chunk_body = [&](int buf, auto more_tag) {
+    constexpr bool MORE = decltype(more_tag)::value;
+    const char* Ab = As + buf * A_ST + (kh * BM + wm * 64 + li) * 16;
+    const char* Xb = Xs + buf * X_ST + (kh * SLP + wn * 64 + li) * 16;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 a[3][2], b[2][3];
+#pragma unroll
+      for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+          a[tap][mi] = *reinterpret_cast<const bf16x8*>(Ab + ((tap * KG + 2 * s) * BM + mi * 32) * 16);
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap)
+          b[ni][tap] = *reinterpret_cast<const bf16x8*>(Xb + (2 * s * SLP + ni * 32 + tap) * 16);
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        b[ni][0] = mask_l[ni] ? b[ni][0] : zero8;
+        b[ni][2] = mask_r[ni] ? b[ni][2] : zero8;
+      }
+#pragma unroll
+      for (int tap = 0; tap < 3; ++tap) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tap][0], b[0][tap], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tap][0], b[1][tap], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tap][1], b[0][tap], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tap][1], b[1][tap], acc[1][1], 0, 0, 0);
+        if (MORE) {
+          if (s == 0 && tap == 0) { TSPN_STAGE(buf ^ 1, 0); TSPN_STAGE(buf ^ 1, 1); }
+          if (s == 0 && tap == 1) { TSPN_STAGE(buf ^ 1, 2); TSPN_STAGE(buf ^ 1, 3); }
+          if (s == 0 && tap == 2) { TSPN_STAGE(buf ^ 1, 4); }
+          if (s == 1 && tap == 0) { TSPN_STAGE(buf ^ 1, 5); TSPN_STAGE(buf ^ 1, 6); }
+          if (s == 1 && tap == 1) { TSPN_STAGE(buf ^ 1, 7); }
+          if (s == 1 && tap == 2) { TSPN_STAGE(buf ^ 1, 8); }
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA of the next chunk has landed
+    __syncthreads();
+  };
+  for (int c = 0; c + 1 < nchunks; ++c) chunk_body(c & 1, std::true_type{});
+  chunk_body((nchunks - 1) & 1, std::false_type{});
+#undef TSPN_STAGE
+
+  // epilogue: channels-last y[n][m]; a lane holds 4 consecutive channels per register quad
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int64_t n = n0 + wn * 64 + ni * 32 + li;
+    if (n >= ncols) continue;
+    float* yrow = y + n * (int64_t)ldm;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+      for (int eq = 0; eq < 4; ++eq) {
+        const int m = m0 + wm * 64 + mi * 32 + 8 * eq + 4 * kh;
+        if (m < M) {
+          f32x4 v = {acc[mi][ni][4 * eq], acc[mi][ni][4 * eq + 1], acc[mi][ni][4 * eq + 2],
+                     acc[mi][ni][4 * eq + 3]};
+          if (bias != nullptr) v += *reinterpret_cast<const f32x4*>(bias + m);
+          *reinterpret_cast<f32x4*>(yrow + m) = v;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pair stage, bf16: out[p][h][t] = bh[h] + sum_c Wh[h][c] * bf16(relu(U[s][t][c] + V[o][t][c])) for
+// the canonical pair table.  Workgroup = (video, 8 subjects x 8 objects, 16 frames); wave w owns
+// subjects 2w, 2w+1 x 8 objects (16 accumulator tiles of 16 heads x 16 frames).  Per k-step of 32
+// channels the 16 projection rows (8 U + 8 V) x 16 frames x 32 ch fp32 = 32 KB are staged by LDS-DMA
+// (double-buffered, 64 KB -> 2 workgroups/CU).  The DMA source of each lane is chosen so that the LDS
+// image of a row is [half j][channel group kg][frame f] (16-byte units): the B fragment of lane
+// (f = l&15, kg = l>>4) -- channels 8kg .. 8kg+7 of frame f -- is two conflict-free ds_read_b128
+// at unit l and unit 64 + l.  The kernel is VALU-bound (1.5 packed VALU per activation), not MFMA-bound.
+constexpr int HP_FB = 16;
+constexpr int HP_KC = 32;
+constexpr int HP_ROW = HP_FB * HP_KC * 4;  // 2048 B
+constexpr int HP_ST = 16 * HP_ROW;         // 32 KB
+constexpr size_t HP_SMEM = 2 * (size_t)HP_ST;
+
+__device__ __forceinline__ unsigned relu_pack(float a, float b) {
+  f32x2 s = {a, b};
+  const bf16x2 h = __builtin_convertvector(s, bf16x2);
+  const s16x2 z = {0, 0};
+  // ReLU on the packed pair: negative floats are negative int16 (v_pk_max_i16); -0 -> +0
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, h), z));
+}
+
+__global__ __launch_bounds__(THREADS, 2) void heads_pairgrid_bf16_kernel(
+    const float* __restrict__ y, int64_t ldm, int B, int N, int C, int T,
+    const __bf16* __restrict__ Whp, const float* __restrict__ bh, int H, float* __restrict__ out,
+    int nsb, int nfb) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int ob = wg % nsb;
+  wg /= nsb;
+  const int sb = wg % nsb;
+  wg /= nsb;
+  const int fb = wg % nfb;
+  const int b = wg / nfb;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int f = lane & 15, kg = lane >> 4;
+  const int t0 = fb * HP_FB;
+
+  // DMA sources: wave w stages rows 4w .. 4w+3 (2 pieces each); row r < 8: subject 8 sb + r (U half,
+  // channels [0,C)), r >= 8: object 8 ob + r - 8 (V half, channels [C,2C))
+  const float* src[8];
+  {
+    const int t = min(t0 + f, T - 1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = wave * 4 + (i >> 1), j = i & 1;
+      int trk = r < 8 ? sb * 8 + r : ob * 8 + r - 8;
+      trk = min(trk, N - 1);
+      const int q = 2 * kg + j;
+      src[i] = y + (((int64_t)b * N + trk) * T + t) * ldm + (r < 8 ? 0 : C) + 4 * q;
+    }
+  }
+  auto stage = [&](int buf) {
+    char* dst = smem + buf * HP_ST + wave * 4 * HP_ROW;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      glds16(src[i], dst + i * 1024);
+      src[i] += HP_KC;
+    }
+  };
+
+  f32x4 acc[2][8];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int o = 0; o < 8; ++o) acc[s][o] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = C / HP_KC;
+  const bf16x8* wsrc = reinterpret_cast<const bf16x8*>(Whp) + kg * 16 + f;  // + 64 per k-step
+  stage(0);
+  bf16x8 wfrag = wsrc[0];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int k = 0; k < nk; ++k) {
+    const int buf = k & 1;
+    if (k + 1 < nk) stage(buf ^ 1);
+    const bf16x8 wnext = wsrc[(int64_t)min(k + 1, nk - 1) * 64];
+    const char* base = smem + buf * HP_ST + lane * 16;
+    f32x4 u[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      u[s][0] = *reinterpret_cast<const f32x4*>(base + (2 * wave + s) * HP_ROW);
+      u[s][1] = *reinterpret_cast<const f32x4*>(base + (2 * wave + s) * HP_ROW + 1024);
+    }
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(base + (8 + o) * HP_ROW);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(base + (8 + o) * HP_ROW + 1024);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const f32x4 a0 = u[s][0] + v0, a1 = u[s][1] + v1;
+        u32x4 pk = {relu_pack(a0[0], a0[1]), relu_pack(a0[2], a0[3]), relu_pack(a1[0], a1[1]),
+                    relu_pack(a1[2], a1[3])};
+        acc[s][o] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag, __builtin_bit_cast(bf16x8, pk),
+                                                             acc[s][o], 0, 0, 0);
+      }
+    }
+    wfrag = wnext;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA of the next k-step has landed
+    __syncthreads();
+  }
+
+  // epilogue: lane = (frame f, head group hg): heads 4 hg .. 4 hg + 3
+  const int t = t0 + f;
+  const int hg = lane >> 4;
+  float bias[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bias[r] = (4 * hg + r < H) ? bh[4 * hg + r] : 0.f;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int sg = sb * 8 + 2 * wave + s;
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+      const int og = ob * 8 + o;
+      if (sg >= N || og >= N || sg == og || t >= T) continue;
+      const int64_t p = (int64_t)b * N * (N - 1) + (int64_t)sg * (N - 1) + (og < sg ? og : og - 1);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int h = 4 * hg + r;
+        if (h < H) out[(p * H + h) * T + t] = acc[s][o][r] + bias[r];
+      }
+    }
+  }
+}
+
+int set_smem(const void* fn, size_t bytes, const char* what) {
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return tspn::fail(TSPN_ELAUNCH, "%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
+  return TSPN_OK;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int tspn_cast_bf16(const float* src, int64_t n, uint16_t* dst, void* stream) {
+  TSPN_REQUIRE(n >= 0, TSPN_EINVAL, "tspn_cast_bf16: n=%lld", (long long)n);
+  if (n == 0) return TSPN_OK;
+  TSPN_REQUIRE(src && dst, TSPN_EINVAL, "tspn_cast_bf16: null pointer");
+  const int blocks = (int)std::min<int64_t>(tspn::ceil_div(n, 256), 16384);
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks), dim3(256), 0, TSPN_STREAM(stream), src, n,
+                     reinterpret_cast<__bf16*>(dst));
+  return tspn::check_launch("tspn_cast_bf16");
+}
+
+extern "C" int tspn_pack_conv3_bf16(const float* W, int64_t M, int64_t Cin, int64_t split,
+                                    uint16_t* packed, void* stream) {
+  TSPN_REQUIRE(W && packed && M > 0 && Cin > 0 && split >= 0, TSPN_EINVAL,
+               "tspn_pack_conv3_bf16: bad arguments");
+  TSPN_REQUIRE(split == 0 || Cin == 2 * split, TSPN_EINVAL,
+               "tspn_pack_conv3_bf16: split=%lld requires Cin == 2*split (Cin=%lld)", (long long)split,
+               (long long)Cin);
+  TSPN_REQUIRE((split > 0 ? split : Cin) % 8 == 0, TSPN_EUNSUPPORTED,
+               "tspn_pack_conv3_bf16: packed input channels must be a multiple of 8");
+  const int64_t total = 3 * M * Cin;
+  const int blocks = (int)std::min<int64_t>(tspn::ceil_div(total, 256), 8192);
+  hipLaunchKernelGGL(pack_conv3_bf16_kernel, dim3(blocks), dim3(256), 0, TSPN_STREAM(stream), W, M, Cin,
+                     split, reinterpret_cast<__bf16*>(packed));
+  return tspn::check_launch("tspn_pack_conv3_bf16");
+}
+
+extern "C" int tspn_pack_heads_bf16(const float* W, int64_t H, int64_t C, uint16_t* packed, void* stream) {
+  TSPN_REQUIRE(W && packed && H > 0 && H <= 16 && C > 0 && C % 8 == 0, TSPN_EINVAL,
+               "tspn_pack_heads_bf16: bad arguments (H=%lld <= 16, C=%lld %% 8 == 0)", (long long)H,
+               (long long)C);
+  const int blocks = (int)std::min<int64_t>(tspn::ceil_div(C * 16, 256), 8192);
+  hipLaunchKernelGGL(pack_heads_bf16_kernel, dim3(blocks), dim3(256), 0, TSPN_STREAM(stream), W, H, C,
+                     reinterpret_cast<__bf16*>(packed));
+  return tspn::check_launch("tspn_pack_heads_bf16");
+}
+
+extern "C" int tspn_temporal_mean_bf16(const uint16_t* x, int64_t R, int64_t T, int64_t D, float* out,
+                                       void* stream) {
+  TSPN_REQUIRE(R >= 0 && T > 0 && D > 0 && D % 8 == 0 && T < (1 << 30) && D < (1 << 30), TSPN_EINVAL,
+               "tspn_temporal_mean_bf16: bad sizes R=%lld T=%lld D=%lld (D %% 8 == 0)", (long long)R,
+               (long long)T, (long long)D);
+  if (R == 0) return TSPN_OK;
+  TSPN_REQUIRE(x && out && aligned16(x), TSPN_EINVAL, "tspn_temporal_mean_bf16: null / unaligned pointer");
+  const int64_t items = R * (D / 8);
+  hipLaunchKernelGGL(temporal_mean_bf16_kernel, dim3((unsigned)tspn::ceil_div(items, 64)), dim3(256), 0,
+                     TSPN_STREAM(stream), reinterpret_cast<const __bf16*>(x), R, (int)T, (int)D, out);
+  return tspn::check_launch("tspn_temporal_mean_bf16");
+}
+
+extern "C" int tspn_conv3_tc_bf16(const uint16_t* x, int64_t B, int64_t T, int64_t Cin,
+                                  const uint16_t* packed, int64_t M, const float* bias, float* y,
+                                  int64_t ldm, void* stream) {
+  TSPN_REQUIRE(B >= 0 && Cin > 0 && T > 0 && M > 0 && ldm >= M, TSPN_EINVAL,
+               "tspn_conv3_tc_bf16: bad sizes B=%lld T=%lld Cin=%lld M=%lld ldm=%lld", (long long)B,
+               (long long)T, (long long)Cin, (long long)M, (long long)ldm);
+  if (B == 0) return TSPN_OK;
+  TSPN_REQUIRE(x && packed && y, TSPN_EINVAL, "tspn_conv3_tc_bf16: null pointer");
+  TSPN_REQUIRE(Cin % KC == 0 && M % 4 == 0 && ldm % 4 == 0, TSPN_EUNSUPPORTED,
+               "tspn_conv3_tc_bf16: needs Cin %% 32 == 0, M %% 4 == 0, ldm %% 4 == 0 (Cin=%lld M=%lld ldm=%lld)",
+               (long long)Cin, (long long)M, (long long)ldm);
+  TSPN_REQUIRE(aligned16(x) && aligned16(packed) && aligned16(y) && (bias == nullptr || aligned16(bias)),
+               TSPN_EUNSUPPORTED, "tspn_conv3_tc_bf16: pointers must be 16-byte aligned");
+  TSPN_REQUIRE(Cin < (1 << 24) && T < (1 << 24) && M < (1 << 24) && ldm < (1 << 24), TSPN_EUNSUPPORTED,
+               "tspn_conv3_tc_bf16: dimension too large");
+  const int64_t ncols = B * T;
+  const int64_t tiles_m = tspn::ceil_div(M, BM), tiles_n = tspn::ceil_div(ncols, BN);
+  TSPN_REQUIRE(tiles_m * tiles_n < (1LL << 31), TSPN_EUNSUPPORTED, "tspn_conv3_tc_bf16: grid too large");
+  static thread_local bool attr = false;
+  if (!attr) {
+    int rc = set_smem(reinterpret_cast<const void*>(conv3_bf16_cl_kernel), CONV_SMEM, "tspn_conv3_tc_bf16");
+    if (rc) return rc;
+    attr = true;
+  }
+  hipLaunchKernelGGL(conv3_bf16_cl_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(THREADS), CONV_SMEM,
+                     TSPN_STREAM(stream), reinterpret_cast<const __bf16*>(x),
+                     reinterpret_cast<const __bf16*>(packed), bias, y, (int)Cin, (int)T, (int)M, ncols,
+                     (int)tiles_m, (int)tiles_n, (int)ldm);
+  return tspn::check_launch("tspn_conv3_tc_bf16");
+}
+
+extern "C" int tspn_heads_pairgrid_bf16(const float* y, int64_t ldm, int64_t B, int64_t N, int64_t C,
+                                        int64_t T, const uint16_t* head_packed, const float* head_b,
+                                        int64_t H, float* out, void* stream) {
+  TSPN_REQUIRE(B >= 0 && N >= 0 && C > 0 && T > 0 && H > 0 && H <= 16 && ldm >= 2 * C, TSPN_EINVAL,
+               "tspn_heads_pairgrid_bf16: bad sizes B=%lld N=%lld C=%lld T=%lld H=%lld ldm=%lld",
+               (long long)B, (long long)N, (long long)C, (long long)T, (long long)H, (long long)ldm);
+  if (B == 0 || N < 2) return TSPN_OK;
+  TSPN_REQUIRE(y && head_packed && head_b && out, TSPN_EINVAL, "tspn_heads_pairgrid_bf16: null pointer");
+  TSPN_REQUIRE(C % HP_KC == 0 && ldm % 4 == 0 && aligned16(y) && aligned16(head_packed), TSPN_EUNSUPPORTED,
+               "tspn_heads_pairgrid_bf16: needs C %% 32 == 0, ldm %% 4 == 0, 16-byte aligned y / weights");
+  const int64_t nsb = tspn::ceil_div(N, 8), nfb = tspn::ceil_div(T, HP_FB);
+  const int64_t grid = B * nsb * nsb * nfb;
+  TSPN_REQUIRE(grid < (1LL << 31) && N < (1 << 20) && T < (1 << 24) && C < (1 << 24), TSPN_EUNSUPPORTED,
+               "tspn_heads_pairgrid_bf16: problem too large");
+  static thread_local bool attr = false;
+  if (!attr) {
+    int rc = set_smem(reinterpret_cast<const void*>(heads_pairgrid_bf16_kernel), HP_SMEM,
+                      "tspn_heads_pairgrid_bf16");
+    if (rc) return rc;
+    attr = true;
+  }
+  hipLaunchKernelGGL(heads_pairgrid_bf16_kernel, dim3((unsigned)grid), dim3(THREADS), HP_SMEM,
+                     TSPN_STREAM(stream), y, ldm, (int)B, (int)N, (int)C, (int)T,
+                     reinterpret_cast<const __bf16*>(head_packed), head_b, (int)H, out, (int)nsb, (int)nfb);
+  return tspn::check_launch("tspn_heads_pairgrid_bf16");
+}
+
+// ---- whole pass ---------------------------------------------------------------------------------
+namespace {
+struct Bf16Layout {
+  size_t bias2, y, fbar, lin, lin_bytes, total;
+};
+Bf16Layout bf16_layout(const tspn_fused_bf16_desc* d) {
+  Bf16Layout L{};
+  const size_t NT = (size_t)d->B * d->N, C = 2 * (size_t)d->D;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    const size_t at = off;
+    off += tspn::align_up(bytes, 256);
+    return at;
+  };
+  L.bias2 = take(2 * C * sizeof(float));
+  L.y = take(NT * d->T * 2 * C * sizeof(float));
+  L.fbar = take(NT * d->D * sizeof(float));
+  L.lin_bytes = tspn::pair_predicate_workspace_bytes((int64_t)NT, d->D, d->K);
+  L.lin = take(L.lin_bytes);
+  L.total = off;
+  return L;
+}
+}  // namespace
+
+extern "C" size_t tspn_forward_fused_bf16_workspace_bytes(const tspn_fused_bf16_desc* d) {
+  if (!d || d->B <= 0 || d->N <= 0 || d->T <= 0 || d->D <= 0 || d->K <= 0) return 0;
+  return bf16_layout(d).total;
+}
+
+extern "C" int tspn_forward_fused_bf16(const tspn_fused_bf16_desc* d, void* stream) {
+  TSPN_REQUIRE(d, TSPN_EINVAL, "tspn_forward_fused_bf16: null descriptor");
+  TSPN_REQUIRE(d->B >= 0 && d->N >= 0 && d->T > 0 && d->D > 0 && d->A > 0 && d->K > 0, TSPN_EINVAL,
+               "tspn_forward_fused_bf16: bad sizes");
+  TSPN_REQUIRE(3 * d->A <= 16, TSPN_EUNSUPPORTED, "tspn_forward_fused_bf16: 3A=%lld > 16", (long long)(3 * d->A));
+  const int64_t NT = d->B * d->N, P = d->B * d->N * (d->N - 1), C = 2 * d->D;
+  TSPN_REQUIRE(d->P == P, TSPN_EINVAL,
+               "tspn_forward_fused_bf16: P=%lld, the canonical pair table has B*N*(N-1)=%lld rows",
+               (long long)d->P, (long long)P);
+  if (P == 0) return TSPN_OK;
+  TSPN_REQUIRE(d->feats && d->pairs && d->conv_packed && d->conv_bias && d->head_packed && d->head_b &&
+                   d->cls_w && d->cls_b && d->out_heads && d->out_logits && d->workspace,
+               TSPN_EINVAL, "tspn_forward_fused_bf16: null pointer");
+  TSPN_REQUIRE(d->D % 32 == 0, TSPN_EUNSUPPORTED, "tspn_forward_fused_bf16: needs D %% 32 == 0 (D=%lld)",
+               (long long)d->D);
+  const Bf16Layout L = bf16_layout(d);
+  TSPN_REQUIRE(d->workspace_bytes >= L.total, TSPN_EWORKSPACE,
+               "tspn_forward_fused_bf16: workspace %zu < %zu bytes", d->workspace_bytes, L.total);
+  TSPN_REQUIRE((reinterpret_cast<uintptr_t>(d->workspace) & 255) == 0, TSPN_EINVAL,
+               "tspn_forward_fused_bf16: workspace must be 256-byte aligned");
+  char* ws = static_cast<char*>(d->workspace);
+  float* bias2 = reinterpret_cast<float*>(ws + L.bias2);
+  float* y = reinterpret_cast<float*>(ws + L.y);
+  float* fbar = reinterpret_cast<float*>(ws + L.fbar);
+  hipStream_t s = TSPN_STREAM(stream);
+  // conv bias rides on the subject half: U' = U + b, V' = V
+  if (hipMemsetAsync(bias2 + C, 0, C * sizeof(float), s) != hipSuccess ||
+      hipMemcpyAsync(bias2, d->conv_bias, C * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
+    return tspn::fail(TSPN_ELAUNCH, "tspn_forward_fused_bf16: bias staging failed");
+  int rc;
+  if (d->ev_conv_begin) (void)hipEventRecord(static_cast<hipEvent_t>(d->ev_conv_begin), s);
+  rc = tspn_conv3_tc_bf16(d->feats, NT, d->T, d->D, d->conv_packed, 2 * C, bias2, y, 2 * C, stream);
+  if (d->ev_conv_end) (void)hipEventRecord(static_cast<hipEvent_t>(d->ev_conv_end), s);
+  if (rc) return rc;
+  if ((rc = tspn_heads_pairgrid_bf16(y, 2 * C, d->B, d->N, C, d->T, d->head_packed, d->head_b, 3 * d->A,
+                                     d->out_heads, stream)))
+    return rc;
+  if ((rc = tspn_temporal_mean_bf16(d->feats, NT, d->T, d->D, fbar, stream))) return rc;
+  return tspn::pair_predicate(fbar, NT, d->D, d->pairs, P, d->cls_w, d->cls_b, d->K, d->out_logits,
+                              ws + L.lin, L.lin_bytes, stream);
+}

@@ -274,6 +274,20 @@ class DPN(nn.Module):
         return self._cache.get("conv_split", (c.weight, c.bias), dev,
                                lambda ts: (ops.pack_conv3(ts[0], split=half), ts[1]))
 
+    def _bf16_weights(self, dev):
+        """bf16 operand set of the factorised path (csrc/tspn_bf16.hip): packed conv / head weights
+        in bf16, biases as fp32 tensors holding bf16-rounded values."""
+        c = self.dpn_head.conv
+        half = self.dpn_head.in_channels // 2
+        rnd = lambda t: ops.cast_bf16(t.contiguous()).float()
+
+        def build(ts):
+            cw, cb, rw, rb, dw, db = ts
+            hw = torch.cat([rw[:, :, 0], dw[:, :, 0]], dim=0).contiguous()
+            return (ops.pack_conv3_bf16(cw, split=half), rnd(cb), ops.pack_heads_bf16(hw),
+                    rnd(torch.cat([rb, db])))
+        return self._cache.get("bf16", (c.weight, c.bias) + tuple(self.dpn_head.head_params()), dev, build)
+
     def _wrap(self, heads):
         a = self.dpn_head.num_windows
         return TemporalProposals(heads[:, :a], heads[:, a:], heads)
@@ -419,10 +433,31 @@ class BaseModel(nn.Module):
         for i, plist in enumerate(pair_list):
             f = plist.get_field("tracklet_feats")
             # segments with an explicit pair table are scored on their own
-            key = (tuple(f.shape), i + 1 if custom_pairs(plist) is not None else 0)
+            key = (tuple(f.shape), i + 1 if custom_pairs(plist) is not None else 0, f.dtype == torch.bfloat16)
             groups.setdefault(key, []).append(i)
-        for (shape, _), members in groups.items():
+        for (shape, _, bf16), members in groups.items():
             n, t, d = shape
+            if bf16:
+                # bf16 tracklet features select the bf16-operand kernels (BASELINE config 3)
+                if any(custom_pairs(pair_list[i]) is not None for i in members):
+                    raise NotImplementedError("the bf16 path scores the canonical pair table only")
+                if d % 32:
+                    raise ValueError(f"the bf16 path needs D % 32 == 0 (D={d})")
+                feats = torch.cat([pair_list[i].get_field("tracklet_feats").to(dev).contiguous()
+                                   for i in members])
+                allp = torch.cat([ops.pair_index(n, dev, base=k * n) for k in range(len(members))])
+                packed, cbias, hpk, hb16 = dpn._bf16_weights(dev)
+                cw16, cb16 = self.classifier._cache.get(
+                    "cls_bf16", (cls.weight, cls.bias), dev,
+                    lambda ts: tuple(ops.cast_bf16(x.contiguous()).float() for x in ts))
+                heads, lg = ops.forward_fused_bf16(feats, allp, len(members), n, packed, cbias, hpk, hb16,
+                                                   cw16, cb16)
+                per = n * (n - 1)
+                for k, i in enumerate(members):
+                    src_dev = pair_list[i].get_field("tracklet_feats").device
+                    durations[i] = dpn._wrap(heads[k * per:(k + 1) * per].to(src_dev))
+                    logits[i] = lg[k * per:(k + 1) * per].to(src_dev)
+                continue
             feats = torch.cat([_f32(pair_list[i].get_field("tracklet_feats"), dev) for i in members])
             pairs = []
             canonical = True

@@ -15,6 +15,8 @@ __all__ = [
     "predicate_head", "feature_preprocess_", "ppn_pair_matrix_topk", "traj_iou", "pair_index",
     "pair_gather", "pack_conv3", "conv3", "conv3_tc", "pack_conv3_wino", "conv3_tc_wino", "heads", "heads_pairgrid", "temporal_mean", "pair_rows", "transpose_td",
     "forward_fused", "temporal_encoder_heads", "fused_workspace_bytes", "decode_topk", "decode_spans",
+    "cast_bf16", "pack_conv3_bf16", "pack_heads_bf16", "conv3_tc_bf16", "heads_pairgrid_bf16",
+    "temporal_mean_bf16", "forward_fused_bf16",
 ]
 
 
@@ -470,3 +472,117 @@ def temporal_encoder_heads(x, conv_packed, conv_bias, head_w, head_b, h_ws=None)
         _p(x), P, C, T, _p(conv_packed), _p(conv_bias), _p(head_w), _p(head_b), H, _p(h_ws), _p(out),
         _stream()))
     return out
+
+
+# --------------------------------------------------------------------------- #
+# bf16-operand path (BASELINE config 3); semantics in csrc/tspn_bf16.hip / oracle.forward_bf16
+# --------------------------------------------------------------------------- #
+def cast_bf16(x):
+    """fp32 -> bf16, round to nearest even (tspn_cast_bf16)."""
+    _dev(x, "x")
+    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    _abi.check(_abi.lib().tspn_cast_bf16(_p(x), x.numel(), _p(out), _stream()))
+    return out
+
+
+def pack_conv3_bf16(weight, split=0):
+    """conv.weight [M,Cin,3] fp32 -> bf16 [3, Cp/8, Mp, 8] (split as in pack_conv3)."""
+    _dev(weight, "weight")
+    if weight.dim() != 3 or weight.shape[2] != 3:
+        raise ValueError("pack_conv3_bf16: weight must be [M, Cin, 3]")
+    M, Cin, _ = weight.shape
+    Mp, Cp = (2 * M, split) if split else (M, Cin)
+    out = torch.empty((3, Cp // 8, Mp, 8), dtype=torch.bfloat16, device=weight.device)
+    _abi.check(_abi.lib().tspn_pack_conv3_bf16(_p(weight), M, Cin, split, _p(out), _stream()))
+    return out
+
+
+def pack_heads_bf16(head_w):
+    """[H<=16, C] fp32 -> bf16 [C/8, 16, 8] (zero rows above H)."""
+    _dev(head_w, "head_w")
+    H, C = head_w.shape
+    out = torch.empty((C // 8, 16, 8), dtype=torch.bfloat16, device=head_w.device)
+    _abi.check(_abi.lib().tspn_pack_heads_bf16(_p(head_w), H, C, _p(out), _stream()))
+    return out
+
+
+def conv3_tc_bf16(x, packed, bias=None):
+    """k=3 conv over time, bf16 operands: x bf16 [B,T,Cin] -> y fp32 channels-last [B,T,M]."""
+    _dev(x, "x", torch.bfloat16); _dev(packed, "packed", torch.bfloat16)
+    if bias is not None:
+        _dev(bias, "bias")
+    B, T, Cin = x.shape
+    if packed.dim() != 4 or packed.shape[0] != 3 or packed.shape[1] * 8 != Cin or packed.shape[3] != 8:
+        raise ValueError(f"conv3_tc_bf16: packed {tuple(packed.shape)} does not match Cin={Cin}")
+    M = packed.shape[2]
+    y = torch.empty((B, T, M), dtype=torch.float32, device=x.device)
+    _abi.check(_abi.lib().tspn_conv3_tc_bf16(_p(x), B, T, Cin, _p(packed), M, _p(bias), _p(y), M, _stream()))
+    return y
+
+
+def heads_pairgrid_bf16(y, B, N, head_packed, head_b, H):
+    """Pair stage on y fp32 [B*N, T, 2C] (U | V halves) -> heads fp32 [B*N*(N-1), H, T]."""
+    _dev(y, "y"); _dev(head_packed, "head_packed", torch.bfloat16); _dev(head_b, "head_b")
+    BN, T, C2 = y.shape
+    if BN != B * N or C2 % 2 or head_packed.shape != (C2 // 16, 16, 8) or head_b.numel() != H:
+        raise ValueError("heads_pairgrid_bf16: shape mismatch")
+    out = torch.empty((B * N * (N - 1), H, T), dtype=torch.float32, device=y.device)
+    _abi.check(_abi.lib().tspn_heads_pairgrid_bf16(_p(y), C2, B, N, C2 // 2, T, _p(head_packed), _p(head_b),
+                                                   H, _p(out), _stream()))
+    return out
+
+
+def temporal_mean_bf16(x):
+    """bf16 [R,T,D] -> fp32 [R,D] holding bf16-rounded means."""
+    _dev(x, "x", torch.bfloat16)
+    R, T, D = x.shape
+    out = torch.empty((R, D), dtype=torch.float32, device=x.device)
+    _abi.check(_abi.lib().tspn_temporal_mean_bf16(_p(x), R, T, D, _p(out), _stream()))
+    return out
+
+
+def forward_fused_bf16(feats, pairs, B, N, conv_packed, conv_bias, head_packed, head_b, cls_w, cls_b,
+                       workspace=None, conv_events=None):
+    """Whole scoring pass, bf16 operands (tspn_forward_fused_bf16), canonical pair table only.
+
+    feats bf16 [B*N,T,D]; conv_packed = pack_conv3_bf16(conv.weight, split=D); head_packed =
+    pack_heads_bf16([3A,C]); cls_w fp32 [K,C] holding bf16-rounded values.
+    Returns (heads fp32 [P,3A,T], rel_logits fp32 [P,K])."""
+    _dev(feats, "feats", torch.bfloat16); _dev(pairs, "pairs", torch.int64)
+    _dev(conv_packed, "conv_packed", torch.bfloat16); _dev(conv_bias, "conv_bias")
+    _dev(head_packed, "head_packed", torch.bfloat16); _dev(head_b, "head_b")
+    _dev(cls_w, "cls_w"); _dev(cls_b, "cls_b")
+    BN, T, D = feats.shape
+    C = 2 * D
+    if BN != B * N:
+        raise ValueError("forward_fused_bf16: feats rows != B*N")
+    if tuple(conv_packed.shape) != (3, D // 8, 2 * C, 8):
+        raise ValueError(f"forward_fused_bf16: conv_packed {tuple(conv_packed.shape)} != {(3, D // 8, 2 * C, 8)}")
+    if tuple(head_packed.shape) != (C // 8, 16, 8) or head_b.numel() % 3:
+        raise ValueError("forward_fused_bf16: head weights do not match C")
+    A, K = head_b.numel() // 3, cls_w.shape[0]
+    if tuple(cls_w.shape) != (K, C) or conv_bias.numel() != C or cls_b.numel() != K:
+        raise ValueError("forward_fused_bf16: classifier / bias shapes do not match")
+    P = pairs.shape[0]
+    if tuple(pairs.shape) != (B * N * (N - 1), 2):
+        raise ValueError("forward_fused_bf16: needs the canonical pair table [B*N*(N-1), 2]")
+    d = _abi.FusedBf16Desc()
+    d.B, d.N, d.T, d.D, d.A, d.K, d.P = B, N, T, D, A, K, P
+    d.feats, d.pairs = feats.data_ptr(), pairs.data_ptr()
+    d.conv_packed, d.conv_bias = conv_packed.data_ptr(), conv_bias.data_ptr()
+    d.head_packed, d.head_b = head_packed.data_ptr(), head_b.data_ptr()
+    d.cls_w, d.cls_b = cls_w.data_ptr(), cls_b.data_ptr()
+    l = _abi.lib()
+    need = l.tspn_forward_fused_bf16_workspace_bytes(ctypes.byref(d))
+    if workspace is None:
+        workspace = _ws(need, feats.device)
+    elif workspace.numel() * workspace.element_size() < need:
+        raise ValueError("forward_fused_bf16: workspace too small")
+    out_heads = torch.empty((P, 3 * A, T), dtype=torch.float32, device=feats.device)
+    out_logits = torch.empty((P, K), dtype=torch.float32, device=feats.device)
+    d.out_heads, d.out_logits = out_heads.data_ptr(), out_logits.data_ptr()
+    d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
+    if conv_events is not None:
+        d.ev_conv_begin, d.ev_conv_end = conv_events[0].cuda_event, conv_events[1].cuda_event
+    _abi.check(l.tspn_forward_fused_bf16(ctypes.byref(d), _stream()))
+    return out_heads, out_logits

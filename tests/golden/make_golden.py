@@ -55,6 +55,7 @@ for _name, _attrs in (("dlib", ("drectangle", "correlation_tracker")), ("h5py", 
 
 from lib.modeling import segment_video  # noqa: E402
 from lib.modeling.model import BaseModel as RefBaseModel  # noqa: E402
+from lib.modeling.model import RelationPredictor as RefRelationPredictor  # noqa: E402
 from lib.modeling.relpn.dpn import DPNHead as RefDPNHead  # noqa: E402
 from lib.modeling.relpn.anchor_generator import AnchorGenerator as RefAnchorGenerator  # noqa: E402
 from lib.modeling.relpn.sampler import BalancedPositiveNegativePairSampler as RefSampler  # noqa: E402
@@ -230,6 +231,35 @@ def g7_misc():
     save("g7_misc.npz", sampler_counts=np.array([int(pos[0].sum()), int(neg[0].sum())]), **segs)
 
 
+def g8_bf16():
+    """The reference's own DPNHead and RelationPredictor cast with .bfloat16() and run by torch's CPU
+    bf16 kernels on the (bf16-rounded) g3 / g1 inputs: pins the rounding points of the build's bf16
+    semantics (oracle.dpn_head_bf16 / predicate_head_bf16).  Outputs are stored as fp32."""
+    out = {}
+    pre = "relpn.duration_proposal_network.dpn_head."
+    for tag in cases.G3_SHAPES:
+        c = cases.g3_inputs(tag)
+        head = RefDPNHead(c["c"], 4)
+        head.load_state_dict({k[len(pre):]: t(v) for k, v in c["state_dict"].items()
+                              if k.startswith(pre) and "relness" not in k})
+        head = head.bfloat16()
+        with torch.no_grad():
+            y = head(t(c["x"]).bfloat16())
+        assert y.dtype == torch.bfloat16
+        out[f"{tag}_duration"] = y.float().numpy()
+    c = cases.g1_inputs()
+    feats = RefVRDataset._feature_preprocess(None, t(c["raw"].copy()))
+    feats = (feats if isinstance(feats, torch.Tensor) else t(feats)).float()
+    pred = RefRelationPredictor(feats.shape[1], 132)
+    pred.load_state_dict({"rel_predictor.weight": t(c["state_dict"]["classifier.rel_predictor.weight"]),
+                          "rel_predictor.bias": t(c["state_dict"]["classifier.rel_predictor.bias"])})
+    pred = pred.bfloat16()
+    with torch.no_grad():
+        lg = pred(feats.bfloat16())
+    out["cfg1_rel_logits"] = lg.float().numpy()
+    save("g8_bf16.npz", **out)
+
+
 def main():
     g1_baseline()
     g2_ppn()
@@ -238,6 +268,7 @@ def main():
     g5_anchors()
     g6_decode()
     g7_misc()
+    g8_bf16()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,205 @@
+"""bf16-operand path (BASELINE config 3: N=64, T=900, D=1024, bf16) on the GPU against the oracle's
+bf16 restatement (pinned by golden g8) and float64 references of the single kernels.
+
+Tolerances: products of bf16 values are exact in fp32, so the kernels differ from a float64
+evaluation of the same bf16 operands only by fp32 accumulation order (~1e-6 relative to the sum of
+magnitudes) and — downstream of a rounding point — by rare one-ulp flips of a bf16 activation."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+DPN_PRE = "relpn.duration_proposal_network.dpn_head."
+
+
+def t(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def r16(x):
+    """bf16 rounding on the host (torch's cast), kept in fp32."""
+    return t(np.asarray(x, dtype=np.float32)).to(torch.bfloat16).float()
+
+
+def test_cast_bf16_bit_exact(tspn, device):
+    x = tspn.hashrng.normal(80, "x", (70001,), std=3.0)
+    x[:8] = [0.0, -0.0, 1.0, 1.00390625, 1.001953125, 3.3895314e38, 1e-40, -2.5]  # ties, overflow edge, denormal
+    got = tspn.ops.cast_bf16(t(x).to(device)).cpu()
+    assert got.dtype == torch.bfloat16
+    assert torch.equal(got.view(torch.int16), t(x).to(torch.bfloat16).view(torch.int16))
+
+
+def test_pack_layouts_bf16(tspn, device):
+    M, Cin = 12, 32
+    w = tspn.hashrng.normal(81, "w", (M, Cin, 3), std=0.1)
+    p = tspn.ops.pack_conv3_bf16(t(w).to(device)).cpu().float().numpy()        # [3, Cin/8, M, 8]
+    exp = r16(w).numpy().transpose(2, 1, 0).reshape(3, Cin // 8, 8, M).transpose(0, 1, 3, 2)
+    np.testing.assert_array_equal(p, exp)
+    half = Cin // 2
+    ps = tspn.ops.pack_conv3_bf16(t(w).to(device), split=half).cpu().float().numpy()   # [3, half/8, 2M, 8]
+    ws = np.concatenate([w[:, :half], w[:, half:]], axis=0)                     # [2M, half, 3]
+    exps = r16(ws).numpy().transpose(2, 1, 0).reshape(3, half // 8, 8, 2 * M).transpose(0, 1, 3, 2)
+    np.testing.assert_array_equal(ps, exps)
+    hw = tspn.hashrng.normal(81, "hw", (12, 64), std=0.1)
+    hp = tspn.ops.pack_heads_bf16(t(hw).to(device)).cpu().float().numpy()       # [C/8, 16, 8]
+    exph = np.zeros((8, 16, 8), np.float32)
+    exph[:, :12] = r16(hw).numpy().reshape(12, 8, 8).transpose(1, 0, 2)
+    np.testing.assert_array_equal(hp, exph)
+
+
+def conv_ref64(xb, wb, b):
+    """x [B,T,Cin], w [M,Cin,3] (bf16-valued) -> [B,T,M] float64."""
+    y = torch.nn.functional.conv1d(xb.double().transpose(1, 2), wb.double(), None if b is None else b.double(),
+                                   padding=1)
+    return y.transpose(1, 2).contiguous()
+
+
+@pytest.mark.parametrize("B,T,Cin,M", [(1, 1, 32, 4), (2, 5, 32, 8), (3, 30, 64, 128), (5, 33, 96, 132),
+                                       (2, 257, 128, 260), (7, 150, 64, 64), (40, 30, 32, 36)])
+def test_conv3_bf16_vs_fp64(tspn, device, B, T, Cin, M):
+    x = r16(tspn.hashrng.uniform(82, "x", (B, T, Cin), -1, 1))
+    w = tspn.hashrng.normal(82, "w", (M, Cin, 3), std=0.1)
+    b = tspn.hashrng.normal(82, "b", (M,), std=0.1)
+    packed = tspn.ops.pack_conv3_bf16(t(w).to(device))
+    y = tspn.ops.conv3_tc_bf16(x.to(torch.bfloat16).to(device), packed, t(b).to(device))
+    ref = conv_ref64(x, r16(w), t(b))
+    assert y.shape == (B, T, M)
+    np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), rtol=0, atol=2e-5)
+    y0 = tspn.ops.conv3_tc_bf16(x.to(torch.bfloat16).to(device), packed, None)
+    np.testing.assert_allclose(y0.cpu().numpy(), conv_ref64(x, r16(w), None).numpy(), rtol=0, atol=2e-5)
+
+
+def test_conv3_bf16_exact_integers_and_limits(tspn, device):
+    """Small-integer operands are bf16-exact and every partial sum is fp32-exact: bit-identical to
+    the float64 conv, which checks the MFMA fragment maps and the sequence-end masks exactly."""
+    B, C, T, M = 3, 64, 131, 132
+    x = ((np.arange(B * T * C, dtype=np.float32).reshape(B, T, C) * 7) % 23) - 11.0
+    w = ((np.arange(M * C * 3, dtype=np.float32).reshape(M, C, 3) * 5) % 9) - 4.0
+    y = tspn.ops.conv3_tc_bf16(t(x).to(torch.bfloat16).to(device), tspn.ops.pack_conv3_bf16(t(w).to(device)))
+    np.testing.assert_array_equal(y.cpu().numpy(), conv_ref64(t(x), t(w), None).float().numpy())
+    with pytest.raises(tspn._abi.TspnError) as e:
+        tspn.ops.conv3_tc_bf16(torch.zeros(2, 30, 16, dtype=torch.bfloat16, device=device),
+                               torch.zeros(3, 2, 8, 8, dtype=torch.bfloat16, device=device))
+    assert e.value.code == tspn._abi.TSPN_EUNSUPPORTED
+    with pytest.raises(RuntimeError):
+        tspn.ops.conv3_tc_bf16(torch.zeros(2, 30, 32, dtype=torch.bfloat16), torch.zeros(3, 4, 8, 8, dtype=torch.bfloat16))
+
+
+def heads_ref64(y, B, N, hw, hb):
+    """y [B*N,T,2C] fp32; -> [B*N*(N-1), H, T] float64 with the kernel's rounding point."""
+    C = y.shape[2] // 2
+    out = []
+    for b in range(B):
+        yy = y[b * N:(b + 1) * N]
+        pairs = oracle.pair_index(N)
+        a = torch.relu(yy[pairs[:, 0], :, :C] + yy[pairs[:, 1], :, C:])        # fp32 add, as on the GPU
+        a = a.to(torch.bfloat16).double()                                       # [P,T,C]
+        out.append(torch.einsum("ptc,hc->pht", a, hw.double()) + hb.double().view(1, -1, 1))
+    return torch.cat(out)
+
+
+@pytest.mark.parametrize("B,N,T,C", [(1, 2, 1, 32), (2, 5, 30, 64), (1, 8, 16, 32), (1, 11, 37, 96), (3, 9, 150, 64),
+                                     (1, 17, 20, 32)])
+def test_heads_pairgrid_bf16_vs_fp64(tspn, device, B, N, T, C):
+    y = t(tspn.hashrng.normal(83, "y", (B * N, T, 2 * C), std=1.0))
+    hw = r16(tspn.hashrng.normal(83, "hw", (12, C), std=0.1))
+    hb = t(tspn.hashrng.normal(83, "hb", (12,), std=0.1))
+    out = tspn.ops.heads_pairgrid_bf16(y.to(device), B, N, tspn.ops.pack_heads_bf16(hw.to(device)), hb.to(device), 12)
+    ref = heads_ref64(y, B, N, hw, hb)
+    assert out.shape == ref.shape
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=0, atol=3e-5)
+
+
+def test_temporal_mean_bf16(tspn, device):
+    x = r16(tspn.hashrng.uniform(84, "x", (37, 53, 40)))
+    got = tspn.ops.temporal_mean_bf16(x.to(torch.bfloat16).to(device)).cpu()
+    ref = x.double().mean(dim=1)
+    np.testing.assert_array_equal(got.numpy(), r16(got.numpy()).numpy())        # values are bf16
+    same = (got == ref.float().to(torch.bfloat16).float()).float().mean()
+    assert same > 0.995
+    assert float((got.double() - ref).abs().max()) <= 2.0 ** -8                 # <= 1 ulp below 1.0
+
+
+def oracle_weights(sd):
+    return {"conv_w": t(sd[DPN_PRE + "conv.weight"]), "conv_b": t(sd[DPN_PRE + "conv.bias"]),
+            "dur_w": t(sd[DPN_PRE + "duration_pred.weight"]), "dur_b": t(sd[DPN_PRE + "duration_pred.bias"]),
+            "rel_w": t(sd[DPN_PRE + "relness_pred.weight"]), "rel_b": t(sd[DPN_PRE + "relness_pred.bias"]),
+            "cls_w": t(sd["classifier.rel_predictor.weight"]), "cls_b": t(sd["classifier.rel_predictor.bias"])}
+
+
+def temporal_cfg(D):
+    return cases.baseline_cfg(**{"RELPN.USE_PPN": True, "RELPN.USE_DPN": True,
+                                 "RELPN.DPN.IN_CHANNELS": 2 * D, "PREDICT.FEATURE_DIM": 2 * D})
+
+
+def check_against_oracle(out, ref, what):
+    scale = max(float(ref.abs().max()), 1e-3)
+    err = float((out - ref).abs().max())
+    # one flipped bf16 activation moves a head output by ~2^-8 |a| |w|; allow a few of them
+    assert err <= 2e-3 * scale, (what, err, scale)
+
+
+def test_model_forward_bf16_tracklets_vs_oracle(tspn, device):
+    """BaseModel.forward on bf16 tracklet features (ragged batch) == oracle.forward_bf16."""
+    D = 32
+    sd = tspn.synth.make_weights(0, c=2 * D, bias_std=0.05)
+    model = tspn.BaseModel(temporal_cfg(D))
+    own = model.state_dict()
+    model.load_state_dict({k: t(v) for k, v in sd.items() if k in own})
+    model.eval()
+    shapes = [(6, 30), (9, 17), (6, 30), (3, 1)]
+    vids = [tspn.synth.make_video(90 + i, n, tt, D) for i, (n, tt) in enumerate(shapes)]
+    plists = [tspn.PairList.from_tracklets(t(v["tracklet_feats"]).to(torch.bfloat16), t(v["tracklet_boxes"]),
+                                           t(v["track_cls_logits"])) for v in vids]
+    pp, dp, logits = model(plists, None)
+    w = oracle_weights(sd)
+    for i, v in enumerate(vids):
+        n = shapes[i][0]
+        ref = oracle.forward_bf16(t(v["tracklet_feats"]), oracle.pair_index(n), w)
+        assert dp[i].relness.dtype == torch.float32 and dp[i].relness.shape == ref["relness"].shape
+        check_against_oracle(dp[i].relness, ref["relness"], "relness")
+        check_against_oracle(dp[i].duration, ref["duration"], "duration")
+        check_against_oracle(logits[i], ref["rel_logits"], "rel_logits")
+        assert logits[i].device.type == "cpu" and pp[i].shape == (min(256, n * n),)
+
+
+def test_forward_fused_bf16_matches_fp32_path_on_rounded_operands(tspn, device):
+    """Mid-size property check (N=16, T=150, D=128): the bf16 kernels agree with the fp32 HIP path
+    run on the same bf16-rounded operands up to the one activation rounding (2^-8 relative)."""
+    N, T, D, A, K = 16, 150, 128, 4, 132
+    C = 2 * D
+    v = tspn.synth.make_video(95, N, T, D)
+    sd = tspn.synth.make_weights(0, c=C, bias_std=0.05)
+    w = {k: r16(x.numpy()).to(device) for k, x in oracle_weights(sd).items()}
+    feats = r16(v["tracklet_feats"]).to(device)
+    pairs = tspn.ops.pair_index(N, device)
+    hw = torch.cat([w["rel_w"][:, :, 0], w["dur_w"][:, :, 0]]).contiguous()
+    hb = torch.cat([w["rel_b"], w["dur_b"]]).contiguous()
+    h16, l16 = tspn.ops.forward_fused_bf16(feats.to(torch.bfloat16), pairs, 1, N,
+                                           tspn.ops.pack_conv3_bf16(w["conv_w"], split=D), w["conv_b"],
+                                           tspn.ops.pack_heads_bf16(hw), hb, w["cls_w"], w["cls_b"])
+    h32, l32 = tspn.ops.forward_fused(feats, pairs, 1, N, tspn.ops.pack_conv3(w["conv_w"], split=D), w["conv_b"],
+                                      hw, hb, w["cls_w"], w["cls_b"], canonical_pairs=True)
+    scale = float(h32.abs().max())
+    assert float((h16 - h32).abs().max()) <= 2.0 ** -8 * scale
+    assert float((l16 - l32).abs().max()) <= 2.0 ** -8
+    # and a checksum of checksums is reproducible run to run (no races)
+    h16b, l16b = tspn.ops.forward_fused_bf16(feats.to(torch.bfloat16), pairs, 1, N,
+                                             tspn.ops.pack_conv3_bf16(w["conv_w"], split=D), w["conv_b"],
+                                             tspn.ops.pack_heads_bf16(hw), hb, w["cls_w"], w["cls_b"])
+    assert torch.equal(h16, h16b) and torch.equal(l16, l16b)
+
+
+def test_bf16_path_rejects_what_it_cannot_do(tspn, device):
+    D = 16
+    model = tspn.BaseModel(temporal_cfg(D))
+    model.eval()
+    v = tspn.synth.make_video(96, 4, 10, D)
+    pl = tspn.PairList.from_tracklets(t(v["tracklet_feats"]).to(torch.bfloat16), t(v["tracklet_boxes"]),
+                                      t(v["track_cls_logits"]))
+    with pytest.raises(ValueError, match="D % 32"):
+        model([pl], None)

@@ -152,3 +152,51 @@ def test_rel_oi_pool_spans():
     np.testing.assert_allclose(out[0].numpy(), x[0, :, 1:3].mean(1).numpy())
     np.testing.assert_allclose(out[1].numpy(), x[1].mean(1).numpy())
     assert oracle.rel_oi_pool(torch.ones(4, 7)).shape == (4, 7)
+
+
+def test_g8_bf16_semantics_pinned_by_reference_bf16_modules():
+    """The bf16 restatement (operands bf16, exact products, wide sums, encoder activation rounded
+    once) against the reference's DPNHead / RelationPredictor cast with .bfloat16() (torch CPU
+    bf16 kernels): rounding the oracle's unrounded output to bf16 reproduces the reference's output
+    on (nearly) every element, and never differs by more than two bf16 ulps."""
+    g = cases.load("g8_bf16.npz")
+    for tag in cases.G3_SHAPES:
+        c = cases.g3_inputs(tag)
+        sd = sd_t(c["state_dict"])
+        rel, dur, h = oracle.dpn_head_bf16(t(c["x"]), sd[DPN_PRE + "conv.weight"], sd[DPN_PRE + "conv.bias"],
+                                           sd[DPN_PRE + "duration_pred.weight"], sd[DPN_PRE + "duration_pred.bias"],
+                                           sd[DPN_PRE + "relness_pred.weight"], sd[DPN_PRE + "relness_pred.bias"])
+        ref = g[f"{tag}_duration"]
+        same = (oracle.bf16_round(dur).numpy() == ref).mean()
+        assert same > 0.999, same
+        ulp = np.maximum(np.abs(ref), 2.0 ** -126) * 2.0 ** -7   # spacing of bf16 at |ref| (upper bound)
+        assert np.all(np.abs(dur.numpy() - ref) <= 2 * ulp)
+        np.testing.assert_array_equal(oracle.bf16_round(h).numpy(), h.numpy())   # activation is bf16
+        assert rel.shape == (c["x"].shape[0], 4, c["x"].shape[2])
+    c = cases.g1_inputs()
+    feats = oracle.feature_preprocess(t(c["raw"].copy()))
+    lg = oracle.predicate_head_bf16(feats, t(c["state_dict"]["classifier.rel_predictor.weight"]),
+                                    t(c["state_dict"]["classifier.rel_predictor.bias"]))
+    # the reference rounds the pre-sigmoid logit AND the sigmoid to bf16: within 1.5 ulp at 0.5
+    np.testing.assert_allclose(lg.numpy(), g["cfg1_rel_logits"], rtol=0, atol=1.5 * 2.0 ** -9)
+
+
+def test_forward_bf16_is_forward_dense_on_rounded_operands_up_to_one_rounding():
+    """forward_bf16 differs from the fp32 dense forward on bf16-rounded operands only by the single
+    rounding of the encoder activation and of the pooled feature."""
+    import tspn_mi355x as tspn
+    n, tt, d = 5, 12, 16
+    v = tspn.synth.make_video(31, n, tt, d)
+    sd = tspn.synth.make_weights(0, c=2 * d, bias_std=0.05)
+    w = {"conv_w": t(sd[DPN_PRE + "conv.weight"]), "conv_b": t(sd[DPN_PRE + "conv.bias"]),
+         "dur_w": t(sd[DPN_PRE + "duration_pred.weight"]), "dur_b": t(sd[DPN_PRE + "duration_pred.bias"]),
+         "rel_w": t(sd[DPN_PRE + "relness_pred.weight"]), "rel_b": t(sd[DPN_PRE + "relness_pred.bias"]),
+         "cls_w": t(sd["classifier.rel_predictor.weight"]), "cls_b": t(sd["classifier.rel_predictor.bias"])}
+    pairs = oracle.pair_index(n)
+    out = oracle.forward_bf16(t(v["tracklet_feats"]), pairs, w)
+    wr = {k: oracle.bf16_round(x) for k, x in w.items()}
+    ref = oracle.forward_dense(oracle.bf16_round(t(v["tracklet_feats"])), t(v["tracklet_boxes"]), pairs, wr)
+    for k in ("relness", "duration", "rel_logits"):
+        assert out[k].shape == ref[k].shape
+        scale = float(ref[k].abs().max())
+        assert float((out[k] - ref[k]).abs().max()) <= 2.0 ** -8 * max(scale, 1.0)
