@@ -19,6 +19,7 @@
 //                               on v_mfma_f32_16x16x32_bf16;
 //   helpers                     fp32->bf16 cast, weight packing, temporal mean.
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "tspn_common.h"
@@ -284,6 +285,407 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_bf16_cl_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// conv3 bf16, second structure: a chunk of the first kernel is only 24 MFMAs = 768 cycles, shorter
+// than the memory latency, so prefetching one chunk ahead leaves the workgroup waiting at every
+// barrier.  Here a chunk is ONE k-step (16 input channels x 3 taps = 12 MFMAs per wave) and the LDS
+// holds a ring of 4 stages (16.1 KB each, 64.5 KB -> still 2 workgroups/CU): the DMA of chunk c+3 is
+// issued while chunk c is computed, `s_waitcnt vmcnt(N)` counts only the pieces of chunk c+1 out, and
+// the barrier is a bare s_barrier (no fence, which would drain the whole DMA queue).
+constexpr int R_KC = 16, R_KG = 2, R_NST = 4;
+constexpr int R_A_ST = 3 * R_KG * BM * 16;  // 12288
+constexpr int R_X_ST = R_KG * SLP * 16;     // 4224
+constexpr int R_ST = R_A_ST + R_X_ST;       // 16512
+constexpr int R_X_UNITS = R_KG * SLP;       // 264 -> 5 pieces
+constexpr size_t R_SMEM = (size_t)R_NST * R_ST;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__global__ __launch_bounds__(THREADS, 2) void conv3_bf16_ring_kernel(
+    const __bf16* __restrict__ x, const __bf16* __restrict__ Wp, const float* __restrict__ bias,
+    float* __restrict__ y, int Cin, int T, int M, int64_t ncols, int tiles_m, int tiles_n, int ldm) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  constexpr int GM = 2;
+  const int group_sz = GM * tiles_n;
+  const int group = wg / group_sz;
+  const int first_m = group * GM;
+  const int gm = min(GM, tiles_m - first_m);
+  const int in_group = wg - group * group_sz;
+  const int tile_m = first_m + in_group % gm;
+  const int tile_n = in_group / gm;
+  const int m0 = tile_m * BM;
+  const int64_t n0 = (int64_t)tile_n * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, kh = lane >> 5;
+
+  // weight pieces: pa = (tap*2 + group)*2 + half; wave w stages pa = 3w .. 3w+2
+  const __bf16* asrc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int pa = wave * 3 + i;
+    const int tap = pa >> 2, kg = (pa >> 1) & 1, half = pa & 1;
+    int m = m0 + 64 * half + lane;
+    m = m < M ? m : 0;
+    asrc[i] = Wp + (((int64_t)tap * (Cin >> 3) + kg) * M + m) * 8;
+  }
+  const int64_t a_step = (int64_t)R_KG * M * 8;
+  // x pieces: wave w stages units [64w, 64w+64); wave 0 also the 8 units of piece 4
+  const __bf16* bsrc[2];
+  bool bval[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int u = 64 * (wave + 4 * q) + lane;
+    const int g = u / SLP, slot = u - g * SLP;
+    bval[q] = u < R_X_UNITS && slot < BN + 2 && (q == 0 || wave == 0);
+    int64_t n = n0 + slot - 1;
+    n = n < 0 ? 0 : (n < ncols ? n : ncols - 1);
+    bsrc[q] = x + n * Cin + 8 * (g < R_KG ? g : 0);
+  }
+  auto stage_chunk = [&](int st) {
+#if defined(TSPN_BF16_ABL_NODMA)
+    return;
+#endif
+    char* sa = smem + st * R_ST;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      glds16(asrc[i], sa + (wave * 3 + i) * 1024);
+      asrc[i] += a_step;
+    }
+    if (bval[0]) glds16(bsrc[0], sa + R_A_ST + 64 * wave * 16);
+    bsrc[0] += R_KC;
+    if (wave == 0) {
+      if (bval[1]) glds16(bsrc[1], sa + R_A_ST + 64 * 4 * 16);
+      bsrc[1] += R_KC;
+    }
+  };
+  // pieces in flight per chunk: 4 (waves 1-3) or 5 (wave 0)
+  auto wait_keep = [&](auto chunks_tag) {
+    constexpr int CH = decltype(chunks_tag)::value;
+    if (wave == 0) wait_vmcnt<5 * CH>(); else wait_vmcnt<4 * CH>();
+  };
+  using K0 = std::integral_constant<int, 0>;
+  using K1 = std::integral_constant<int, 1>;
+  using K2 = std::integral_constant<int, 2>;
+
+  bool mask_l[2], mask_r[2];
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int64_t n = n0 + wn * 64 + ni * 32 + li;
+    const int t = (int)(n % T);
+    mask_l[ni] = t != 0;
+    mask_r[ni] = t != T - 1;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  const int nchunks = Cin / R_KC;
+  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto compute = [&](int st) {
+    const char* Ab = smem + st * R_ST + (kh * BM + wm * 64 + li) * 16;
+    const char* Xb = smem + st * R_ST + R_A_ST + (kh * SLP + wn * 64 + li) * 16;
+    bf16x8 a[3][2], b[2][3];
+#if defined(TSPN_BF16_ABL_NOLDS)
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[tap][i] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)st, (unsigned)tap, (unsigned)i, (unsigned)lane});
+        b[i][tap] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)lane, (unsigned)i, (unsigned)tap, (unsigned)st});
+      }
+    (void)Ab; (void)Xb;
+#else
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+        a[tap][mi] = *reinterpret_cast<const bf16x8*>(Ab + (tap * R_KG * BM + mi * 32) * 16);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int tap = 0; tap < 3; ++tap)
+        b[ni][tap] = *reinterpret_cast<const bf16x8*>(Xb + (ni * 32 + tap) * 16);
+#endif
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      b[ni][0] = mask_l[ni] ? b[ni][0] : zero8;
+      b[ni][2] = mask_r[ni] ? b[ni][2] : zero8;
+    }
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap) {
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tap][0], b[0][tap], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tap][0], b[1][tap], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tap][1], b[0][tap], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tap][1], b[1][tap], acc[1][1], 0, 0, 0);
+    }
+  };
+
+  // prologue: chunks 0..2 in flight, chunk 0 landed
+  stage_chunk(0);
+  if (nchunks > 1) stage_chunk(1);
+  if (nchunks > 2) stage_chunk(2);
+  if (nchunks > 2) wait_keep(K2{}); else if (nchunks > 1) wait_keep(K1{}); else wait_keep(K0{});
+  __builtin_amdgcn_s_barrier();
+
+  int c = 0;
+  for (; c + 3 < nchunks; ++c) {        // steady state: chunk c+3 exists
+    stage_chunk((c + 3) & 3);
+    compute(c & 3);
+    wait_keep(K2{});                    // chunks c+2, c+3 may still fly; c+1 has landed
+    __builtin_amdgcn_s_barrier();
+  }
+  for (; c < nchunks; ++c) {            // tail: nothing left to issue
+    compute(c & 3);
+    wait_keep(K0{});
+    __builtin_amdgcn_s_barrier();
+  }
+
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int64_t n = n0 + wn * 64 + ni * 32 + li;
+    if (n >= ncols) continue;
+    float* yrow = y + n * (int64_t)ldm;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+      for (int eq = 0; eq < 4; ++eq) {
+        const int m = m0 + wm * 64 + mi * 32 + 8 * eq + 4 * kh;
+        if (m < M) {
+          f32x4 v = {acc[mi][ni][4 * eq], acc[mi][ni][4 * eq + 1], acc[mi][ni][4 * eq + 2],
+                     acc[mi][ni][4 * eq + 3]};
+          if (bias != nullptr) v += *reinterpret_cast<const f32x4*>(bias + m);
+          *reinterpret_cast<f32x4*>(yrow + m) = v;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv3 bf16, third structure (shipped): 256 x 256 tile, 8 waves (2 x 4, wave tile 128 m x 64 n =
+// 4 x 2 blocks), ring of 4 stages of one k-step each (32.1 KB per stage, 128.5 KB, 1 workgroup/CU with
+// 2 waves per SIMD).  Ablation of the 128 x 128 kernels above at the config-3 shape: MFMA + epilogue
+// 3.1 ms, + LDS fragment reads 4.1, + LDS-DMA 6.5 -- the operand stream from L2 (61 GB per launch,
+// 9.4 TB/s) and one ds_read_b128 per MFMA are the limiters, both set by the tile: 256 x 256 halves the
+// bytes per MFMA from L2 and needs 0.75 fragment reads per MFMA.
+constexpr int G_THREADS = 512;
+constexpr int G_BM = 256, G_BN = 256;
+constexpr int G_SLP = 260;
+constexpr int G_A_ST = 3 * R_KG * G_BM * 16;  // 24576
+constexpr int G_X_ST = R_KG * G_SLP * 16;     // 8320
+constexpr int G_ST = G_A_ST + G_X_ST;         // 32896
+constexpr int G_X_UNITS = R_KG * G_SLP;       // 520 -> 9 pieces
+constexpr size_t G_SMEM = (size_t)R_NST * G_ST;
+
+__global__ __launch_bounds__(G_THREADS, 1) void conv3_bf16_big_kernel(
+    const __bf16* __restrict__ x, const __bf16* __restrict__ Wp, const float* __restrict__ bias,
+    float* __restrict__ y, int Cin, int T, int M, int64_t ncols, int tiles_m, int tiles_n, int ldm) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  // workgroup -> tile: bijective XCD remap, then groups of 2 weight panels x all column tiles
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  constexpr int GM = 2;
+  const int group_sz = GM * tiles_n;
+  const int group = wg / group_sz;
+  const int first_m = group * GM;
+  const int gm = min(GM, tiles_m - first_m);
+  const int in_group = wg - group * group_sz;
+  const int tile_m = first_m + in_group % gm;
+  const int tile_n = in_group / gm;
+  const int m0 = tile_m * G_BM;
+  const int64_t n0 = (int64_t)tile_n * G_BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int li = lane & 31, kh = lane >> 5;
+
+  // weight pieces: pa = ((tap*2 + group)*4 + quarter), 64 rows each; wave w stages pa = 3w .. 3w+2
+  const __bf16* asrc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int pa = wave * 3 + i;
+    const int tap = pa >> 3, kg = (pa >> 2) & 1, quarter = pa & 3;
+    int m = m0 + 64 * quarter + lane;
+    m = m < M ? m : 0;
+    asrc[i] = Wp + (((int64_t)tap * (Cin >> 3) + kg) * M + m) * 8;
+  }
+  const int64_t a_step = (int64_t)R_KG * M * 8;
+  // x pieces: wave w stages units [64w, 64w+64); wave 0 also the 8 units of piece 8
+  const __bf16* bsrc[2];
+  bool bval[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int u = 64 * (wave + 8 * q) + lane;
+    const int g = u / G_SLP, slot = u - g * G_SLP;
+    bval[q] = u < G_X_UNITS && slot < G_BN + 2 && (q == 0 || wave == 0);
+    int64_t n = n0 + slot - 1;
+    n = n < 0 ? 0 : (n < ncols ? n : ncols - 1);
+    bsrc[q] = x + n * Cin + 8 * (g < R_KG ? g : 0);
+  }
+  auto stage_chunk = [&](int st) {
+#if defined(TSPN_BF16_ABL_NODMA)
+    return;
+#endif
+    char* sa = smem + st * G_ST;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      glds16(asrc[i], sa + (wave * 3 + i) * 1024);
+      asrc[i] += a_step;
+    }
+    if (bval[0]) glds16(bsrc[0], sa + G_A_ST + 64 * wave * 16);
+    bsrc[0] += R_KC;
+    if (wave == 0) {
+      if (bval[1]) glds16(bsrc[1], sa + G_A_ST + 64 * 8 * 16);
+      bsrc[1] += R_KC;
+    }
+  };
+  auto wait_keep = [&](auto chunks_tag) {   // pieces in flight per chunk: 4 (waves 1-7) or 5 (wave 0)
+    constexpr int CH = decltype(chunks_tag)::value;
+    if (wave == 0) wait_vmcnt<5 * CH>(); else wait_vmcnt<4 * CH>();
+  };
+  using K0 = std::integral_constant<int, 0>;
+  using K1 = std::integral_constant<int, 1>;
+  using K2 = std::integral_constant<int, 2>;
+
+  bool mask_l[2], mask_r[2];
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int64_t n = n0 + wn * 64 + ni * 32 + li;
+    const int t = (int)(n % T);
+    mask_l[ni] = t != 0;
+    mask_r[ni] = t != T - 1;
+  }
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  const int nchunks = Cin / R_KC;
+  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto compute = [&](int st) {
+    const char* Ab = smem + st * G_ST + (kh * G_BM + wm * 128 + li) * 16;
+    const char* Xb = smem + st * G_ST + G_A_ST + (kh * G_SLP + wn * 64 + li) * 16;
+    bf16x8 a[3][4], b[3][2];
+    auto load_tap = [&](int tap) {
+#if defined(TSPN_BF16_ABL_NOLDS)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+        a[tap][mi] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)st, (unsigned)tap, (unsigned)mi, (unsigned)lane});
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+        b[tap][ni] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)lane, (unsigned)ni, (unsigned)tap, (unsigned)st});
+      return;
+#endif
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+        a[tap][mi] = *reinterpret_cast<const bf16x8*>(Ab + (tap * R_KG * G_BM + mi * 32) * 16);
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+        b[tap][ni] = *reinterpret_cast<const bf16x8*>(Xb + (ni * 32 + tap) * 16);
+    };
+    auto mfma_tap = [&](int tap) {
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        bf16x8 bb = b[tap][ni];
+        if (tap == 0) bb = mask_l[ni] ? bb : zero8;
+        if (tap == 2) bb = mask_r[ni] ? bb : zero8;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tap][mi], bb, acc[mi][ni], 0, 0, 0);
+      }
+    };
+    load_tap(0);
+    load_tap(1);
+    mfma_tap(0);
+    load_tap(2);
+    mfma_tap(1);
+    mfma_tap(2);
+  };
+
+  stage_chunk(0);
+  if (nchunks > 1) stage_chunk(1);
+  if (nchunks > 2) stage_chunk(2);
+  if (nchunks > 2) wait_keep(K2{}); else if (nchunks > 1) wait_keep(K1{}); else wait_keep(K0{});
+  __builtin_amdgcn_s_barrier();
+
+  int c = 0;
+  for (; c + 3 < nchunks; ++c) {        // steady state: chunk c+3 exists
+    stage_chunk((c + 3) & 3);
+    compute(c & 3);
+    wait_keep(K2{});                    // chunks c+2, c+3 may still fly; c+1 has landed
+    __builtin_amdgcn_s_barrier();
+  }
+  for (; c < nchunks; ++c) {            // tail: nothing left to issue
+    compute(c & 3);
+    wait_keep(K0{});
+    __builtin_amdgcn_s_barrier();
+  }
+
+  // ---- epilogue.  A lane holds 4 consecutive channels of ONE frame per register quad, so direct
+  // stores would touch 32 different 16-KB-strided rows per instruction (measured: 1.1 ms of 6.0 at the
+  // config-3 shape).  Each wave instead transposes its 128 m x 32 n half-tiles through 16 KB of the
+  // (now idle) stage memory -- unit (16 B) u of row n is kept at u ^ n, conflict-free both ways -- and
+  // stores two full 512-byte row segments per instruction.
+  {
+    char* tw = smem + wave * 16384;
+    const int unit = lane & 31, rsel = lane >> 5;
+    const int mcol = m0 + wm * 128 + unit * 4;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias != nullptr && mcol < M) bv = *reinterpret_cast<const f32x4*>(bias + mcol);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int eq = 0; eq < 4; ++eq) {
+          const int u = mi * 8 + 2 * eq + kh;  // 16-byte unit of channels mi*32 + 8 eq + 4 kh .. +3
+          const f32x4 v = {acc[mi][ni][4 * eq], acc[mi][ni][4 * eq + 1], acc[mi][ni][4 * eq + 2],
+                           acc[mi][ni][4 * eq + 3]};
+          *reinterpret_cast<f32x4*>(tw + li * 512 + ((u ^ li) << 4)) = v;
+        }
+      // (same wave wrote and reads: the compiler's lgkmcnt wait orders the two)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = 2 * r + rsel;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(tw + row * 512 + ((unit ^ row) << 4)) + bv;
+        const int64_t n = n0 + wn * 64 + ni * 32 + row;
+#if defined(TSPN_BF16_ABL_NOSTORE)
+        if (n < ncols && mcol < M && v[0] == 12345.678f)
+#else
+        if (n < ncols && mcol < M)
+#endif
+          *reinterpret_cast<f32x4*>(y + n * (int64_t)ldm + mcol) = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Pair stage, bf16: out[p][h][t] = bh[h] + sum_c Wh[h][c] * bf16(relu(U[s][t][c] + V[o][t][c])) for
 // the canonical pair table.  Workgroup = (video, 8 subjects x 8 objects, 16 frames); wave w owns
 // subjects 2w, 2w+1 x 8 objects (16 accumulator tiles of 16 heads x 16 frames).  Per k-step of 32
@@ -498,7 +900,31 @@ extern "C" int tspn_conv3_tc_bf16(const uint16_t* x, int64_t B, int64_t T, int64
   if (!attr) {
     int rc = set_smem(reinterpret_cast<const void*>(conv3_bf16_cl_kernel), CONV_SMEM, "tspn_conv3_tc_bf16");
     if (rc) return rc;
+    rc = set_smem(reinterpret_cast<const void*>(conv3_bf16_ring_kernel), R_SMEM, "tspn_conv3_tc_bf16");
+    if (rc) return rc;
     attr = true;
+  }
+  const char* variant = getenv("TSPN_BF16_CONV");
+  if (variant == nullptr || atoi(variant) == 3) {
+    static thread_local bool attr3 = false;
+    if (!attr3) {
+      int rc = set_smem(reinterpret_cast<const void*>(conv3_bf16_big_kernel), G_SMEM, "tspn_conv3_tc_bf16");
+      if (rc) return rc;
+      attr3 = true;
+    }
+    const int64_t tm = tspn::ceil_div(M, G_BM), tn = tspn::ceil_div(ncols, G_BN);
+    hipLaunchKernelGGL(conv3_bf16_big_kernel, dim3((unsigned)(tm * tn)), dim3(G_THREADS), G_SMEM,
+                       TSPN_STREAM(stream), reinterpret_cast<const __bf16*>(x),
+                       reinterpret_cast<const __bf16*>(packed), bias, y, (int)Cin, (int)T, (int)M, ncols,
+                       (int)tm, (int)tn, (int)ldm);
+    return tspn::check_launch("tspn_conv3_tc_bf16");
+  }
+  if (atoi(variant) == 2) {
+    hipLaunchKernelGGL(conv3_bf16_ring_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(THREADS), R_SMEM,
+                       TSPN_STREAM(stream), reinterpret_cast<const __bf16*>(x),
+                       reinterpret_cast<const __bf16*>(packed), bias, y, (int)Cin, (int)T, (int)M, ncols,
+                       (int)tiles_m, (int)tiles_n, (int)ldm);
+    return tspn::check_launch("tspn_conv3_tc_bf16");
   }
   hipLaunchKernelGGL(conv3_bf16_cl_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(THREADS), CONV_SMEM,
                      TSPN_STREAM(stream), reinterpret_cast<const __bf16*>(x),
