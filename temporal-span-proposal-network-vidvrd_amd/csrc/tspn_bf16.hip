@@ -587,44 +587,44 @@ __global__ __launch_bounds__(G_THREADS, 1) void conv3_bf16_big_kernel(
 
   const int nchunks = Cin / R_KC;
   const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-  auto compute = [&](int st) {
+  // Software pipeline across chunks (fragment registers a/b[tap]):
+  //   top of chunk c:  tap 0 of chunk c is already in registers
+  //   MFMA tap 0, with the reads of taps 1, 2 between them
+  //   wait for the DMA of chunk c+1, barrier, issue the DMA of chunk c+3
+  //   MFMA tap 1, with the tap-0 reads of chunk c+1 between them | MFMA tap 2
+  // The barrier sits in the middle of a chunk, so the LDS reads of the next chunk start under the
+  // MFMAs of this one; a stage is re-filled only after the barrier that follows its last read.
+  bf16x8 a[3][4], b[3][2];
+  auto load_tap = [&](int st, int tap) {
     const char* Ab = smem + st * G_ST + (kh * G_BM + wm * 128 + li) * 16;
     const char* Xb = smem + st * G_ST + G_A_ST + (kh * G_SLP + wn * 64 + li) * 16;
-    bf16x8 a[3][4], b[3][2];
-    auto load_tap = [&](int tap) {
 #if defined(TSPN_BF16_ABL_NOLDS)
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-        a[tap][mi] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)st, (unsigned)tap, (unsigned)mi, (unsigned)lane});
+    for (int mi = 0; mi < 4; ++mi)
+      a[tap][mi] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)st, (unsigned)tap, (unsigned)mi, (unsigned)lane});
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-        b[tap][ni] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)lane, (unsigned)ni, (unsigned)tap, (unsigned)st});
-      return;
+    for (int ni = 0; ni < 2; ++ni)
+      b[tap][ni] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)lane, (unsigned)ni, (unsigned)tap, (unsigned)st});
+    (void)Ab; (void)Xb;
+    return;
 #endif
 #pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+      a[tap][mi] = *reinterpret_cast<const bf16x8*>(Ab + (tap * R_KG * G_BM + mi * 32) * 16);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+      b[tap][ni] = *reinterpret_cast<const bf16x8*>(Xb + (ni * 32 + tap) * 16);
+  };
+  auto mfma_tap = [&](int tap) {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      bf16x8 bb = b[tap][ni];
+      if (tap == 0) bb = mask_l[ni] ? bb : zero8;
+      if (tap == 2) bb = mask_r[ni] ? bb : zero8;
+#pragma unroll
       for (int mi = 0; mi < 4; ++mi)
-        a[tap][mi] = *reinterpret_cast<const bf16x8*>(Ab + (tap * R_KG * G_BM + mi * 32) * 16);
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-        b[tap][ni] = *reinterpret_cast<const bf16x8*>(Xb + (ni * 32 + tap) * 16);
-    };
-    auto mfma_tap = [&](int tap) {
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        bf16x8 bb = b[tap][ni];
-        if (tap == 0) bb = mask_l[ni] ? bb : zero8;
-        if (tap == 2) bb = mask_r[ni] ? bb : zero8;
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tap][mi], bb, acc[mi][ni], 0, 0, 0);
-      }
-    };
-    load_tap(0);
-    load_tap(1);
-    mfma_tap(0);
-    load_tap(2);
-    mfma_tap(1);
-    mfma_tap(2);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tap][mi], bb, acc[mi][ni], 0, 0, 0);
+    }
   };
 
   stage_chunk(0);
@@ -632,19 +632,47 @@ __global__ __launch_bounds__(G_THREADS, 1) void conv3_bf16_big_kernel(
   if (nchunks > 2) stage_chunk(2);
   if (nchunks > 2) wait_keep(K2{}); else if (nchunks > 1) wait_keep(K1{}); else wait_keep(K0{});
   __builtin_amdgcn_s_barrier();
+  load_tap(0, 0);
 
   int c = 0;
-  for (; c + 3 < nchunks; ++c) {        // steady state: chunk c+3 exists
-    stage_chunk((c + 3) & 3);
-    compute(c & 3);
-    wait_keep(K2{});                    // chunks c+2, c+3 may still fly; c+1 has landed
+  for (; c + 3 < nchunks; ++c) {        // steady state: chunks c+1 .. c+3 exist
+    const int st = c & 3;
+    mfma_tap(0);
+    load_tap(st, 1);
+    load_tap(st, 2);
+    // 8 MFMAs; two fragment reads behind each of the first six
+#define TSPN_MR(NM, NR)                                \
+  __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);  \
+  __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+    TSPN_MR(1, 2) TSPN_MR(1, 2) TSPN_MR(1, 2) TSPN_MR(1, 2) TSPN_MR(1, 2) TSPN_MR(1, 2) TSPN_MR(2, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    wait_keep(K1{});                    // chunk c+2 may still fly; c+1 has landed
     __builtin_amdgcn_s_barrier();
+    // the two waves of a SIMD (w and w+4) issue their DMA pieces at different times
+    if (wm == 0) stage_chunk((c + 3) & 3);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_tap(1);
+    load_tap((c + 1) & 3, 0);
+    TSPN_MR(2, 1) TSPN_MR(1, 1) TSPN_MR(1, 1) TSPN_MR(1, 1) TSPN_MR(1, 1) TSPN_MR(1, 1) TSPN_MR(1, 0)
+#undef TSPN_MR
+    __builtin_amdgcn_sched_barrier(0);
+    if (wm != 0) stage_chunk((c + 3) & 3);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_tap(2);
+    __builtin_amdgcn_sched_barrier(0);
   }
   for (; c < nchunks; ++c) {            // tail: nothing left to issue
-    compute(c & 3);
-    wait_keep(K0{});
+    const int st = c & 3;
+    load_tap(st, 1);
+    load_tap(st, 2);
+    mfma_tap(0);
+    if (c + 2 < nchunks) wait_keep(K1{}); else wait_keep(K0{});
     __builtin_amdgcn_s_barrier();
+    mfma_tap(1);
+    if (c + 1 < nchunks) load_tap((c + 1) & 3, 0);
+    mfma_tap(2);
   }
+  __builtin_amdgcn_s_barrier();         // every wave is done with the stages before the epilogue reuses them
 
   // ---- epilogue.  A lane holds 4 consecutive channels of ONE frame per register quad, so direct
   // stores would touch 32 different 16-KB-strided rows per instruction (measured: 1.1 ms of 6.0 at the
@@ -690,15 +718,13 @@ __global__ __launch_bounds__(G_THREADS, 1) void conv3_bf16_big_kernel(
 // the canonical pair table.  Workgroup = (video, 8 subjects x 8 objects, 16 frames); wave w owns
 // subjects 2w, 2w+1 x 8 objects (16 accumulator tiles of 16 heads x 16 frames).  Per k-step of 32
 // channels the 16 projection rows (8 U + 8 V) x 16 frames x 32 ch fp32 = 32 KB are staged by LDS-DMA
-// (double-buffered, 64 KB -> 2 workgroups/CU).  The DMA source of each lane is chosen so that the LDS
-// image of a row is [half j][channel group kg][frame f] (16-byte units): the B fragment of lane
-// (f = l&15, kg = l>>4) -- channels 8kg .. 8kg+7 of frame f -- is two conflict-free ds_read_b128
-// at unit l and unit 64 + l.  The kernel is VALU-bound (1.5 packed VALU per activation), not MFMA-bound.
+// (double-buffered).  The DMA source of each lane is chosen (comment at `src` below) so that a piece
+// fetches complete 128-byte lines AND the B fragment of lane (f = l&15, kg = l>>4) -- channels
+// 8kg .. 8kg+7 of frame f -- is two conflict-free ds_read_b128.  The VALU work (1.5 packed
+// instructions per activation) hides under the operand stream, which is what bounds the kernel.
 constexpr int HP_FB = 16;
 constexpr int HP_KC = 32;
 constexpr int HP_ROW = HP_FB * HP_KC * 4;  // 2048 B
-constexpr int HP_ST = 16 * HP_ROW;         // 32 KB
-constexpr size_t HP_SMEM = 2 * (size_t)HP_ST;
 
 __device__ __forceinline__ unsigned relu_pack(float a, float b) {
   f32x2 s = {a, b};
@@ -708,18 +734,28 @@ __device__ __forceinline__ unsigned relu_pack(float a, float b) {
   return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, h), z));
 }
 
-__global__ __launch_bounds__(THREADS, 2) void heads_pairgrid_bf16_kernel(
+// NW waves; workgroup = 2 NW subjects x OB objects x 16 frames, wave w owns subjects 2w, 2w+1.
+// <4, 8>: 8 x 8 pairs, 32 KB per stage, 2 workgroups/CU (small N).  <8, 16>: 16 x 16 pairs, 64 KB per
+// stage, 1 workgroup/CU -- half the bytes streamed from L2 per activation, which is what bounds the
+// kernel (ablation at the config-3 shape, 8 x 8: 4.5 ms, without the DMA stream 2.2, without the
+// VALU work still 4.5).
+template <int NW, int OB>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void heads_pairgrid_bf16_kernel(
     const float* __restrict__ y, int64_t ldm, int B, int N, int C, int T,
     const __bf16* __restrict__ Whp, const float* __restrict__ bh, int H, float* __restrict__ out,
-    int nsb, int nfb) {
+    int nsb, int nob, int nfb) {
+  constexpr int SBLK = 2 * NW;
+  constexpr int ROWS = SBLK + OB;
+  constexpr int ST = ROWS * HP_ROW + 1024;  // + the k-step's slice of the head weights (one piece)
+  static_assert(ROWS == 4 * NW, "each wave stages 4 rows");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int nwg = gridDim.x;
   const int bid = blockIdx.x;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
   int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int ob = wg % nsb;
-  wg /= nsb;
+  const int ob = wg % nob;
+  wg /= nob;
   const int sb = wg % nsb;
   wg /= nsb;
   const int fb = wg % nfb;
@@ -731,69 +767,112 @@ __global__ __launch_bounds__(THREADS, 2) void heads_pairgrid_bf16_kernel(
   const int f = lane & 15, kg = lane >> 4;
   const int t0 = fb * HP_FB;
 
-  // DMA sources: wave w stages rows 4w .. 4w+3 (2 pieces each); row r < 8: subject 8 sb + r (U half,
-  // channels [0,C)), r >= 8: object 8 ob + r - 8 (V half, channels [C,2C))
+  // DMA sources: wave w stages rows 4w .. 4w+3 (2 pieces each); row r < SBLK: subject SBLK sb + r
+  // (U half, channels [0,C)), else object OB ob + r - SBLK (V half, channels [C,2C))
+  // LDS image of a row: two pieces of 8 frames; inside a piece position = 16 X + slot with
+  //   slot = (f & 7) + 8 ((q >> 1) & 1),  X = 2 (q >> 2) + (q & 1)      (q = 16-byte channel quad 0..7)
+  // so that (a) one DMA piece fetches 8 complete 128-byte lines of y (8 frames x 32 channels) and
+  // (b) the fragment read of lane (f, kg) for quad 2 kg + r sits at slot (f & 7) + 8 (kg & 1): the
+  // four 16-lane groups of a ds_read_b128 each cover all 16 slots -- conflict-free.
   const float* src[8];
   {
-    const int t = min(t0 + f, T - 1);
+    const int fq = lane & 7;
+    const int q = (lane >> 5) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 4) & 1);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int r = wave * 4 + (i >> 1), j = i & 1;
-      int trk = r < 8 ? sb * 8 + r : ob * 8 + r - 8;
+      int trk = r < SBLK ? sb * SBLK + r : ob * OB + r - SBLK;
       trk = min(trk, N - 1);
-      const int q = 2 * kg + j;
-      src[i] = y + (((int64_t)b * N + trk) * T + t) * ldm + (r < 8 ? 0 : C) + 4 * q;
+      const int t = min(t0 + 8 * j + fq, T - 1);
+      src[i] = y + (((int64_t)b * N + trk) * T + t) * ldm + (r < SBLK ? 0 : C) + 4 * q;
     }
   }
+  const bf16x8* wsrc = reinterpret_cast<const bf16x8*>(Whp) + lane;          // + 64 per k-step
   auto stage = [&](int buf) {
-    char* dst = smem + buf * HP_ST + wave * 4 * HP_ROW;
+#if defined(TSPN_HPB_ABL_NODMA)
+    return;
+#endif
+    char* dst = smem + buf * ST + wave * 4 * HP_ROW;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       glds16(src[i], dst + i * 1024);
       src[i] += HP_KC;
     }
+    // head weights of the k-step, [4 kg][16 h][8 ch] bf16 = the packed layout itself; staged through
+    // LDS as well so that no register-returning global load (whose wait the compiler would place at the
+    // top of the loop, serialising the whole DMA queue with the compute) is left in the loop
+    if (wave == 0) {
+      glds16(wsrc, smem + buf * ST + ROWS * HP_ROW);
+      wsrc += 64;
+    }
   };
 
-  f32x4 acc[2][8];
+  f32x4 acc[2][OB];
 #pragma unroll
   for (int s = 0; s < 2; ++s)
 #pragma unroll
-    for (int o = 0; o < 8; ++o) acc[s][o] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int o = 0; o < OB; ++o) acc[s][o] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = C / HP_KC;
-  const bf16x8* wsrc = reinterpret_cast<const bf16x8*>(Whp) + kg * 16 + f;  // + 64 per k-step
+  // fragment of lane (f, kg): quads 2 kg (here) and 2 kg + 1 (256 bytes further)
+  const int frag_off = (64 * (f >> 3) + 32 * (kg >> 1) + 8 * (kg & 1) + (f & 7)) * 16;
   stage(0);
-  bf16x8 wfrag = wsrc[0];
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  __builtin_amdgcn_s_waitcnt(0x0070);                 // vmcnt(0) lgkmcnt(0)
+  __builtin_amdgcn_s_barrier();
 
   for (int k = 0; k < nk; ++k) {
     const int buf = k & 1;
     if (k + 1 < nk) stage(buf ^ 1);
-    const bf16x8 wnext = wsrc[(int64_t)min(k + 1, nk - 1) * 64];
-    const char* base = smem + buf * HP_ST + lane * 16;
+    __builtin_amdgcn_sched_barrier(0);
+    const bf16x8 wfrag = *reinterpret_cast<const bf16x8*>(smem + buf * ST + ROWS * HP_ROW + lane * 16);
+    const char* base = smem + buf * ST + frag_off;
     f32x4 u[2][2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       u[s][0] = *reinterpret_cast<const f32x4*>(base + (2 * wave + s) * HP_ROW);
-      u[s][1] = *reinterpret_cast<const f32x4*>(base + (2 * wave + s) * HP_ROW + 1024);
+      u[s][1] = *reinterpret_cast<const f32x4*>(base + (2 * wave + s) * HP_ROW + 256);
     }
+    // V fragments are read two objects ahead of their use (LDS latency off the critical path).  The
+    // reads and their counted waits are written out: left to itself the compiler issues every
+    // fragment read right before its first use and waits for it at once (32 exposed LDS round trips
+    // per k-step).  LDS returns in order, so "lgkmcnt(n)" = all but the newest n reads have landed.
+    const unsigned vaddr = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(base);
+    f32x4 vq[3][2];
+#define TSPN_VREAD(slot, o)                                                                             \
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(vq[slot][0]) : "v"(vaddr), "n"((SBLK + (o)) * HP_ROW)); \
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(vq[slot][1]) : "v"(vaddr), "n"((SBLK + (o)) * HP_ROW + 256));
+    TSPN_VREAD(0, 0)
+    TSPN_VREAD(1, 1)
 #pragma unroll
-    for (int o = 0; o < 8; ++o) {
-      const f32x4 v0 = *reinterpret_cast<const f32x4*>(base + (8 + o) * HP_ROW);
-      const f32x4 v1 = *reinterpret_cast<const f32x4*>(base + (8 + o) * HP_ROW + 1024);
+    for (int o = 0; o < OB; ++o) {
+      if (o + 2 < OB) {
+        TSPN_VREAD((o + 2) % 3, o + 2)
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(vq[o % 3][0]), "+v"(vq[o % 3][1]));
+      } else if (o + 1 < OB) {
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(vq[o % 3][0]), "+v"(vq[o % 3][1]));
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vq[o % 3][0]), "+v"(vq[o % 3][1]));
+      }
+      const f32x4 v0 = vq[o % 3][0], v1 = vq[o % 3][1];
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
+#if defined(TSPN_HPB_ABL_NOVALU)
+        u32x4 pk = {__builtin_bit_cast(unsigned, u[s][0][0]) ^ __builtin_bit_cast(unsigned, v0[0]),
+                    __builtin_bit_cast(unsigned, u[s][0][1]) ^ __builtin_bit_cast(unsigned, v0[2]),
+                    __builtin_bit_cast(unsigned, u[s][1][0]) ^ __builtin_bit_cast(unsigned, v1[1]),
+                    __builtin_bit_cast(unsigned, u[s][1][1]) ^ __builtin_bit_cast(unsigned, v1[3])};
+#else
         const f32x4 a0 = u[s][0] + v0, a1 = u[s][1] + v1;
         u32x4 pk = {relu_pack(a0[0], a0[1]), relu_pack(a0[2], a0[3]), relu_pack(a1[0], a1[1]),
                     relu_pack(a1[2], a1[3])};
+#endif
         acc[s][o] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag, __builtin_bit_cast(bf16x8, pk),
                                                              acc[s][o], 0, 0, 0);
       }
     }
-    wfrag = wnext;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA of the next k-step has landed
-    __syncthreads();
+#undef TSPN_VREAD
+    __builtin_amdgcn_s_waitcnt(0x0070);               // vmcnt(0) lgkmcnt(0): the next k-step is in LDS
+    __builtin_amdgcn_s_barrier();
   }
 
   // epilogue: lane = (frame f, head group hg): heads 4 hg .. 4 hg + 3
@@ -804,10 +883,10 @@ __global__ __launch_bounds__(THREADS, 2) void heads_pairgrid_bf16_kernel(
   for (int r = 0; r < 4; ++r) bias[r] = (4 * hg + r < H) ? bh[4 * hg + r] : 0.f;
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    const int sg = sb * 8 + 2 * wave + s;
+    const int sg = sb * SBLK + 2 * wave + s;
 #pragma unroll
-    for (int o = 0; o < 8; ++o) {
-      const int og = ob * 8 + o;
+    for (int o = 0; o < OB; ++o) {
+      const int og = ob * OB + o;
       if (sg >= N || og >= N || sg == og || t >= T) continue;
       const int64_t p = (int64_t)b * N * (N - 1) + (int64_t)sg * (N - 1) + (og < sg ? og : og - 1);
 #pragma unroll
@@ -943,20 +1022,33 @@ extern "C" int tspn_heads_pairgrid_bf16(const float* y, int64_t ldm, int64_t B, 
   TSPN_REQUIRE(y && head_packed && head_b && out, TSPN_EINVAL, "tspn_heads_pairgrid_bf16: null pointer");
   TSPN_REQUIRE(C % HP_KC == 0 && ldm % 4 == 0 && aligned16(y) && aligned16(head_packed), TSPN_EUNSUPPORTED,
                "tspn_heads_pairgrid_bf16: needs C %% 32 == 0, ldm %% 4 == 0, 16-byte aligned y / weights");
-  const int64_t nsb = tspn::ceil_div(N, 8), nfb = tspn::ceil_div(T, HP_FB);
+  const bool big = N > 12 && getenv("TSPN_BF16_HEADS_SMALL") == nullptr;
+  const int64_t sblk = big ? 16 : 8;
+  const int64_t nsb = tspn::ceil_div(N, sblk), nfb = tspn::ceil_div(T, HP_FB);
   const int64_t grid = B * nsb * nsb * nfb;
   TSPN_REQUIRE(grid < (1LL << 31) && N < (1 << 20) && T < (1 << 24) && C < (1 << 24), TSPN_EUNSUPPORTED,
                "tspn_heads_pairgrid_bf16: problem too large");
+  const size_t smem = 2 * ((size_t)(2 * sblk) * HP_ROW + 1024);
   static thread_local bool attr = false;
   if (!attr) {
-    int rc = set_smem(reinterpret_cast<const void*>(heads_pairgrid_bf16_kernel), HP_SMEM,
+    int rc = set_smem(reinterpret_cast<const void*>(heads_pairgrid_bf16_kernel<4, 8>), 2 * (16 * HP_ROW + 1024),
                       "tspn_heads_pairgrid_bf16");
+    if (rc) return rc;
+    rc = set_smem(reinterpret_cast<const void*>(heads_pairgrid_bf16_kernel<8, 16>), 2 * (32 * HP_ROW + 1024),
+                  "tspn_heads_pairgrid_bf16");
     if (rc) return rc;
     attr = true;
   }
-  hipLaunchKernelGGL(heads_pairgrid_bf16_kernel, dim3((unsigned)grid), dim3(THREADS), HP_SMEM,
-                     TSPN_STREAM(stream), y, ldm, (int)B, (int)N, (int)C, (int)T,
-                     reinterpret_cast<const __bf16*>(head_packed), head_b, (int)H, out, (int)nsb, (int)nfb);
+  if (big)
+    hipLaunchKernelGGL((heads_pairgrid_bf16_kernel<8, 16>), dim3((unsigned)grid), dim3(512), smem,
+                       TSPN_STREAM(stream), y, ldm, (int)B, (int)N, (int)C, (int)T,
+                       reinterpret_cast<const __bf16*>(head_packed), head_b, (int)H, out, (int)nsb, (int)nsb,
+                       (int)nfb);
+  else
+    hipLaunchKernelGGL((heads_pairgrid_bf16_kernel<4, 8>), dim3((unsigned)grid), dim3(256), smem,
+                       TSPN_STREAM(stream), y, ldm, (int)B, (int)N, (int)C, (int)T,
+                       reinterpret_cast<const __bf16*>(head_packed), head_b, (int)H, out, (int)nsb, (int)nsb,
+                       (int)nfb);
   return tspn::check_launch("tspn_heads_pairgrid_bf16");
 }
 

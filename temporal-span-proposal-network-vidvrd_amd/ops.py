@@ -506,8 +506,9 @@ def pack_heads_bf16(head_w):
     return out
 
 
-def conv3_tc_bf16(x, packed, bias=None):
-    """k=3 conv over time, bf16 operands: x bf16 [B,T,Cin] -> y fp32 channels-last [B,T,M]."""
+def conv3_tc_bf16(x, packed, bias=None, ldm=None):
+    """k=3 conv over time, bf16 operands: x bf16 [B,T,Cin] -> y fp32 channels-last [B,T,M]
+    (`ldm` > M: rows padded to ldm floats, returned as [B,T,ldm] with the pad uninitialised)."""
     _dev(x, "x", torch.bfloat16); _dev(packed, "packed", torch.bfloat16)
     if bias is not None:
         _dev(bias, "bias")
@@ -515,19 +516,22 @@ def conv3_tc_bf16(x, packed, bias=None):
     if packed.dim() != 4 or packed.shape[0] != 3 or packed.shape[1] * 8 != Cin or packed.shape[3] != 8:
         raise ValueError(f"conv3_tc_bf16: packed {tuple(packed.shape)} does not match Cin={Cin}")
     M = packed.shape[2]
-    y = torch.empty((B, T, M), dtype=torch.float32, device=x.device)
-    _abi.check(_abi.lib().tspn_conv3_tc_bf16(_p(x), B, T, Cin, _p(packed), M, _p(bias), _p(y), M, _stream()))
+    ldm = M if ldm is None else int(ldm)
+    y = torch.empty((B, T, ldm), dtype=torch.float32, device=x.device)
+    _abi.check(_abi.lib().tspn_conv3_tc_bf16(_p(x), B, T, Cin, _p(packed), M, _p(bias), _p(y), ldm, _stream()))
     return y
 
 
 def heads_pairgrid_bf16(y, B, N, head_packed, head_b, H):
-    """Pair stage on y fp32 [B*N, T, 2C] (U | V halves) -> heads fp32 [B*N*(N-1), H, T]."""
+    """Pair stage on y fp32 [B*N, T, ldm >= 2C] (U | V halves, C from head_packed) -> heads fp32
+    [B*N*(N-1), H, T]."""
     _dev(y, "y"); _dev(head_packed, "head_packed", torch.bfloat16); _dev(head_b, "head_b")
-    BN, T, C2 = y.shape
-    if BN != B * N or C2 % 2 or head_packed.shape != (C2 // 16, 16, 8) or head_b.numel() != H:
+    BN, T, ldm = y.shape
+    C = head_packed.shape[0] * 8
+    if BN != B * N or ldm < 2 * C or tuple(head_packed.shape[1:]) != (16, 8) or head_b.numel() != H:
         raise ValueError("heads_pairgrid_bf16: shape mismatch")
     out = torch.empty((B * N * (N - 1), H, T), dtype=torch.float32, device=y.device)
-    _abi.check(_abi.lib().tspn_heads_pairgrid_bf16(_p(y), C2, B, N, C2 // 2, T, _p(head_packed), _p(head_b),
+    _abi.check(_abi.lib().tspn_heads_pairgrid_bf16(_p(y), ldm, B, N, C, T, _p(head_packed), _p(head_b),
                                                    H, _p(out), _stream()))
     return out
 

@@ -16,6 +16,7 @@ ap.add_argument("--n", type=int, default=64)
 ap.add_argument("--t", type=int, default=900)
 ap.add_argument("--d", type=int, default=1024)
 ap.add_argument("--iters", type=int, default=5)
+ap.add_argument("--pad", type=int, default=0, help="floats of padding per row of y")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 B, N, T, D = args.videos, args.n, args.t, args.d
@@ -49,7 +50,7 @@ def timed(fn):
     return ms[len(ms) // 2], out
 
 
-ms_conv, y = timed(lambda: tspn.ops.conv3_tc_bf16(feats, packed, bias2))
+ms_conv, y = timed(lambda: tspn.ops.conv3_tc_bf16(feats, packed, bias2, ldm=2 * C + args.pad))
 flop = 2.0 * (2 * C) * 3 * D * B * N * T
 print(f"conv3 bf16  B*N={B * N} T={T} D={D} M={2 * C}: {ms_conv:.3f} ms -> {flop / ms_conv / 1e9:.0f} TFLOP/s")
 ms_heads, _ = timed(lambda: tspn.ops.heads_pairgrid_bf16(y, B, N, hpk, hb, 3 * A))
