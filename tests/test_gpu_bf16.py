@@ -203,3 +203,38 @@ def test_bf16_path_rejects_what_it_cannot_do(tspn, device):
                                       t(v["track_cls_logits"]))
     with pytest.raises(ValueError, match="D % 32"):
         model([pl], None)
+
+
+def test_cfg3_full_size_bf16_vs_fp32_path(tspn, device):
+    """BASELINE config 3 at full size (N=64, T=900, D=1024 -> P=4032, C=2048): the bf16 kernels against
+    the fp32 HIP path (itself oracle-checked) on the same bf16-rounded operands: they differ only by the
+    one rounding of the encoder activation / pooled feature (<= 2^-8 relative to the output range), and
+    the result is bit-reproducible run to run.  Also exercises 3600-workgroup grids, T % 16 != 0 and the
+    1-video launch (912 pair-stage workgroups on 256 CUs)."""
+    N, T, D = 64, 900, 1024
+    C = 2 * D
+    v = tspn.synth.make_video(97, N, T, D)
+    sd = tspn.synth.make_weights(0, c=C, bias_std=0.05)
+    w = {k: r16(x.numpy()).to(device) for k, x in oracle_weights(sd).items()}
+    feats = r16(v["tracklet_feats"]).to(device)
+    pairs = tspn.ops.pair_index(N, device)
+    hw = torch.cat([w["rel_w"][:, :, 0], w["dur_w"][:, :, 0]]).contiguous()
+    hb = torch.cat([w["rel_b"], w["dur_b"]]).contiguous()
+    args16 = (feats.to(torch.bfloat16), pairs, 1, N, tspn.ops.pack_conv3_bf16(w["conv_w"], split=D), w["conv_b"],
+              tspn.ops.pack_heads_bf16(hw), hb, w["cls_w"], w["cls_b"])
+    h16, l16 = tspn.ops.forward_fused_bf16(*args16)
+    h32, l32 = tspn.ops.forward_fused(feats, pairs, 1, N, tspn.ops.pack_conv3_wino(w["conv_w"], split=D),
+                                      w["conv_b"], hw, hb, w["cls_w"], w["cls_b"], canonical_pairs=True)
+    assert h16.shape == (N * (N - 1), 12, T) and l16.shape == (N * (N - 1), 132)
+    scale = float(h32.abs().max())
+    assert float((h16 - h32).abs().max()) <= 2.0 ** -8 * scale
+    assert float((l16 - l32).abs().max()) <= 2.0 ** -8
+    assert torch.isfinite(h16).all() and torch.isfinite(l16).all()
+    h16b, l16b = tspn.ops.forward_fused_bf16(*args16)
+    assert torch.equal(h16, h16b) and torch.equal(l16, l16b)
+    # span decode of the bf16 heads runs at T=900 (A*T = 3600 candidates per pair)
+    sizes = [(a + 1) * T / 4 for a in range(4)]
+    res = tspn.ops.decode_spans(h16[:64].contiguous(), sizes, top_k=16)
+    assert res["span"].shape == (64, 16, 2) and int(res["count"].min()) >= 1
+    ok = res["span"][..., 0] >= 0
+    assert bool((res["span"][..., 1][ok] <= T).all()) and bool((res["span"][..., 0][ok] < res["span"][..., 1][ok]).all())
