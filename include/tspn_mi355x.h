@@ -267,6 +267,18 @@ typedef struct tspn_fused_desc {
 size_t tspn_forward_fused_workspace_bytes(const tspn_fused_desc* d);
 int tspn_forward_fused_f32(const tspn_fused_desc* d, void* stream);
 
+/* ---- span-restricted RelOIPool + predicate head --------------------------
+ * Build-defined meaning of RelOIPool with duration proposals (reference lib/modeling/model.py:68-73 indexes
+ * a list with a tensor and cannot run): the pair feature cat(f_s, f_o) is averaged over
+ * the pair's own span [start, end) of frames before RelationPredictor (model.py:85-88):
+ *   out[p] = sigmoid(cls_w . mean_{t in [start_p, end_p)} cat(f[s_p, t], f[o_p, t]) + cls_b).
+ * feats [NT, T, D]; pairs [P,2] global tracklet ids; spans int64 [P,2], e.g. the top span of
+ * tspn_decode_spans_f32 (a negative start selects the whole segment).                               */
+size_t tspn_span_predicate_workspace_bytes(int64_t NT, int64_t T, int64_t D, int64_t K);
+int tspn_span_predicate_f32(const float* feats, int64_t NT, int64_t T, int64_t D, const int64_t* pairs,
+                            const int64_t* spans, int64_t P, const float* cls_w, const float* cls_b,
+                            int64_t K, float* out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- bf16-operand path (BASELINE config 3: N=64, T=900, D=1024, bf16) ----
  * Semantics (build-defined; pinned by tests/golden/g8 against the reference's own DPNHead /
  * RelationPredictor modules cast with .bfloat16(), lib/modeling/relpn/dpn.py:55-73, model.py:76-88):

@@ -53,7 +53,10 @@ _DEFAULTS = {
         "PPN": {"NUM_PAIR_PROPOSALS": 256, "IN_CHANNELS": 35, "HIDDEN_CHANNELS": 64,
                 "OUT_CHANNELS": 35, "BATCH_SIZE_PER_SEGMENT": 256, "POSITIVE_FRACTION": 0.5},
         "DPN": {"NUM_DURATION_PROPOSALS": 64, "DPN_ONLY": False, "IN_CHANNELS": 1024,
-                "NUM_ANCHORS_PER_LOCATION": 4, "ANCHOR_SIZES": 35, "ANCHOR_STRIDE": 132},
+                "NUM_ANCHORS_PER_LOCATION": 4, "ANCHOR_SIZES": 35, "ANCHOR_STRIDE": 132,
+                # build extension (not in the reference's defaults.py): RelOIPool restricted to each
+                # pair's top temporal span instead of the whole segment (model.py:68-73 is a stub)
+                "POOL_TOP_SPAN": False},
     },
     "ETC": {"RANDOM_SEED": 0, "MODEL_DUMP_FILE": "baseline_weights_epoch_100.pt"},
 }

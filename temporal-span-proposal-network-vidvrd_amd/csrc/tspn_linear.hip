@@ -214,6 +214,46 @@ __global__ void pair_combine_kernel(const float* __restrict__ rs, const float* _
   }
 }
 
+// Span-restricted RelOIPool + predicate head.  The head is linear, so instead of pooling the pair
+// features over each pair's span it is applied to every (tracklet, frame) row first -- G = f W'^T with
+// W' = cls_w [K,2D] read as [2K, D] (column 2k: subject half, 2k+1: object half) -- prefix-summed over
+// time in float64, and a pair's logit is a difference of two prefix rows per half divided by the span length.
+__global__ void span_prefix_kernel(const float* __restrict__ G, int64_t NT, int T, int K2,
+                                   double* __restrict__ PS) {
+  const int64_t total = NT * K2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t trk = i / K2, c = i - trk * K2;
+    const float* g = G + (trk * T) * (int64_t)K2 + c;
+    double* ps = PS + (trk * (T + 1)) * (int64_t)K2 + c;
+    double acc = 0.0;
+    ps[0] = 0.0;
+    for (int t = 0; t < T; ++t) {
+      acc += (double)g[(int64_t)t * K2];
+      ps[(int64_t)(t + 1) * K2] = acc;
+    }
+  }
+}
+
+__global__ void span_combine_kernel(const double* __restrict__ PS, const int64_t* __restrict__ pairs,
+                                    const int64_t* __restrict__ spans, int64_t P, int T, int K,
+                                    const float* __restrict__ b, float* __restrict__ out) {
+  const int64_t total = P * K;
+  const int64_t K2 = 2 * (int64_t)K;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = i / K, k = i - p * K;
+    int64_t a = spans[2 * p], e = spans[2 * p + 1];
+    a = a < 0 ? 0 : (a > T - 1 ? T - 1 : a);       // out-of-range / unused (-1) spans fall back to
+    e = e < a + 1 ? (spans[2 * p] < 0 ? T : a + 1) : (e > T ? T : e);  // the whole segment / one frame
+    const double* ps = PS + (pairs[2 * p] * (T + 1)) * K2 + 2 * k;
+    const double* po = PS + (pairs[2 * p + 1] * (T + 1)) * K2 + 2 * k + 1;
+    double v = ((ps[e * K2] - ps[a * K2]) + (po[e * K2] - po[a * K2])) / (double)(e - a);
+    if (b != nullptr) v += (double)b[k];
+    out[i] = (float)(1.0 / (1.0 + exp(-v)));
+  }
+}
+
 int choose_splits(int64_t P, int64_t F, int64_t K) {
   const int64_t tiles = tspn::ceil_div(P, TM) * tspn::ceil_div(K, TN);
   int64_t s = tspn::ceil_div(512, tiles);
@@ -346,4 +386,52 @@ int tspn::pair_predicate(const float* fbar, int64_t NT, int64_t D, const int64_t
   hipLaunchKernelGGL(pair_combine_kernel, dim3(blocks), dim3(256), 0, TSPN_STREAM(stream), rs, ro, pairs,
                      P, K, cls_b, out);
   return tspn::check_launch("pair_predicate(combine)");
+}
+
+
+namespace {
+struct SpanLayout {
+  size_t lin, g, ps, total;
+};
+SpanLayout span_layout(int64_t NT, int64_t T, int64_t D, int64_t K) {
+  SpanLayout L{};
+  L.lin = tspn::align_up(tspn_predicate_head_workspace_bytes(NT * T, D, 2 * K), 256);
+  L.g = tspn::align_up((size_t)NT * T * 2 * K * sizeof(float), 256);
+  L.ps = tspn::align_up((size_t)NT * (T + 1) * 2 * K * sizeof(double), 256);
+  L.total = L.lin + L.g + L.ps;
+  return L;
+}
+}  // namespace
+
+extern "C" size_t tspn_span_predicate_workspace_bytes(int64_t NT, int64_t T, int64_t D, int64_t K) {
+  if (NT <= 0 || T <= 0 || D <= 0 || K <= 0) return 0;
+  return span_layout(NT, T, D, K).total;
+}
+
+extern "C" int tspn_span_predicate_f32(const float* feats, int64_t NT, int64_t T, int64_t D,
+                                       const int64_t* pairs, const int64_t* spans, int64_t P,
+                                       const float* cls_w, const float* cls_b, int64_t K, float* out,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
+  TSPN_REQUIRE(NT >= 0 && T > 0 && D > 0 && K > 0 && P >= 0 && T < (1 << 30) && K < (1 << 20), TSPN_EINVAL,
+               "tspn_span_predicate_f32: bad sizes NT=%lld T=%lld D=%lld K=%lld P=%lld", (long long)NT,
+               (long long)T, (long long)D, (long long)K, (long long)P);
+  if (P == 0 || NT == 0) return TSPN_OK;
+  TSPN_REQUIRE(feats && pairs && spans && cls_w && out, TSPN_EINVAL, "tspn_span_predicate_f32: null pointer");
+  const SpanLayout L = span_layout(NT, T, D, K);
+  TSPN_REQUIRE(workspace && workspace_bytes >= L.total, TSPN_EWORKSPACE,
+               "tspn_span_predicate_f32: workspace %zu < %zu bytes", workspace_bytes, L.total);
+  char* ws = static_cast<char*>(workspace);
+  float* G = reinterpret_cast<float*>(ws + L.lin);
+  double* PS = reinterpret_cast<double*>(ws + L.lin + L.g);
+  // G[(trk, t), 2k + half] = f[trk, t, :] . cls_w[k, half*D : (half+1)*D]
+  int rc = tspn::linear(feats, NT * T, D, D, cls_w, D, nullptr, 2 * K, G, 0, ws, L.lin, stream);
+  if (rc) return rc;
+  hipStream_t s = TSPN_STREAM(stream);
+  const int b1 = (int)std::min<int64_t>(tspn::ceil_div(NT * 2 * K, 256), 8192);
+  hipLaunchKernelGGL(span_prefix_kernel, dim3(b1), dim3(256), 0, s, G, NT, (int)T, (int)(2 * K), PS);
+  if ((rc = tspn::check_launch("tspn_span_predicate_f32(prefix)"))) return rc;
+  const int b2 = (int)std::min<int64_t>(tspn::ceil_div(P * K, 256), 8192);
+  hipLaunchKernelGGL(span_combine_kernel, dim3(b2), dim3(256), 0, s, PS, pairs, spans, P, (int)T, (int)K,
+                     cls_b, out);
+  return tspn::check_launch("tspn_span_predicate_f32(combine)");
 }

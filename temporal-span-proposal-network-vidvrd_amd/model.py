@@ -349,6 +349,7 @@ class BaseModel(nn.Module):
                                             out_channels=cfg.PREDICT.PREDICATE_NUM,
                                             fuse_preprocess=getattr(cfg.PREDICT, "FUSE_PREPROCESS", False))
         self._anchor_sizes_cfg = getattr(cfg.RELPN.DPN, "ANCHOR_SIZES", None)
+        self.pool_top_span = bool(getattr(cfg.RELPN.DPN, "POOL_TOP_SPAN", False))
 
     def forward(self, pair_list, target_list=None):
         if self.training:
@@ -477,6 +478,10 @@ class BaseModel(nn.Module):
             packed, cbias = dpn._conv_split(dev, winograd=(t % 2 == 0 and d % 16 == 0))
             heads, lg = ops.forward_fused(feats, allp, len(members), n, packed, cbias, hw, hb, cw, cb,
                                           check_pairs=False, canonical_pairs=canonical)
+            if self.pool_top_span and allp.shape[0]:
+                # RelOIPool over each pair's best span (decode + NMS, top-1) instead of the whole segment
+                top = ops.decode_spans(heads, self.anchor_sizes(t), top_k=1)["span"][:, 0].contiguous()
+                lg = ops.span_predicate(feats, allp, top, cw, cb)
             off = 0
             for k, i in enumerate(members):
                 src_dev = pair_list[i].get_field("tracklet_feats").device
@@ -557,6 +562,27 @@ class BaseModel(nn.Module):
             sz = sizes if sizes is not None else self.anchor_sizes(heads.shape[2])
             res = ops.decode_spans(_f32(heads, dev), sz, top_k=top_k, nms_threshold=nms_threshold)
             out.append({k: v.to(heads.device) for k, v in res.items()})
+        return out
+
+    def classify_spans(self, pair_list, spans):
+        """Predicate logits with RelOIPool restricted to given spans: per segment `spans[i]` int64 [P,2]
+        frames [start,end) (e.g. decode_spans(...)[i]["span"][:, j]); the build-defined meaning of
+        RelOIPool.__call__(feats, duration_proposals) (reference model.py:68-73) + RelationPredictor."""
+        cls = self.classifier.rel_predictor
+        out = []
+        with torch.no_grad():
+            for plist, sp in zip(pair_list, spans):
+                f = plist.get_field("tracklet_feats")
+                dev = _compute_device(f, cls.weight)
+                cw, cb = self.classifier._cache.get("cls", (cls.weight, cls.bias), dev, lambda ts: ts)
+                n = f.shape[0]
+                if plist.has_field("tracklet_pairs") and plist.get_field("tracklet_pairs") is not None:
+                    p = plist.get_field("tracklet_pairs")
+                    p = (p.detach() if isinstance(p, torch.Tensor) else torch.as_tensor(np.asarray(p))).long().to(dev)
+                else:
+                    p = ops.pair_index(n, dev)
+                sp = (sp if isinstance(sp, torch.Tensor) else torch.as_tensor(np.asarray(sp))).long().to(dev)
+                out.append(ops.span_predicate(_f32(f, dev), p.contiguous(), sp.contiguous(), cw, cb).to(f.device))
         return out
 
     def pair_geometry(self, pair_list):

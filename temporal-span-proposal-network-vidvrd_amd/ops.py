@@ -16,7 +16,7 @@ __all__ = [
     "pair_gather", "pack_conv3", "conv3", "conv3_tc", "pack_conv3_wino", "conv3_tc_wino", "heads", "heads_pairgrid", "temporal_mean", "pair_rows", "transpose_td",
     "forward_fused", "temporal_encoder_heads", "fused_workspace_bytes", "decode_topk", "decode_spans",
     "cast_bf16", "pack_conv3_bf16", "pack_heads_bf16", "conv3_tc_bf16", "heads_pairgrid_bf16",
-    "temporal_mean_bf16", "forward_fused_bf16",
+    "temporal_mean_bf16", "forward_fused_bf16", "span_predicate",
 ]
 
 
@@ -590,3 +590,25 @@ def forward_fused_bf16(feats, pairs, B, N, conv_packed, conv_bias, head_packed, 
         d.ev_conv_begin, d.ev_conv_end = conv_events[0].cuda_event, conv_events[1].cuda_event
     _abi.check(l.tspn_forward_fused_bf16(ctypes.byref(d), _stream()))
     return out_heads, out_logits
+
+
+def span_predicate(feats, pairs, spans, cls_w, cls_b):
+    """Span-restricted RelOIPool + predicate head (tspn_span_predicate_f32): feats [NT,T,D], pairs [P,2]
+    global tracklet ids, spans int64 [P,2] frames [start,end) -> sigmoid logits [P,K]."""
+    _dev(feats, "feats"); _dev(pairs, "pairs", torch.int64); _dev(spans, "spans", torch.int64)
+    _dev(cls_w, "cls_w")
+    if cls_b is not None:
+        _dev(cls_b, "cls_b")
+    NT, T, D = feats.shape
+    K = cls_w.shape[0]
+    P = pairs.shape[0]
+    if tuple(cls_w.shape) != (K, 2 * D) or tuple(pairs.shape) != (P, 2) or tuple(spans.shape) != (P, 2):
+        raise ValueError("span_predicate: shape mismatch")
+    if P and (int(pairs.min()) < 0 or int(pairs.max()) >= NT):
+        raise IndexError("span_predicate: pair index out of range")
+    l = _abi.lib()
+    ws = _ws(l.tspn_span_predicate_workspace_bytes(NT, T, D, K), feats.device)
+    out = torch.empty((P, K), dtype=torch.float32, device=feats.device)
+    _abi.check(l.tspn_span_predicate_f32(_p(feats), NT, T, D, _p(pairs), _p(spans), P, _p(cls_w), _p(cls_b), K,
+                                         _p(out), _p(ws), ws.numel(), _stream()))
+    return out

@@ -270,3 +270,46 @@ def test_baseline_forward_fused_preprocess_flag(tspn, device):
     model.eval()
     _, _, logits = model([tspn.PairList(t(c["raw"]))], None)
     np.testing.assert_allclose(logits[0].numpy(), g["rel_logits"], rtol=0, atol=2e-6)
+
+
+def test_span_restricted_reloipool(tspn, device):
+    """RelOIPool over a pair's own span + predicate head == oracle.rel_oi_pool(feats, spans) ->
+    predicate_head; whole-segment spans reproduce forward()'s logits; POOL_TOP_SPAN wires the top
+    decoded span into forward()."""
+    D, n, tt = 24, 7, 30
+    sd = tspn.synth.make_weights(0, c=2 * D, bias_std=0.05)
+    model = tspn.BaseModel(temporal_cfg(D))
+    load(model, sd)
+    model.eval()
+    v = tspn.synth.make_video(75, n, tt, D)
+    pl = tspn.PairList.from_tracklets(t(v["tracklet_feats"]), t(v["tracklet_boxes"]), t(v["track_cls_logits"]))
+    pp, dp, logits = model([pl], None)
+    P = n * (n - 1)
+    rng = np.random.RandomState(3)
+    a = rng.randint(0, tt - 1, size=P)
+    e = np.minimum(a + 1 + rng.randint(0, tt, size=P), tt)
+    spans = np.stack([a, e], axis=1).astype(np.int64)
+    spans[0] = (0, tt)
+    spans[1] = (tt - 1, tt)
+    got = model.classify_spans([pl], [spans])[0]
+    w = oracle_weights(sd)
+    pf, _ = oracle.pair_gather(t(v["tracklet_feats"]), t(v["tracklet_boxes"]), oracle.pair_index(n))
+    ref = oracle.predicate_head(oracle.rel_oi_pool(pf, t(spans)), w["cls_w"], w["cls_b"])
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=0, atol=1e-5)
+    whole = np.tile(np.array([[0, tt]], np.int64), (P, 1))
+    np.testing.assert_allclose(model.classify_spans([pl], [whole])[0].numpy(), logits[0].numpy(), rtol=0, atol=1e-5)
+    unused = np.tile(np.array([[-1, -1]], np.int64), (P, 1))     # "no span": whole segment
+    np.testing.assert_allclose(model.classify_spans([pl], [unused])[0].numpy(), logits[0].numpy(), rtol=0, atol=1e-5)
+    # forward() with POOL_TOP_SPAN: logits pooled over decode_spans' first span
+    cfg = temporal_cfg(D)
+    cfg.RELPN.DPN.POOL_TOP_SPAN = True
+    m2 = tspn.BaseModel(cfg)
+    load(m2, sd)
+    m2.eval()
+    _, dp2, lg2 = m2([pl], None)
+    top = m2.decode_spans(dp2, top_k=1)[0]["span"][:, 0]
+    ref_heads = oracle.forward_dense(t(v["tracklet_feats"]), t(v["tracklet_boxes"]), oracle.pair_index(n), w)
+    ref_sp = oracle.decode_spans(ref_heads["relness"], ref_heads["duration"], m2.anchor_sizes(tt), top_k=1)
+    np.testing.assert_array_equal(top.numpy(), ref_sp["span"][:, 0])
+    ref2 = oracle.predicate_head(oracle.rel_oi_pool(pf, t(ref_sp["span"][:, 0])), w["cls_w"], w["cls_b"])
+    np.testing.assert_allclose(lg2[0].numpy(), ref2.numpy(), rtol=0, atol=1e-5)
