@@ -292,7 +292,7 @@ int tspn_pack_conv3_bf16(const float* W, int64_t M, int64_t Cin, int64_t split, 
 /* 1x1 head weights [H <= 16, C] fp32 -> [C/8][16][8] bf16 (rows H..15 zero) */
 int tspn_pack_heads_bf16(const float* W, int64_t H, int64_t C, uint16_t* packed, void* stream);
 /* k=3, pad=1 conv over time; x bf16 channels-last [B, T, Cin]; y fp32 channels-last [B*T, ldm]
- * (y[n][m], n = b*T + t), + bias[m] if given.  Needs Cin % 32 == 0, M % 4 == 0, ldm % 4 == 0. */
+ * (y[n][m], n = b*T + t), + bias[m] if given.  Needs Cin % 16 == 0, M % 4 == 0, ldm % 4 == 0. */
 int tspn_conv3_tc_bf16(const uint16_t* x, int64_t B, int64_t T, int64_t Cin, const uint16_t* packed,
                        int64_t M, const float* bias, float* y, int64_t ldm, void* stream);
 /* pair stage on the canonical pair table: y fp32 [B*N*T, ldm] with U = channels [0,C), V = [C,2C);
@@ -305,7 +305,7 @@ int tspn_heads_pairgrid_bf16(const float* y, int64_t ldm, int64_t B, int64_t N, 
 int tspn_temporal_mean_bf16(const uint16_t* x, int64_t R, int64_t T, int64_t D, float* out, void* stream);
 
 typedef struct tspn_fused_bf16_desc {
-  int64_t B, N, T, D;            /* C = 2D; D % 32 == 0 */
+  int64_t B, N, T, D;            /* C = 2D; D % 16 == 0 */
   int64_t A, K;
   const uint16_t* feats;         /* bf16 [B*N, T, D] */
   const int64_t* pairs;          /* canonical table of tspn_pair_index_i64 for every video, global ids */

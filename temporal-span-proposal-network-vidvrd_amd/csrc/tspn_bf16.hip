@@ -10,7 +10,7 @@
 // and only relu(U[s] + V[o]) is rounded.
 //
 // Kernels:
-//   conv3_bf16_cl_kernel        k=3 temporal conv of the tracklet projections as implicit GEMM on
+//   conv3_bf16_big_kernel       k=3 temporal conv of the tracklet projections as implicit GEMM on
 //                               v_mfma_f32_32x32x16_bf16; channels-last x AND channels-last fp32 y
 //                               ([tracklet*frame][2C]) so that the pair stage finds the 8 channels a
 //                               lane needs contiguous;
@@ -112,185 +112,20 @@ __global__ __launch_bounds__(256) void temporal_mean_bf16_kernel(const __bf16* _
 }
 
 // ------------------------------------------------------------------------------------------------
-// conv3, bf16 operands.  Workgroup tile 128 output channels x 128 flat (tracklet, frame) columns,
-// 4 waves x (2 x 2 blocks of 32 x 32), K chunk = 32 input channels x 3 taps = 24 MFMAs per wave.
-// LDS images (both filled by 16-byte LDS-DMA pieces, double-buffered, 64.5 KB -> 2 workgroups/CU):
-//   weights [3 taps][4 channel groups][128 m][8 ch]   a lane's A fragment = one ds_read_b128
-//   x       [4 channel groups][132 column slots][8 ch] read at 3 shifts (halo columns are ordinary
+// conv3, bf16 operands: implicit GEMM on v_mfma_f32_32x32x16_bf16 (lanes k = 0 / 1 take the two
+// 8-channel groups of a 16-channel k-step).  LDS images, both filled by 16-byte LDS-DMA pieces:
+//   weights [3 taps][2 channel groups][BM m][8 ch]     a lane's A fragment = one ds_read_b128
+//   x       [2 channel groups][BN + 4 column slots][8 ch]   read at 3 shifts (halo columns are ordinary
 //                                                      units of the same DMA; no im2col)
-// Lanes k = 0 / 1 of the 32x32x16 MFMA take channel groups 2s / 2s+1 of k-step s.
 constexpr int BM = 128, BN = 128;
-constexpr int KC = 32, KG = KC / 8;
 constexpr int SLP = 132;
-constexpr int A_ST = 3 * KG * BM * 16;   // bytes per stage
-constexpr int X_ST = KG * SLP * 16;
-constexpr int X_UNITS = KG * SLP;
-constexpr size_t CONV_SMEM = 2 * (size_t)(A_ST + X_ST);
-
-__global__ __launch_bounds__(THREADS, 2) void conv3_bf16_cl_kernel(
-    const __bf16* __restrict__ x, const __bf16* __restrict__ Wp, const float* __restrict__ bias,
-    float* __restrict__ y, int Cin, int T, int M, int64_t ncols, int tiles_m, int tiles_n, int ldm) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* As = smem;
-  char* Xs = smem + 2 * A_ST;
-
-  // workgroup -> tile: bijective XCD remap, then groups of 2 weight panels x all column tiles
-  const int nwg = gridDim.x;
-  const int bid = blockIdx.x;
-  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  constexpr int GM = 2;
-  const int group_sz = GM * tiles_n;
-  const int group = wg / group_sz;
-  const int first_m = group * GM;
-  const int gm = min(GM, tiles_m - first_m);
-  const int in_group = wg - group * group_sz;
-  const int tile_m = first_m + in_group % gm;
-  const int tile_n = in_group / gm;
-  const int m0 = tile_m * BM;
-  const int64_t n0 = (int64_t)tile_n * BN;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int li = lane & 31, kh = lane >> 5;
-
-  // weight pieces: piece pa = (tap*4 + group)*2 + half covers 64 rows m; wave w stages pa = 6w .. 6w+5
-  const __bf16* asrc[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const int pa = wave * 6 + i;
-    const int tap = pa >> 3, kg = (pa >> 1) & 3, half = pa & 1;
-    int m = m0 + 64 * half + lane;
-    m = m < M ? m : 0;
-    asrc[i] = Wp + (((int64_t)tap * (Cin >> 3) + kg) * M + m) * 8;
-  }
-  const int64_t a_step = (int64_t)KG * M * 8;
-  // x pieces: piece p = wave + 4q covers units [64p, 64p+64); unit u = (group u/132, slot u%132),
-  // slot <-> column n0 + slot - 1 (clamped; clamped columns are masked or never stored)
-  const __bf16* bsrc[3];
-  bool bval[3];
-#pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    const int u = 64 * (wave + 4 * q) + lane;
-    const int g = u / SLP, slot = u - g * SLP;
-    bval[q] = u < X_UNITS && slot < BN + 2;
-    int64_t n = n0 + slot - 1;
-    n = n < 0 ? 0 : (n < ncols ? n : ncols - 1);
-    bsrc[q] = x + n * Cin + 8 * (g < KG ? g : 0);
-  }
-  auto stage_one = [&](int buf, auto d_tag) {
-    constexpr int d = decltype(d_tag)::value;
-    if constexpr (d < 6) {
-      glds16(asrc[d], As + buf * A_ST + (wave * 6 + d) * 1024);
-      asrc[d] += a_step;
-    } else {
-      constexpr int q = d - 6;
-      if (bval[q]) glds16(bsrc[q], Xs + buf * X_ST + 64 * (wave + 4 * q) * 16);
-      bsrc[q] += KC;
-    }
-  };
-#define TSPN_STAGE(buf, d) stage_one(buf, std::integral_constant<int, d>{})
-
-  bool mask_l[2], mask_r[2];
-#pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int64_t n = n0 + wn * 64 + ni * 32 + li;
-    const int t = (int)(n % T);
-    mask_l[ni] = t != 0;
-    mask_r[ni] = t != T - 1;
-  }
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
-
-  const int nchunks = Cin / KC;
-  TSPN_STAGE(0, 0); TSPN_STAGE(0, 1); TSPN_STAGE(0, 2); TSPN_STAGE(0, 3); TSPN_STAGE(0, 4);
-  TSPN_STAGE(0, 5); TSPN_STAGE(0, 6); TSPN_STAGE(0, 7); TSPN_STAGE(0, 8);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-  auto chunk_body = [&](int buf, auto more_tag) {
-    constexpr bool MORE = decltype(more_tag)::value;
-    const char* Ab = As + buf * A_ST + (kh * BM + wm * 64 + li) * 16;
-    const char* Xb = Xs + buf * X_ST + (kh * SLP + wn * 64 + li) * 16;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      bf16x8 a[3][2], b[2][3];
-#pragma unroll
-      for (int tap = 0; tap < 3; ++tap)
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-          a[tap][mi] = *reinterpret_cast<const bf16x8*>(Ab + ((tap * KG + 2 * s) * BM + mi * 32) * 16);
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int tap = 0; tap < 3; ++tap)
-          b[ni][tap] = *reinterpret_cast<const bf16x8*>(Xb + (2 * s * SLP + ni * 32 + tap) * 16);
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        b[ni][0] = mask_l[ni] ? b[ni][0] : zero8;
-        b[ni][2] = mask_r[ni] ? b[ni][2] : zero8;
-      }
-#pragma unroll
-      for (int tap = 0; tap < 3; ++tap) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tap][0], b[0][tap], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tap][0], b[1][tap], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tap][1], b[0][tap], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tap][1], b[1][tap], acc[1][1], 0, 0, 0);
-        if (MORE) {
-          if (s == 0 && tap == 0) { TSPN_STAGE(buf ^ 1, 0); TSPN_STAGE(buf ^ 1, 1); }
-          if (s == 0 && tap == 1) { TSPN_STAGE(buf ^ 1, 2); TSPN_STAGE(buf ^ 1, 3); }
-          if (s == 0 && tap == 2) { TSPN_STAGE(buf ^ 1, 4); }
-          if (s == 1 && tap == 0) { TSPN_STAGE(buf ^ 1, 5); TSPN_STAGE(buf ^ 1, 6); }
-          if (s == 1 && tap == 1) { TSPN_STAGE(buf ^ 1, 7); }
-          if (s == 1 && tap == 2) { TSPN_STAGE(buf ^ 1, 8); }
-        }
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA of the next chunk has landed
-    __syncthreads();
-  };
-  for (int c = 0; c + 1 < nchunks; ++c) chunk_body(c & 1, std::true_type{});
-  chunk_body((nchunks - 1) & 1, std::false_type{});
-#undef TSPN_STAGE
-
-  // epilogue: channels-last y[n][m]; a lane holds 4 consecutive channels per register quad
-#pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int64_t n = n0 + wn * 64 + ni * 32 + li;
-    if (n >= ncols) continue;
-    float* yrow = y + n * (int64_t)ldm;
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-      for (int eq = 0; eq < 4; ++eq) {
-        const int m = m0 + wm * 64 + mi * 32 + 8 * eq + 4 * kh;
-        if (m < M) {
-          f32x4 v = {acc[mi][ni][4 * eq], acc[mi][ni][4 * eq + 1], acc[mi][ni][4 * eq + 2],
-                     acc[mi][ni][4 * eq + 3]};
-          if (bias != nullptr) v += *reinterpret_cast<const f32x4*>(bias + m);
-          *reinterpret_cast<f32x4*>(yrow + m) = v;
-        }
-      }
-    }
-  }
-}
 
 // ------------------------------------------------------------------------------------------------
-// conv3 bf16, second structure: a chunk of the first kernel is only 24 MFMAs = 768 cycles, shorter
-// than the memory latency, so prefetching one chunk ahead leaves the workgroup waiting at every
-// barrier.  Here a chunk is ONE k-step (16 input channels x 3 taps = 12 MFMAs per wave) and the LDS
-// holds a ring of 4 stages (16.1 KB each, 64.5 KB -> still 2 workgroups/CU): the DMA of chunk c+3 is
-// issued while chunk c is computed, `s_waitcnt vmcnt(N)` counts only the pieces of chunk c+1 out, and
-// the barrier is a bare s_barrier (no fence, which would drain the whole DMA queue).
+// 128 x 128 tile, 4 waves x (2 x 2 blocks of 32 x 32), kept for A/B timing (TSPN_BF16_CONV=2).  A chunk
+// is ONE k-step (16 input channels x 3 taps = 12 MFMAs per wave) and the LDS holds a ring of 4 stages
+// (16.1 KB each, 64.5 KB -> 2 workgroups/CU): the DMA of chunk c+3 is issued while chunk c is computed,
+// `s_waitcnt vmcnt(N)` counts only the pieces of chunk c+1 out, and the barrier is a bare s_barrier
+// (no fence, which would drain the whole DMA queue).
 constexpr int R_KC = 16, R_KG = 2, R_NST = 4;
 constexpr int R_A_ST = 3 * R_KG * BM * 16;  // 12288
 constexpr int R_X_ST = R_KG * SLP * 16;     // 4224
@@ -965,8 +800,8 @@ extern "C" int tspn_conv3_tc_bf16(const uint16_t* x, int64_t B, int64_t T, int64
                (long long)T, (long long)Cin, (long long)M, (long long)ldm);
   if (B == 0) return TSPN_OK;
   TSPN_REQUIRE(x && packed && y, TSPN_EINVAL, "tspn_conv3_tc_bf16: null pointer");
-  TSPN_REQUIRE(Cin % KC == 0 && M % 4 == 0 && ldm % 4 == 0, TSPN_EUNSUPPORTED,
-               "tspn_conv3_tc_bf16: needs Cin %% 32 == 0, M %% 4 == 0, ldm %% 4 == 0 (Cin=%lld M=%lld ldm=%lld)",
+  TSPN_REQUIRE(Cin % R_KC == 0 && M % 4 == 0 && ldm % 4 == 0, TSPN_EUNSUPPORTED,
+               "tspn_conv3_tc_bf16: needs Cin %% 16 == 0, M %% 4 == 0, ldm %% 4 == 0 (Cin=%lld M=%lld ldm=%lld)",
                (long long)Cin, (long long)M, (long long)ldm);
   TSPN_REQUIRE(aligned16(x) && aligned16(packed) && aligned16(y) && (bias == nullptr || aligned16(bias)),
                TSPN_EUNSUPPORTED, "tspn_conv3_tc_bf16: pointers must be 16-byte aligned");
@@ -975,14 +810,6 @@ extern "C" int tspn_conv3_tc_bf16(const uint16_t* x, int64_t B, int64_t T, int64
   const int64_t ncols = B * T;
   const int64_t tiles_m = tspn::ceil_div(M, BM), tiles_n = tspn::ceil_div(ncols, BN);
   TSPN_REQUIRE(tiles_m * tiles_n < (1LL << 31), TSPN_EUNSUPPORTED, "tspn_conv3_tc_bf16: grid too large");
-  static thread_local bool attr = false;
-  if (!attr) {
-    int rc = set_smem(reinterpret_cast<const void*>(conv3_bf16_cl_kernel), CONV_SMEM, "tspn_conv3_tc_bf16");
-    if (rc) return rc;
-    rc = set_smem(reinterpret_cast<const void*>(conv3_bf16_ring_kernel), R_SMEM, "tspn_conv3_tc_bf16");
-    if (rc) return rc;
-    attr = true;
-  }
   const char* variant = getenv("TSPN_BF16_CONV");
   if (variant == nullptr || atoi(variant) == 3) {
     static thread_local bool attr3 = false;
@@ -998,14 +825,13 @@ extern "C" int tspn_conv3_tc_bf16(const uint16_t* x, int64_t B, int64_t T, int64
                        (int)tm, (int)tn, (int)ldm);
     return tspn::check_launch("tspn_conv3_tc_bf16");
   }
-  if (atoi(variant) == 2) {
-    hipLaunchKernelGGL(conv3_bf16_ring_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(THREADS), R_SMEM,
-                       TSPN_STREAM(stream), reinterpret_cast<const __bf16*>(x),
-                       reinterpret_cast<const __bf16*>(packed), bias, y, (int)Cin, (int)T, (int)M, ncols,
-                       (int)tiles_m, (int)tiles_n, (int)ldm);
-    return tspn::check_launch("tspn_conv3_tc_bf16");
+  static thread_local bool attr2 = false;
+  if (!attr2) {
+    int rc = set_smem(reinterpret_cast<const void*>(conv3_bf16_ring_kernel), R_SMEM, "tspn_conv3_tc_bf16");
+    if (rc) return rc;
+    attr2 = true;
   }
-  hipLaunchKernelGGL(conv3_bf16_cl_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(THREADS), CONV_SMEM,
+  hipLaunchKernelGGL(conv3_bf16_ring_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(THREADS), R_SMEM,
                      TSPN_STREAM(stream), reinterpret_cast<const __bf16*>(x),
                      reinterpret_cast<const __bf16*>(packed), bias, y, (int)Cin, (int)T, (int)M, ncols,
                      (int)tiles_m, (int)tiles_n, (int)ldm);
@@ -1094,7 +920,7 @@ extern "C" int tspn_forward_fused_bf16(const tspn_fused_bf16_desc* d, void* stre
   TSPN_REQUIRE(d->feats && d->pairs && d->conv_packed && d->conv_bias && d->head_packed && d->head_b &&
                    d->cls_w && d->cls_b && d->out_heads && d->out_logits && d->workspace,
                TSPN_EINVAL, "tspn_forward_fused_bf16: null pointer");
-  TSPN_REQUIRE(d->D % 32 == 0, TSPN_EUNSUPPORTED, "tspn_forward_fused_bf16: needs D %% 32 == 0 (D=%lld)",
+  TSPN_REQUIRE(d->D % 16 == 0, TSPN_EUNSUPPORTED, "tspn_forward_fused_bf16: needs D %% 16 == 0 (D=%lld)",
                (long long)d->D);
   const Bf16Layout L = bf16_layout(d);
   TSPN_REQUIRE(d->workspace_bytes >= L.total, TSPN_EWORKSPACE,

@@ -442,8 +442,8 @@ class BaseModel(nn.Module):
                 # bf16 tracklet features select the bf16-operand kernels (BASELINE config 3)
                 if any(custom_pairs(pair_list[i]) is not None for i in members):
                     raise NotImplementedError("the bf16 path scores the canonical pair table only")
-                if d % 32:
-                    raise ValueError(f"the bf16 path needs D % 32 == 0 (D={d})")
+                if d % 16:
+                    raise ValueError(f"the bf16 path needs D % 16 == 0 (D={d})")
                 feats = torch.cat([pair_list[i].get_field("tracklet_feats").to(dev).contiguous()
                                    for i in members])
                 allp = torch.cat([ops.pair_index(n, dev, base=k * n) for k in range(len(members))])

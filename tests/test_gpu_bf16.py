@@ -58,7 +58,7 @@ def conv_ref64(xb, wb, b):
     return y.transpose(1, 2).contiguous()
 
 
-@pytest.mark.parametrize("B,T,Cin,M", [(1, 1, 32, 4), (2, 5, 32, 8), (3, 30, 64, 128), (5, 33, 96, 132),
+@pytest.mark.parametrize("B,T,Cin,M", [(1, 1, 16, 4), (2, 5, 32, 8), (3, 30, 64, 128), (5, 33, 48, 132),
                                        (2, 257, 128, 260), (7, 150, 64, 64), (40, 30, 32, 36)])
 def test_conv3_bf16_vs_fp64(tspn, device, B, T, Cin, M):
     x = r16(tspn.hashrng.uniform(82, "x", (B, T, Cin), -1, 1))
@@ -82,8 +82,8 @@ def test_conv3_bf16_exact_integers_and_limits(tspn, device):
     y = tspn.ops.conv3_tc_bf16(t(x).to(torch.bfloat16).to(device), tspn.ops.pack_conv3_bf16(t(w).to(device)))
     np.testing.assert_array_equal(y.cpu().numpy(), conv_ref64(t(x), t(w), None).float().numpy())
     with pytest.raises(tspn._abi.TspnError) as e:
-        tspn.ops.conv3_tc_bf16(torch.zeros(2, 30, 16, dtype=torch.bfloat16, device=device),
-                               torch.zeros(3, 2, 8, 8, dtype=torch.bfloat16, device=device))
+        tspn.ops.conv3_tc_bf16(torch.zeros(2, 30, 8, dtype=torch.bfloat16, device=device),
+                               torch.zeros(3, 1, 8, 8, dtype=torch.bfloat16, device=device))
     assert e.value.code == tspn._abi.TSPN_EUNSUPPORTED
     with pytest.raises(RuntimeError):
         tspn.ops.conv3_tc_bf16(torch.zeros(2, 30, 32, dtype=torch.bfloat16), torch.zeros(3, 4, 8, 8, dtype=torch.bfloat16))
@@ -195,13 +195,13 @@ def test_forward_fused_bf16_matches_fp32_path_on_rounded_operands(tspn, device):
 
 
 def test_bf16_path_rejects_what_it_cannot_do(tspn, device):
-    D = 16
+    D = 8
     model = tspn.BaseModel(temporal_cfg(D))
     model.eval()
     v = tspn.synth.make_video(96, 4, 10, D)
     pl = tspn.PairList.from_tracklets(t(v["tracklet_feats"]).to(torch.bfloat16), t(v["tracklet_boxes"]),
                                       t(v["track_cls_logits"]))
-    with pytest.raises(ValueError, match="D % 32"):
+    with pytest.raises(ValueError, match="D % 16"):
         model([pl], None)
 
 
