@@ -1,0 +1,206 @@
+"""Greedy relational association of short-term relation predictions into video-level relations.
+
+Host-side mirror of the reference's `lib/modeling/association.py` (same entry point, same argument
+meaning, same output dicts) without dlib: trajectories are plain lists of (left, top, right, bottom)
+float tuples.  It is downstream of the GPU path: the inputs are the per-segment
+top-k triplets of `BaseModel.decode` / predict.py:59-117, a few hundred small items per video, and the
+algorithm is sequential by construction, so it stays on the host.
+
+Behaviour reproduced as is (each checked against the reference's own code by tests/golden/g9):
+  * segments are visited in order of `int(fstart)`; per segment the predictions are sorted by score,
+    descending and stable, and cut to `max_traj_num_in_clip` (association.py:117-130);
+  * in the first segment every prediction opens a relation with its score; in later segments a
+    prediction is merged into the best-scoring (mean confidence, stable order) relation modified in the
+    PREVIOUS segment that has the same triplet, starts before that relation's end and overlaps both
+    trajectories with IoU >= 0.5 on the common frames (association.py:141-170); otherwise it opens a
+    relation whose confidence list starts with 1 — the constructor default, not the prediction's
+    score (association.py:166, 66);
+  * merging averages the boxes over the overlap and appends the rest (association.py:16-31), IN PLACE
+    on the trajectory object of the earlier segment — relations that share a tracklet share the object,
+    so one merge lengthens the trajectory seen by the others (association.py:101-106); `fend` of a
+    relation is only refreshed when that relation itself is extended, from the OBJECT trajectory;
+  * the IoU arithmetic follows lib/modeling/trajectory.py:85-141: intersections in float32 (+1
+    inclusive pixels), areas in float64, quotient stored as float32.
+"""
+import json
+import os
+
+import numpy as np
+
+__all__ = ["Track", "VideoRelation", "greedy_relational_association", "load_trajectories"]
+
+
+class Track:
+    """Box trajectory over frames [pstart, pend) (reference lib/modeling/trajectory.py:12-83)."""
+
+    __slots__ = ("pstart", "pend", "rois", "score", "category", "classeme", "vsig", "gt_trackid")
+
+    def __init__(self, pstart, pend, rois, score=0.0, category=-1, classeme=(), vsig=None, gt_trackid=-1):
+        rois = [tuple(float(v) for v in r) for r in rois]
+        if len(rois) != pend - pstart:
+            raise ValueError(f"Track: {len(rois)} boxes for frames [{pstart}, {pend})")
+        self.pstart, self.pend, self.rois = int(pstart), int(pend), rois
+        self.score, self.category, self.classeme = score, category, classeme
+        self.vsig, self.gt_trackid = vsig, gt_trackid
+
+    def length(self):
+        return self.pend - self.pstart
+
+    def serialize_rois(self):
+        return [tuple(r) for r in self.rois]
+
+
+def _cubic_iou_1x1(boxes1, boxes2):
+    """Volumetric IoU of one trajectory against one ([L,4] float64 each) with the roundings of
+    trajectory.py:85-141: per-frame overlap extents and products in float32 (+1 inclusive pixels),
+    accumulated frame by frame in float32; areas and their sums in float64; the quotient is formed in
+    float64 and stored as float32."""
+    b1 = np.asarray(boxes1, dtype=np.float64).reshape(-1, 4)
+    b2 = np.asarray(boxes2, dtype=np.float64).reshape(-1, 4)
+    if b1.shape[0] != b2.shape[0]:
+        raise AssertionError("trajectories of different length")  # trajectory.py:89
+    f32 = np.float32
+    one = f32(1)
+    w = np.clip((np.minimum(b1[:, 2], b2[:, 2]).astype(f32) + one) - np.maximum(b1[:, 0], b2[:, 0]).astype(f32), 0, None)
+    h = np.clip((np.minimum(b1[:, 3], b2[:, 3]).astype(f32) + one) - np.maximum(b1[:, 1], b2[:, 1]).astype(f32), 0, None)
+    inter = np.cumsum(w * h, dtype=f32)[-1] if b1.shape[0] else f32(0)   # cumsum = strictly sequential
+    area = lambda b: np.sum((b[:, 2] - b[:, 0] + 1) * (b[:, 3] - b[:, 1] + 1))   # noqa: E731
+    union = (area(b1) + area(b2)) - np.float64(inter)
+    return f32(np.float64(inter) / union)
+
+
+def _traj_iou(t1, t2):
+    """IoU on the common frames of two trajectories (association.py:34-50)."""
+    if t1.pend <= t2.pstart or t2.pend <= t1.pstart:
+        return 0
+    if t1.pstart > t2.pstart:
+        t1, t2 = t2, t1
+    a = t1.rois[t2.pstart - t1.pstart:t1.pend - t1.pstart]
+    b = t2.rois[0:t1.pend - t2.pstart]
+    return _cubic_iou_1x1(a, b)
+
+
+def _merge_trajs(t1, t2):
+    """association.py:16-31: average over the overlap, append the rest; t1 is modified in place."""
+    overlap = max(t1.pend - t2.pstart, 0)
+    n1 = t1.length()
+    for i in range(overlap):
+        r1, r2 = t1.rois[n1 - overlap + i], t2.rois[i]
+        t1.rois[n1 - overlap + i] = tuple((a + b) / 2 for a, b in zip(r1, r2))
+    for i in range(overlap, t2.length()):
+        t1.rois.append(t2.rois[i])
+        t1.pend += 1
+    return t1
+
+
+class VideoRelation:
+    """association.py:53-112."""
+
+    def __init__(self, vid, s_cid, pid, o_cid, straj, otraj, confs=1):
+        self.vid, self.s_cid, self.pid, self.o_cid = vid, s_cid, pid, o_cid
+        self.straj, self.otraj = straj, otraj
+        self.confs_list = [confs]
+        self.fstart, self.fend = straj.pstart, straj.pend
+
+    def triplet(self):
+        return (self.s_cid, self.pid, self.o_cid)
+
+    def mean_confs(self):
+        return np.mean(self.confs_list)
+
+    def both_overlap(self, straj, otraj, iou_thr=0.5):
+        return bool(_traj_iou(self.straj, straj) >= iou_thr and _traj_iou(self.otraj, otraj) >= iou_thr)
+
+    def extend(self, straj, otraj, confs):
+        self.straj = _merge_trajs(self.straj, straj)
+        self.otraj = _merge_trajs(self.otraj, otraj)
+        self.confs_list.append(confs)
+        self.fstart = self.straj.pstart
+        self.fend = self.otraj.pend
+
+    def serialize(self, dataset=None):
+        name = (lambda f, i: getattr(dataset, f)(i)) if dataset is not None else (lambda f, i: int(i))
+        return {"triplet": [name("get_object_name", self.s_cid), name("get_predicate_name", self.pid),
+                            name("get_object_name", self.o_cid)],
+                "score": float(self.mean_confs()),
+                "duration": [int(self.fstart), int(self.fend)],
+                "sub_traj": self.straj.serialize_rois(),
+                "obj_traj": self.otraj.serialize_rois()}
+
+
+def load_trajectories(vid, fstart, fend, root="./vidvrd-baseline-output"):
+    """The reference's on-disk tracklet proposals of a segment (`traj_cls` JSON written by its
+    preprocessing; lib/modeling/trajectory.py:169-196, path from lib/modeling/__init__.py:6-22)."""
+    vsig = "{}-{:04d}-{:04d}".format(vid, fstart, fend)
+    path = os.path.join(root, "features", "traj_cls", vid, f"{vsig}-traj_cls.json")
+    if not os.path.exists(path):
+        return []
+    with open(path, "r") as fin:
+        return [Track(**t) for t in json.load(fin)]
+
+
+def _as_tracks(trajs, fstart, fend):
+    out = []
+    for t in trajs:
+        if isinstance(t, Track):
+            out.append(t)
+        elif isinstance(t, dict):
+            out.append(Track(**t))
+        else:  # [L,4] boxes
+            out.append(Track(fstart, fend, np.asarray(t, dtype=np.float64).tolist()))
+    return out
+
+
+def greedy_relational_association(dataset, short_term_relations, max_traj_num_in_clip=100, trajectories=None):
+    """Reference `greedy_relational_association` (association.py:117-175).
+
+    `short_term_relations`: list of `((vid, fstart, fend), (pred_list, iou, trackid))` with
+    `pred_list` = [(score, (s_cid, pid, o_cid), (s_idx, o_idx)), ...] as predict.py:106-116 emits.
+    `trajectories`: callable `(vid, fstart, fend) -> tracklets` (Track objects, `traj_cls` dicts or
+    [L,4] box arrays, indexed like the predictions' tracklet ids) or a dict keyed by that triple;
+    default = the reference's on-disk proposals (`load_trajectories`).
+    Returns the list of serialised video relations (`dataset` supplies the names; None keeps ids)."""
+    if trajectories is None:
+        provider = load_trajectories
+    elif callable(trajectories):
+        provider = trajectories
+    else:
+        provider = lambda vid, fs, fe: trajectories[(vid, fs, fe)]  # noqa: E731
+    short_term_relations.sort(key=lambda x: int(x[0][1]))   # in place, like the reference
+    video_relation_list = []
+    last_modify_rel_list = []
+    for i, (index, prediction) in enumerate(short_term_relations):
+        vid, fstart, fend = index
+        pred_list = prediction[0]
+        sorted_pred_list = sorted(pred_list, key=lambda x: x[0], reverse=True)[:max_traj_num_in_clip]
+        trajs = _as_tracks(provider(vid, fstart, fend), fstart, fend)
+        for traj in trajs:
+            traj.pstart, traj.pend = fstart, fend
+            traj.vsig = "{}-{:04d}-{:04d}".format(vid, fstart, fend)
+        cur_modify_rel_list = []
+        for pred in sorted_pred_list:
+            conf_score = pred[0]
+            s_cid, pid, o_cid = pred[1]
+            s_idx, o_idx = pred[2]
+            straj, otraj = trajs[int(s_idx)], trajs[int(o_idx)]
+            if i == 0:
+                r = VideoRelation(vid, s_cid, pid, o_cid, straj, otraj, confs=conf_score)
+                video_relation_list.append(r)
+                cur_modify_rel_list.append(r)
+                continue
+            last_modify_rel_list.sort(key=lambda r: r.mean_confs(), reverse=True)
+            merged = False
+            for r in last_modify_rel_list:
+                if bool(np.all(np.asarray(pred[1]) == np.asarray(r.triplet()))):
+                    if (straj.pstart < r.fend and otraj.pstart < r.fend) and r.both_overlap(straj, otraj):
+                        r.extend(straj, otraj, conf_score)
+                        last_modify_rel_list.remove(r)
+                        cur_modify_rel_list.append(r)
+                        merged = True
+                        break
+            if not merged:
+                r = VideoRelation(vid, s_cid, pid, o_cid, straj, otraj)   # confs = 1 (reference default)
+                video_relation_list.append(r)
+                cur_modify_rel_list.append(r)
+        last_modify_rel_list = cur_modify_rel_list
+    return [rel.serialize(dataset) for rel in video_relation_list]

@@ -86,3 +86,45 @@ def g6_inputs():
     rel_logit = ((perm.astype(np.float64) + 0.5) / (p * k)).astype(np.float32).reshape(p, k)
     feat70 = tspn.hashrng.uniform(7, "decode_feat70", (p, 70))
     return {"n": n, "rel_logit": rel_logit, "feat70": feat70, "pairs": ref_pairs(n)}
+
+
+def g9_scenario(seed=11, n_seg=5, n_trk=7, n_pred=40):
+    """Synthetic multi-segment video for the association: 30-frame segments with stride 15
+    (lib/modeling/__init__.py:35-41), tracklets that mostly continue from segment to segment (so the
+    overlap IoU is high), a few that jump, predictions that repeat triplets and share tracklets (so the
+    in-place trajectory aliasing of the reference is exercised), and score ties.
+    Returns (short_term_relations list, trajectories dict keyed by (vid, fstart, fend))."""
+    rs = np.random.RandomState(seed)
+    vid = "vid0"
+    total = 30 + 15 * (n_seg - 1)
+    base = np.zeros((n_trk, total, 4))
+    for k in range(n_trk):
+        x, y = rs.randint(0, 400), rs.randint(0, 300)
+        w, h = rs.randint(40, 200), rs.randint(40, 200)
+        dx, dy = rs.uniform(-2, 2), rs.uniform(-2, 2)
+        f = np.arange(total)
+        base[k, :, 0] = np.round(x + dx * f)
+        base[k, :, 1] = np.round(y + dy * f)
+        base[k, :, 2] = base[k, :, 0] + w
+        base[k, :, 3] = base[k, :, 1] + h
+    rels, trajs = [], {}
+    for s in range(n_seg):
+        fs, fe = 15 * s, 15 * s + 30
+        boxes = base[:, fs:fe].copy() + rs.randint(-3, 4, size=(n_trk, 30, 4))   # detector jitter
+        perm = np.arange(n_trk)
+        if s % 2 == 1:
+            perm = np.roll(perm, 1)                                              # tracklet ids change
+        boxes = boxes[perm]
+        if s >= 2:
+            boxes[0] += 500                                                      # one track jumps away
+        trajs[(vid, fs, fe)] = boxes
+        inv = np.argsort(perm)
+        preds = []
+        for _ in range(n_pred):
+            a, b = rs.choice(n_trk, 2, replace=False)                            # base-track ids
+            trip = np.array([a % 5, (a * 3 + b) % 6, b % 5])
+            score = np.array(np.round(rs.uniform(0.05, 0.95), 2))                # 2 decimals: ties occur
+            preds.append((score, trip, np.array([inv[a], inv[b]])))
+        rels.append(((vid, fs, fe), (preds, np.zeros((n_trk, n_trk)), -np.ones(n_trk))))
+    order = rs.permutation(n_seg)                                                # unsorted on purpose
+    return [rels[i] for i in order], trajs

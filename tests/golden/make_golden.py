@@ -46,11 +46,38 @@ import cases  # noqa: E402
 if not hasattr(np, "float"):
     np.float = float
 
+class _Rect:
+    """Stand-in for dlib.drectangle (dlib is absent here), used ONLY by g9: a value class with the
+    accessors the reference's association / trajectory code calls on it.  The association's control
+    flow, merging and IoU arithmetic that g9 pins are the reference's own code."""
+
+    def __init__(self, left, top, right, bottom):
+        self._v = (float(left), float(top), float(right), float(bottom))
+
+    def left(self):
+        return self._v[0]
+
+    def top(self):
+        return self._v[1]
+
+    def right(self):
+        return self._v[2]
+
+    def bottom(self):
+        return self._v[3]
+
+    def width(self):
+        return self._v[2] - self._v[0] + 1
+
+    def height(self):
+        return self._v[3] - self._v[1] + 1
+
+
 for _name, _attrs in (("dlib", ("drectangle", "correlation_tracker")), ("h5py", ()), ("IPython", ())):
     if _name not in sys.modules:
         _m = types.ModuleType(_name)
         for _a in _attrs:
-            setattr(_m, _a, object)
+            setattr(_m, _a, _Rect if _a == "drectangle" else object)
         sys.modules[_name] = _m
 
 from lib.modeling import segment_video  # noqa: E402
@@ -60,6 +87,8 @@ from lib.modeling.relpn.dpn import DPNHead as RefDPNHead  # noqa: E402
 from lib.modeling.relpn.anchor_generator import AnchorGenerator as RefAnchorGenerator  # noqa: E402
 from lib.modeling.relpn.sampler import BalancedPositiveNegativePairSampler as RefSampler  # noqa: E402
 from lib.modeling.trajectory import cubic_iou as ref_cubic_iou  # noqa: E402
+from lib.modeling.trajectory import Trajectory as RefTrajectory  # noqa: E402
+import lib.modeling.association as ref_association  # noqa: E402
 from lib.dataset.list_pair import PairList as RefPairList  # noqa: E402
 from lib.dataset.list_target import TargetList as RefTargetList  # noqa: E402
 from lib.dataset.vrdataset import VRDataset as RefVRDataset  # noqa: E402
@@ -260,6 +289,40 @@ def g8_bf16():
     save("g8_bf16.npz", **out)
 
 
+def g9_association():
+    """The reference's greedy_relational_association (lib/modeling/association.py:117-175, with its
+    VideoRelation / _merge_trajs / _traj_iou and trajectory.py's cubic IoU) on the synthetic
+    multi-segment scenario of cases.g9_scenario.  Only the file access of
+    `object_trajectory_proposal` is replaced (it reads per-segment JSON written by the reference's
+    preprocessing) and dlib.drectangle is the stand-in above."""
+    import copy
+    rels, trajs = cases.g9_scenario()
+
+    def proposals(dataset, vid, fstart, fend, gt=False, verbose=False):
+        return [RefTrajectory(fstart, fend, b.tolist(), 0.0, 0, [], None) for b in trajs[(vid, fstart, fend)]]
+
+    class Names:
+        def get_object_name(self, i):
+            return int(i)
+
+        def get_predicate_name(self, i):
+            return int(i)
+
+    ref_association.object_trajectory_proposal = proposals
+    out = {}
+    for cap in (100, 25):
+        res = ref_association.greedy_relational_association(Names(), copy.deepcopy(rels), max_traj_num_in_clip=cap)
+        out[f"cap{cap}_triplet"] = np.array([r["triplet"] for r in res], dtype=np.int64)
+        out[f"cap{cap}_score"] = np.array([r["score"] for r in res], dtype=np.float64)
+        out[f"cap{cap}_duration"] = np.array([r["duration"] for r in res], dtype=np.int64)
+        for side in ("sub_traj", "obj_traj"):
+            out[f"cap{cap}_{side}_len"] = np.array([len(r[side]) for r in res], dtype=np.int64)
+            out[f"cap{cap}_{side}"] = np.array([b for r in res for b in r[side]], dtype=np.float64).reshape(-1, 4)
+        lens = out[f"cap{cap}_sub_traj_len"]
+        print(f"  cap {cap}: {len(res)} relations, {int((lens > 30).sum())} extended, longest {int(lens.max())} frames")
+    save("g9_association.npz", **out)
+
+
 def main():
     g1_baseline()
     g2_ppn()
@@ -269,6 +332,7 @@ def main():
     g6_decode()
     g7_misc()
     g8_bf16()
+    g9_association()
 
 
 if __name__ == "__main__":

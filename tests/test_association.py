@@ -1,0 +1,82 @@
+"""Greedy relational association (host post-processing): the product's host module and
+the oracle's restatement against the golden produced by the reference's own
+`greedy_relational_association` (tests/golden/make_golden.py:g9_association)."""
+import copy
+
+import numpy as np
+import pytest
+
+import cases
+import oracle
+
+
+def unpack(res, key_traj=("sub_traj", "obj_traj")):
+    out = {"triplet": np.array([r["triplet"] for r in res], dtype=np.int64),
+           "score": np.array([r["score"] for r in res], dtype=np.float64),
+           "duration": np.array([r["duration"] for r in res], dtype=np.int64)}
+    for side in key_traj:
+        out[side + "_len"] = np.array([len(r[side]) for r in res], dtype=np.int64)
+        out[side] = np.array([b for r in res for b in np.asarray(r[side]).reshape(-1, 4)], dtype=np.float64).reshape(-1, 4)
+    return out
+
+
+def check(res, g, cap):
+    got = unpack(res)
+    for k, v in got.items():
+        np.testing.assert_array_equal(v, g[f"cap{cap}_{k}"], err_msg=k)
+
+
+@pytest.mark.parametrize("cap", [100, 25])
+def test_host_association_matches_reference(tspn, cap):
+    g = cases.load("g9_association.npz")
+    rels, trajs = cases.g9_scenario()
+    res = tspn.association.greedy_relational_association(None, copy.deepcopy(rels), max_traj_num_in_clip=cap,
+                                                         trajectories=trajs)
+    check(res, g, cap)
+    # the same through a callable provider handing over traj_cls-style dicts
+    def provider(vid, fs, fe):
+        return [{"pstart": fs, "pend": fe, "rois": b.tolist(), "score": 0.5, "category": 1, "classeme": [0.0]}
+                for b in trajs[(vid, fs, fe)]]
+    res2 = tspn.association.greedy_relational_association(None, copy.deepcopy(rels), max_traj_num_in_clip=cap,
+                                                          trajectories=provider)
+    check(res2, g, cap)
+
+
+@pytest.mark.parametrize("cap", [100, 25])
+def test_oracle_association_matches_reference(cap):
+    g = cases.load("g9_association.npz")
+    rels, trajs = cases.g9_scenario()
+    check(oracle.greedy_association(copy.deepcopy(rels), trajs, max_traj_num_in_clip=cap), g, cap)
+
+
+def test_association_quirks_and_names(tspn):
+    """Known answers on a two-segment toy: merge averages the overlap and appends the rest; a relation
+    opened after the first segment starts its confidence list with 1 (reference association.py:166);
+    relations sharing a tracklet see each other's merge (in-place trajectories); names come from the dataset."""
+    A = tspn.association
+    box = lambda x: [[x, 0, x + 50, 60]] * 30          # noqa: E731
+    trajs = {("v", 0, 30): [box(0), box(200)], ("v", 15, 45): [box(2), box(204), box(600)]}
+    tri = np.array([1, 2, 3])
+    rels = [(("v", 15, 45), ([(np.array(0.9), tri, np.array([0, 1])), (np.array(0.4), np.array([4, 4, 4]), np.array([2, 1]))], None, None)),
+            (("v", 0, 30), ([(np.array(0.5), tri, np.array([0, 1])), (np.array(0.3), np.array([1, 0, 3]), np.array([0, 1]))], None, None))]
+
+    class Names:
+        def get_object_name(self, i):
+            return f"obj{int(i)}"
+
+        def get_predicate_name(self, i):
+            return f"pred{int(i)}"
+
+    res = A.greedy_relational_association(Names(), rels, trajectories=trajs)
+    assert [r["triplet"] for r in res] == [["obj1", "pred2", "obj3"], ["obj1", "pred0", "obj3"], ["obj4", "pred4", "obj4"]]
+    assert res[0]["duration"] == [0, 45] and res[0]["score"] == pytest.approx(0.7)
+    assert len(res[0]["sub_traj"]) == 45
+    assert res[0]["sub_traj"][0] == (0.0, 0.0, 50.0, 60.0) and res[0]["sub_traj"][20] == (1.0, 0.0, 51.0, 60.0)
+    assert res[0]["sub_traj"][40] == (2.0, 0.0, 52.0, 60.0)
+    # the second first-segment relation shares both tracklets: its trajectories grew too, its duration did not
+    assert len(res[1]["sub_traj"]) == 45 and res[1]["duration"] == [0, 30] and res[1]["score"] == pytest.approx(0.3)
+    # opened in the second segment: confidence 1, not 0.4
+    assert res[2]["score"] == 1.0 and res[2]["duration"] == [15, 45]
+    assert A._traj_iou(A.Track(0, 10, box(0)[:10]), A.Track(10, 20, box(0)[:10])) == 0   # no common frame
+    with pytest.raises(ValueError):
+        A.Track(0, 5, box(0))
