@@ -467,8 +467,13 @@ __global__ __launch_bounds__(G_THREADS, 1) void conv3_bf16_big_kernel(
   if (nchunks > 2) stage_chunk(2);
   if (nchunks > 2) wait_keep(K2{}); else if (nchunks > 1) wait_keep(K1{}); else wait_keep(K0{});
   __builtin_amdgcn_s_barrier();
-  load_tap(0, 0);
 
+  // (Tried: the two waves of every SIMD as two groups half a chunk apart -- one in its MFMA phase while
+  // the other issues DMA and reads fragments, swapping at every barrier.  5.6 ms against 4.8: the memory
+  // phase, i.e. the operand stream from L2 into LDS, is the longer one.  33 KB per chunk and CU at the
+  // ~70 GB/s per CU an L2-resident gather into LDS reaches is 1100+ cycles against 1536 cycles of MFMA
+  // per chunk; the stream and the MFMAs have to overlap almost perfectly to go beyond ~55 % of peak.)
+  load_tap(0, 0);
   int c = 0;
   for (; c + 3 < nchunks; ++c) {        // steady state: chunks c+1 .. c+3 exist
     const int st = c & 3;
