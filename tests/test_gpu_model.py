@@ -313,3 +313,52 @@ def test_span_restricted_reloipool(tspn, device):
     np.testing.assert_array_equal(top.numpy(), ref_sp["span"][:, 0])
     ref2 = oracle.predicate_head(oracle.rel_oi_pool(pf, t(ref_sp["span"][:, 0])), w["cls_w"], w["cls_b"])
     np.testing.assert_allclose(lg2[0].numpy(), ref2.numpy(), rtol=0, atol=1e-5)
+
+
+def test_predict_like_pipeline_forward_decode_associate(tspn, device):
+    """The chain the reference's base.py:89-105 runs per video — forward on every 30-frame segment,
+    top-k triplet decode (predict.py:59-117), greedy association across segments — on the GPU path +
+    host association against the oracle chain on the same synthetic video."""
+    D, n = 16, 5
+    sd = tspn.synth.make_weights(0, c=2 * D, bias_std=0.05)
+    model = tspn.BaseModel(temporal_cfg(D, use_ppn=False))
+    load(model, sd)
+    model.eval()
+    w = oracle_weights(sd)
+    total = 75
+    vid = tspn.synth.make_video(120, n, total, D)
+    vid["track_cls_logits"] = 8.0 * vid["track_cls_logits"]
+    segs = oracle.segment_video(0, total)                      # [(0,30), (15,45), (30,60), (45,75)]
+    assert len(segs) == 4
+    plists, trajs = [], {}
+    for fs, fe in segs:
+        plists.append(tspn.PairList.from_tracklets(t(vid["tracklet_feats"][:, fs:fe].copy()),
+                                                   t(vid["tracklet_boxes"][:, fs:fe].copy()),
+                                                   t(vid["track_cls_logits"])))
+        trajs[("v0", fs, fe)] = vid["tracklet_boxes"][:, fs:fe].astype(np.float64)
+    _, dp, logits = model(plists, None)
+    dec = model.decode(plists, logits, topk_per_pair=3, topk_per_seg=12)
+    rels_gpu, rels_ref = [], []
+    for (fs, fe), lg, (sc, trip, tids) in zip(segs, logits, dec):
+        ref = oracle.forward_dense(t(vid["tracklet_feats"][:, fs:fe].copy()), t(vid["tracklet_boxes"][:, fs:fe].copy()),
+                                   oracle.pair_index(n), w)
+        np.testing.assert_allclose(lg.numpy(), ref["rel_logits"].numpy(), rtol=0, atol=1e-5)
+        cls = t(vid["track_cls_logits"])
+        pairs = oracle.pair_index(n)
+        # oracle decode on the GPU logits (index parity is defined on identical scores); tracklet samples
+        # read the class of tracklet `tid` directly: rows = tracklets, "num_tracklets - 1" = 1
+        rsc, rtrip, rtids = oracle.decode_topk(lg, torch.cat([cls, cls], dim=1), pairs, 2, 3, 12)
+        np.testing.assert_array_equal(trip.numpy(), rtrip.numpy())
+        np.testing.assert_array_equal(tids.numpy(), rtids.numpy())
+        np.testing.assert_array_equal(sc.numpy(), rsc.numpy())
+        preds = [(np.array(s), np.array(tr), np.array(td)) for s, tr, td in zip(sc.numpy(), trip.numpy(), tids.numpy())]
+        rels_gpu.append((("v0", fs, fe), (preds, None, None)))
+        rels_ref.append((("v0", fs, fe), (list(preds), None, None)))
+    out = tspn.association.greedy_relational_association(None, rels_gpu, trajectories=trajs)
+    ref_out = oracle.greedy_association(rels_ref, trajs)
+    assert len(out) == len(ref_out) and len(out) >= 12
+    assert max(len(r["sub_traj"]) for r in out) > 30           # something was associated across segments
+    for a, b in zip(out, ref_out):
+        assert a["triplet"] == b["triplet"] and a["duration"] == b["duration"] and a["score"] == b["score"]
+        np.testing.assert_array_equal(np.asarray(a["sub_traj"]), b["sub_traj"])
+        np.testing.assert_array_equal(np.asarray(a["obj_traj"]), b["obj_traj"])
