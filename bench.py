@@ -5,6 +5,9 @@
     python bench.py --gpus N --steps K --warmup W
     (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
+`--workload cfg3` runs BASELINE.json's configs[2] instead (N=64, T=900, D=1024, bf16 operands,
+4 videos per step) through the same harness; the default (cfg2) is the headline.
+
 A "step" = one pass of the hot path over one batch of `--videos` (default 16) synthetic videos per GPU
 (inputs resident in HBM): tracklet tensors -> [pair builder + temporal encoder +
 relationness/span heads + RelOIPool + predicate head] (tspn_forward_fused_f32) + PPN
@@ -37,6 +40,9 @@ import tspn_mi355x as tspn  # noqa: E402
 
 N_TRK, T_FRAMES, D_ROI, A_ANCH, K_PRED = 32, 150, 2048, 4, 132
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 (no sparsity), v_mfma_f32_32x32x16_bf16
+# --workload cfg3: BASELINE.json configs[2] (VidOR long-clip shape, bf16 operands); not the headline
+CFG3 = (64, 900, 1024)
 DPN_PRE = "relpn.duration_proposal_network.dpn_head."
 PPN_PRE = "relpn.pair_proposal_network.ppn_head."
 
@@ -51,6 +57,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time")
     ap.add_argument("--conv", choices=["winograd", "direct"], default="winograd",
                     help="temporal-conv algorithm of the tracklet projections (both exact fp32 MFMA)")
+    ap.add_argument("--workload", choices=["cfg2", "cfg3"], default="cfg2",
+                    help="cfg2 = headline (N=32,T=150,D=2048, fp32); cfg3 = N=64,T=900,D=1024 bf16 operands")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the RCCL result gather even with one rank (exercises the N>1 code path)")
     return ap.parse_args()
@@ -120,6 +128,11 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     B, N, T, D, C = args.videos, N_TRK, T_FRAMES, D_ROI, 2 * D_ROI
+    bf16 = args.workload == "cfg3"
+    if bf16:
+        N, T, D = CFG3
+        C = 2 * D
+        B = args.videos if "--videos" in sys.argv else 4
     P_vid = N * (N - 1)
 
     # ---- weights (seed 0) and inputs (seed 1 + global video index), random-init / synthetic
@@ -130,26 +143,36 @@ def main():
            "cls_w": sd["classifier.rel_predictor.weight"], "cls_b": sd["classifier.rel_predictor.bias"]}
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
     conv_w = d(wnp["conv_w"])
-    packed = (tspn.ops.pack_conv3(conv_w, split=D) if args.conv == "direct"
-              else tspn.ops.pack_conv3_wino(conv_w, split=D))
+    r16 = lambda x: tspn.ops.cast_bf16(x.contiguous()).float()  # noqa: E731
+    if bf16:
+        packed = tspn.ops.pack_conv3_bf16(conv_w, split=D)
+    else:
+        packed = (tspn.ops.pack_conv3(conv_w, split=D) if args.conv == "direct"
+                  else tspn.ops.pack_conv3_wino(conv_w, split=D))
     del conv_w
     conv_b = d(wnp["conv_b"])
     head_w = d(np.concatenate([wnp["rel_w"][:, :, 0], wnp["dur_w"][:, :, 0]]))
     head_b = d(np.concatenate([wnp["rel_b"], wnp["dur_b"]]))
     cls_w, cls_b = d(wnp["cls_w"]), d(wnp["cls_b"])
+    if bf16:
+        conv_b, head_b, cls_w, cls_b = r16(conv_b), r16(head_b), r16(cls_w), r16(cls_b)
+        head_pk = tspn.ops.pack_heads_bf16(head_w)
     ppn_w = {k[len(PPN_PRE):]: d(v) for k, v in sd.items() if k.startswith(PPN_PRE)}
 
     vids = [tspn.synth.make_video(1 + rank * B + b, N, T, D) for b in range(B)]
     feats = d(np.concatenate([v["tracklet_feats"] for v in vids]))
+    if bf16:
+        feats = tspn.ops.cast_bf16(feats)
     cls = d(np.stack([v["track_cls_logits"] for v in vids]))
     del vids
     pairs = torch.cat([tspn.ops.pair_index(N, dev, base=b * N) for b in range(B)]).contiguous()
     P = pairs.shape[0]
 
-    ws = torch.empty(tspn.ops.fused_workspace_bytes(B, N, T, D, A_ANCH, K_PRED, P), dtype=torch.uint8,
-                     device=dev)
+    ws = None if bf16 else torch.empty(tspn.ops.fused_workspace_bytes(B, N, T, D, A_ANCH, K_PRED, P),
+                                       dtype=torch.uint8, device=dev)
     out_heads = torch.empty((P, 3 * A_ANCH, T), dtype=torch.float32, device=dev)
     out_logits = torch.empty((P, K_PRED), dtype=torch.float32, device=dev)
+    state = {}
     total_steps = args.warmup + args.steps
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
               for _ in range(total_steps)]
@@ -158,12 +181,23 @@ def main():
     torch.cuda.synchronize()
 
     def step(i):
-        tspn.ops.forward_fused(feats, pairs, B, N, packed, conv_b, head_w, head_b, cls_w, cls_b,
-                               workspace=ws, out_heads=out_heads, out_logits=out_logits,
-                               check_pairs=False, conv_events=events[i], canonical_pairs=True)
+        if bf16:
+            if "ws" not in state:   # allocate the workspace once (first warm-up step), then reuse it
+                d16 = tspn._abi.FusedBf16Desc()
+                d16.B, d16.N, d16.T, d16.D, d16.A, d16.K, d16.P = B, N, T, D, A_ANCH, K_PRED, P
+                state["ws"] = torch.empty(tspn._abi.lib().tspn_forward_fused_bf16_workspace_bytes(d16),
+                                          dtype=torch.uint8, device=dev)
+            h16, l16 = tspn.ops.forward_fused_bf16(feats, pairs, B, N, packed, conv_b, head_pk, head_b, cls_w,
+                                                   cls_b, workspace=state["ws"], conv_events=events[i])
+            state["logits"] = l16
+        else:
+            tspn.ops.forward_fused(feats, pairs, B, N, packed, conv_b, head_w, head_b, cls_w, cls_b,
+                                   workspace=ws, out_heads=out_heads, out_logits=out_logits,
+                                   check_pairs=False, conv_events=events[i], canonical_pairs=True)
         _, idx = tspn.ops.ppn_pair_matrix_topk(cls, ppn_w, 256)
         if use_dist:  # the one collective of the path: final result gather over RCCL
-            tspn.dist.gather_results(out_logits.view(B, P_vid, K_PRED), world * B, force=True)
+            lg = state["logits"] if bf16 else out_logits
+            tspn.dist.gather_results(lg.view(B, P_vid, K_PRED), world * B, force=True)
             tspn.dist.gather_results(idx, world * B, force=True)
 
     for i in range(args.warmup):
@@ -188,40 +222,46 @@ def main():
     conv_avg_s = float(np.mean(conv_ms)) * 1e-3
     conv_flop_direct = 2.0 * (2 * C) * (3 * D) * (B * N * T)  # M=2C, K=3D, columns=B*N*T
     # Winograd F(2,3) issues 4 channel-GEMMs on half the columns: 2/3 of the direct MFMA work
-    conv_flop = conv_flop_direct * (2.0 / 3.0 if args.conv == "winograd" else 1.0)
+    conv_flop = conv_flop_direct * (2.0 / 3.0 if (args.conv == "winograd" and not bf16) else 1.0)
     achieved = conv_flop / conv_avg_s / 1e12
+    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
 
     if rank == 0:
         pairs_total = world * P * args.steps
         out = {
-            "metric": "tracklet-pairs/sec scored (N=32, T=150, D=2048)",
+            "metric": f"tracklet-pairs/sec scored (N={N}, T={T}, D={D})",
             "value": pairs_total / elapsed,
             "unit": "tracklet-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE cfg2: synthetic VidVRD shape N=32 T=150 D=2048 (C=4096, A=4, "
-                                   "K=132), fp32, random-init weights",
+            "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
+            "config": {"workload": ("BASELINE cfg3: VidOR long-clip shape N=64 T=900 D=1024 (C=2048, A=4, K=132), "
+                                    "bf16 operands / fp32 accumulation, random-init weights" if bf16 else
+                                    "BASELINE cfg2: synthetic VidVRD shape N=32 T=150 D=2048 (C=4096, A=4, "
+                                    "K=132), fp32, random-init weights"),
                        "videos_per_gpu_per_step": B, "pairs_per_video": P_vid,
-                       "path": "fused/factorised (tspn_forward_fused_f32) + PPN top-k"
+                       "path": ("fused/factorised (tspn_forward_fused_bf16) + PPN top-k" if bf16 else
+                                "fused/factorised (tspn_forward_fused_f32) + PPN top-k")
                                + (" + RCCL all-gather of logits/top-k" if use_dist else ""),
                        "dense_equivalent_gflop_per_pair": (2.0 * T * C * (3 * C + 3 * A_ANCH) + 2.0 * C * K_PRED) / 1e9,
-                       "conv_algo": args.conv,
+                       "conv_algo": "direct" if bf16 else args.conv,
                        "executed_gflop_per_pair": (conv_flop + 2.0 * P * T * C * 16 + 2.0 * P * C * K_PRED) / P / 1e9},
             "roofline": {"bound": "mfma",
-                         "kernel": ("conv3_wino2_cl_kernel (tracklet projections: k=3 conv, Winograd F(2,3), "
+                         "kernel": ("conv3_bf16_big_kernel (tracklet projections: k=3 conv as bf16 32x32x16 MFMA "
+                                    "implicit GEMM, M=2C, K=3D)" if bf16 else
+                                    "conv3_wino2_cl_kernel (tracklet projections: k=3 conv, Winograd F(2,3), "
                                     "fp32 32x32x2 MFMA, M=2C, 4 channel-GEMMs of K=D on half the columns)"
                                     if args.conv == "winograd" else
                                     "conv3_mfma_cl_kernel (tracklet projections: k=3 conv as fp32 32x32x2 "
                                     "MFMA implicit GEMM, M=2C, K=3D)"),
-                         "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, **pmc_traffic(B, args.conv),
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, **({"traffic": None} if bf16 else pmc_traffic(B, args.conv)),
                          "direct_equivalent_tflops": conv_flop_direct / conv_avg_s / 1e12,
                          "flop_per_launch": conv_flop, "avg_launch_ms": conv_avg_s * 1e3,
                          "share_of_step": conv_avg_s / (elapsed / args.steps)},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not bf16:
             out["cpu_baseline"] = cpu_baseline(wnp, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if use_dist:
