@@ -80,3 +80,17 @@ def test_association_quirks_and_names(tspn):
     assert A._traj_iou(A.Track(0, 10, box(0)[:10]), A.Track(10, 20, box(0)[:10])) == 0   # no common frame
     with pytest.raises(ValueError):
         A.Track(0, 5, box(0))
+
+
+def test_association_empty_and_capped_inputs(tspn):
+    A = tspn.association
+    assert A.greedy_relational_association(None, [], trajectories={}) == []
+    box = [[0, 0, 10, 10]] * 30
+    rels = [(("v", 0, 30), ([], None, None)), (("v", 15, 45), ([(np.array(0.5), np.array([1, 1, 1]), np.array([0, 1]))], None, None))]
+    out = A.greedy_relational_association(None, rels, trajectories={("v", 0, 30): [box, box], ("v", 15, 45): [box, box]})
+    assert len(out) == 1 and out[0]["duration"] == [15, 45] and out[0]["score"] == 1.0   # opened after segment 0
+    many = [(np.array(0.01 * i), np.array([i % 3, 0, 1]), np.array([0, 1])) for i in range(10)]
+    out = A.greedy_relational_association(None, [(("v", 0, 30), (many, None, None))], max_traj_num_in_clip=4,
+                                          trajectories={("v", 0, 30): [box, box]})
+    assert [round(r["score"], 2) for r in out] == [0.09, 0.08, 0.07, 0.06]
+    assert A.load_trajectories("no-such-video", 0, 30, root="/nonexistent") == []

@@ -238,3 +238,46 @@ def test_cfg3_full_size_bf16_vs_fp32_path(tspn, device):
     assert res["span"].shape == (64, 16, 2) and int(res["count"].min()) >= 1
     ok = res["span"][..., 0] >= 0
     assert bool((res["span"][..., 1][ok] <= T).all()) and bool((res["span"][..., 0][ok] < res["span"][..., 1][ok]).all())
+
+
+def test_bf16_and_span_entry_points_edge_cases(tspn, device):
+    """Empty and degenerate shapes of the newer entry points: zero videos / pairs return empty outputs,
+    T = 1 and one-frame spans work, bad arguments are reported through the ABI's error convention."""
+    ops = tspn.ops
+    D, C = 16, 32
+    w = torch.zeros((C, C, 3), device=device)
+    packed = ops.pack_conv3_bf16(w, split=D)
+    hp = ops.pack_heads_bf16(torch.zeros((12, C), device=device))
+    z = lambda *s: torch.zeros(s, device=device)     # noqa: E731
+    # N = 1: no pairs
+    h, l = ops.forward_fused_bf16(torch.zeros((1, 5, D), dtype=torch.bfloat16, device=device),
+                                  torch.zeros((0, 2), dtype=torch.int64, device=device), 1, 1, packed, z(C), hp,
+                                  z(12), z(132, C), z(132))
+    assert h.shape == (0, 12, 5) and l.shape == (0, 132)
+    # T = 1 (both sequence-end masks on the same column)
+    x = r16(tspn.hashrng.uniform(85, "x", (3, 1, D), -1, 1))
+    wc = tspn.hashrng.normal(85, "w", (8, D, 3), std=0.1)
+    y = ops.conv3_tc_bf16(x.to(torch.bfloat16).to(device), ops.pack_conv3_bf16(t(wc).to(device)))
+    ref = torch.einsum("btc,mc->btm", x.double(), r16(wc)[:, :, 1].double())
+    np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), rtol=0, atol=1e-5)
+    # span pooling: empty pair list, one-frame spans, error code for a short workspace via the raw ABI
+    feats = t(tspn.hashrng.uniform(86, "f", (4, 6, D))).to(device)
+    cw, cb = t(tspn.hashrng.normal(86, "w", (132, 2 * D), std=0.1)).to(device), z(132)
+    e = ops.span_predicate(feats, torch.zeros((0, 2), dtype=torch.int64, device=device),
+                           torch.zeros((0, 2), dtype=torch.int64, device=device), cw, cb)
+    assert e.shape == (0, 132)
+    pairs = ops.pair_index(4, device)
+    one = torch.tensor([[3, 4]] * 12, dtype=torch.int64, device=device)
+    got = ops.span_predicate(feats, pairs, one, cw, cb).cpu()
+    f3 = feats.cpu()[:, 3]
+    ref = torch.sigmoid(torch.cat([f3[pairs.cpu()[:, 0]], f3[pairs.cpu()[:, 1]]], 1).double() @ cw.cpu().double().t())
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=0, atol=1e-6)
+    with pytest.raises(IndexError):
+        ops.span_predicate(feats, pairs + 4, one, cw, cb)
+    lib = tspn._abi.lib()
+    import ctypes
+    rc = lib.tspn_span_predicate_f32(ctypes.c_void_p(feats.data_ptr()), 4, 6, D, ctypes.c_void_p(pairs.data_ptr()),
+                                     ctypes.c_void_p(one.data_ptr()), 12, ctypes.c_void_p(cw.data_ptr()),
+                                     ctypes.c_void_p(cb.data_ptr()), 132, ctypes.c_void_p(got.data_ptr()),
+                                     ctypes.c_void_p(feats.data_ptr()), 16, None)
+    assert rc == tspn._abi.TSPN_EWORKSPACE and b"workspace" in lib.tspn_last_error()
