@@ -15,6 +15,7 @@ from .config import Cfg, default_cfg, load_cfg, merge_from_file  # noqa: F401
 from .model import (BaseModel, DPN, DPNHead, PPN, PPNHead, RelOIPool, RelPN,  # noqa: F401
                     RelationPredictor, TemporalProposals, make_relpn)
 from .pair_list import PairList, TargetList  # noqa: F401
+from .sampler import BalancedPositiveNegativePairSampler  # noqa: F401
 from . import dist  # noqa: F401
 
 __version__ = "0.1.0"

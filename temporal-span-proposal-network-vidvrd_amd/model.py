@@ -26,6 +26,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
+from .sampler import BalancedPositiveNegativePairSampler
 
 TemporalProposals = namedtuple("TemporalProposals", ["relness", "duration", "heads"])
 TemporalProposals.__doc__ = """Per-segment output of the temporal branch:
@@ -164,6 +165,9 @@ class PPN(nn.Module):
         # the reference also constructs (and never calls) a balanced sampler: ppn.py:20-23
         self.batch_size_per_segment = cfg.RELPN.PPN.BATCH_SIZE_PER_SEGMENT
         self.positive_fraction = cfg.RELPN.PPN.POSITIVE_FRACTION
+        # constructed like the reference (relpn/ppn.py:20-23); it never calls it either
+        self.fg_bg_sampler = BalancedPositiveNegativePairSampler(
+            batch_size_per_image=self.batch_size_per_segment, positive_fraction=self.positive_fraction)
         self._cache = _DeviceCache()
 
     def propose(self, cls_logits):

@@ -257,7 +257,13 @@ def g7_misc():
     sampler = RefSampler(256, 0.25)
     labels = torch.cat([torch.ones(100), torch.zeros(900)]).long()
     pos, neg = sampler([labels])
-    save("g7_misc.npz", sampler_counts=np.array([int(pos[0].sum()), int(neg[0].sum())]), **segs)
+    # the drawn masks themselves under a fixed seed (ragged case: fewer positives than the quota)
+    torch.manual_seed(1234)
+    lab2 = [torch.cat([torch.ones(100), torch.zeros(900), -torch.ones(24)]).long(),
+            torch.cat([torch.zeros(300), 2 * torch.ones(7)]).long(), torch.zeros(5).long()]
+    pos2, neg2 = sampler(lab2)
+    masks = {f"sampler_{k}_{i}": m.numpy() for k, ms in (("pos", pos2), ("neg", neg2)) for i, m in enumerate(ms)}
+    save("g7_misc.npz", sampler_counts=np.array([int(pos[0].sum()), int(neg[0].sum())]), **segs, **masks)
 
 
 def g8_bf16():

@@ -162,3 +162,23 @@ def test_hashrng_is_stable(tspn):
     b = tspn.synth.make_video(1, 3, 4, 2)["tracklet_boxes"]
     assert np.all(b == np.round(b)) and np.all(b[..., 2] > b[..., 0]) and np.all(b[..., 3] > b[..., 1])
     assert int(tspn.hashrng.bits(0, "x", 1)[0]) == int(tspn.hashrng.bits(0, "x", 3)[0])
+
+
+def test_sampler_draws_match_reference_under_the_same_seed(tspn):
+    """BalancedPositiveNegativePairSampler (reference relpn/sampler.py:3-66): same masks as the
+    reference under torch.manual_seed(1234) (golden g7), quotas respected on ragged inputs."""
+    import torch
+    import cases
+    g = cases.load("g7_misc.npz")
+    s = tspn.BalancedPositiveNegativePairSampler(256, 0.25)
+    torch.manual_seed(1234)
+    labels = [torch.cat([torch.ones(100), torch.zeros(900), -torch.ones(24)]).long(),
+              torch.cat([torch.zeros(300), 2 * torch.ones(7)]).long(), torch.zeros(5).long()]
+    pos, neg = s(labels)
+    for i in range(3):
+        assert pos[i].dtype == torch.uint8
+        assert (pos[i].numpy() == g[f"sampler_pos_{i}"]).all() and (neg[i].numpy() == g[f"sampler_neg_{i}"]).all()
+    assert [int(p.sum()) for p in pos] == [64, 7, 0] and [int(n.sum()) for n in neg] == [192, 249, 5]
+    assert int((pos[0][1000:] + neg[0][1000:]).sum()) == 0        # ignored (-1) entries are never drawn
+    m = tspn.BaseModel(tspn.load_cfg(None, **{"RELPN.USE_PPN": True}))
+    assert isinstance(m.relpn.pair_proposal_network.fg_bg_sampler, tspn.BalancedPositiveNegativePairSampler)
