@@ -16,6 +16,7 @@ from .model import (BaseModel, DPN, DPNHead, PPN, PPNHead, RelOIPool, RelPN,  # 
                     RelationPredictor, TemporalProposals, make_relpn)
 from .pair_list import PairList, TargetList  # noqa: F401
 from .sampler import BalancedPositiveNegativePairSampler  # noqa: F401
+from .anchor_generator import AnchorGenerator, generate_anchors, make_anchor_generator  # noqa: F401
 from . import dist  # noqa: F401
 
 __version__ = "0.1.0"

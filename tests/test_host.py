@@ -182,3 +182,20 @@ def test_sampler_draws_match_reference_under_the_same_seed(tspn):
     assert int((pos[0][1000:] + neg[0][1000:]).sum()) == 0        # ignored (-1) entries are never drawn
     m = tspn.BaseModel(tspn.load_cfg(None, **{"RELPN.USE_PPN": True}))
     assert isinstance(m.relpn.pair_proposal_network.fg_bg_sampler, tspn.BalancedPositiveNegativePairSampler)
+
+
+def test_anchor_generator_matches_reference(tspn):
+    """AnchorGenerator (reference relpn/anchor_generator.py:31-64) against golden g5; the product's
+    span decode enumerates candidates in the same location-major / size-minor order."""
+    import torch
+    import cases
+    g = cases.load("g5_anchors.npz")
+    for i, (sizes, stride, tw) in enumerate(cases.G5_SPECS):
+        gen = tspn.AnchorGenerator(sizes, stride)
+        a = gen(torch.zeros(2, 3, tw))
+        assert len(a) == 1 and a[0].dtype == torch.float32
+        np.testing.assert_array_equal(a[0].numpy(), g[f"anchors_{i}"])
+        assert gen.num_anchors_per_location() == [len(sizes)]
+        assert set(gen.state_dict()) == {"cell_anchors_0"}
+    gen = tspn.make_anchor_generator(tspn.load_cfg(None))
+    assert gen.grid_anchors(60)[0].shape == (len(range(0, 61, 132)) * 4, 2)
