@@ -1,0 +1,53 @@
+"""Short-term relation prediction over a data loader — host mirror of the loop in the reference's
+`lib/modeling/predict.py:39-123`, with the per-segment Python decode (three list comprehensions over
+200 items, 6 ms per segment on the reference's CPU path) replaced by `BaseModel.decode` on the GPU.
+
+Building the model from a checkpoint and the data loader (predict.py:14-36) stay the caller's business:
+the dataset code (h5py / VRDataset) is outside this build's scope."""
+import numpy as np
+import torch
+
+__all__ = ["predict_short_term_relations"]
+
+
+def _host(x):
+    if isinstance(x, torch.Tensor):
+        return x.detach().cpu().numpy()
+    return np.array(x)
+
+
+def predict_short_term_relations(model, data_loader, topk_per_pair=20, topk_per_seg=200, on_segment=None):
+    """`data_loader` yields `(pair_list, target_list, indexs)` like the reference's test loader
+    (lib/dataset/build.py collate): `pair_list` a list of PairList with the fields set in
+    vrdataset.py:75-81 ('tracklet_pairs', 'track_cls_logits', 'num_tracklets', 'ious', 'track_ids'),
+    `indexs` the (vid, fstart, fend) triple of every segment.
+
+    Returns `{index: (predictions, iou, trackid)}` with `predictions` =
+    [(score, triplet[3], pair_tid[2]), ...] as numpy values, top `topk_per_seg` per segment in
+    descending score order — the structure `greedy_relational_association` consumes
+    (predict.py:106-116).  Segments with fewer than two tracklets are skipped (predict.py:61-64).
+    `on_segment(index)` is called after every segment (progress hook)."""
+    short_term_relations = {}
+    was_training = model.training
+    model.eval()
+    try:
+        with torch.no_grad():
+            for pair_list, _, indexs in data_loader:
+                _, _, rel_logits = model(pair_list, None)
+                decoded = model.decode(pair_list, rel_logits, topk_per_pair=topk_per_pair,
+                                       topk_per_seg=topk_per_seg)
+                for index, plist, (score, triplet, pair_tid) in zip(indexs, pair_list, decoded):
+                    n = int(plist.get_field("num_tracklets")) if plist.has_field("num_tracklets") else \
+                        int(plist.get_field("track_cls_logits").shape[0])
+                    if n > 1:
+                        predictions = [(np.array(s), np.array(t), np.array(p))
+                                       for s, t, p in zip(_host(score), _host(triplet), _host(pair_tid))]
+                        iou = _host(plist.get_field("ious")) if plist.has_field("ious") else np.zeros((0, 0))
+                        tid = _host(plist.get_field("track_ids")) if plist.has_field("track_ids") else np.zeros((0,))
+                        short_term_relations[tuple(index) if not isinstance(index, tuple) else index] = (
+                            predictions, iou, tid)
+                    if on_segment is not None:
+                        on_segment(index)
+    finally:
+        model.train(was_training)
+    return short_term_relations

@@ -362,3 +362,44 @@ def test_predict_like_pipeline_forward_decode_associate(tspn, device):
         assert a["triplet"] == b["triplet"] and a["duration"] == b["duration"] and a["score"] == b["score"]
         np.testing.assert_array_equal(np.asarray(a["sub_traj"]), b["sub_traj"])
         np.testing.assert_array_equal(np.asarray(a["obj_traj"]), b["obj_traj"])
+
+
+def test_predict_loop_like_predict_py(tspn, device):
+    """tspn.predict.predict_short_term_relations == the loop of reference predict.py:39-123 restated with
+    the oracle's decode, on configs/baseline.yaml-style segments (2-D features, reference field set)."""
+    c = cases.g6_inputs()
+    n = c["n"]
+    c["feature"] = np.concatenate([c["feat70"], tspn.hashrng.uniform(8, "rest", (c["feat70"].shape[0], 58))], axis=1)
+    model = tspn.BaseModel(cases.baseline_cfg(**{"PREDICT.FEATURE_DIM": c["feature"].shape[1]}))
+    model.eval()
+
+    def segment(seed):
+        feats = t(c["feature"]) + 0.001 * seed
+        pl = tspn.PairList(feats)
+        pl.add_field("tracklet_pairs", c["pairs"])                     # numpy, as vrdataset.py:75-81 leaves it
+        pl.add_field("track_cls_logits", torch.zeros(n, 35))
+        pl.add_field("num_tracklets", np.int64(n))
+        pl.add_field("ious", np.eye(n, dtype=np.float32))
+        pl.add_field("track_ids", -np.ones(n, dtype=np.int64))
+        return pl
+
+    lonely = tspn.PairList(torch.zeros((0, c["feature"].shape[1])))
+    lonely.add_field("tracklet_pairs", np.zeros((0, 2), np.int64))
+    lonely.add_field("track_cls_logits", torch.zeros(1, 35))
+    lonely.add_field("num_tracklets", np.int64(1))
+    loader = [([segment(0), segment(1)], None, [("v", 0, 30), ("v", 15, 45)]), ([lonely], None, [("v", 30, 60)])]
+    seen = []
+    rels = tspn.predict.predict_short_term_relations(model, loader, topk_per_pair=5, topk_per_seg=40,
+                                                     on_segment=seen.append)
+    assert seen == [("v", 0, 30), ("v", 15, 45), ("v", 30, 60)] and set(rels) == {("v", 0, 30), ("v", 15, 45)}
+    for k, seed in ((("v", 0, 30), 0), (("v", 15, 45), 1)):
+        preds, iou, tid = rels[k]
+        feats = t(c["feature"]) + 0.001 * seed
+        with torch.no_grad():
+            lg = model([segment(seed)], None)[2][0]
+        sc, trip, tids = oracle.decode_topk(lg, feats[:, :70], t(c["pairs"]), n, 5, 40)
+        assert len(preds) == 40 and iou.shape == (n, n) and tid.shape == (n,)
+        np.testing.assert_array_equal(np.array([p[0] for p in preds]), sc.numpy())
+        np.testing.assert_array_equal(np.stack([p[1] for p in preds]), trip.numpy())
+        np.testing.assert_array_equal(np.stack([p[2] for p in preds]), tids.numpy())
+        assert preds[0][0].shape == () and preds[0][1].shape == (3,) and preds[0][2].shape == (2,)
