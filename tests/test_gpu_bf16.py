@@ -281,3 +281,32 @@ def test_bf16_and_span_entry_points_edge_cases(tspn, device):
                                      ctypes.c_void_p(cb.data_ptr()), 132, ctypes.c_void_p(got.data_ptr()),
                                      ctypes.c_void_p(feats.data_ptr()), 16, None)
     assert rc == tspn._abi.TSPN_EWORKSPACE and b"workspace" in lib.tspn_last_error()
+
+
+@pytest.mark.parametrize("case", range(10))
+def test_random_shapes_fp32_and_bf16_paths_vs_oracle(tspn, device, case):
+    """Seeded random (videos, N, T, D) draws: ragged tiles in every dimension for both operand types."""
+    rs = np.random.RandomState(1000 + case)
+    B, N, T, D = int(rs.randint(1, 4)), int(rs.randint(2, 21)), int(rs.randint(1, 71)), int(rs.choice([16, 32, 48]))
+    C = 2 * D
+    sd = tspn.synth.make_weights(case, c=C, bias_std=0.05)
+    w = oracle_weights(sd)
+    vids = [tspn.synth.make_video(500 + 10 * case + b, N, T, D) for b in range(B)]
+    model = tspn.BaseModel(temporal_cfg(D))
+    own = model.state_dict()
+    model.load_state_dict({k: t(v) for k, v in sd.items() if k in own})
+    model.eval()
+    for dtype in (torch.float32, torch.bfloat16):
+        plists = [tspn.PairList.from_tracklets(t(v["tracklet_feats"]).to(dtype), t(v["tracklet_boxes"]),
+                                               t(v["track_cls_logits"])) for v in vids]
+        _, dp, logits = model(plists, None)
+        for b, v in enumerate(vids):
+            if dtype == torch.float32:
+                ref = oracle.forward_dense(t(v["tracklet_feats"]), t(v["tracklet_boxes"]), oracle.pair_index(N), w)
+                for got, key in ((dp[b].relness, "relness"), (dp[b].duration, "duration"), (logits[b], "rel_logits")):
+                    np.testing.assert_allclose(got.numpy(), ref[key].numpy(), rtol=0, atol=1e-5, err_msg=f"{key} {B,N,T,D}")
+            else:
+                ref = oracle.forward_bf16(t(v["tracklet_feats"]), oracle.pair_index(N), w)
+                check_against_oracle(dp[b].relness, ref["relness"], f"relness {B,N,T,D}")
+                check_against_oracle(dp[b].duration, ref["duration"], f"duration {B,N,T,D}")
+                check_against_oracle(logits[b], ref["rel_logits"], f"rel_logits {B,N,T,D}")
