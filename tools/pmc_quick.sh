@@ -18,7 +18,7 @@ for r in csv.DictReader(open(sys.argv[1])):
     k = (m.group(1) + (m.group(2) or "")) if m else r["Kernel_Name"][:40]
     agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
 for (k, c), v in sorted(agg.items()):
-    if "bf16" in k and ("conv3" in k or "heads" in k):
+    if ("conv3" in k or "heads" in k) and "pack" not in k:
         print(f"{k:45s} {c:38s} n={len(v):3d} avg={sum(v)/len(v):.4g}")
 PY
   i=$((i+1))
