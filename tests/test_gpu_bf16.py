@@ -310,3 +310,60 @@ def test_random_shapes_fp32_and_bf16_paths_vs_oracle(tspn, device, case):
                 check_against_oracle(dp[b].relness, ref["relness"], f"relness {B,N,T,D}")
                 check_against_oracle(dp[b].duration, ref["duration"], f"duration {B,N,T,D}")
                 check_against_oracle(logits[b], ref["rel_logits"], f"rel_logits {B,N,T,D}")
+
+
+def test_fused_passes_are_graph_capturable(tspn, device):
+    """The ABI neither allocates nor synchronises and takes the stream explicitly: after
+    one warm-up call (which sets kernel attributes) a whole fused pass -- fp32 and bf16 -- is captured
+    into a HIP graph and replayed on new inputs with the results of a direct call."""
+    N, T, D, B = 9, 30, 32, 2
+    C = 2 * D
+    sd = tspn.synth.make_weights(3, c=C, bias_std=0.05)
+    w = {k: x.to(device) for k, x in oracle_weights(sd).items()}
+    hw = torch.cat([w["rel_w"][:, :, 0], w["dur_w"][:, :, 0]]).contiguous()
+    hb = torch.cat([w["rel_b"], w["dur_b"]]).contiguous()
+    pairs = torch.cat([tspn.ops.pair_index(N, device, base=b * N) for b in range(B)])
+    P = pairs.shape[0]
+    f_a = t(np.concatenate([tspn.synth.make_video(130 + b, N, T, D)["tracklet_feats"] for b in range(B)])).to(device)
+    f_b = t(np.concatenate([tspn.synth.make_video(140 + b, N, T, D)["tracklet_feats"] for b in range(B)])).to(device)
+    # ---- fp32
+    packed = tspn.ops.pack_conv3_wino(w["conv_w"], split=D)
+    ws = torch.empty(tspn.ops.fused_workspace_bytes(B, N, T, D, 4, 132, P), dtype=torch.uint8, device=device)
+    oh, ol = torch.empty((P, 12, T), device=device), torch.empty((P, 132), device=device)
+    feats = f_a.clone()
+    run = lambda: tspn.ops.forward_fused(feats, pairs, B, N, packed, w["conv_b"], hw, hb, w["cls_w"], w["cls_b"],   # noqa: E731
+                                         workspace=ws, out_heads=oh, out_logits=ol, check_pairs=False,
+                                         canonical_pairs=True)
+    run()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        run()
+    feats.copy_(f_b)
+    g.replay()
+    torch.cuda.synchronize()
+    got_h, got_l = oh.clone(), ol.clone()
+    ref_h, ref_l = tspn.ops.forward_fused(f_b, pairs, B, N, packed, w["conv_b"], hw, hb, w["cls_w"], w["cls_b"],
+                                          canonical_pairs=True)
+    assert torch.equal(got_h, ref_h) and torch.equal(got_l, ref_l)
+    # ---- bf16
+    p16, h16 = tspn.ops.pack_conv3_bf16(w["conv_w"], split=D), tspn.ops.pack_heads_bf16(hw)
+    d16 = tspn._abi.FusedBf16Desc()
+    d16.B, d16.N, d16.T, d16.D, d16.A, d16.K, d16.P = B, N, T, D, 4, 132, P
+    ws16 = torch.empty(tspn._abi.lib().tspn_forward_fused_bf16_workspace_bytes(d16), dtype=torch.uint8, device=device)
+    x16 = f_a.to(torch.bfloat16)
+    out = {}
+
+    def run16():
+        out["h"], out["l"] = tspn.ops.forward_fused_bf16(x16, pairs, B, N, p16, w["conv_b"], h16, hb, w["cls_w"],
+                                                         w["cls_b"], workspace=ws16)
+    run16()
+    torch.cuda.synchronize()
+    g16 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g16):
+        run16()
+    x16.copy_(f_b.to(torch.bfloat16))
+    g16.replay()
+    torch.cuda.synchronize()
+    rh, rl = tspn.ops.forward_fused_bf16(f_b.to(torch.bfloat16), pairs, B, N, p16, w["conv_b"], h16, hb, w["cls_w"], w["cls_b"])
+    assert torch.equal(out["h"], rh) and torch.equal(out["l"], rl)
