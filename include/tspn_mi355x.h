@@ -159,6 +159,15 @@ int tspn_conv3_tc_wino_f32(const float* x, int64_t B, int64_t T, int64_t Cin,
                            const float* packed4, int64_t M, const float* bias, int relu,
                            float* y, void* stream);
 
+/* Winograd F(4,3) form of the same conv: 4 output frames from 6 inputs, 6 channel-GEMMs on a quarter of the
+ * columns = half the MFMA work of the direct form.  packed6 = tspn_pack_conv3_wino43_f32(W, M, Cin, split,
+ * ...) -> [6][Cp][Mp] (G g, from fp64).  Any T (a tracklet's last quad is masked); needs Cin % 8 == 0,
+ * M % 4 == 0.  fp32 error within ~2.5x of the direct form's own rounding error (tspn_wino43.hip). */
+int tspn_pack_conv3_wino43_f32(const float* W, int64_t M, int64_t Cin, int64_t split, float* packed6,
+                               void* stream);
+int tspn_conv3_tc_wino43_f32(const float* x, int64_t B, int64_t T, int64_t Cin, const float* packed6,
+                             int64_t M, const float* bias, int relu, float* y, void* stream);
+
 /* ---- a8/a10: relationness + span-regression heads -----------------------
  * Replaces duration_pred (lib/modeling/relpn/dpn.py:71) and relness_pred
  * (lib/modeling/relpn/dpn_anchor.py:105) as ONE [H, C] 1x1 GEMM:
@@ -248,7 +257,8 @@ typedef struct tspn_fused_desc {
                                   video in order (P == B*N*(N-1)): enables the blocked pair stage */
   const float* conv_packed;    /* conv_algo 0: tspn_pack_conv3_f32(conv.weight [C,C,3], split=D): [3][D][2C]
                                   conv_algo 1: tspn_pack_conv3_wino_f32(..., split=D):          [4][D][2C] */
-  int64_t conv_algo;           /* 0 = direct k=3 taps; 1 = Winograd F(2,3) (needs T even, D % 16 == 0) */
+  int64_t conv_algo;           /* 0 = direct k=3 taps; 1 = Winograd F(2,3) (needs T even, D % 16 == 0);
+                                  2 = Winograd F(4,3): conv_packed = tspn_pack_conv3_wino43_f32(..., split=D): [6][D][2C] */
   const float* conv_bias;      /* [C] */
   const float* head_w;         /* [3A, C]: rows [0,A) relness_pred, [A,3A) duration_pred */
   const float* head_b;         /* [3A] */

@@ -97,6 +97,8 @@ PROTOTYPES = {
     "tspn_forward_fused_f32": (_int, [ctypes.POINTER(FusedDesc), _vp]),
     "tspn_temporal_encoder_heads_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64,
                                                _vp, _vp, _vp]),
+    "tspn_pack_conv3_wino43_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
+    "tspn_conv3_tc_wino43_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _int, _vp, _vp]),
     "tspn_span_predicate_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "tspn_span_predicate_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _sz, _vp]),
     "tspn_cast_bf16": (_int, [_vp, _i64, _vp, _vp]),

@@ -37,6 +37,8 @@ int conv3_tc_direct(const float* x, int64_t B, int64_t T, int64_t Cin, const flo
                     const float* bias, int relu, float* y, int64_t ldy, void* stream);
 int conv3_tc_wino(const float* x, int64_t B, int64_t T, int64_t Cin, const float* packed4, int64_t M,
                   const float* bias, int relu, float* y, int64_t ldy, void* stream);
+int conv3_tc_wino43(const float* x, int64_t B, int64_t T, int64_t Cin, const float* packed6, int64_t M,
+                    const float* bias, int relu, float* y, int64_t ldy, void* stream);
 int heads_pairgrid(const float* y, int64_t ldt, int64_t B, int64_t N, int64_t C, int64_t T,
                    const float* Wh, const float* bh, int64_t H, float* out, void* stream);
 inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }

@@ -13,7 +13,7 @@ from . import _abi
 
 __all__ = [
     "predicate_head", "feature_preprocess_", "ppn_pair_matrix_topk", "traj_iou", "pair_index",
-    "pair_gather", "pack_conv3", "conv3", "conv3_tc", "pack_conv3_wino", "conv3_tc_wino", "heads", "heads_pairgrid", "temporal_mean", "pair_rows", "transpose_td",
+    "pair_gather", "pack_conv3", "conv3", "conv3_tc", "pack_conv3_wino", "conv3_tc_wino", "pack_conv3_wino43", "conv3_tc_wino43", "heads", "heads_pairgrid", "temporal_mean", "pair_rows", "transpose_td",
     "forward_fused", "temporal_encoder_heads", "fused_workspace_bytes", "decode_topk", "decode_spans",
     "cast_bf16", "pack_conv3_bf16", "pack_heads_bf16", "conv3_tc_bf16", "heads_pairgrid_bf16",
     "temporal_mean_bf16", "forward_fused_bf16", "span_predicate",
@@ -246,6 +246,33 @@ def conv3_tc_wino(x, packed4, bias=None, relu=False):
     y = torch.empty((B, M, T), dtype=torch.float32, device=x.device)
     _abi.check(_abi.lib().tspn_conv3_tc_wino_f32(_p(x), B, T, Cin, _p(packed4), M, _p(bias),
                                                  1 if relu else 0, _p(y), _stream()))
+    return y
+
+
+def pack_conv3_wino43(weight, split=0):
+    """nn.Conv1d weight [M,Cin,3] -> Winograd F(4,3) layout [6][Cin'][M'] (tspn_pack_conv3_wino43_f32)."""
+    _dev(weight, "conv weight")
+    if weight.dim() != 3 or weight.shape[2] != 3:
+        raise ValueError("pack_conv3_wino43: weight must be [M,Cin,3]")
+    M, Cin, _ = weight.shape
+    shape = (6, split, 2 * M) if split else (6, Cin, M)
+    packed = torch.empty(shape, dtype=torch.float32, device=weight.device)
+    _abi.check(_abi.lib().tspn_pack_conv3_wino43_f32(_p(weight), M, Cin, split, _p(packed), _stream()))
+    return packed
+
+
+def conv3_tc_wino43(x, packed6, bias=None, relu=False):
+    """Winograd F(4,3) conv3 on channels-last x[B,T,Cin] -> y[B,M,T]; any T, Cin % 8 == 0."""
+    _dev(x, "x"); _dev(packed6, "packed6")
+    if bias is not None:
+        _dev(bias, "bias")
+    B, T, Cin = x.shape
+    if packed6.dim() != 3 or packed6.shape[0] != 6 or packed6.shape[1] != Cin:
+        raise ValueError(f"conv3_tc_wino43: packed weights {tuple(packed6.shape)} do not match Cin={Cin}")
+    M = packed6.shape[2]
+    y = torch.empty((B, M, T), dtype=torch.float32, device=x.device)
+    _abi.check(_abi.lib().tspn_conv3_tc_wino43_f32(_p(x), B, T, Cin, _p(packed6), M, _p(bias),
+                                                   1 if relu else 0, _p(y), _stream()))
     return y
 
 

@@ -577,3 +577,25 @@ def test_cfg4_batch_independence(tspn, device):
     # determinism: two runs of the same launch are bitwise identical (no atomics anywhere)
     hb2, lb2 = run_fused(tspn, device, feats, pairs, B, N, w, canonical=True)
     assert torch.equal(hb, hb2) and torch.equal(lb, lb2)
+
+
+@pytest.mark.parametrize("B,Cin,T,M", [(1, 8, 1, 4), (2, 8, 5, 8), (3, 16, 30, 128), (5, 24, 33, 132),
+                                       (7, 64, 150, 64), (2, 136, 257, 260), (40, 32, 30, 36), (3, 16, 7, 12)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_conv3_winograd43_vs_fp64(tspn, device, B, Cin, T, M, relu):
+    """Winograd F(4,3) kernel == the conv (fp64 reference) for any T (quads are masked at tracklet ends);
+    its fp32 error stays within a small multiple of the direct kernel's."""
+    x = tspn.hashrng.uniform(47, "x", (B, T, Cin), -1, 1)
+    w = tspn.hashrng.normal(47, "w", (M, Cin, 3), std=0.1)
+    b = tspn.hashrng.normal(47, "b", (M,), std=0.1)
+    p6 = tspn.ops.pack_conv3_wino43(t(w).to(device))
+    g = w.astype(np.float64).transpose(2, 1, 0)  # [3][Cin][M]
+    u = np.stack([g[0] / 4, -(g[0] + g[1] + g[2]) / 6, -(g[0] - g[1] + g[2]) / 6,
+                  g[0] / 24 + g[1] / 12 + g[2] / 6, g[0] / 24 - g[1] / 12 + g[2] / 6, g[2]]).astype(np.float32)
+    np.testing.assert_array_equal(p6.cpu().numpy(), u)
+    y = tspn.ops.conv3_tc_wino43(t(x).to(device), p6, t(b).to(device), relu=relu)
+    ref = conv_ref(np.ascontiguousarray(x.transpose(0, 2, 1)), w, b, relu)
+    np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=0, atol=6e-5)
+    y0 = tspn.ops.conv3_tc_wino43(t(x).to(device), p6, None, relu=relu)
+    np.testing.assert_allclose(y0.cpu().numpy(), conv_ref(np.ascontiguousarray(x.transpose(0, 2, 1)), w, None, relu),
+                               rtol=0, atol=6e-5)
