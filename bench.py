@@ -55,8 +55,9 @@ def parse():
     ap.add_argument("--videos", type=int, default=16, help="videos per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time")
-    ap.add_argument("--conv", choices=["winograd", "direct"], default="winograd",
-                    help="temporal-conv algorithm of the tracklet projections (both exact fp32 MFMA)")
+    ap.add_argument("--conv", choices=["winograd4", "winograd2", "winograd", "direct"], default="winograd4",
+                    help="temporal-conv algorithm of the tracklet projections (all fp32 MFMA): Winograd F(4,3) "
+                         "(default), F(2,3) (= winograd), direct taps")
     ap.add_argument("--workload", choices=["cfg2", "cfg3"], default="cfg2",
                     help="cfg2 = headline (N=32,T=150,D=2048, fp32); cfg3 = N=64,T=900,D=1024 bf16 operands")
     ap.add_argument("--force-collective", action="store_true",
@@ -101,7 +102,8 @@ def pmc_traffic(videos, conv):
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         data = json.load(open(path))
-        k = data["kernels"]["conv3_wino2_cl_kernel" if conv == "winograd" else "conv3_mfma_cl_kernel"]
+        k = data["kernels"][{"winograd4": "conv3_wino43_cl_kernel", "winograd2": "conv3_wino2_cl_kernel"}.get(
+            conv, "conv3_mfma_cl_kernel")]
         if data["videos_per_launch"] == videos:
             return {"traffic": k["hbm_bytes"], "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE)",
                     "traffic_source": data["source"]}
@@ -147,8 +149,10 @@ def main():
     if bf16:
         packed = tspn.ops.pack_conv3_bf16(conv_w, split=D)
     else:
-        packed = (tspn.ops.pack_conv3(conv_w, split=D) if args.conv == "direct"
-                  else tspn.ops.pack_conv3_wino(conv_w, split=D))
+        if args.conv == "winograd":
+            args.conv = "winograd2"
+        packed = {"direct": tspn.ops.pack_conv3, "winograd2": tspn.ops.pack_conv3_wino,
+                  "winograd4": tspn.ops.pack_conv3_wino43}[args.conv](conv_w, split=D)
     del conv_w
     conv_b = d(wnp["conv_b"])
     head_w = d(np.concatenate([wnp["rel_w"][:, :, 0], wnp["dur_w"][:, :, 0]]))
@@ -221,8 +225,10 @@ def main():
     conv_ms = [a.elapsed_time(b) for a, b in events[args.warmup:]]
     conv_avg_s = float(np.mean(conv_ms)) * 1e-3
     conv_flop_direct = 2.0 * (2 * C) * (3 * D) * (B * N * T)  # M=2C, K=3D, columns=B*N*T
-    # Winograd F(2,3) issues 4 channel-GEMMs on half the columns: 2/3 of the direct MFMA work
-    conv_flop = conv_flop_direct * (2.0 / 3.0 if (args.conv == "winograd" and not bf16) else 1.0)
+    # Winograd F(2,3) issues 4 channel-GEMMs on half the columns: 2/3 of the direct MFMA work;
+    # F(4,3) issues 6 on a quarter of the columns (ceil(T/4) quads per tracklet): 1/2
+    frac = {"direct": 1.0, "winograd2": 2.0 / 3.0, "winograd4": 0.5 * (4 * -(-T // 4)) / T}[args.conv]
+    conv_flop = conv_flop_direct * (1.0 if bf16 else frac)
     achieved = conv_flop / conv_avg_s / 1e12
     peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
 
@@ -250,9 +256,12 @@ def main():
             "roofline": {"bound": "mfma",
                          "kernel": ("conv3_bf16_big_kernel (tracklet projections: k=3 conv as bf16 32x32x16 MFMA "
                                     "implicit GEMM, M=2C, K=3D)" if bf16 else
+                                    "conv3_wino43_cl_kernel (tracklet projections: k=3 conv, Winograd F(4,3), "
+                                    "fp32 32x32x2 MFMA, M=2C, 6 channel-GEMMs of K=D on a quarter of the columns)"
+                                    if args.conv == "winograd4" else
                                     "conv3_wino2_cl_kernel (tracklet projections: k=3 conv, Winograd F(2,3), "
                                     "fp32 32x32x2 MFMA, M=2C, 4 channel-GEMMs of K=D on half the columns)"
-                                    if args.conv == "winograd" else
+                                    if args.conv == "winograd2" else
                                     "conv3_mfma_cl_kernel (tracklet projections: k=3 conv as fp32 32x32x2 "
                                     "MFMA implicit GEMM, M=2C, K=3D)"),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",

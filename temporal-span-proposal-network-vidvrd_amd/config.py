@@ -56,7 +56,10 @@ _DEFAULTS = {
                 "NUM_ANCHORS_PER_LOCATION": 4, "ANCHOR_SIZES": 35, "ANCHOR_STRIDE": 132,
                 # build extension (not in the reference's defaults.py): RelOIPool restricted to each
                 # pair's top temporal span instead of the whole segment (model.py:68-73 is a stub)
-                "POOL_TOP_SPAN": False},
+                "POOL_TOP_SPAN": False,
+                # build extension: algorithm of the k=3 temporal conv on the GPU (all exact fp32 MFMA):
+                # "winograd4" = F(4,3), "winograd2" = F(2,3), "direct"
+                "CONV_ALGO": "winograd4"},
     },
     "ETC": {"RANDOM_SEED": 0, "MODEL_DUMP_FILE": "baseline_weights_epoch_100.pt"},
 }

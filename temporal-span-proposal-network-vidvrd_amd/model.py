@@ -269,9 +269,12 @@ class DPN(nn.Module):
 
     def _conv_split(self, dev, winograd=False):
         """Packed weights of the factorised pair form (subject / object halves stacked along M);
-        `winograd` selects the F(2,3) packing used when T is even and D % 16 == 0."""
+        `winograd`: False = direct taps, 2 = F(2,3) (T even, D % 16 == 0), 4 = F(4,3) (D % 16 == 0)."""
         c = self.dpn_head.conv
         half = self.dpn_head.in_channels // 2
+        if winograd == 4:
+            return self._cache.get("conv_split_wino43", (c.weight, c.bias), dev,
+                                   lambda ts: (ops.pack_conv3_wino43(ts[0], split=half), ts[1]))
         if winograd:
             return self._cache.get("conv_split_wino", (c.weight, c.bias), dev,
                                    lambda ts: (ops.pack_conv3_wino(ts[0], split=half), ts[1]))
@@ -354,6 +357,9 @@ class BaseModel(nn.Module):
                                             fuse_preprocess=getattr(cfg.PREDICT, "FUSE_PREPROCESS", False))
         self._anchor_sizes_cfg = getattr(cfg.RELPN.DPN, "ANCHOR_SIZES", None)
         self.pool_top_span = bool(getattr(cfg.RELPN.DPN, "POOL_TOP_SPAN", False))
+        self.conv_algo = str(getattr(cfg.RELPN.DPN, "CONV_ALGO", "winograd4"))
+        if self.conv_algo not in ("winograd4", "winograd2", "direct"):
+            raise ValueError(f"RELPN.DPN.CONV_ALGO must be winograd4, winograd2 or direct (got {self.conv_algo})")
 
     def forward(self, pair_list, target_list=None):
         if self.training:
@@ -479,7 +485,12 @@ class BaseModel(nn.Module):
                     pairs.append(p.to(dev) + k * n)
             counts = [p.shape[0] for p in pairs]
             allp = torch.cat(pairs).contiguous()
-            packed, cbias = dpn._conv_split(dev, winograd=(t % 2 == 0 and d % 16 == 0))
+            # temporal conv algorithm: RELPN.DPN.CONV_ALGO = "winograd4" (default; F(4,3), half the MFMA
+            # work), "winograd2" (F(2,3), the most accurate), "direct"
+            algo = self.conv_algo
+            wino = 4 if (algo == "winograd4" and d % 16 == 0) else \
+                (2 if (algo in ("winograd4", "winograd2") and t % 2 == 0 and d % 16 == 0) else False)
+            packed, cbias = dpn._conv_split(dev, winograd=wino)
             heads, lg = ops.forward_fused(feats, allp, len(members), n, packed, cbias, hw, hb, cw, cb,
                                           check_pairs=False, canonical_pairs=canonical)
             if self.pool_top_span and allp.shape[0]:

@@ -426,9 +426,9 @@ def _fused_desc(feats, pairs, B, N, conv_packed, conv_bias, head_w, head_b, cls_
     H = head_w.shape[0]
     if H % 3 or head_w.shape[1] != C or head_b.shape != (H,):
         raise ValueError("forward_fused: head_w must be [3A, 2D]")
-    if tuple(conv_packed.shape) not in ((3, D, 2 * C), (4, D, 2 * C)) or conv_bias.shape != (C,):
-        raise ValueError(f"forward_fused: conv_packed must be [3 or 4, D={D}, 4D={2 * C}] "
-                         "(pack_conv3(w, split=D) or pack_conv3_wino(w, split=D))")
+    if tuple(conv_packed.shape) not in ((3, D, 2 * C), (4, D, 2 * C), (6, D, 2 * C)) or conv_bias.shape != (C,):
+        raise ValueError(f"forward_fused: conv_packed must be [3, 4 or 6, D={D}, 4D={2 * C}] "
+                         "(pack_conv3 / pack_conv3_wino / pack_conv3_wino43 with split=D)")
     if cls_w.dim() != 2 or cls_w.shape[1] != C or cls_b.shape != (cls_w.shape[0],):
         raise ValueError("forward_fused: cls_w must be [K, 2D]")
     d = _abi.FusedDesc()
@@ -436,7 +436,8 @@ def _fused_desc(feats, pairs, B, N, conv_packed, conv_bias, head_w, head_b, cls_
     d.A, d.K = H // 3, cls_w.shape[0]
     d.feats, d.pairs, d.P = feats.data_ptr(), pairs.data_ptr(), pairs.shape[0]
     d.conv_packed, d.conv_bias = conv_packed.data_ptr(), conv_bias.data_ptr()
-    d.conv_algo = 1 if conv_packed.shape[0] == 4 else 0  # Winograd F(2,3) packing has 4 matrices
+    # direct: 3 tap matrices; Winograd F(2,3): 4 transformed matrices; F(4,3): 6
+    d.conv_algo = {3: 0, 4: 1, 6: 2}[conv_packed.shape[0]]
     d.head_w, d.head_b = head_w.data_ptr(), head_b.data_ptr()
     d.cls_w, d.cls_b = cls_w.data_ptr(), cls_b.data_ptr()
     return d
