@@ -599,3 +599,24 @@ def test_conv3_winograd43_vs_fp64(tspn, device, B, Cin, T, M, relu):
     y0 = tspn.ops.conv3_tc_wino43(t(x).to(device), p6, None, relu=relu)
     np.testing.assert_allclose(y0.cpu().numpy(), conv_ref(np.ascontiguousarray(x.transpose(0, 2, 1)), w, None, relu),
                                rtol=0, atol=6e-5)
+
+
+def test_conv3_algorithms_error_at_headline_depth(tspn, device):
+    """fp32 error of the three temporal-conv kernels against float64 at the contraction depth of the
+    headline config (K = 3 x 2048 channels, inputs in [0,1), weights N(0, 0.01^2)): F(2,3) <= direct;
+    F(4,3) within a small multiple of the direct kernel's own rounding error and far inside the path's
+    1e-4 bound (the number DESIGN.md quotes for the default algorithm)."""
+    B, T, Cin, M = 3, 150, 2048, 128
+    x = tspn.hashrng.uniform(48, "x", (B, T, Cin))
+    w = tspn.hashrng.normal(48, "w", (M, Cin, 3), std=0.01)
+    ref = conv_ref(np.ascontiguousarray(x.transpose(0, 2, 1)), w, None, False).astype(np.float64)
+    ref = torch.nn.functional.conv1d(t(x).double().transpose(1, 2), t(w).double(), None, padding=1).numpy()
+    xd, wd = t(x).to(device), t(w).to(device)
+    err = {}
+    err["direct"] = np.abs(tspn.ops.conv3_tc(xd, tspn.ops.pack_conv3(wd)).cpu().numpy() - ref).max()
+    err["F(2,3)"] = np.abs(tspn.ops.conv3_tc_wino(xd, tspn.ops.pack_conv3_wino(wd)).cpu().numpy() - ref).max()
+    err["F(4,3)"] = np.abs(tspn.ops.conv3_tc_wino43(xd, tspn.ops.pack_conv3_wino43(wd)).cpu().numpy() - ref).max()
+    scale = np.abs(ref).max()
+    print("conv3 max abs error vs float64 (|y| max %.3f):" % scale, {k: "%.2e" % v for k, v in err.items()})
+    assert err["F(2,3)"] <= 1.5 * err["direct"]
+    assert err["F(4,3)"] <= 4.0 * err["direct"] and err["F(4,3)"] <= 3e-5
