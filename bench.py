@@ -16,7 +16,8 @@ with N>1 each step ends with ONE RCCL all-gather of the per-pair predicate logit
 top-k pair indices (the "final result gather").
 
 Printed JSON (rank 0): see the task contract; extras:
-  roofline     dominant kernel = conv3_mfma (tracklet projections, fp32 MFMA implicit GEMM);
+  roofline     dominant kernel = the temporal conv of the tracklet projections (fp32 MFMA; Winograd
+               F(4,3) by default, --conv winograd2 | direct for the other two algorithms);
                achieved = executed FLOP per launch / HIP-event time of that launch inside the
                timed steps (events recorded on the launch stream by the C ABI's hook).
   cpu_baseline the oracle's reference-faithful dense forward on a bounded sample of pairs,
