@@ -168,6 +168,17 @@ int tspn_pack_conv3_wino43_f32(const float* W, int64_t M, int64_t Cin, int64_t s
 int tspn_conv3_tc_wino43_f32(const float* x, int64_t B, int64_t T, int64_t Cin, const float* packed6,
                              int64_t M, const float* bias, int relu, float* y, void* stream);
 
+/* Same F(4,3) arithmetic on FRAGMENT-MAJOR weights (tspn_wino43r.hip): the A operands of one (32-row
+ * block, 8-channel chunk, position j) are one contiguous 1-KiB line, which the kernel loads straight into
+ * MFMA operand registers (no LDS transit for weights, one barrier per chunk).
+ *   frag[M/32][Cin/8][6][64 lanes = 32 kh + li][4 e] = packed6[j][8 chunk + 4 kh + e][32 (m/32) + li]
+ * tspn_repack_wino43_frag_f32 converts the canonical packed6 (6*Cin*M floats, out of place).  Needs
+ * Cin % 8 == 0 and M % 32 == 0 (else TSPN_EUNSUPPORTED: use the canonical kernel).  Results are
+ * bit-identical to tspn_conv3_tc_wino43_f32 (same contraction order). */
+int tspn_repack_wino43_frag_f32(const float* packed6, int64_t Cin, int64_t M, float* frag, void* stream);
+int tspn_conv3_tc_wino43r_f32(const float* x, int64_t B, int64_t T, int64_t Cin, const float* frag,
+                              int64_t M, const float* bias, int relu, float* y, void* stream);
+
 /* ---- a8/a10: relationness + span-regression heads -----------------------
  * Replaces duration_pred (lib/modeling/relpn/dpn.py:71) and relness_pred
  * (lib/modeling/relpn/dpn_anchor.py:105) as ONE [H, C] 1x1 GEMM:
@@ -258,7 +269,9 @@ typedef struct tspn_fused_desc {
   const float* conv_packed;    /* conv_algo 0: tspn_pack_conv3_f32(conv.weight [C,C,3], split=D): [3][D][2C]
                                   conv_algo 1: tspn_pack_conv3_wino_f32(..., split=D):          [4][D][2C] */
   int64_t conv_algo;           /* 0 = direct k=3 taps; 1 = Winograd F(2,3) (needs T even, D % 16 == 0);
-                                  2 = Winograd F(4,3): conv_packed = tspn_pack_conv3_wino43_f32(..., split=D): [6][D][2C] */
+                                  2 = Winograd F(4,3): conv_packed = tspn_pack_conv3_wino43_f32(..., split=D): [6][D][2C]
+                                  3 = Winograd F(4,3) on fragment-major weights: conv_packed =
+                                      tspn_repack_wino43_frag_f32(packed6 of algo 2, D, 2C) */
   const float* conv_bias;      /* [C] */
   const float* head_w;         /* [3A, C]: rows [0,A) relness_pred, [A,3A) duration_pred */
   const float* head_b;         /* [3A] */

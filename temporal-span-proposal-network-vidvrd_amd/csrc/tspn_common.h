@@ -39,6 +39,10 @@ int conv3_tc_wino(const float* x, int64_t B, int64_t T, int64_t Cin, const float
                   const float* bias, int relu, float* y, int64_t ldy, void* stream);
 int conv3_tc_wino43(const float* x, int64_t B, int64_t T, int64_t Cin, const float* packed6, int64_t M,
                     const float* bias, int relu, float* y, int64_t ldy, void* stream);
+// fragment-major weights (tspn_repack_wino43_frag_f32): registers-direct kernel of tspn_wino43r.hip
+bool wino43_frag_supported(int64_t Cin, int64_t M);
+int conv3_tc_wino43r(const float* x, int64_t B, int64_t T, int64_t Cin, const float* frag, int64_t M,
+                     const float* bias, int relu, float* y, int64_t ldy, void* stream);
 int heads_pairgrid(const float* y, int64_t ldt, int64_t B, int64_t N, int64_t C, int64_t T,
                    const float* Wh, const float* bh, int64_t H, float* out, void* stream);
 inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }

@@ -98,12 +98,15 @@ extern "C" int tspn_forward_fused_f32(const tspn_fused_desc* d, void* stream) {
   // through a transpose to channels-first [NT,D,T] and the general kernel.
   const bool tc = (D % 16 == 0) && ((reinterpret_cast<uintptr_t>(d->feats) & 15) == 0) &&
                   ((reinterpret_cast<uintptr_t>(d->conv_packed) & 15) == 0);
-  TSPN_REQUIRE(d->conv_algo >= 0 && d->conv_algo <= 2, TSPN_EINVAL,
-               "tspn_forward_fused: conv_algo must be 0, 1 or 2");
+  TSPN_REQUIRE(d->conv_algo >= 0 && d->conv_algo <= 3, TSPN_EINVAL,
+               "tspn_forward_fused: conv_algo must be 0, 1, 2 or 3");
   TSPN_REQUIRE(d->conv_algo != 1 || (tc && T % 2 == 0), TSPN_EUNSUPPORTED,
                "tspn_forward_fused: conv_algo 1 (Winograd F(2,3)) needs T even, D %% 16 == 0, aligned operands");
   TSPN_REQUIRE(d->conv_algo != 2 || tc, TSPN_EUNSUPPORTED,
                "tspn_forward_fused: conv_algo 2 (Winograd F(4,3)) needs D %% 16 == 0, aligned operands");
+  TSPN_REQUIRE(d->conv_algo != 3 || (tc && tspn::wino43_frag_supported(D, 2 * C)), TSPN_EUNSUPPORTED,
+               "tspn_forward_fused: conv_algo 3 (Winograd F(4,3), fragment-major weights) needs D %% 16 == 0, "
+               "aligned operands");
   // On the fast path the rows of y are padded to ldy = ceil4(T) frames so that the blocked pair stage
   // can stage them with 16-byte LDS-DMA pieces that never leave a row (pad frames are never read out).
   // (needs what the DMA pair-stage kernel needs: even T, C % 16 == 0 — implied by tc)
@@ -111,7 +114,9 @@ extern "C" int tspn_forward_fused_f32(const tspn_fused_desc* d, void* stream) {
       (tc && d->canonical_pairs && T % 2 == 0) ? (int64_t)tspn::align_up((size_t)T, 4) : T;
   if (!tc && (rc = tspn_transpose_td_f32(d->feats, NT, T, D, xt, stream))) return rc;
   if (d->ev_conv_begin) (void)hipEventRecord(static_cast<hipEvent_t>(d->ev_conv_begin), s);
-  if (d->conv_algo == 2)
+  if (d->conv_algo == 3)
+    rc = tspn::conv3_tc_wino43r(d->feats, NT, T, D, d->conv_packed, 2 * C, bias2, 0, y, ldy, stream);
+  else if (d->conv_algo == 2)
     rc = tspn::conv3_tc_wino43(d->feats, NT, T, D, d->conv_packed, 2 * C, bias2, 0, y, ldy, stream);
   else if (d->conv_algo == 1)
     rc = tspn::conv3_tc_wino(d->feats, NT, T, D, d->conv_packed, 2 * C, bias2, 0, y, ldy, stream);

@@ -1,0 +1,409 @@
+// Winograd F(4,3) temporal conv, second structure: weight fragments straight from global memory into
+// registers (gfx950, fp32).  Same arithmetic as tspn_wino43.hip (same transforms, same MFMA order of the
+// contraction), different data movement:
+//
+//   * In conv3_wino43_cl_kernel the four waves of a workgroup own disjoint 32-row slices of the weight
+//     tile, so the LDS was only a transit buffer for the weights (6 DMA pieces + 24 ds_read_b32 per wave
+//     and chunk, and a barrier that had to wait for them).  Here the weights are packed FRAGMENT-MAJOR,
+//         Wf[m / 32][chunk = ch / 8][j = 0..5][lane = 32 kh + li][e = 0..3]  =  U_j[8 chunk + 4 kh + e][32 (m/32) + li],
+//     so that the A operands of the four k-steps of (chunk, j) are ONE global_load_dwordx4 per lane
+//     (a contiguous 1-KiB line per wave, 6 KiB per wave and chunk, one linear stream per wave).
+//   * Both operands of chunk c+1 are fetched into the registers of chunk c as soon as those are free
+//     (after the MFMAs of their position pair): weights from global memory, V from the LDS tile that was
+//     transformed one chunk earlier.  At the top of a chunk every operand is already in registers.
+//   * LDS holds only x (2 stages, LDS-DMA, issued three chunks ahead of its MFMAs) and V (3 stages):
+//     30 KB.  One bare s_barrier per chunk with a counted vmcnt (the weight loads of the next chunk stay
+//     in flight across it).
+//
+// Needs M % 32 == 0 and Cin % 8 == 0 (the canonical kernel takes everything else).
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+
+#include "tspn_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int THREADS = 256;
+constexpr int BM = 128;
+constexpr int QT = 32;                 // quads per workgroup
+constexpr int KC = 8;
+constexpr int SLP = 132;               // x slots per channel group (4 QT + 2 = 130 used)
+constexpr int X_ST = 2 * SLP * 4;      // floats per x stage
+constexpr int V_ST = 2 * 7 * QT * 4;   // [2 g][6 j + 1 scratch plane][32 quads][4 ch]
+constexpr int NXS = 2, NVS = 3;
+constexpr size_t SMEM_BYTES = sizeof(float) * (NXS * X_ST + NVS * V_ST);
+
+__device__ __forceinline__ void glds16(const float* g, float* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+// canonical [6][Cin][M] -> fragment-major [M/32][Cin/8][6][64][4]
+__global__ void repack_wino43_frag_kernel(const float* __restrict__ in, int64_t Cin, int64_t M,
+                                          float* __restrict__ out) {
+  const int64_t total = 6 * Cin * M;
+  const int64_t nch = Cin / KC;
+  for (int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; o < total;
+       o += (int64_t)gridDim.x * blockDim.x) {
+    const int e = (int)(o & 3);
+    const int lane = (int)((o >> 2) & 63);
+    const int64_t r = o >> 8;
+    const int j = (int)(r % 6);
+    const int64_t c = (r / 6) % nch;
+    const int64_t mb = r / (6 * nch);
+    const int64_t ch = 8 * c + 4 * (lane >> 5) + e;
+    const int64_t m = 32 * mb + (lane & 31);
+    out[o] = in[((int64_t)j * Cin + ch) * M + m];
+  }
+}
+
+// The weight loads are inline asm (the compiler does not see them as asynchronous), so every use of
+// their destination registers is preceded by one of these counted waits, tied to the registers by "+v".
+template <int VM>
+__device__ __forceinline__ void wait_a(f32x4& r0, f32x4& r1) {
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r0), "+v"(r1) : "n"(VM));
+}
+template <int VM>
+__device__ __forceinline__ void wait_vm_lgkm0() {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(VM) : "memory");
+}
+// one 1-KiB fragment line: lane offset in a VGPR, wave-uniform base in SGPRs, immediate line offset
+template <int OFF>
+__device__ __forceinline__ void load_frag(f32x4& dst, unsigned lane_off, const char* base) {
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(lane_off), "s"(base), "n"(OFF) : "memory");
+}
+
+__global__ __launch_bounds__(THREADS, 2) void conv3_wino43r_kernel(
+    const float* __restrict__ x, const float* __restrict__ Wf, const float* __restrict__ bias,
+    float* __restrict__ y, int Cin, int T, int M, int nq, int64_t nquads, int64_t ncols, int tiles_m,
+    int tiles_n, int relu, int ldy, int GM, int vec4) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* Xs = reinterpret_cast<float*>(smem_raw);
+  float* Vs = Xs + NXS * X_ST;
+
+  // workgroup -> tile: bijective XCD remap, then groups of GM weight panels x all quad tiles
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int group_sz = GM * tiles_n;
+  const int group = wg / group_sz;
+  const int first_m = group * GM;
+  const int gm = min(GM, tiles_m - first_m);
+  const int in_group = wg - group * group_sz;
+  const int tile_m = first_m + in_group % gm;
+  const int tile_n = in_group / gm;
+  const int m0 = tile_m * BM;
+  const int64_t Q0 = (int64_t)tile_n * QT;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kh = lane >> 5;
+  const int nchunks = Cin / KC;
+
+  // quad Q -> (tracklet b, quad q in it); row of its first output frame in the flat [B*T] frame space
+  auto quad_row = [&](int64_t Q, int& q) -> int64_t {
+    const int64_t b = Q / nq;
+    q = (int)(Q - b * nq);
+    return b * T + 4 * q;
+  };
+  int q_first;
+  const int64_t row0 = quad_row(Q0, q_first) - 1;   // slot s of the x tile <-> frame row row0 + s
+
+  // ---- weight fragment stream of this wave (32 output rows); rows beyond M: re-read block 0, never stored
+  const char* abase;            // wave-uniform; advanced by one chunk (6 KiB) per refill round
+  const unsigned aoff = lane * 16;
+  {
+    int mb = (m0 >> 5) + wave;
+    mb = mb < (M >> 5) ? mb : 0;
+    abase = reinterpret_cast<const char*>(Wf) + (int64_t)mb * nchunks * (6 * 64 * 16);
+  }
+
+  // ---- x tile DMA: unit u = (channel group g, slot), 2 x 130 valid units.  Piece 0 of wave w = units
+  // [64 w, 64 w + 64); piece 1 = two of the last six units (256 + 2 (w % 3) + lane, lanes 0 and 1; wave 3
+  // repeats wave 0's) -- so EVERY wave issues exactly two pieces per chunk and the counted waits below are
+  // the same for all waves.
+  const float* bsrc[2];
+  bool bval[2];
+  int bunit[2];
+  bunit[0] = 64 * wave;
+  bunit[1] = 256 + 2 * (wave == 3 ? 0 : wave);
+#pragma unroll
+  for (int qq = 0; qq < 2; ++qq) {
+    const int u = bunit[qq] + lane;
+    const int g = u / SLP, slot = u - g * SLP;
+    bval[qq] = u < 2 * SLP && slot < 4 * QT + 2 && (qq == 0 || lane < 2);
+    int64_t n = row0 + slot;
+    n = n < 0 ? 0 : (n < ncols ? n : ncols - 1);
+    bsrc[qq] = x + n * Cin + 4 * (g < 2 ? g : 0);
+  }
+  auto stage_x = [&](int buf) {
+#if !defined(TSPN_W43R_ABL_NODMA)
+    if (bval[0]) glds16(bsrc[0], Xs + buf * X_ST + bunit[0] * 4);
+    if (bval[1]) glds16(bsrc[1], Xs + buf * X_ST + bunit[1] * 4);
+#endif
+    bsrc[0] += KC;
+    bsrc[1] += KC;
+  };
+
+  // ---- transform item of this thread: quad tk, channel group tg; wave = part (V0 | V5 | V1,V2 | V3,V4);
+  // sequence-end masks folded into the coefficients (see tspn_wino43.hip)
+  const int tk = tid & 31, tg = (tid >> 5) & 1;
+  int tslot;
+  float tc[4];
+  {
+    const int64_t Q = Q0 + tk;
+    int q = 0;
+    const bool okq = Q < nquads;
+    const int64_t r = okq ? quad_row(Q, q) : row0 + 1;
+    tslot = (int)(r - 1 - row0);
+    float tm[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int t = 4 * q + i - 1;
+      tm[i] = (okq && t >= 0 && t < T) ? 1.f : 0.f;
+    }
+    if (wave == 0) {          // V0 = 4 d0 - 5 d2 + d4
+      tc[0] = 4.f * tm[0]; tc[1] = -5.f * tm[2]; tc[2] = tm[4]; tc[3] = 0.f;
+    } else if (wave == 1) {   // V5 = 4 d1 - 5 d3 + d5
+      tc[0] = 4.f * tm[1]; tc[1] = -5.f * tm[3]; tc[2] = tm[5]; tc[3] = 0.f;
+    } else if (wave == 2) {   // s = d4 - 4 d2, r = 4 d1 - d3: V1 = s - r, V2 = s + r
+      tc[0] = tm[4]; tc[1] = -4.f * tm[2]; tc[2] = 4.f * tm[1]; tc[3] = -tm[3];
+    } else {                  // s = d4 - d2, r = 2 d1 - 2 d3: V3 = s - r, V4 = s + r
+      tc[0] = tm[4]; tc[1] = -tm[2]; tc[2] = 2.f * tm[1]; tc[3] = -2.f * tm[3];
+    }
+  }
+  // two phases, so that the LDS reads of the x tile fly under the MFMAs that precede the arithmetic:
+  // part p reads d[i]: V0: d0,d2,d4 | V5: d1,d3,d5 | V1,V2 and V3,V4: d1,d2,d3,d4
+  f32x4 td[4];
+  auto transform_read = [&](int xbuf) {
+#if defined(TSPN_W43R_ABL_NOXFORM)
+    return;
+#endif
+    const float* xp = Xs + xbuf * X_ST + (tg * SLP + tslot) * 4;
+    auto D = [&](int i) { return *reinterpret_cast<const f32x4*>(xp + 4 * i); };
+    if (wave < 2) {
+      td[0] = D(wave); td[1] = D(wave + 2); td[2] = D(wave + 4);
+    } else {
+      td[0] = D(4); td[1] = D(2); td[2] = D(1); td[3] = D(3);
+    }
+  };
+  auto transform_write = [&](int vst) {
+#if defined(TSPN_W43R_ABL_NOXFORM)
+    return;
+#endif
+    float* vp = Vs + vst * V_ST + (tg * 7 * QT + tk) * 4;
+    auto bc = [](float v) { return f32x4{v, v, v, v}; };
+    if (wave < 2) {
+      const f32x4 v = __builtin_elementwise_fma(bc(tc[0]), td[0],
+                                                __builtin_elementwise_fma(bc(tc[1]), td[1], bc(tc[2]) * td[2]));
+      *reinterpret_cast<f32x4*>(vp + (wave == 0 ? 0 : 5) * QT * 4) = v;
+    } else {
+      const f32x4 sv = __builtin_elementwise_fma(bc(tc[0]), td[0], bc(tc[1]) * td[1]);
+      const f32x4 rv = __builtin_elementwise_fma(bc(tc[2]), td[2], bc(tc[3]) * td[3]);
+      const int j = wave == 2 ? 1 : 3;
+      *reinterpret_cast<f32x4*>(vp + j * QT * 4) = sv - rv;
+      *reinterpret_cast<f32x4*>(vp + (j + 1) * QT * 4) = sv + rv;
+    }
+  };
+  auto transform = [&](int xbuf, int vst) { transform_read(xbuf); transform_write(vst); };
+
+  f32x16 acc[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+  f32x4 a[6], v[6];
+  const int voff = (kh * 7 * QT + li) * 4;
+  auto load_v = [&](int vst, int j) {
+    v[j] = *reinterpret_cast<const f32x4*>(Vs + vst * V_ST + voff + j * QT * 4);
+  };
+  auto load_a_pair = [&](auto jp_tag) {     // positions 2 jp, 2 jp + 1 of the chunk at abase
+    constexpr int JP = decltype(jp_tag)::value;
+#if !defined(TSPN_W43R_ABL_NOALOAD)
+    if (JP == 0) { load_frag<0>(a[0], aoff, abase); load_frag<1024>(a[1], aoff, abase); }
+    if (JP == 1) { load_frag<2048>(a[2], aoff, abase); load_frag<3072>(a[3], aoff, abase); }
+    if (JP == 2) { load_frag<0>(a[4], aoff, abase + 4096); load_frag<1024>(a[5], aoff, abase + 4096); }
+#endif
+  };
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  using P2 = std::integral_constant<int, 2>;
+  auto mfma_pair = [&](int ja, int jb) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      acc[ja] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ja][e], v[ja][e], acc[ja], 0, 0, 0);
+      acc[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jb][e], v[jb][e], acc[jb], 0, 0, 0);
+    }
+  };
+
+  // ---- prologue: A_0 and V_0 in registers, V_1 in LDS, x_2 landed
+  stage_x(0);
+  if (nchunks > 1) stage_x(1);
+  __syncthreads();
+  transform(0, 0);
+  if (nchunks > 1) transform(1, 1);
+  __syncthreads();
+  if (nchunks > 2) stage_x(0);
+#pragma unroll
+  for (int j = 0; j < 6; ++j) load_v(0, j);
+  wait_vm_lgkm0<0>();
+  __syncthreads();
+  // the weights of chunk 0 are the youngest VMEM operations, in the order the waits of a chunk expect
+  load_a_pair(P0{}); load_a_pair(P1{}); load_a_pair(P2{});
+  abase += 6 * 1024;
+  __builtin_amdgcn_sched_barrier(0);
+
+  // chunk c: MFMAs on the registers (A_c, V_c); meanwhile DMA x_{c+3}, transform x_{c+2} -> V_{c+2},
+  // and refill the registers with (A_{c+1}, V_{c+1}) position pair by position pair.
+  // VMEM issue order of a steady-state chunk: [x pieces: ND] a0 a1 | a2 a3 | a4 a5; vmcnt counts are the
+  // number of YOUNGER operations at each wait (ND = 2 x pieces per wave).
+  auto chunk_body = [&](int c, int vs1, int vs2, auto has1_tag, auto has2_tag, auto has3_tag) {
+    constexpr bool HAS1 = decltype(has1_tag)::value;   // chunk c+1 exists: refill
+    constexpr bool HAS2 = decltype(has2_tag)::value;   // chunk c+2 exists: transform
+    constexpr bool HAS3 = decltype(has3_tag)::value;   // chunk c+3 exists: x DMA
+    constexpr int ND = HAS3 ? 2 : 0, NA = HAS1 ? 2 : 0;
+    wait_a<4>(a[0], a[1]);
+    if (HAS3) stage_x((c + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (HAS2) transform_read(c & 1);
+    mfma_pair(0, 1);
+    if (HAS1) { load_a_pair(P0{}); load_v(vs1, 0); load_v(vs1, 1); }
+    __builtin_amdgcn_sched_barrier(0);
+    wait_a<2 + ND + NA>(a[2], a[3]);
+    if (HAS2) transform_write(vs2);
+    mfma_pair(2, 3);
+    if (HAS1) { load_a_pair(P1{}); load_v(vs1, 2); load_v(vs1, 3); }
+    __builtin_amdgcn_sched_barrier(0);
+    wait_a<ND + 2 * NA>(a[4], a[5]);
+    mfma_pair(4, 5);
+    if (HAS1) { load_a_pair(P2{}); load_v(vs1, 4); load_v(vs1, 5); abase += 6 * 1024; }
+    __builtin_amdgcn_sched_barrier(0);
+    // x_{c+3} (the oldest VMEM ops of this chunk) has landed, V_{c+2} is written; the six weight loads
+    // of chunk c+1 may stay in flight
+    if (HAS1) wait_vm_lgkm0<6>(); else wait_vm_lgkm0<0>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  {
+    using TT = std::true_type;
+    using FF = std::false_type;
+    int c = 0, s0 = 0;   // s0 = c % 3
+    auto nxt = [](int s) { return s == 2 ? 0 : s + 1; };
+    for (; c + 3 < nchunks; ++c) {
+      const int s1 = nxt(s0), s2 = nxt(s1);
+      chunk_body(c, s1, s2, TT{}, TT{}, TT{});
+      s0 = s1;
+    }
+    if (c + 2 < nchunks) {
+      const int s1 = nxt(s0), s2 = nxt(s1);
+      chunk_body(c, s1, s2, TT{}, TT{}, FF{});
+      s0 = s1; ++c;
+    }
+    if (c + 1 < nchunks) {
+      chunk_body(c, nxt(s0), 0, TT{}, FF{}, FF{});
+      ++c;
+    }
+    chunk_body(c, 0, 0, FF{}, FF{}, FF{});
+  }
+
+  // ---- output transform + store: lane column = quad -> frames 4q .. 4q+3
+  {
+    const int64_t Q = Q0 + li;
+    if (Q < nquads) {
+      int q;
+      const int64_t r = quad_row(Q, q);
+      const int64_t b = (r - 4 * q) / T;
+      const int t = 4 * q;
+      float* ycol = y + (b * M) * (int64_t)ldy + t;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        if (m < M) {
+          const float p12 = acc[1][e] + acc[2][e], m12 = acc[1][e] - acc[2][e];
+          const float p34 = acc[3][e] + acc[4][e], m34 = acc[3][e] - acc[4][e];
+          float o0 = acc[0][e] + p12 + p34;
+          float o1 = m12 + 2.f * m34;
+          float o2 = p12 + 4.f * p34;
+          float o3 = m12 + 8.f * m34 + acc[5][e];
+          if (bias != nullptr) {
+            const float bb = bias[m];
+            o0 += bb; o1 += bb; o2 += bb; o3 += bb;
+          }
+          if (relu) {
+            o0 = fmaxf(o0, 0.f); o1 = fmaxf(o1, 0.f); o2 = fmaxf(o2, 0.f); o3 = fmaxf(o3, 0.f);
+          }
+          float* dst = ycol + (int64_t)m * ldy;
+          if (vec4) {   // rows padded to >= 4 nq frames and 16-byte aligned: frames >= T land in the padding
+            *reinterpret_cast<float4*>(dst) = make_float4(o0, o1, o2, o3);
+          } else {
+            dst[0] = o0;
+            if (t + 1 < T) dst[1] = o1;
+            if (t + 2 < T) dst[2] = o2;
+            if (t + 3 < T) dst[3] = o3;
+          }
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+bool tspn::wino43_frag_supported(int64_t Cin, int64_t M) { return Cin > 0 && M > 0 && Cin % KC == 0 && M % 32 == 0; }
+
+extern "C" int tspn_repack_wino43_frag_f32(const float* packed6, int64_t Cin, int64_t M, float* frag,
+                                           void* stream) {
+  TSPN_REQUIRE(packed6 && frag, TSPN_EINVAL, "tspn_repack_wino43_frag_f32: null pointer");
+  TSPN_REQUIRE(packed6 != frag, TSPN_EINVAL, "tspn_repack_wino43_frag_f32: in-place repack is not possible");
+  TSPN_REQUIRE(tspn::wino43_frag_supported(Cin, M), TSPN_EUNSUPPORTED,
+               "tspn_repack_wino43_frag_f32: needs Cin %% 8 == 0 and M %% 32 == 0 (Cin=%lld M=%lld)",
+               (long long)Cin, (long long)M);
+  const int64_t total = 6 * Cin * M;
+  const int blocks = (int)std::min<int64_t>(tspn::ceil_div(total, 256), 8192);
+  hipLaunchKernelGGL(repack_wino43_frag_kernel, dim3(blocks), dim3(256), 0, TSPN_STREAM(stream), packed6, Cin, M,
+                     frag);
+  return tspn::check_launch("tspn_repack_wino43_frag_f32");
+}
+
+int tspn::conv3_tc_wino43r(const float* x, int64_t B, int64_t T, int64_t Cin, const float* frag, int64_t M,
+                           const float* bias, int relu, float* y, int64_t ldy, void* stream) {
+  TSPN_REQUIRE(B >= 0 && Cin > 0 && T > 0 && M > 0 && ldy >= T && ldy < (1 << 24), TSPN_EINVAL,
+               "tspn_conv3_tc_wino43r_f32: bad sizes B=%lld T=%lld Cin=%lld M=%lld ldy=%lld", (long long)B,
+               (long long)T, (long long)Cin, (long long)M, (long long)ldy);
+  if (B == 0) return TSPN_OK;
+  TSPN_REQUIRE(x && frag && y, TSPN_EINVAL, "tspn_conv3_tc_wino43r_f32: null pointer");
+  TSPN_REQUIRE(tspn::wino43_frag_supported(Cin, M), TSPN_EUNSUPPORTED,
+               "tspn_conv3_tc_wino43r_f32: needs Cin %% 8 == 0, M %% 32 == 0 (Cin=%lld M=%lld)", (long long)Cin,
+               (long long)M);
+  TSPN_REQUIRE((reinterpret_cast<uintptr_t>(frag) & 15) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(y) & 3) == 0,
+               TSPN_EUNSUPPORTED, "tspn_conv3_tc_wino43r_f32: x/frag must be 16-byte aligned");
+  TSPN_REQUIRE(Cin < (1 << 24) && T < (1 << 24) && M < (1 << 24), TSPN_EUNSUPPORTED,
+               "tspn_conv3_tc_wino43r_f32: dimension too large");
+  const int64_t nq = tspn::ceil_div(T, 4);
+  const int64_t nquads = B * nq;
+  const int64_t tiles_m = tspn::ceil_div(M, BM), tiles_n = tspn::ceil_div(nquads, QT);
+  TSPN_REQUIRE(tiles_m * tiles_n < (1LL << 31), TSPN_EUNSUPPORTED, "tspn_conv3_tc_wino43r_f32: grid too large");
+  const int vec4 = (ldy % 4 == 0) && (ldy >= 4 * nq) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
+  static const int gm_tiles = [] {
+    const char* e = getenv("TSPN_WINO_GM");
+    const int v = e ? atoi(e) : 2;
+    return v > 0 ? v : 2;
+  }();
+  hipLaunchKernelGGL(conv3_wino43r_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(THREADS), SMEM_BYTES,
+                     TSPN_STREAM(stream), x, frag, bias, y, (int)Cin, (int)T, (int)M, (int)nq, nquads, B * T,
+                     (int)tiles_m, (int)tiles_n, relu, (int)ldy, gm_tiles, vec4);
+  return tspn::check_launch("tspn_conv3_tc_wino43r_f32");
+}
+
+extern "C" int tspn_conv3_tc_wino43r_f32(const float* x, int64_t B, int64_t T, int64_t Cin, const float* frag,
+                                         int64_t M, const float* bias, int relu, float* y, void* stream) {
+  return tspn::conv3_tc_wino43r(x, B, T, Cin, frag, M, bias, relu, y, T, stream);
+}
