@@ -61,6 +61,9 @@ def parse():
                          "(default), F(2,3) (= winograd), direct taps")
     ap.add_argument("--workload", choices=["cfg2", "cfg3"], default="cfg2",
                     help="cfg2 = headline (N=32,T=150,D=2048, fp32); cfg3 = N=64,T=900,D=1024 bf16 operands")
+    ap.add_argument("--canonical-weights", action="store_true",
+                    help="winograd4 only: keep the canonical [6][D][2C] weights (LDS-staged kernel "
+                         "conv3_wino43_cl_kernel) instead of the fragment-major default")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the RCCL result gather even with one rank (exercises the N>1 code path)")
     return ap.parse_args()
@@ -103,8 +106,8 @@ def pmc_traffic(videos, conv):
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         data = json.load(open(path))
-        k = data["kernels"][{"winograd4": "conv3_wino43_cl_kernel", "winograd2": "conv3_wino2_cl_kernel"}.get(
-            conv, "conv3_mfma_cl_kernel")]
+        k = data["kernels"][{"winograd4": "conv3_wino43r_kernel", "winograd4c": "conv3_wino43_cl_kernel",
+                             "winograd2": "conv3_wino2_cl_kernel"}.get(conv, "conv3_mfma_cl_kernel")]
         if data["videos_per_launch"] == videos:
             return {"traffic": k["hbm_bytes"], "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE)",
                     "traffic_source": data["source"]}
@@ -154,6 +157,8 @@ def main():
             args.conv = "winograd2"
         packed = {"direct": tspn.ops.pack_conv3, "winograd2": tspn.ops.pack_conv3_wino,
                   "winograd4": tspn.ops.pack_conv3_wino43}[args.conv](conv_w, split=D)
+        if args.conv == "winograd4" and not args.canonical_weights:
+            packed = tspn.ops.repack_wino43_frag(packed)   # fragment-major: registers-direct kernel
     del conv_w
     conv_b = d(wnp["conv_b"])
     head_w = d(np.concatenate([wnp["rel_w"][:, :, 0], wnp["dur_w"][:, :, 0]]))
@@ -257,7 +262,8 @@ def main():
             "roofline": {"bound": "mfma",
                          "kernel": ("conv3_bf16_big_kernel (tracklet projections: k=3 conv as bf16 32x32x16 MFMA "
                                     "implicit GEMM, M=2C, K=3D)" if bf16 else
-                                    "conv3_wino43_cl_kernel (tracklet projections: k=3 conv, Winograd F(4,3), "
+                                    ("conv3_wino43_cl_kernel" if args.canonical_weights else "conv3_wino43r_kernel") +
+                                    " (tracklet projections: k=3 conv, Winograd F(4,3), "
                                     "fp32 32x32x2 MFMA, M=2C, 6 channel-GEMMs of K=D on a quarter of the columns)"
                                     if args.conv == "winograd4" else
                                     "conv3_wino2_cl_kernel (tracklet projections: k=3 conv, Winograd F(2,3), "
@@ -266,7 +272,8 @@ def main():
                                     "conv3_mfma_cl_kernel (tracklet projections: k=3 conv as fp32 32x32x2 "
                                     "MFMA implicit GEMM, M=2C, K=3D)"),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, **({"traffic": None} if bf16 else pmc_traffic(B, args.conv)),
+                         "frac": achieved / peak, **({"traffic": None} if bf16 else pmc_traffic(
+                             B, "winograd4c" if (args.conv == "winograd4" and args.canonical_weights) else args.conv)),
                          "direct_equivalent_tflops": conv_flop_direct / conv_avg_s / 1e12,
                          "flop_per_launch": conv_flop, "avg_launch_ms": conv_avg_s * 1e3,
                          "share_of_step": conv_avg_s / (elapsed / args.steps)},

@@ -11,9 +11,10 @@
 //   * Both operands of chunk c+1 are fetched into the registers of chunk c as soon as those are free
 //     (after the MFMAs of their position pair): weights from global memory, V from the LDS tile that was
 //     transformed one chunk earlier.  At the top of a chunk every operand is already in registers.
-//   * LDS holds only x (2 stages, LDS-DMA, issued three chunks ahead of its MFMAs) and V (3 stages):
-//     30 KB.  One bare s_barrier per chunk with a counted vmcnt (the weight loads of the next chunk stay
-//     in flight across it).
+//   * LDS holds only x (3 stages, LDS-DMA, issued four chunks ahead of its MFMAs) and V (3 stages):
+//     34 KB.  One bare s_barrier per chunk; every VMEM wait is a counted vmcnt on weight registers (the
+//     weight loads of the next chunk stay in flight across the barrier, and the in-order return of VMEM
+//     data makes the x pieces land before the weights issued after them are consumed).
 //
 // Needs M % 32 == 0 and Cin % 8 == 0 (the canonical kernel takes everything else).
 #include <algorithm>
@@ -34,7 +35,7 @@ constexpr int KC = 8;
 constexpr int SLP = 132;               // x slots per channel group (4 QT + 2 = 130 used)
 constexpr int X_ST = 2 * SLP * 4;      // floats per x stage
 constexpr int V_ST = 2 * 7 * QT * 4;   // [2 g][6 j + 1 scratch plane][32 quads][4 ch]
-constexpr int NXS = 2, NVS = 3;
+constexpr int NXS = 3, NVS = 3;
 constexpr size_t SMEM_BYTES = sizeof(float) * (NXS * X_ST + NVS * V_ST);
 
 __device__ __forceinline__ void glds16(const float* g, float* l) {
@@ -250,7 +251,8 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_wino43r_kernel(
   transform(0, 0);
   if (nchunks > 1) transform(1, 1);
   __syncthreads();
-  if (nchunks > 2) stage_x(0);
+  if (nchunks > 2) stage_x(2);
+  if (nchunks > 3) stage_x(0);
 #pragma unroll
   for (int j = 0; j < 6; ++j) load_v(0, j);
   wait_vm_lgkm0<0>();
@@ -260,34 +262,40 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_wino43r_kernel(
   abase += 6 * 1024;
   __builtin_amdgcn_sched_barrier(0);
 
-  // chunk c: MFMAs on the registers (A_c, V_c); meanwhile DMA x_{c+3}, transform x_{c+2} -> V_{c+2},
-  // and refill the registers with (A_{c+1}, V_{c+1}) position pair by position pair.
+  // chunk c: MFMAs on the registers (A_c, V_c); meanwhile DMA x_{c+4}, transform x_{c+2} -> V_{c+2},
+  // and refill the registers with (A_{c+1}, V_{c+1}) position pair by position pair.  Stage of chunk k:
+  // k % 3 for both x and V (s1 = (c+1) % 3, s2 = (c+2) % 3).
   // VMEM issue order of a steady-state chunk: [x pieces: ND] a0 a1 | a2 a3 | a4 a5; vmcnt counts are the
-  // number of YOUNGER operations at each wait (ND = 2 x pieces per wave).
-  auto chunk_body = [&](int c, int vs1, int vs2, auto has1_tag, auto has2_tag, auto has3_tag) {
+  // number of YOUNGER operations at each wait (ND = 2 x pieces per wave).  The x pieces issued in chunk
+  // c-1 are older than that chunk's weight loads, which the waits of chunk c consume: x_{c+3} has landed
+  // at the barrier that ends chunk c without a wait of its own.
+  auto chunk_body = [&](int s1, int s2, auto has1_tag, auto has2_tag, auto has4_tag) {
     constexpr bool HAS1 = decltype(has1_tag)::value;   // chunk c+1 exists: refill
     constexpr bool HAS2 = decltype(has2_tag)::value;   // chunk c+2 exists: transform
-    constexpr bool HAS3 = decltype(has3_tag)::value;   // chunk c+3 exists: x DMA
-    constexpr int ND = HAS3 ? 2 : 0, NA = HAS1 ? 2 : 0;
+    constexpr bool HAS4 = decltype(has4_tag)::value;   // chunk c+4 exists: x DMA
+    constexpr int ND = HAS4 ? 2 : 0, NA = HAS1 ? 2 : 0;
     wait_a<4>(a[0], a[1]);
-    if (HAS3) stage_x((c + 1) & 1);
+    if (HAS4) stage_x(s1);
     __builtin_amdgcn_sched_barrier(0);
-    if (HAS2) transform_read(c & 1);
+    if (HAS2) transform_read(s2);
     mfma_pair(0, 1);
-    if (HAS1) { load_a_pair(P0{}); load_v(vs1, 0); load_v(vs1, 1); }
+    if (HAS1) { load_a_pair(P0{}); load_v(s1, 0); load_v(s1, 1); }
     __builtin_amdgcn_sched_barrier(0);
     wait_a<2 + ND + NA>(a[2], a[3]);
-    if (HAS2) transform_write(vs2);
+    if (HAS2) transform_write(s2);
     mfma_pair(2, 3);
-    if (HAS1) { load_a_pair(P1{}); load_v(vs1, 2); load_v(vs1, 3); }
+    if (HAS1) { load_a_pair(P1{}); load_v(s1, 2); load_v(s1, 3); }
     __builtin_amdgcn_sched_barrier(0);
     wait_a<ND + 2 * NA>(a[4], a[5]);
     mfma_pair(4, 5);
-    if (HAS1) { load_a_pair(P2{}); load_v(vs1, 4); load_v(vs1, 5); abase += 6 * 1024; }
+    if (HAS1) { load_a_pair(P2{}); load_v(s1, 4); load_v(s1, 5); abase += 6 * 1024; }
     __builtin_amdgcn_sched_barrier(0);
-    // x_{c+3} (the oldest VMEM ops of this chunk) has landed, V_{c+2} is written; the six weight loads
-    // of chunk c+1 may stay in flight
-    if (HAS1) wait_vm_lgkm0<6>(); else wait_vm_lgkm0<0>();
+    // V_{c+2} is written (and every LDS read of this chunk has returned) before the barrier
+#if defined(TSPN_W43R_ABL_NOALOAD)
+    wait_vm_lgkm0<0>();
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -296,21 +304,21 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_wino43r_kernel(
     using FF = std::false_type;
     int c = 0, s0 = 0;   // s0 = c % 3
     auto nxt = [](int s) { return s == 2 ? 0 : s + 1; };
-    for (; c + 3 < nchunks; ++c) {
-      const int s1 = nxt(s0), s2 = nxt(s1);
-      chunk_body(c, s1, s2, TT{}, TT{}, TT{});
+    for (; c + 4 < nchunks; ++c) {
+      const int s1 = nxt(s0);
+      chunk_body(s1, nxt(s1), TT{}, TT{}, TT{});
       s0 = s1;
     }
-    if (c + 2 < nchunks) {
-      const int s1 = nxt(s0), s2 = nxt(s1);
-      chunk_body(c, s1, s2, TT{}, TT{}, FF{});
-      s0 = s1; ++c;
+    for (; c + 2 < nchunks; ++c) {
+      const int s1 = nxt(s0);
+      chunk_body(s1, nxt(s1), TT{}, TT{}, FF{});
+      s0 = s1;
     }
     if (c + 1 < nchunks) {
-      chunk_body(c, nxt(s0), 0, TT{}, FF{}, FF{});
+      chunk_body(nxt(s0), 0, TT{}, FF{}, FF{});
       ++c;
     }
-    chunk_body(c, 0, 0, FF{}, FF{}, FF{});
+    chunk_body(0, 0, FF{}, FF{}, FF{});
   }
 
   // ---- output transform + store: lane column = quad -> frames 4q .. 4q+3

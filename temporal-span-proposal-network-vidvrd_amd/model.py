@@ -273,8 +273,14 @@ class DPN(nn.Module):
         c = self.dpn_head.conv
         half = self.dpn_head.in_channels // 2
         if winograd == 4:
-            return self._cache.get("conv_split_wino43", (c.weight, c.bias), dev,
-                                   lambda ts: (ops.pack_conv3_wino43(ts[0], split=half), ts[1]))
+            def build43(ts):
+                # fragment-major weights select the registers-direct kernel (tspn_wino43r.hip); shapes it
+                # does not take (2C % 32 != 0) keep the canonical layout and kernel
+                p6 = ops.pack_conv3_wino43(ts[0], split=half)
+                if p6.shape[1] % 8 == 0 and p6.shape[2] % 32 == 0:
+                    p6 = ops.repack_wino43_frag(p6)
+                return p6, ts[1]
+            return self._cache.get("conv_split_wino43", (c.weight, c.bias), dev, build43)
         if winograd:
             return self._cache.get("conv_split_wino", (c.weight, c.bias), dev,
                                    lambda ts: (ops.pack_conv3_wino(ts[0], split=half), ts[1]))

@@ -620,3 +620,66 @@ def test_conv3_algorithms_error_at_headline_depth(tspn, device):
     print("conv3 max abs error vs float64 (|y| max %.3f):" % scale, {k: "%.2e" % v for k, v in err.items()})
     assert err["F(2,3)"] <= 1.5 * err["direct"]
     assert err["F(4,3)"] <= 4.0 * err["direct"] and err["F(4,3)"] <= 3e-5
+
+
+@pytest.mark.parametrize("B,Cin,T,M", [(1, 8, 1, 32), (2, 8, 5, 32), (3, 16, 30, 128), (5, 24, 33, 160),
+                                       (7, 64, 150, 64), (2, 136, 257, 288), (40, 32, 30, 96), (3, 16, 7, 32),
+                                       (33, 48, 13, 128), (1, 8, 4, 32)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_conv3_winograd43_fragment_major_kernel(tspn, device, B, Cin, T, M, relu):
+    """Registers-direct F(4,3) kernel (fragment-major weights, tspn_wino43r.hip): the repacked layout is
+    the documented permutation of the canonical one, the result is BIT-IDENTICAL to the canonical kernel
+    (same contraction order) for 1, 2, 3 and many K chunks, ragged T, partial weight / quad tiles, and
+    within the F(4,3) tolerance of the fp64 conv."""
+    x = tspn.hashrng.uniform(49, "x", (B, T, Cin), -1, 1)
+    w = tspn.hashrng.normal(49, "w", (M, Cin, 3), std=0.1)
+    b = tspn.hashrng.normal(49, "b", (M,), std=0.1)
+    p6 = tspn.ops.pack_conv3_wino43(t(w).to(device))
+    fr = tspn.ops.repack_wino43_frag(p6)
+    assert tuple(fr.shape) == (M // 32, Cin // 8, 6, 64, 4) and tspn.ops.wino43_frag_dims(fr) == (Cin, M)
+    # frag[mb][c][j][32 kh + li][e] = packed6[j][8 c + 4 kh + e][32 mb + li]
+    want = p6.cpu().numpy().reshape(6, Cin // 8, 2, 4, M // 32, 32).transpose(4, 1, 0, 2, 5, 3)
+    np.testing.assert_array_equal(fr.cpu().numpy().reshape(M // 32, Cin // 8, 6, 2, 32, 4), want)
+    for bias in (t(b).to(device), None):
+        y0 = tspn.ops.conv3_tc_wino43(t(x).to(device), p6, bias, relu=relu)
+        y1 = tspn.ops.conv3_tc_wino43r(t(x).to(device), fr, bias, relu=relu)
+        assert torch.equal(y0, y1)
+    ref = conv_ref(np.ascontiguousarray(x.transpose(0, 2, 1)), w, b, relu)
+    y = tspn.ops.conv3_tc_wino43r(t(x).to(device), fr, t(b).to(device), relu=relu)
+    np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=0, atol=6e-5)
+
+
+def test_conv3_winograd43_fragment_major_errors(tspn, device):
+    """Shapes the fragment-major kernel does not take are refused (loudly), not silently mis-tiled."""
+    p6 = torch.zeros((6, 8, 36), device=device)
+    with pytest.raises(ValueError):
+        tspn.ops.repack_wino43_frag(p6)                              # M % 32 != 0
+    with pytest.raises(ValueError):
+        tspn.ops.repack_wino43_frag(torch.zeros((6, 12, 32), device=device))   # Cin % 8 != 0
+    rc = tspn._abi.lib().tspn_repack_wino43_frag_f32(p6.data_ptr(), 8, 36, p6.data_ptr(), None)
+    assert rc != 0 and "tspn_repack_wino43_frag_f32" in tspn._abi.lib().tspn_last_error().decode()
+    fr = tspn.ops.repack_wino43_frag(torch.zeros((6, 16, 64), device=device))
+    with pytest.raises(ValueError):
+        tspn.ops.conv3_tc_wino43r(torch.zeros((2, 9, 8), device=device), fr)   # Cin mismatch
+    y = tspn.ops.conv3_tc_wino43r(torch.zeros((0, 9, 16), device=device), fr)   # empty batch
+    assert y.shape == (0, 64, 9)
+
+
+@pytest.mark.parametrize("B,N,T,D", [(2, 5, 30, 16), (1, 9, 33, 32), (3, 4, 150, 48)])
+def test_fused_fragment_major_equals_canonical(tspn, device, B, N, T, D):
+    """tspn_forward_fused_f32 with conv_algo 3 (fragment-major F(4,3) weights) == conv_algo 2, bit for bit."""
+    _, w = make_w(tspn, 50, D)
+    feats = torch.cat([t(tspn.synth.make_video(60 + b, N, T, D)["tracklet_feats"]) for b in range(B)])
+    pairs = torch.cat([oracle.pair_index(N) + b * N for b in range(B)])
+    d = lambda v: v.to(device).contiguous()
+    p6 = tspn.ops.pack_conv3_wino43(d(w["conv_w"]), split=D)
+    hw = d(torch.cat([w["rel_w"][:, :, 0], w["dur_w"][:, :, 0]]))
+    hb = d(torch.cat([w["rel_b"], w["dur_b"]]))
+    outs = []
+    for packed in (p6, tspn.ops.repack_wino43_frag(p6)):
+        outs.append(tspn.ops.forward_fused(d(feats), d(pairs), B, N, packed, d(w["conv_b"]), hw, hb,
+                                           d(w["cls_w"]), d(w["cls_b"]), canonical_pairs=True))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    with pytest.raises(ValueError):   # weights for another D
+        tspn.ops.forward_fused(d(feats), d(pairs), B, N, tspn.ops.repack_wino43_frag(
+            torch.zeros((6, 2 * D, 8 * D), device=device)), d(w["conv_b"]), hw, hb, d(w["cls_w"]), d(w["cls_b"]))
