@@ -11,10 +11,13 @@
 //   * Both operands of chunk c+1 are fetched into the registers of chunk c as soon as those are free
 //     (after the MFMAs of their position pair): weights from global memory, V from the LDS tile that was
 //     transformed one chunk earlier.  At the top of a chunk every operand is already in registers.
-//   * LDS holds only x (3 stages, LDS-DMA, issued four chunks ahead of its MFMAs) and V (3 stages):
-//     34 KB.  One bare s_barrier per chunk; every VMEM wait is a counted vmcnt on weight registers (the
-//     weight loads of the next chunk stay in flight across the barrier, and the in-order return of VMEM
-//     data makes the x pieces land before the weights issued after them are consumed).
+//   * x arrives in SUPER-STAGES of 32 channels (four chunks) with row-major LDS rows [slot][8 groups + pad],
+//     so that a DMA piece covers whole 128-byte lines of x (59 consecutive 16-byte units = 6.5 rows) instead
+//     of 64 quarter-used lines: five pieces per wave, issued as one burst every fourth chunk, more than a
+//     super-stage ahead of their first use (2 buffers).  One bare s_barrier per chunk; every VMEM wait is a
+//     counted vmcnt on weight registers (the weight loads of the next chunk stay in flight across the
+//     barrier, and the in-order return of VMEM data makes the x pieces land before the weights issued
+//     after them are consumed).  LDS: x 2 x 19 KB + V 3 x 7 KB = 59 KB.
 //
 // Needs M % 32 == 0 and Cin % 8 == 0 (the canonical kernel takes everything else).
 #include <algorithm>
@@ -32,11 +35,14 @@ constexpr int THREADS = 256;
 constexpr int BM = 128;
 constexpr int QT = 32;                 // quads per workgroup
 constexpr int KC = 8;
-constexpr int SLP = 132;               // x slots per channel group (4 QT + 2 = 130 used)
-constexpr int X_ST = 2 * SLP * 4;      // floats per x stage
+constexpr int NSLOT = 4 * QT + 2;      // frame rows of the x tile (one halo row on each side)
+constexpr int XROW = 9;                // 16-byte units per row of an x super-stage: 8 channel groups + 1 pad
+constexpr int XS_UNITS = NSLOT * XROW; // 1170
+constexpr int XP_UNITS = 59;           // units per DMA piece: 20 pieces (5 per wave) cover 1180 >= 1170
+constexpr int XS_ST = 20 * XP_UNITS * 4 + 32;   // floats per super-stage buffer
 constexpr int V_ST = 2 * 7 * QT * 4;   // [2 g][6 j + 1 scratch plane][32 quads][4 ch]
-constexpr int NXS = 3, NVS = 3;
-constexpr size_t SMEM_BYTES = sizeof(float) * (NXS * X_ST + NVS * V_ST);
+constexpr int NXS = 2, NVS = 3;
+constexpr size_t SMEM_BYTES = sizeof(float) * (NXS * XS_ST + NVS * V_ST);
 
 __device__ __forceinline__ void glds16(const float* g, float* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -84,7 +90,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_wino43r_kernel(
     int tiles_n, int relu, int ldy, int GM, int vec4) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* Xs = reinterpret_cast<float*>(smem_raw);
-  float* Vs = Xs + NXS * X_ST;
+  float* Vs = Xs + NXS * XS_ST;
 
   // workgroup -> tile: bijective XCD remap, then groups of GM weight panels x all quad tiles
   const int nwg = gridDim.x;
@@ -125,31 +131,34 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_wino43r_kernel(
     abase = reinterpret_cast<const char*>(Wf) + (int64_t)mb * nchunks * (6 * 64 * 16);
   }
 
-  // ---- x tile DMA: unit u = (channel group g, slot), 2 x 130 valid units.  Piece 0 of wave w = units
-  // [64 w, 64 w + 64); piece 1 = two of the last six units (256 + 2 (w % 3) + lane, lanes 0 and 1; wave 3
-  // repeats wave 0's) -- so EVERY wave issues exactly two pieces per chunk and the counted waits below are
-  // the same for all waves.
-  const float* bsrc[2];
-  bool bval[2];
-  int bunit[2];
-  bunit[0] = 64 * wave;
-  bunit[1] = 256 + 2 * (wave == 3 ? 0 : wave);
+  // ---- x super-stage DMA.  Unit U of a buffer = (slot = U / 9, group g = U % 9; g == 8 is padding);
+  // piece pg = 5 wave + k holds units [59 pg, 59 pg + 59) in lanes 0..58.  Every piece has valid lanes for
+  // every super-stage (also a last one with fewer than 8 channel groups), so each wave issues exactly
+  // five pieces per burst and the counted waits below are the same for all waves.
+  const int ngroups = Cin >> 2;                  // 4-channel groups in a row of x
+  const int nsuper = (ngroups + 7) >> 3;         // super-stages (the last may be partial)
+  const float* bptr[5];
+  int bgrp[5];                                   // channel group of the lane's unit (99 = never valid)
 #pragma unroll
-  for (int qq = 0; qq < 2; ++qq) {
-    const int u = bunit[qq] + lane;
-    const int g = u / SLP, slot = u - g * SLP;
-    bval[qq] = u < 2 * SLP && slot < 4 * QT + 2 && (qq == 0 || lane < 2);
+  for (int k = 0; k < 5; ++k) {
+    const int U = XP_UNITS * (5 * wave + k) + lane;
+    const int slot = U / XROW, g = U - slot * XROW;
+    const bool ok = lane < XP_UNITS && slot < NSLOT && g < 8;
+    bgrp[k] = ok ? g : 99;
     int64_t n = row0 + slot;
     n = n < 0 ? 0 : (n < ncols ? n : ncols - 1);
-    bsrc[qq] = x + n * Cin + 4 * (g < 2 ? g : 0);
+    bptr[k] = x + n * Cin + 4 * (ok ? g : 0);
   }
-  auto stage_x = [&](int buf) {
+  auto stage_burst = [&](int S) {                // super-stage S -> buffer S & 1
+    const int glim = min(8, ngroups - 8 * S);
+    float* dst = Xs + (S & 1) * XS_ST + XP_UNITS * 5 * wave * 4;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
 #if !defined(TSPN_W43R_ABL_NODMA)
-    if (bval[0]) glds16(bsrc[0], Xs + buf * X_ST + bunit[0] * 4);
-    if (bval[1]) glds16(bsrc[1], Xs + buf * X_ST + bunit[1] * 4);
+      if (bgrp[k] < glim) glds16(bptr[k], dst + XP_UNITS * k * 4);
 #endif
-    bsrc[0] += KC;
-    bsrc[1] += KC;
+      bptr[k] += 32;
+    }
   };
 
   // ---- transform item of this thread: quad tk, channel group tg; wave = part (V0 | V5 | V1,V2 | V3,V4);
@@ -182,14 +191,15 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_wino43r_kernel(
   // two phases, so that the LDS reads of the x tile fly under the MFMAs that precede the arithmetic:
   // part p reads d[i]: V0: d0,d2,d4 | V5: d1,d3,d5 | V1,V2 and V3,V4: d1,d2,d3,d4
   f32x4 td[4];
-  auto transform_read = [&](int xbuf) {
+  auto transform_read = [&](int c2) {           // x of chunk c2: super-stage c2 / 4, channel groups 2 (c2 % 4) + tg
 #if defined(TSPN_W43R_ABL_NOXFORM)
     return;
 #endif
-    const float* xp = Xs + xbuf * X_ST + (tg * SLP + tslot) * 4;
-    auto D = [&](int i) { return *reinterpret_cast<const f32x4*>(xp + 4 * i); };
+    const float* xp = Xs + ((c2 >> 2) & 1) * XS_ST + (tslot * XROW + 2 * (c2 & 3) + tg) * 4;
+    auto D = [&](int i) { return *reinterpret_cast<const f32x4*>(xp + 4 * XROW * i); };
     if (wave < 2) {
       td[0] = D(wave); td[1] = D(wave + 2); td[2] = D(wave + 4);
+      td[3] = f32x4{0.f, 0.f, 0.f, 0.f};   // (defined on every path: no loop-carried copy of stale registers)
     } else {
       td[0] = D(4); td[1] = D(2); td[2] = D(1); td[3] = D(3);
     }
@@ -212,7 +222,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_wino43r_kernel(
       *reinterpret_cast<f32x4*>(vp + (j + 1) * QT * 4) = sv + rv;
     }
   };
-  auto transform = [&](int xbuf, int vst) { transform_read(xbuf); transform_write(vst); };
+  auto transform = [&](int c2, int vst) { transform_read(c2); transform_write(vst); };
 
   f32x16 acc[6];
 #pragma unroll
@@ -237,22 +247,26 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_wino43r_kernel(
   using P1 = std::integral_constant<int, 1>;
   using P2 = std::integral_constant<int, 2>;
   auto mfma_pair = [&](int ja, int jb) {
+#if defined(TSPN_W43R_SETPRIO)
+    __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       acc[ja] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ja][e], v[ja][e], acc[ja], 0, 0, 0);
       acc[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jb][e], v[jb][e], acc[jb], 0, 0, 0);
     }
+#if defined(TSPN_W43R_SETPRIO)
+    __builtin_amdgcn_s_setprio(0);
+#endif
   };
 
-  // ---- prologue: A_0 and V_0 in registers, V_1 in LDS, x_2 landed
-  stage_x(0);
-  if (nchunks > 1) stage_x(1);
+  // ---- prologue: x super-stages 0 and 1 landed, V_0 in registers, V_1 in LDS, A_0 in flight
+  stage_burst(0);
+  if (nsuper > 1) stage_burst(1);
   __syncthreads();
   transform(0, 0);
   if (nchunks > 1) transform(1, 1);
   __syncthreads();
-  if (nchunks > 2) stage_x(2);
-  if (nchunks > 3) stage_x(0);
 #pragma unroll
   for (int j = 0; j < 6; ++j) load_v(0, j);
   wait_vm_lgkm0<0>();
@@ -262,22 +276,23 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_wino43r_kernel(
   abase += 6 * 1024;
   __builtin_amdgcn_sched_barrier(0);
 
-  // chunk c: MFMAs on the registers (A_c, V_c); meanwhile DMA x_{c+4}, transform x_{c+2} -> V_{c+2},
-  // and refill the registers with (A_{c+1}, V_{c+1}) position pair by position pair.  Stage of chunk k:
-  // k % 3 for both x and V (s1 = (c+1) % 3, s2 = (c+2) % 3).
-  // VMEM issue order of a steady-state chunk: [x pieces: ND] a0 a1 | a2 a3 | a4 a5; vmcnt counts are the
-  // number of YOUNGER operations at each wait (ND = 2 x pieces per wave).  The x pieces issued in chunk
-  // c-1 are older than that chunk's weight loads, which the waits of chunk c consume: x_{c+3} has landed
-  // at the barrier that ends chunk c without a wait of its own.
-  auto chunk_body = [&](int s1, int s2, auto has1_tag, auto has2_tag, auto has4_tag) {
+  // chunk c: MFMAs on the registers (A_c, V_c); meanwhile transform x_{c+2} -> V_{c+2}, refill the
+  // registers with (A_{c+1}, V_{c+1}) position pair by position pair, and -- in the third chunk of a
+  // super-stage S -- issue the DMA burst of super-stage S+2 into the buffer S has just left (its last
+  // read was the transform of chunk 4S+3 during chunk 4S+1).  V stage of chunk k: k % 3.
+  // VMEM issue order of a chunk: [x pieces: ND] a0 a1 | a2 a3 | a4 a5; vmcnt counts are the number of
+  // YOUNGER operations at each wait.  The burst is older than the weight loads of its chunk, which the
+  // next chunk consumes: it has landed long before its first reader (4 chunks later) without a wait of
+  // its own.
+  auto chunk_body = [&](int c, int s1, int s2, auto has1_tag, auto has2_tag, auto burst_tag) {
     constexpr bool HAS1 = decltype(has1_tag)::value;   // chunk c+1 exists: refill
     constexpr bool HAS2 = decltype(has2_tag)::value;   // chunk c+2 exists: transform
-    constexpr bool HAS4 = decltype(has4_tag)::value;   // chunk c+4 exists: x DMA
-    constexpr int ND = HAS4 ? 2 : 0, NA = HAS1 ? 2 : 0;
+    constexpr bool BURST = decltype(burst_tag)::value; // c = 4S+2 and super-stage S+2 exists
+    constexpr int ND = BURST ? 5 : 0, NA = HAS1 ? 2 : 0;
     wait_a<4>(a[0], a[1]);
-    if (HAS4) stage_x(s1);
+    if (BURST) stage_burst((c >> 2) + 2);
     __builtin_amdgcn_sched_barrier(0);
-    if (HAS2) transform_read(s2);
+    if (HAS2) transform_read(c + 2);
     mfma_pair(0, 1);
     if (HAS1) { load_a_pair(P0{}); load_v(s1, 0); load_v(s1, 1); }
     __builtin_amdgcn_sched_barrier(0);
@@ -290,11 +305,14 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_wino43r_kernel(
     mfma_pair(4, 5);
     if (HAS1) { load_a_pair(P2{}); load_v(s1, 4); load_v(s1, 5); abase += 6 * 1024; }
     __builtin_amdgcn_sched_barrier(0);
-    // V_{c+2} is written (and every LDS read of this chunk has returned) before the barrier
 #if defined(TSPN_W43R_ABL_NOALOAD)
     wait_vm_lgkm0<0>();
 #else
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // LDS operations return in order: behind the transform's ds_writes only the four refill reads of
+    // positions 2..5 were issued, and those may stay in flight across the barrier (their stage is not
+    // rewritten before the barrier after next)
+    if (HAS1) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -304,21 +322,26 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_wino43r_kernel(
     using FF = std::false_type;
     int c = 0, s0 = 0;   // s0 = c % 3
     auto nxt = [](int s) { return s == 2 ? 0 : s + 1; };
-    for (; c + 4 < nchunks; ++c) {
-      const int s1 = nxt(s0);
-      chunk_body(s1, nxt(s1), TT{}, TT{}, TT{});
-      s0 = s1;
+    // super-stages whose four chunks are all steady state and that are followed by two more
+    for (int S = 0; S + 2 < nsuper; ++S) {
+      int s1 = nxt(s0), s2 = nxt(s1);
+      chunk_body(c, s1, s2, TT{}, TT{}, FF{});
+      chunk_body(c + 1, s2, s0, TT{}, TT{}, FF{});
+      chunk_body(c + 2, s0, s1, TT{}, TT{}, TT{});
+      chunk_body(c + 3, s1, s2, TT{}, TT{}, FF{});
+      c += 4;
+      s0 = s1;       // (c + 4) % 3 = (c + 1) % 3
     }
     for (; c + 2 < nchunks; ++c) {
       const int s1 = nxt(s0);
-      chunk_body(s1, nxt(s1), TT{}, TT{}, FF{});
+      chunk_body(c, s1, nxt(s1), TT{}, TT{}, FF{});
       s0 = s1;
     }
     if (c + 1 < nchunks) {
-      chunk_body(nxt(s0), 0, TT{}, FF{}, FF{});
+      chunk_body(c, nxt(s0), 0, TT{}, FF{}, FF{});
       ++c;
     }
-    chunk_body(0, 0, FF{}, FF{}, FF{});
+    chunk_body(c, 0, 0, FF{}, FF{}, FF{});
   }
 
   // ---- output transform + store: lane column = quad -> frames 4q .. 4q+3

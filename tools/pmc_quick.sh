@@ -1,25 +1,21 @@
 #!/bin/bash
-# usage: tools/pmc_quick.sh <outdir> <counter-set>... -- <python args>   (each set is one rocprofv3 --pmc pass)
-export TMPDIR=/tmp
-out=$1; shift
-sets=()
-while [ "$1" != "--" ]; do sets+=("$1"); shift; done
-shift
-i=0
-for s in "${sets[@]}"; do
-  d=$out/p$i; mkdir -p $d
-  rocprofv3 --pmc $s --output-format csv -d $d -- python3 "$@" > $d/log.txt 2>&1
-  f=$(find $d -name "*counter_collection.csv" | head -1)
-  python3 - "$f" <<'PY'
-import csv, sys, collections, re
-agg = collections.defaultdict(list)
-for r in csv.DictReader(open(sys.argv[1])):
+# One rocprofv3 --pmc pass (no tracing flags besides the implied kernel dispatch records):
+#   tools/pmc_quick.sh OUTDIR "CTR1 CTR2 ..." -- script.py args...
+# prints the per-kernel average of every counter.  Run from the repo root on the GPU box.
+set -e
+OUT=$1; CTRS=$2; shift 3
+cd /tmp && export TMPDIR=/tmp
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+rm -rf $ROOT/$OUT; mkdir -p $ROOT/$OUT
+( cd $ROOT && rocprofv3 --pmc $CTRS --output-format csv -d $ROOT/$OUT -- python3 "$@" > $ROOT/$OUT/run.log 2>&1 )
+python3 - "$ROOT/$OUT" <<'PY'
+import collections, csv, glob, os, re, sys
+f = max(glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open(f)):
     m = re.search(r"([A-Za-z0-9_]+)(<[^>]*>)?\(", r["Kernel_Name"])
-    k = (m.group(1) + (m.group(2) or "")) if m else r["Kernel_Name"][:40]
-    agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
-for (k, c), v in sorted(agg.items()):
-    if ("conv3" in k or "heads" in k) and "pack" not in k:
-        print(f"{k:45s} {c:38s} n={len(v):3d} avg={sum(v)/len(v):.4g}")
+    k = (m.group(1) + (m.group(2) or "")) if m else r["Kernel_Name"][:50]
+    agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, d in sorted(agg.items()):
+    print(k, {c: "%.4g (n=%d)" % (sum(v) / len(v), len(v)) for c, v in sorted(d.items())})
 PY
-  i=$((i+1))
-done
