@@ -314,7 +314,9 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_wino43r_kernel(
     if (HAS1) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
+#if !defined(TSPN_W43R_ABL_NOBARRIER)    // timing probe only
     __builtin_amdgcn_s_barrier();
+#endif
     __builtin_amdgcn_sched_barrier(0);
   };
   {
