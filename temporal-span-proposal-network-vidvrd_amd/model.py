@@ -12,7 +12,8 @@ Differences from the reference, all in code the reference cannot execute:
   * USE_DPN=True: the reference raises NameError (relpn/dpn.py:24-28).  Here the
     temporal branch runs: pair builder -> temporal encoder -> relationness +
     span-regression heads, RelOIPool over the segment, predicate head
-    (semantics frozen in DESIGN.md §2).
+    (semantics frozen in DESIGN.md §2); in train mode it returns the loss the
+    reference intended (`loss_duration`, relpn/dpn.py:40-49).
   * `relness_pred` (relpn/dpn_anchor.py:88-90) is an extra parameter; reference
     checkpoints that lack it still load (see DPNHead._load_from_state_dict).
 There is no CPU execution path: without the HIP library or a HIP device,
@@ -50,6 +51,19 @@ def _f32(t, device):
     return t.to(device=device, dtype=torch.float32).contiguous()
 
 
+def _segment_pairs(plist, n, device):
+    """int64 [P,2] pair table of a tracklet segment: its 'tracklet_pairs' field or all ordered pairs."""
+    if plist.has_field("tracklet_pairs") and plist.get_field("tracklet_pairs") is not None:
+        p = plist.get_field("tracklet_pairs")
+        p = (p.detach() if isinstance(p, torch.Tensor) else torch.as_tensor(np.asarray(p))).long().to(device)
+        if p.dim() != 2 or p.shape[1] != 2:
+            raise ValueError("tracklet_pairs must be [P,2]")
+        if p.numel() and (int(p.min()) < 0 or int(p.max()) >= n):
+            raise IndexError("tracklet_pairs index out of range")
+        return p.contiguous()
+    return ops.pair_index(n, device)
+
+
 class _DeviceCache:
     """Device-resident (and packed) copies of parameters, refreshed when a parameter changes."""
 
@@ -84,6 +98,80 @@ class _PredicateHeadFn(torch.autograd.Function):
         x, w, out = ctx.saved_tensors
         gz = g * out * (1.0 - out)
         return gz @ w, gz.t() @ x, gz.sum(0)
+
+
+def _conv3_weight_grad(x_cf, dz):
+    """dL/dW of y = Conv1d(k=3, padding=1)(x): W[m, c, k] += sum_{n,t} dz[n, m, t] x[n, c, t + k - 1]
+    (three plain GEMMs on shifted views; x_cf [R, Cin, T], dz [R, M, T])."""
+    xp = F.pad(x_cf, (1, 1))
+    t = x_cf.shape[2]
+    return torch.stack([torch.einsum("nmt,nct->mc", dz, xp[:, :, k:k + t]) for k in range(3)], dim=2)
+
+
+class _TemporalHeadsDenseFn(torch.autograd.Function):
+    """DPNHead on a materialised x [P,C,T] (reference relpn/dpn.py:69-73) for training: HIP forward
+    (tspn_temporal_encoder_heads_f32); backward recomputes the encoder activation with the HIP conv and
+    uses plain torch GEMMs (training is outside the measured path, like _PredicateHeadFn)."""
+
+    @staticmethod
+    def forward(ctx, x, conv_w, conv_b, head_w, head_b):
+        heads = ops.temporal_encoder_heads(x, ops.pack_conv3(conv_w), conv_b, head_w, head_b)
+        ctx.save_for_backward(x, conv_w, conv_b, head_w)
+        return heads
+
+    @staticmethod
+    def backward(ctx, g):
+        x, conv_w, conv_b, head_w = ctx.saved_tensors
+        g = g.contiguous()
+        act = ops.conv3(x, ops.pack_conv3(conv_w), conv_b, relu=True)          # relu(conv(x) + b) [P,C,T]
+        dz = torch.einsum("hc,pht->pct", head_w, g) * (act > 0)
+        d_head_w = torch.einsum("pht,pct->hc", g, act)
+        dx = torch.nn.grad.conv1d_input(x.shape, conv_w, dz, padding=1) if ctx.needs_input_grad[0] else None
+        return dx, _conv3_weight_grad(x, dz), dz.sum((0, 2)), d_head_w, g.sum((0, 2))
+
+
+class _TemporalHeadsTrackletFn(torch.autograd.Function):
+    """Factorised pair encoder + heads on tracklet tensors for training.  Forward: the HIP
+    projections U‖V (tspn_conv3_tc_f32 on the split-packed weight) and the indexed pair stage
+    (tspn_heads_f32).  Backward: dZ_p = (head_w^T g_p) . [relu(U[s]+V[o]) > 0] per block of pairs,
+    scattered back onto dU[s], dV[o]; the conv weight gradient is then a per-TRACKLET contraction (the
+    same N-1 saving as the forward)."""
+
+    PAIR_BLOCK = 256
+
+    @staticmethod
+    def forward(ctx, feats, pairs, conv_w, conv_b, head_w, head_b):
+        d = feats.shape[2]
+        c = 2 * d
+        bias2 = torch.cat([conv_b, torch.zeros_like(conv_b)])
+        y = ops.conv3_tc(feats, ops.pack_conv3(conv_w, split=d), bias2)          # [NT, 2C, T]
+        s, o = pairs[:, 0].contiguous(), pairs[:, 1].contiguous()
+        heads = ops.heads(y[:, :c].contiguous(), head_w, head_b, b=y[:, c:].contiguous(), ia=s, ib=o)
+        ctx.save_for_backward(feats, pairs, conv_w, conv_b, head_w)
+        return heads
+
+    @staticmethod
+    def backward(ctx, g):
+        feats, pairs, conv_w, conv_b, head_w = ctx.saved_tensors
+        g = g.contiguous()
+        d = feats.shape[2]
+        c = 2 * d
+        bias2 = torch.cat([conv_b, torch.zeros_like(conv_b)])
+        y = ops.conv3_tc(feats, ops.pack_conv3(conv_w, split=d), bias2)
+        u, v = y[:, :c], y[:, c:]
+        du, dv = torch.zeros_like(u), torch.zeros_like(v)
+        d_head_w = torch.zeros_like(head_w)
+        for lo in range(0, pairs.shape[0], _TemporalHeadsTrackletFn.PAIR_BLOCK):
+            blk = slice(lo, lo + _TemporalHeadsTrackletFn.PAIR_BLOCK)
+            s, o, gb = pairs[blk, 0], pairs[blk, 1], g[blk]
+            act = torch.relu(u[s] + v[o])
+            dz = torch.einsum("hc,pht->pct", head_w, gb) * (act > 0)
+            d_head_w += torch.einsum("pht,pct->hc", gb, act)
+            du.index_add_(0, s, dz)
+            dv.index_add_(0, o, dz)
+        x_cf = feats.transpose(1, 2)
+        d_conv_w = torch.cat([_conv3_weight_grad(x_cf, du), _conv3_weight_grad(x_cf, dv)], dim=1)
+        return None, None, d_conv_w, du.sum((0, 2)), d_head_w, g.sum((0, 2))
 
 
 class RelationPredictor(nn.Module):
@@ -315,11 +403,58 @@ class DPN(nn.Module):
             out.append(self._wrap(ops.temporal_encoder_heads(_f32(f, dev), packed, cbias, hw, hb)))
         return out
 
+    def _train_heads(self, plist):
+        """Heads [P,3A,T] of one segment with autograd onto the DPNHead parameters."""
+        h = self.dpn_head
+        if not h.conv.weight.is_cuda:
+            raise RuntimeError("training needs the model on the HIP device (model.cuda())")
+        dev = h.conv.weight.device
+        rw, rb, dw, db = h.head_params()
+        head_w = torch.cat([rw[:, :, 0], dw[:, :, 0]], dim=0)
+        head_b = torch.cat([rb, db])
+        if plist.has_field("tracklet_feats"):
+            f = _f32(plist.get_field("tracklet_feats"), dev)
+            if 2 * f.shape[2] != h.in_channels:
+                raise ValueError(f"tracklet_feats dim D={f.shape[2]} needs RELPN.DPN.IN_CHANNELS = 2*D")
+            return _TemporalHeadsTrackletFn.apply(f, _segment_pairs(plist, f.shape[0], dev), h.conv.weight,
+                                                  h.conv.bias, head_w, head_b)
+        x = plist.features
+        if x.dim() != 3:
+            raise ValueError("RELPN.USE_DPN=True needs temporal inputs: PairList.features [P,C,T] or the "
+                             "field 'tracklet_feats' [N,T,D] (the reference raises NameError here, "
+                             "relpn/dpn.py:24-28)")
+        return _TemporalHeadsDenseFn.apply(_f32(x, dev), h.conv.weight, h.conv.bias, head_w, head_b)
+
+    def _forward_train(self, pair_list, target_list):
+        """The reference's intent (relpn/dpn.py:40-49; its own code raises NameError):
+        duration_proposals = dpn_head(pair feats); loss_duration = BCEWithLogits(duration_proposals,
+        target.get_field('duration')), summed over the segments like loss_rel (model.py:62-64).  A target
+        field 'relness' [P,A,T], when present, adds `loss_relationness` on the relationness head (loss name
+        from relpn/dpn_anchor.py:62-65)."""
+        if target_list is None:
+            raise ValueError("DPN training needs target_list with a 'duration' field [P,2A,T]")
+        props, loss_dur, loss_rel = [], 0, None
+        for plist, tlist in zip(pair_list, target_list):
+            tp = self._wrap(self._train_heads(plist))
+            gt = tlist.get_field("duration")
+            gt = (gt if isinstance(gt, torch.Tensor) else torch.as_tensor(np.asarray(gt))).to(tp.duration)
+            if gt.shape != tp.duration.shape:
+                raise ValueError(f"target field 'duration' must be [P,2A,T] = {tuple(tp.duration.shape)}, "
+                                 f"got {tuple(gt.shape)}")
+            loss_dur = loss_dur + F.binary_cross_entropy_with_logits(tp.duration, gt)
+            if tlist.has_field("relness"):
+                gr = tlist.get_field("relness")
+                gr = (gr if isinstance(gr, torch.Tensor) else torch.as_tensor(np.asarray(gr))).to(tp.relness)
+                loss_rel = (0 if loss_rel is None else loss_rel) + F.binary_cross_entropy_with_logits(tp.relness, gr)
+            props.append(tp)
+        losses = {"loss_duration": loss_dur}
+        if loss_rel is not None:
+            losses["loss_relationness"] = loss_rel
+        return props, losses
+
     def forward(self, pair_list, target_list=None):
         if self.training:
-            raise NotImplementedError(
-                "training the temporal (DPN) branch is outside the hot-path scope of this build "
-                "(the reference's own DPN training path raises NameError, relpn/dpn.py:24-28)")
+            return self._forward_train(pair_list, target_list)
         return self.forward_dense([plist.features for plist in pair_list]), {}
 
 
@@ -381,6 +516,11 @@ class BaseModel(nn.Module):
         if self.use_ppn or self.use_dpn:
             _, duration_proposals, relpn_losses = self.relpn(pair_list, target_list)
             loss_dict.update(relpn_losses)
+        if duration_proposals is not None:
+            # RelOIPool over the segment; tracklet samples: cat of the two tracklet means
+            dev = self.classifier.rel_predictor.weight.device
+            feats = [self._pooled_pair_feats(p, dev) if self._is_tracklet_sample(p) else _f32(p.features, dev)
+                     for p in pair_list]
         reloi_feats = self.rel_of_interest_pool(feats, duration_proposals)
         loss_relation = 0
         for reloi_feat, target in zip(reloi_feats, targets):
@@ -393,6 +533,12 @@ class BaseModel(nn.Module):
     @staticmethod
     def _is_tracklet_sample(plist):
         return plist.has_field("tracklet_feats")
+
+    @staticmethod
+    def _pooled_pair_feats(plist, dev):
+        """[P, 2D] = cat(mean_t f[s], mean_t f[o]): the segment-pooled pair feature of a tracklet sample."""
+        f = _f32(plist.get_field("tracklet_feats"), dev)
+        return ops.pair_rows(ops.temporal_mean(f, layout_tc=True), _segment_pairs(plist, f.shape[0], dev))
 
     def _forward_test(self, pair_list):
         with torch.no_grad():

@@ -403,3 +403,96 @@ def test_predict_loop_like_predict_py(tspn, device):
         np.testing.assert_array_equal(np.stack([p[1] for p in preds]), trip.numpy())
         np.testing.assert_array_equal(np.stack([p[2] for p in preds]), tids.numpy())
         assert preds[0][0].shape == () and preds[0][1].shape == (3,) and preds[0][2].shape == (2,)
+
+
+def _oracle_train_reference(v, pairs, sd, gt_dur, gt_rel, targets):
+    """The reference's intended DPN training step in plain torch autograd (CPU, float64): materialised
+    pair features -> oracle.dpn_head (relpn/dpn.py:69-73) -> BCEWithLogits (dpn.py:44); RelOIPool over the
+    segment -> RelationPredictor -> BCE (model.py:59-64).  Returns losses and parameter gradients."""
+    w = {k: x.double().requires_grad_(True) for k, x in oracle_weights(sd).items()}
+    pf, _ = oracle.pair_gather(t(v["tracklet_feats"]), t(v["tracklet_boxes"]), pairs)
+    rel, dur, _ = oracle.dpn_head(pf.double(), w["conv_w"], w["conv_b"], w["dur_w"], w["dur_b"], w["rel_w"], w["rel_b"])
+    losses = {"loss_duration": torch.nn.functional.binary_cross_entropy_with_logits(dur, gt_dur.double())}
+    if gt_rel is not None:
+        losses["loss_relationness"] = torch.nn.functional.binary_cross_entropy_with_logits(rel, gt_rel.double())
+    logit = oracle.predicate_head(pf.double().mean(dim=2), w["cls_w"], w["cls_b"])
+    losses["loss_rel"] = torch.nn.functional.binary_cross_entropy(logit, targets.double())
+    sum(losses.values()).backward()
+    return {k: float(x) for k, x in losses.items()}, {k: x.grad for k, x in w.items()}
+
+
+@pytest.mark.parametrize("form,with_relness", [("tracklets", True), ("tracklets", False), ("dense", True)])
+def test_temporal_branch_training_losses_and_grads(tspn, device, form, with_relness):
+    """USE_DPN=True in train mode (the reference's own path raises NameError, relpn/dpn.py:24-28): the loss
+    dict of train.py:74-78 gains `loss_duration` (+ `loss_relationness`); losses and every parameter
+    gradient equal the dense float64 autograd restatement — for tracklet samples (factorised encoder,
+    gradients accumulated per tracklet) and for materialised [P,C,T] features."""
+    D, N, T, A, K = 16, 6, 14, 4, 132
+    sd = tspn.synth.make_weights(3, c=2 * D, bias_std=0.05)
+    model = tspn.BaseModel(temporal_cfg(D, use_ppn=False))
+    load(model, sd)
+    model.to(device).train()
+    v = tspn.synth.make_video(90, N, T, D)
+    pairs = oracle.pair_index(N)
+    P = pairs.shape[0]
+    gt_dur = t((tspn.hashrng.uniform(91, "gt_dur", (P, 2 * A, T)) < 0.3).astype(np.float32))
+    gt_rel = t((tspn.hashrng.uniform(91, "gt_rel", (P, A, T)) < 0.3).astype(np.float32)) if with_relness else None
+    targets = t((tspn.hashrng.uniform(91, "tg", (P, K)) < 0.05).astype(np.float32))
+    if form == "tracklets":
+        plist = tspn.PairList.from_tracklets(t(v["tracklet_feats"]), t(v["tracklet_boxes"]), t(v["track_cls_logits"]))
+    else:
+        plist = tspn.PairList(oracle.pair_gather(t(v["tracklet_feats"]), t(v["tracklet_boxes"]), pairs)[0])
+    tlist = tspn.TargetList(targets)
+    tlist.add_field("duration", gt_dur)
+    if with_relness:
+        tlist.add_field("relness", gt_rel)
+    loss = model([plist.to(device)], [tlist.to(device)])
+    want_keys = {"loss_duration", "loss_rel"} | ({"loss_relationness"} if with_relness else set())
+    assert set(loss) == want_keys and all(x.dim() == 0 for x in loss.values())
+    sum(loss.values()).backward()
+    ref_loss, ref_grad = _oracle_train_reference(v, pairs, sd, gt_dur, gt_rel, targets)
+    for k in want_keys:
+        np.testing.assert_allclose(loss[k].item(), ref_loss[k], rtol=2e-5)
+    h = model.relpn.duration_proposal_network.dpn_head
+    got = {"conv_w": h.conv.weight.grad, "conv_b": h.conv.bias.grad,
+           "dur_w": h.duration_pred.weight.grad, "dur_b": h.duration_pred.bias.grad,
+           "cls_w": model.classifier.rel_predictor.weight.grad, "cls_b": model.classifier.rel_predictor.bias.grad}
+    if with_relness:
+        got.update({"rel_w": h.relness_pred.weight.grad, "rel_b": h.relness_pred.bias.grad})
+    else:
+        assert h.relness_pred.weight.grad is None or float(h.relness_pred.weight.grad.abs().max()) == 0.0
+    for k, gq in got.items():
+        r = ref_grad[k].numpy()
+        np.testing.assert_allclose(gq.cpu().numpy(), r, rtol=0, atol=2e-4 * np.abs(r).max() + 1e-9, err_msg=k)
+    # one optimiser step moves the loss down (the train.py loop: zero_grad / backward / step)
+    opt = torch.optim.SGD(model.parameters(), lr=0.5)
+    opt.step()
+    opt.zero_grad()
+    loss2 = model([plist.to(device)], [tlist.to(device)])
+    assert float(sum(loss2.values())) < float(sum(loss.values()))
+    # eval after training uses the updated weights (device caches are refreshed by parameter version)
+    model.eval()
+    with torch.no_grad():
+        _, dp, _ = model([plist], None)
+    w2 = {k: x.detach().cpu() for k, x in (("conv_w", h.conv.weight), ("conv_b", h.conv.bias),
+                                            ("dur_w", h.duration_pred.weight), ("dur_b", h.duration_pred.bias),
+                                            ("rel_w", h.relness_pred.weight), ("rel_b", h.relness_pred.bias))}
+    pf, _ = oracle.pair_gather(t(v["tracklet_feats"]), t(v["tracklet_boxes"]), pairs)
+    _, dur2, _ = oracle.dpn_head(pf, w2["conv_w"], w2["conv_b"], w2["dur_w"], w2["dur_b"], w2["rel_w"], w2["rel_b"])
+    np.testing.assert_allclose(dp[0].duration.cpu().numpy(), dur2.numpy(), rtol=0, atol=1e-5)
+
+
+def test_temporal_branch_training_errors(tspn, device):
+    D, N, T = 16, 4, 8
+    model = tspn.BaseModel(temporal_cfg(D, use_ppn=False)).to(device).train()
+    v = tspn.synth.make_video(92, N, T, D)
+    plist = tspn.PairList.from_tracklets(t(v["tracklet_feats"])).to(device)
+    tl = tspn.TargetList(torch.zeros((12, 132)))
+    with pytest.raises(KeyError):
+        model([plist], [tl.to(device)])                       # no 'duration' field (dpn.py:30-32 reads it)
+    tl.add_field("duration", torch.zeros((12, 8, T + 1)))
+    with pytest.raises(ValueError):
+        model([plist], [tl.to(device)])                       # wrong shape
+    cpu_model = tspn.BaseModel(temporal_cfg(D, use_ppn=False)).train()
+    with pytest.raises(RuntimeError):
+        cpu_model([plist], [tl.to(device)])                   # parameters not on the HIP device
