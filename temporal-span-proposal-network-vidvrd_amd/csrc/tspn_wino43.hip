@@ -169,10 +169,12 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_wino43_cl_kernel(
       const int t = 4 * q + i - 1;
       tm[i] = (okq && t >= 0 && t < T) ? 1.f : 0.f;
     }
-    if (wave == 0) {          // V0 = 4 d0 - 5 d2 + d4
-      tc[0] = 4.f * tm[0]; tc[1] = -5.f * tm[2]; tc[2] = tm[4]; tc[3] = 0.f;
-    } else if (wave == 1) {   // V5 = 4 d1 - 5 d3 + d5
-      tc[0] = 4.f * tm[1]; tc[1] = -5.f * tm[3]; tc[2] = tm[5]; tc[3] = 0.f;
+    // (V0 / V5 in the same s - r form and rounding order as the branch-free transform of tspn_wino43r.hip,
+    // so that the two kernels stay bit-identical)
+    if (wave == 0) {          // V0 = (4 d0 - 5 d2) - (-d4)
+      tc[0] = 4.f * tm[0]; tc[1] = -5.f * tm[2]; tc[2] = -tm[4]; tc[3] = 0.f;
+    } else if (wave == 1) {   // V5 = (4 d1 - 5 d3) - (-d5)
+      tc[0] = 4.f * tm[1]; tc[1] = -5.f * tm[3]; tc[2] = -tm[5]; tc[3] = 0.f;
     } else if (wave == 2) {   // s = d4 - 4 d2, r = 4 d1 - d3: V1 = s - r, V2 = s + r
       tc[0] = tm[4]; tc[1] = -4.f * tm[2]; tc[2] = 4.f * tm[1]; tc[3] = -tm[3];
     } else {                  // s = d4 - d2, r = 2 d1 - 2 d3: V3 = s - r, V4 = s + r
@@ -188,9 +190,8 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_wino43_cl_kernel(
     auto D = [&](int i) { return *reinterpret_cast<const f32x4*>(xp + 4 * i); };
     auto bc = [](float v) { return f32x4{v, v, v, v}; };
     if (wave < 2) {
-      const f32x4 v = __builtin_elementwise_fma(bc(tc[0]), D(wave),
-                                                __builtin_elementwise_fma(bc(tc[1]), D(wave + 2), bc(tc[2]) * D(wave + 4)));
-      *reinterpret_cast<f32x4*>(vp + (wave == 0 ? 0 : 5) * QT * 4) = v;
+      const f32x4 sv = __builtin_elementwise_fma(bc(tc[0]), D(wave), bc(tc[1]) * D(wave + 2));
+      *reinterpret_cast<f32x4*>(vp + (wave == 0 ? 0 : 5) * QT * 4) = sv - bc(tc[2]) * D(wave + 4);
     } else {
       const f32x4 sv = __builtin_elementwise_fma(bc(tc[0]), D(4), bc(tc[1]) * D(2));
       const f32x4 rv = __builtin_elementwise_fma(bc(tc[2]), D(1), bc(tc[3]) * D(3));

@@ -17,7 +17,7 @@
 //     super-stage ahead of their first use (2 buffers).  One bare s_barrier per chunk; every VMEM wait is a
 //     counted vmcnt on weight registers (the weight loads of the next chunk stay in flight across the
 //     barrier, and the in-order return of VMEM data makes the x pieces land before the weights issued
-//     after them are consumed).  LDS: x 2 x 19 KB + V 3 x 7 KB = 59 KB.
+//     after them are consumed).  LDS: x 2 x 19 KB + V 4 x 7 KB = 66 KB.
 //
 // Needs M % 32 == 0 and Cin % 8 == 0 (the canonical kernel takes everything else).
 #include <algorithm>
@@ -30,6 +30,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int THREADS = 256;
 constexpr int BM = 128;
@@ -41,7 +42,7 @@ constexpr int XS_UNITS = NSLOT * XROW; // 1170
 constexpr int XP_UNITS = 59;           // units per DMA piece: 20 pieces (5 per wave) cover 1180 >= 1170
 constexpr int XS_ST = 20 * XP_UNITS * 4 + 32;   // floats per super-stage buffer
 constexpr int V_ST = 2 * 7 * QT * 4;   // [2 g][6 j + 1 scratch plane][32 quads][4 ch]
-constexpr int NXS = 2, NVS = 3;
+constexpr int NXS = 2, NVS = 4;       // V stage of chunk k: k % 4 (static in the unrolled loop)
 constexpr size_t SMEM_BYTES = sizeof(float) * (NXS * XS_ST + NVS * V_ST);
 
 __device__ __forceinline__ void glds16(const float* g, float* l) {
@@ -157,15 +158,26 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_wino43r_kernel(
 #if !defined(TSPN_W43R_ABL_NODMA)
       if (bgrp[k] < glim) glds16(bptr[k], dst + XP_UNITS * k * 4);
 #endif
+#if !defined(TSPN_W43R_PROBE_HOTX)   // probe: re-read the same channels of x (cache-hot bursts, wrong results)
       bptr[k] += 32;
+#endif
     }
   };
 
-  // ---- transform item of this thread: quad tk, channel group tg; wave = part (V0 | V5 | V1,V2 | V3,V4);
-  // sequence-end masks folded into the coefficients (see tspn_wino43.hip)
+  // ---- transform item of this thread: quad tk, channel group tg; wave = part (V0 | V5 | V1,V2 | V3,V4).
+  // ONE branch-free form for all four parts, so that its VALU can be interleaved with the MFMAs:
+  //     s = c0 X0 + c1 X1,  r = c2 X2 + c3 X3,  plane p1 <- s - r,  plane p2 <- s + r
+  //   part   X0 X1 X2 X3      c0    c1     c2    c3      p1  p2
+  //   V0     d0 d2 d4 d4     4 m0  -5 m2  -m4    0        0   6 (scratch)     V0 = 4 d0 - 5 d2 + d4
+  //   V5     d1 d3 d5 d5     4 m1  -5 m3  -m5    0        5   6 (scratch)     V5 = 4 d1 - 5 d3 + d5
+  //   V1,V2  d4 d2 d1 d3      m4   -4 m2   4 m1  -m3      1   2               s = d4 - 4 d2, r = 4 d1 - d3
+  //   V3,V4  d4 d2 d1 d3      m4   -m2     2 m1  -2 m3    3   4               s = d4 - d2,   r = 2 d1 - 2 d3
+  // (m_i = 1 if frame 4q + i - 1 lies inside the tracklet, else 0: the sequence-end masks.)
   const int tk = tid & 31, tg = (tid >> 5) & 1;
   int tslot;
   float tc[4];
+  int to[4];           // wave-uniform slot offsets of X0..X3
+  int tp1, tp2;        // wave-uniform output planes
   {
     const int64_t Q = Q0 + tk;
     int q = 0;
@@ -178,49 +190,56 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_wino43r_kernel(
       const int t = 4 * q + i - 1;
       tm[i] = (okq && t >= 0 && t < T) ? 1.f : 0.f;
     }
-    if (wave == 0) {          // V0 = 4 d0 - 5 d2 + d4
-      tc[0] = 4.f * tm[0]; tc[1] = -5.f * tm[2]; tc[2] = tm[4]; tc[3] = 0.f;
-    } else if (wave == 1) {   // V5 = 4 d1 - 5 d3 + d5
-      tc[0] = 4.f * tm[1]; tc[1] = -5.f * tm[3]; tc[2] = tm[5]; tc[3] = 0.f;
-    } else if (wave == 2) {   // s = d4 - 4 d2, r = 4 d1 - d3: V1 = s - r, V2 = s + r
+    if (wave == 0) {
+      to[0] = 0; to[1] = 2; to[2] = 4; to[3] = 4; tp1 = 0; tp2 = 6;
+      tc[0] = 4.f * tm[0]; tc[1] = -5.f * tm[2]; tc[2] = -tm[4]; tc[3] = 0.f;
+    } else if (wave == 1) {
+      to[0] = 1; to[1] = 3; to[2] = 5; to[3] = 5; tp1 = 5; tp2 = 6;
+      tc[0] = 4.f * tm[1]; tc[1] = -5.f * tm[3]; tc[2] = -tm[5]; tc[3] = 0.f;
+    } else if (wave == 2) {
+      to[0] = 4; to[1] = 2; to[2] = 1; to[3] = 3; tp1 = 1; tp2 = 2;
       tc[0] = tm[4]; tc[1] = -4.f * tm[2]; tc[2] = 4.f * tm[1]; tc[3] = -tm[3];
-    } else {                  // s = d4 - d2, r = 2 d1 - 2 d3: V3 = s - r, V4 = s + r
+    } else {
+      to[0] = 4; to[1] = 2; to[2] = 1; to[3] = 3; tp1 = 3; tp2 = 4;
       tc[0] = tm[4]; tc[1] = -tm[2]; tc[2] = 2.f * tm[1]; tc[3] = -2.f * tm[3];
     }
   }
-  // two phases, so that the LDS reads of the x tile fly under the MFMAs that precede the arithmetic:
-  // part p reads d[i]: V0: d0,d2,d4 | V5: d1,d3,d5 | V1,V2 and V3,V4: d1,d2,d3,d4
+  // two phases, so that the LDS reads of the x tile fly under the MFMAs that precede the arithmetic.
+  // All LDS addresses are per-lane constants (4 read pointers into x buffer 0, 2 write pointers into V
+  // stage 0); buffer, channel-group and stage offsets are immediates in the unrolled loop, and the
+  // arithmetic is written on float pairs (v_pk_*): MFMA and VALU share an issue port, so every plain VALU
+  // instruction between two MFMAs can delay the second one.
+  const float* txp[4];
+  float* tvp[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) txp[i] = Xs + ((tslot + to[i]) * XROW + tg) * 4;
+  tvp[0] = Vs + (tg * 7 * QT + tk + tp1 * QT) * 4;
+  tvp[1] = Vs + (tg * 7 * QT + tk + tp2 * QT) * 4;
+  f32x2 tc2[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) tc2[i] = f32x2{tc[i], tc[i]};
   f32x4 td[4];
   auto transform_read = [&](int c2) {           // x of chunk c2: super-stage c2 / 4, channel groups 2 (c2 % 4) + tg
 #if defined(TSPN_W43R_ABL_NOXFORM)
     return;
 #endif
-    const float* xp = Xs + ((c2 >> 2) & 1) * XS_ST + (tslot * XROW + 2 * (c2 & 3) + tg) * 4;
-    auto D = [&](int i) { return *reinterpret_cast<const f32x4*>(xp + 4 * XROW * i); };
-    if (wave < 2) {
-      td[0] = D(wave); td[1] = D(wave + 2); td[2] = D(wave + 4);
-      td[3] = f32x4{0.f, 0.f, 0.f, 0.f};   // (defined on every path: no loop-carried copy of stale registers)
-    } else {
-      td[0] = D(4); td[1] = D(2); td[2] = D(1); td[3] = D(3);
-    }
+    const int off = ((c2 >> 2) & 1) * XS_ST + 8 * (c2 & 3);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) td[i] = *reinterpret_cast<const f32x4*>(txp[i] + off);
   };
   auto transform_write = [&](int vst) {
 #if defined(TSPN_W43R_ABL_NOXFORM)
     return;
 #endif
-    float* vp = Vs + vst * V_ST + (tg * 7 * QT + tk) * 4;
-    auto bc = [](float v) { return f32x4{v, v, v, v}; };
-    if (wave < 2) {
-      const f32x4 v = __builtin_elementwise_fma(bc(tc[0]), td[0],
-                                                __builtin_elementwise_fma(bc(tc[1]), td[1], bc(tc[2]) * td[2]));
-      *reinterpret_cast<f32x4*>(vp + (wave == 0 ? 0 : 5) * QT * 4) = v;
-    } else {
-      const f32x4 sv = __builtin_elementwise_fma(bc(tc[0]), td[0], bc(tc[1]) * td[1]);
-      const f32x4 rv = __builtin_elementwise_fma(bc(tc[2]), td[2], bc(tc[3]) * td[3]);
-      const int j = wave == 2 ? 1 : 3;
-      *reinterpret_cast<f32x4*>(vp + j * QT * 4) = sv - rv;
-      *reinterpret_cast<f32x4*>(vp + (j + 1) * QT * 4) = sv + rv;
-    }
+    auto lo = [](const f32x4& q) { return f32x2{q[0], q[1]}; };
+    auto hi = [](const f32x4& q) { return f32x2{q[2], q[3]}; };
+    const f32x2 s0 = __builtin_elementwise_fma(tc2[0], lo(td[0]), tc2[1] * lo(td[1]));
+    const f32x2 s1 = __builtin_elementwise_fma(tc2[0], hi(td[0]), tc2[1] * hi(td[1]));
+    const f32x2 r0 = __builtin_elementwise_fma(tc2[2], lo(td[2]), tc2[3] * lo(td[3]));
+    const f32x2 r1 = __builtin_elementwise_fma(tc2[2], hi(td[2]), tc2[3] * hi(td[3]));
+    const f32x2 d0 = s0 - r0, d1 = s1 - r1, p0 = s0 + r0, p1 = s1 + r1;
+    *reinterpret_cast<f32x4*>(tvp[0] + vst * V_ST) = f32x4{d0[0], d0[1], d1[0], d1[1]};
+    *reinterpret_cast<f32x4*>(tvp[1] + vst * V_ST) = f32x4{p0[0], p0[1], p1[0], p1[1]};
   };
   auto transform = [&](int c2, int vst) { transform_read(c2); transform_write(vst); };
 
@@ -279,20 +298,24 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_wino43r_kernel(
   // chunk c: MFMAs on the registers (A_c, V_c); meanwhile transform x_{c+2} -> V_{c+2}, refill the
   // registers with (A_{c+1}, V_{c+1}) position pair by position pair, and -- in the third chunk of a
   // super-stage S -- issue the DMA burst of super-stage S+2 into the buffer S has just left (its last
-  // read was the transform of chunk 4S+3 during chunk 4S+1).  V stage of chunk k: k % 3.
+  // read was the transform of chunk 4S+3 during chunk 4S+1).  V stage of chunk k: k % 4.
+  // `cc` = c modulo 8 (a compile-time constant in the unrolled loop: every LDS offset is an immediate);
+  // `S` = c / 4 is only read by the burst.
   // VMEM issue order of a chunk: [x pieces: ND] a0 a1 | a2 a3 | a4 a5; vmcnt counts are the number of
   // YOUNGER operations at each wait.  The burst is older than the weight loads of its chunk, which the
   // next chunk consumes: it has landed long before its first reader (4 chunks later) without a wait of
   // its own.
-  auto chunk_body = [&](int c, int s1, int s2, auto has1_tag, auto has2_tag, auto burst_tag) {
+  auto chunk_body = [&](auto cc_tag, int S, auto has1_tag, auto has2_tag, auto burst_tag) {
+    const int cc = cc_tag;                             // c % 8 (integral_constant or a runtime int)
     constexpr bool HAS1 = decltype(has1_tag)::value;   // chunk c+1 exists: refill
     constexpr bool HAS2 = decltype(has2_tag)::value;   // chunk c+2 exists: transform
     constexpr bool BURST = decltype(burst_tag)::value; // c = 4S+2 and super-stage S+2 exists
     constexpr int ND = BURST ? 5 : 0, NA = HAS1 ? 2 : 0;
+    const int s1 = (cc + 1) & 3, s2 = (cc + 2) & 3;
     wait_a<4>(a[0], a[1]);
-    if (BURST) stage_burst((c >> 2) + 2);
+    if (BURST) stage_burst(S + 2);
     __builtin_amdgcn_sched_barrier(0);
-    if (HAS2) transform_read(c + 2);
+    if (HAS2) transform_read(cc + 2);
     mfma_pair(0, 1);
     if (HAS1) { load_a_pair(P0{}); load_v(s1, 0); load_v(s1, 1); }
     __builtin_amdgcn_sched_barrier(0);
@@ -300,10 +323,24 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_wino43r_kernel(
     if (HAS2) transform_write(s2);
     mfma_pair(2, 3);
     if (HAS1) { load_a_pair(P1{}); load_v(s1, 2); load_v(s1, 3); }
+#if !defined(TSPN_W43R_NOINTERLEAVE)
+    if (HAS2) {   // the transform's arithmetic under the MFMAs of this pair: 1 MFMA : 2 VALU, the stores last
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+    }
+#endif
     __builtin_amdgcn_sched_barrier(0);
     wait_a<ND + 2 * NA>(a[4], a[5]);
     mfma_pair(4, 5);
-    if (HAS1) { load_a_pair(P2{}); load_v(s1, 4); load_v(s1, 5); abase += 6 * 1024; }
+    if (HAS1) { load_a_pair(P2{}); load_v(s1, 4); load_v(s1, 5); }
+#if !defined(TSPN_W43R_PROBE_HOTA)   // probe: re-read the same 6 KiB of weights (cache-hot stream, wrong results)
+    if (HAS1) abase += 6 * 1024;
+#endif
     __builtin_amdgcn_sched_barrier(0);
 #if defined(TSPN_W43R_ABL_NOALOAD)
     wait_vm_lgkm0<0>();
@@ -322,28 +359,40 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_wino43r_kernel(
   {
     using TT = std::true_type;
     using FF = std::false_type;
-    int c = 0, s0 = 0;   // s0 = c % 3
-    auto nxt = [](int s) { return s == 2 ? 0 : s + 1; };
-    // super-stages whose four chunks are all steady state and that are followed by two more
-    for (int S = 0; S + 2 < nsuper; ++S) {
-      int s1 = nxt(s0), s2 = nxt(s1);
-      chunk_body(c, s1, s2, TT{}, TT{}, FF{});
-      chunk_body(c + 1, s2, s0, TT{}, TT{}, FF{});
-      chunk_body(c + 2, s0, s1, TT{}, TT{}, TT{});
-      chunk_body(c + 3, s1, s2, TT{}, TT{}, FF{});
-      c += 4;
-      s0 = s1;       // (c + 4) % 3 = (c + 1) % 3
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    using C2 = std::integral_constant<int, 2>;
+    using C3 = std::integral_constant<int, 3>;
+    using C4 = std::integral_constant<int, 4>;
+    using C5 = std::integral_constant<int, 5>;
+    using C6 = std::integral_constant<int, 6>;
+    using C7 = std::integral_constant<int, 7>;
+    int S = 0;
+    // steady super-stages (all four chunks have successors, super-stage S+2 exists), two per iteration
+    for (; S + 3 < nsuper; S += 2) {
+      chunk_body(C0{}, S, TT{}, TT{}, FF{});
+      chunk_body(C1{}, S, TT{}, TT{}, FF{});
+      chunk_body(C2{}, S, TT{}, TT{}, TT{});
+      chunk_body(C3{}, S, TT{}, TT{}, FF{});
+      chunk_body(C4{}, S + 1, TT{}, TT{}, FF{});
+      chunk_body(C5{}, S + 1, TT{}, TT{}, FF{});
+      chunk_body(C6{}, S + 1, TT{}, TT{}, TT{});
+      chunk_body(C7{}, S + 1, TT{}, TT{}, FF{});
     }
-    for (; c + 2 < nchunks; ++c) {
-      const int s1 = nxt(s0);
-      chunk_body(c, s1, nxt(s1), TT{}, TT{}, FF{});
-      s0 = s1;
+    if (S + 2 < nsuper) {      // one more steady super-stage (S is even here)
+      chunk_body(C0{}, S, TT{}, TT{}, FF{});
+      chunk_body(C1{}, S, TT{}, TT{}, FF{});
+      chunk_body(C2{}, S, TT{}, TT{}, TT{});
+      chunk_body(C3{}, S, TT{}, TT{}, FF{});
+      ++S;
     }
+    int c = 4 * S;             // the last (up to) eight chunks: no bursts left, offsets computed at run time
+    for (; c + 2 < nchunks; ++c) chunk_body(c & 7, c >> 2, TT{}, TT{}, FF{});
     if (c + 1 < nchunks) {
-      chunk_body(c, nxt(s0), 0, TT{}, FF{}, FF{});
+      chunk_body(c & 7, c >> 2, TT{}, FF{}, FF{});
       ++c;
     }
-    chunk_body(c, 0, 0, FF{}, FF{}, FF{});
+    chunk_body(c & 7, c >> 2, FF{}, FF{}, FF{});
   }
 
   // ---- output transform + store: lane column = quad -> frames 4q .. 4q+3
