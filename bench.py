@@ -118,6 +118,12 @@ def pmc_traffic(videos, conv):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON result: native libraries write there too (RCCL prints a
+    # version banner to stdout when the first communicator is created), so fd 1 points at stderr until
+    # the result is printed
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -280,7 +286,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline and not bf16:
             out["cpu_baseline"] = cpu_baseline(wnp, args.cpu_seconds)
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
