@@ -206,9 +206,10 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_wino43r_kernel(
   }
   // two phases, so that the LDS reads of the x tile fly under the MFMAs that precede the arithmetic.
   // All LDS addresses are per-lane constants (4 read pointers into x buffer 0, 2 write pointers into V
-  // stage 0); buffer, channel-group and stage offsets are immediates in the unrolled loop, and the
-  // arithmetic is written on float pairs (v_pk_*): MFMA and VALU share an issue port, so every plain VALU
-  // instruction between two MFMAs can delay the second one.
+  // stage 0); buffer, channel-group and stage offsets are immediates in the unrolled loop: MFMA and VALU
+  // share an issue port, so every address add between two MFMAs can delay the second one.  (The
+  // arithmetic is written on float pairs; hipcc unpacks v_pk_* f32 operations that sit in the shadow of
+  // an MFMA, so the loop carries 24 plain VALU per chunk for it.)
   const float* txp[4];
   float* tvp[2];
 #pragma unroll
@@ -474,6 +475,14 @@ int tspn::conv3_tc_wino43r(const float* x, int64_t B, int64_t T, int64_t Cin, co
   const int64_t tiles_m = tspn::ceil_div(M, BM), tiles_n = tspn::ceil_div(nquads, QT);
   TSPN_REQUIRE(tiles_m * tiles_n < (1LL << 31), TSPN_EUNSUPPORTED, "tspn_conv3_tc_wino43r_f32: grid too large");
   const int vec4 = (ldy % 4 == 0) && (ldy >= 4 * nq) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
+  static thread_local bool attr = false;   // 66.7 KB of dynamic LDS: above the 64 KB default limit
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wino43r_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_BYTES);
+    if (e != hipSuccess)
+      return tspn::fail(TSPN_ELAUNCH, "tspn_conv3_tc_wino43r_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr = true;
+  }
   static const int gm_tiles = [] {
     const char* e = getenv("TSPN_WINO_GM");
     const int v = e ? atoi(e) : 2;
