@@ -359,6 +359,32 @@ int tspn_temporal_encoder_heads_f32(const float* x, int64_t P, int64_t C, int64_
                                     const float* head_w, const float* head_b, int64_t H,
                                     float* h_ws, float* out_heads, void* stream);
 
+/* ---- f4 (first slice): RoI feature head ------------------------------------------------------
+ * The reference extracts tracklet RoI features with detectron2's R101-C4 model, configured in
+ * lib/detectron/trainer.py:23-33 (no code of its own): ROIAlign 14x14 on the res4 map -> res5
+ * (3 bottleneck blocks, FrozenBN) -> mean over 7x7.  These are the operators of that head on
+ * channels-last (NHWC) fp32 tensors; `temporal-span-proposal-network-vidvrd_amd/roi_head.py`
+ * assembles them and hands [N,T,2048] straight to the pair builder.
+ *
+ * tspn_pack_conv2d_f32: Conv2d weight [Cout][Cin][KH][KW] -> [KH*KW][Cin][Cout] (KH*KW <= 32).
+ * tspn_conv2d_nhwc_f32: out[NB,OH,OW,Cout] = act( conv(x[NB,H,W,Cin]) + bias[Cout] + residual[NB,OH,OW,Cout] ),
+ *   zero padding `pad`, `stride`, OH = (H + 2 pad - KH) / stride + 1; bias / residual may be NULL;
+ *   relu != 0 applies max(.,0).  BatchNorm is folded into (packed, bias) by the caller.  Implicit GEMM
+ *   on fp32 MFMA.  Needs Cin % 16 == 0, Cout % 4 == 0, 16-byte aligned tensors (else TSPN_EUNSUPPORTED). */
+int tspn_pack_conv2d_f32(const float* w, int64_t Cout, int64_t Cin, int64_t KH, int64_t KW,
+                         float* packed, void* stream);
+int tspn_conv2d_nhwc_f32(const float* x, int64_t NB, int64_t H, int64_t W, int64_t Cin,
+                         const float* packed, int64_t Cout, int64_t KH, int64_t KW, int64_t stride,
+                         int64_t pad, const float* bias, const float* residual, int relu, float* out,
+                         void* stream);
+/* tspn_roi_align_nhwc_f32: detectron2 ROIAlign on a channels-last map feat[NF,H,W,C]:
+ *   rois[R,5] = (map index, x1, y1, x2, y2) in image coordinates, `spatial_scale` image -> map,
+ *   out[R,P,P,C]; sampling_ratio 0 = adaptive grid ceil(roi size / P) (detectron2's POOLER_SAMPLING_RATIO 0);
+ *   aligned != 0 = the half-pixel-corrected form (ROIAlignV2).  Needs C % 4 == 0. */
+int tspn_roi_align_nhwc_f32(const float* feat, int64_t NF, int64_t H, int64_t W, int64_t C,
+                            const float* rois, int64_t R, int64_t P, float spatial_scale,
+                            int sampling_ratio, int aligned, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

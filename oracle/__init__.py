@@ -23,3 +23,4 @@ gather, relationness head, RelOIPool over time, span decode) are marked
 reference-pinned pieces.
 """
 from .tspn_oracle import *  # noqa: F401,F403
+from . import roi_head_oracle  # noqa: F401  (SURVEY.md §8 f4: RoI feature head; parity unpinned, see its header)

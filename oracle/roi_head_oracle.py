@@ -1,0 +1,142 @@
+"""CPU restatement of the RoI feature head (TEST INFRASTRUCTURE — see oracle/__init__.py for who may import).
+
+SURVEY.md §8 row f4.  The reference owns no code for this step: lib/detectron/trainer.py:23-33 only
+configures detectron2's `COCO-Detection/faster_rcnn_R_101_C4_3x.yaml` model (35 classes), which is NOT
+installed here and not vendored in /root/reference.  Its ROI head is therefore restated from detectron2's
+published algorithm (v0.6, `modeling/roi_heads/roi_heads.py:Res5ROIHeads`, `layers/roi_align.py:ROIAlign`
+with `aligned=True`, `layers/csrc/ROIAlign/ROIAlign_cpu.cpp`, `modeling/backbone/resnet.py:BottleneckBlock`
+with `stride_in_1x1=True`, `layers/batch_norm.py:FrozenBatchNorm2d`):
+
+    box features = ROIAlign(res4 map, boxes; 14 x 14, scale 1/16, sampling_ratio 0, aligned)
+                   -> res5 = 3 BottleneckBlocks (first: stride 2, projection shortcut) -> mean over (H, W)
+
+PARITY UNPINNED by the reference (no runnable counterpart, no fixtures): the convolution / batch-norm
+pieces are torch's own CPU operators; ROIAlign is restated here line by line from the cited CPU kernel.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+__all__ = ["roi_align_nhwc", "frozen_bn", "bottleneck_block", "res5_roi_head", "make_res5_weights"]
+
+BN_EPS = 1e-5
+
+
+def _bilinear(fmap, y, x):
+    """ROIAlign_cpu.cpp:pre_calc_for_bilinear_interpolate (one sample point), float32 arithmetic.
+    fmap [H,W,C] float32 numpy.  Returns [C] float32."""
+    H, W, _ = fmap.shape
+    f = np.float32
+    if y < -1.0 or y > H or x < -1.0 or x > W:
+        return np.zeros(fmap.shape[2], dtype=np.float32)
+    y = max(f(y), f(0))
+    x = max(f(x), f(0))
+    yl, xl = int(y), int(x)
+    if yl >= H - 1:
+        yh = yl = H - 1
+        y = f(yl)
+    else:
+        yh = yl + 1
+    if xl >= W - 1:
+        xh = xl = W - 1
+        x = f(xl)
+    else:
+        xh = xl + 1
+    ly, lx = f(y - f(yl)), f(x - f(xl))
+    hy, hx = f(f(1) - ly), f(f(1) - lx)
+    w1, w2, w3, w4 = f(hy * hx), f(hy * lx), f(ly * hx), f(ly * lx)
+    return (w1 * fmap[yl, xl] + w2 * fmap[yl, xh] + w3 * fmap[yh, xl] + w4 * fmap[yh, xh]).astype(np.float32)
+
+
+def roi_align_nhwc(feat, rois, output_size, spatial_scale, sampling_ratio=0, aligned=True):
+    """detectron2 ROIAlign (layers/csrc/ROIAlign/ROIAlign_cpu.cpp:ROIAlignForward) on a channels-last map.
+    feat [NF,H,W,C], rois [R,5] = (map index, x1, y1, x2, y2) -> [R,P,P,C]; float32 arithmetic in the
+    kernel's order (loops: small cases only)."""
+    feat = np.asarray(feat, dtype=np.float32)
+    rois = np.asarray(rois, dtype=np.float32)
+    f = np.float32
+    P = int(output_size)
+    R = rois.shape[0]
+    out = np.zeros((R, P, P, feat.shape[3]), dtype=np.float32)
+    scale = f(spatial_scale)
+    off = f(0.5) if aligned else f(0)
+    for r in range(R):
+        fmap = feat[int(rois[r, 0])]
+        sw, sh = f(rois[r, 1] * scale - off), f(rois[r, 2] * scale - off)
+        rw, rh = f(f(rois[r, 3] * scale - off) - sw), f(f(rois[r, 4] * scale - off) - sh)
+        if not aligned:
+            rw, rh = max(rw, f(1)), max(rh, f(1))
+        bin_h, bin_w = f(rh / f(P)), f(rw / f(P))
+        gh = sampling_ratio if sampling_ratio > 0 else int(math.ceil(f(rh / f(P))))
+        gw = sampling_ratio if sampling_ratio > 0 else int(math.ceil(f(rw / f(P))))
+        count = f(max(gh * gw, 1))
+        for ph in range(P):
+            for pw in range(P):
+                acc = np.zeros(feat.shape[3], dtype=np.float32)
+                for iy in range(gh):
+                    y = f(f(sh + f(f(ph) * bin_h)) + f(f(f(iy) + f(0.5)) * bin_h) / f(gh))
+                    for ix in range(gw):
+                        x = f(f(sw + f(f(pw) * bin_w)) + f(f(f(ix) + f(0.5)) * bin_w) / f(gw))
+                        acc = acc + _bilinear(fmap, y, x)
+                out[r, ph, pw] = acc / count
+    return torch.from_numpy(out)
+
+
+def frozen_bn(x, p, prefix):
+    """detectron2 FrozenBatchNorm2d.forward (layers/batch_norm.py): x * scale + bias with
+    scale = weight * rsqrt(running_var + eps), bias = bias - running_mean * scale.  x NCHW."""
+    scale = p[prefix + "weight"] * (p[prefix + "running_var"] + BN_EPS).rsqrt()
+    bias = p[prefix + "bias"] - p[prefix + "running_mean"] * scale
+    return x * scale.reshape(1, -1, 1, 1) + bias.reshape(1, -1, 1, 1)
+
+
+def bottleneck_block(x, p, prefix, stride):
+    """detectron2 BottleneckBlock.forward (modeling/backbone/resnet.py), stride_in_1x1=True, FrozenBN.
+    x NCHW; `p` maps '<prefix>conv1.weight', '<prefix>conv1.norm.weight', ... to tensors."""
+    out = F.relu(frozen_bn(F.conv2d(x, p[prefix + "conv1.weight"], stride=stride), p, prefix + "conv1.norm."))
+    out = F.relu(frozen_bn(F.conv2d(out, p[prefix + "conv2.weight"], padding=1), p, prefix + "conv2.norm."))
+    out = frozen_bn(F.conv2d(out, p[prefix + "conv3.weight"]), p, prefix + "conv3.norm.")
+    if prefix + "shortcut.weight" in p:
+        sc = frozen_bn(F.conv2d(x, p[prefix + "shortcut.weight"], stride=stride), p, prefix + "shortcut.norm.")
+    else:
+        sc = x
+    return F.relu(out + sc)
+
+
+def res5_roi_head(feat_nhwc, tracklet_boxes, p, num_blocks=3, pooler_resolution=14, spatial_scale=1.0 / 16,
+                  sampling_ratio=0, first_stride=2, dtype=torch.float32):
+    """Res5ROIHeads._shared_roi_transform + mean([2,3]) (modeling/roi_heads/roi_heads.py) for tracklet boxes:
+    feat_nhwc [T,Hf,Wf,C] (frame t's res4 map), tracklet_boxes [N,T,4] (l,t,r,b) -> [N,T,Cout]."""
+    N, T, _ = tracklet_boxes.shape
+    idx = torch.arange(T, dtype=torch.float32).repeat(N)
+    rois = torch.cat([idx[:, None], tracklet_boxes.reshape(N * T, 4).float()], dim=1)
+    x = roi_align_nhwc(feat_nhwc, rois, pooler_resolution, spatial_scale, sampling_ratio, True)
+    x = x.permute(0, 3, 1, 2).contiguous().to(dtype)
+    pp = {k: v.to(dtype) for k, v in p.items()}
+    for b in range(num_blocks):
+        x = bottleneck_block(x, pp, f"res5.{b}.", first_stride if b == 0 else 1)
+    return x.mean(dim=(2, 3)).reshape(N, T, -1).float()
+
+
+def make_res5_weights(rng_uniform, rng_normal, in_channels, bottleneck_channels, out_channels, num_blocks=3):
+    """Deterministic random res5 parameters (detectron2 key names) from the build's hash RNG callables
+    rng_uniform(name, shape, lo, hi) / rng_normal(name, shape, std) -> numpy float32."""
+    p = {}
+    cin = in_channels
+    for b in range(num_blocks):
+        pre = f"res5.{b}."
+        convs = [("conv1", bottleneck_channels, cin, 1), ("conv2", bottleneck_channels, bottleneck_channels, 3),
+                 ("conv3", out_channels, bottleneck_channels, 1)]
+        if cin != out_channels:
+            convs.append(("shortcut", out_channels, cin, 1))
+        for name, co, ci, k in convs:
+            std = math.sqrt(2.0 / (ci * k * k))
+            p[pre + name + ".weight"] = torch.from_numpy(rng_normal(pre + name + ".w", (co, ci, k, k), std))
+            p[pre + name + ".norm.weight"] = torch.from_numpy(rng_uniform(pre + name + ".g", (co,), 0.5, 1.5))
+            p[pre + name + ".norm.bias"] = torch.from_numpy(rng_uniform(pre + name + ".b", (co,), -0.2, 0.2))
+            p[pre + name + ".norm.running_mean"] = torch.from_numpy(rng_uniform(pre + name + ".m", (co,), -0.2, 0.2))
+            p[pre + name + ".norm.running_var"] = torch.from_numpy(rng_uniform(pre + name + ".v", (co,), 0.5, 1.5))
+        cin = out_channels
+    return p

@@ -18,5 +18,7 @@ from .pair_list import PairList, TargetList  # noqa: F401
 from .sampler import BalancedPositiveNegativePairSampler  # noqa: F401
 from .anchor_generator import AnchorGenerator, generate_anchors, make_anchor_generator  # noqa: F401
 from . import dist  # noqa: F401
+from . import roi_head  # noqa: F401
+from .roi_head import Res5RoIHead  # noqa: F401
 
 __version__ = "0.1.0"

@@ -1,0 +1,324 @@
+// RoI feature head, SURVEY.md §8 row f4 (first slice): from a C4 feature map to per-tracklet RoI features.
+//
+// The reference has no code of its own here: lib/detectron/trainer.py:23-33 configures detectron2's
+// R101-C4 model, whose ROI head is  ROIAlign(14x14, aligned, adaptive sampling) -> res5 (three
+// bottleneck blocks, the first with stride 2, FrozenBN) -> mean over 7x7 -> 2048-d feature per box.
+// These kernels are the two operators that head needs on the GPU (gfx950, fp32):
+//   * conv2d_nhwc_kernel: KHxKW conv (1x1 / 3x3, stride 1 / 2, zero padding) on channels-last tensors as
+//     an implicit GEMM on v_mfma_f32_32x32x2_f32 -- M = output channels, N = output pixels, K = taps x Cin;
+//     128 x 128 tiles, 4 waves x (2 x 2 blocks of 32 x 32), K chunk = 16 channels of ONE tap, operand tiles
+//     staged by LDS-DMA (weights: 512-byte rows; x: one 16-byte piece per (pixel, channel group), the source
+//     of a padding tap is a zero page), double-buffered; epilogue fused: + bias (BatchNorm folded by the
+//     host), + residual, ReLU, float4 stores into the channels-last output.
+//   * roi_align_nhwc_kernel: detectron2's ROIAlign (aligned or legacy, fixed or adaptive sampling grid) on a
+//     channels-last feature map; one workgroup per output bin row, a thread = 4 channels.
+#include <algorithm>
+#include <type_traits>
+
+#include "tspn_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int THREADS = 256;
+constexpr int BM = 128, BN = 128;
+constexpr int KC = 16;                 // channels per K chunk
+constexpr int NG = KC / 4;             // 4-channel groups
+constexpr int SLP = 132;               // padded pixel slots per channel group (128 used)
+constexpr int A_ST = KC * BM;          // floats
+constexpr int B_ST = NG * SLP * 4;     // floats
+constexpr size_t SMEM_BYTES = sizeof(float) * 2 * (A_ST + B_ST);
+
+__device__ float g_zero_page[64];      // source of padding taps (never written)
+
+__device__ __forceinline__ void glds16(const float* g, float* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+// w [Cout][Cin][KH][KW] (torch Conv2d layout) -> packed [KH*KW][Cin][Cout]
+__global__ void pack_conv2d_kernel(const float* __restrict__ w, int64_t Cout, int64_t Cin, int64_t KH,
+                                   int64_t KW, float* __restrict__ packed) {
+  const int64_t total = KH * KW * Cin * Cout;
+  for (int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; o < total;
+       o += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t co = o % Cout;
+    const int64_t ci = (o / Cout) % Cin;
+    const int64_t tap = o / (Cout * Cin);
+    packed[o] = w[(co * Cin + ci) * (KH * KW) + tap];
+  }
+}
+
+__global__ __launch_bounds__(THREADS, 2) void conv2d_nhwc_kernel(
+    const float* __restrict__ x, const float* __restrict__ Wp, const float* __restrict__ bias,
+    const float* __restrict__ residual, float* __restrict__ out, int H, int W, int Cin, int Cout, int KH,
+    int KW, int stride, int pad, int OH, int OW, int64_t npix, int tiles_m, int tiles_n, int relu) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* As = reinterpret_cast<float*>(smem_raw);   // [2][16 ch][128 m]
+  float* Bs = As + 2 * A_ST;                         // [2][4 groups][132 slots][4 ch]
+
+  // workgroup -> tile: bijective XCD remap, then groups of GM weight panels x all pixel tiles
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  constexpr int GM = 4;
+  const int group_sz = GM * tiles_n;
+  const int group = wg / group_sz;
+  const int first_m = group * GM;
+  const int gm = min(GM, tiles_m - first_m);
+  const int in_group = wg - group * group_sz;
+  const int tile_m = first_m + in_group % gm;
+  const int tile_n = in_group / gm;
+  const int m0 = tile_m * BM;
+  const int64_t n0 = (int64_t)tile_n * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, kh = lane >> 5;
+
+  // ---- weight pieces: wave w stages rows 4w .. 4w+3 of the 16 x 128 tile, two rows per piece
+  const int am = (lane & 31) * 4;
+  const int amc = m0 + am < Cout ? m0 + am : 0;       // columns beyond Cout: re-read column 0, never stored
+  const int arow = 4 * wave + (lane >> 5);            // + 2 i
+  // ---- x pieces: both pieces of a lane belong to ONE output pixel (slot), channel groups g and g + 2
+  const int slot = 64 * (wave & 1) + lane;
+  const int bg = wave >> 1;
+  int64_t pbase;          // offset (floats) of input pixel (ih0, iw0) of this lane's output pixel, channel 0
+  unsigned tapmask = 0;   // bit (kh * KW + kw): the tap lies inside the image
+  {
+    const int64_t n = n0 + slot;
+    const bool okn = n < npix;
+    const int64_t nc = okn ? n : 0;
+    const int64_t nb = nc / ((int64_t)OH * OW);
+    const int r = (int)(nc - nb * OH * OW);
+    const int oh = r / OW, ow = r - oh * OW;
+    const int ih0 = oh * stride - pad, iw0 = ow * stride - pad;
+    pbase = ((nb * H + ih0) * (int64_t)W + iw0) * Cin;
+    for (int a = 0; a < KH; ++a)
+      for (int b = 0; b < KW; ++b)
+        if (okn && ih0 + a >= 0 && ih0 + a < H && iw0 + b >= 0 && iw0 + b < W) tapmask |= 1u << (a * KW + b);
+  }
+
+  const int cchunks = Cin / KC;
+  const int nchunks = KH * KW * cchunks;
+  // chunk i = (tap = i / cchunks, c = i % cchunks)
+  auto stage = [&](int buf, int i) {
+    const int tap = i / cchunks, c = i - tap * cchunks;
+    const int ta = tap / KW, tb = tap - ta * KW;
+    const float* wsrc = Wp + ((int64_t)tap * Cin + c * KC + arow) * Cout + amc;
+    glds16(wsrc, As + buf * A_ST + (4 * wave) * BM);
+    glds16(wsrc + 2 * (int64_t)Cout, As + buf * A_ST + (4 * wave + 2) * BM);
+    const bool valid = (tapmask >> tap) & 1u;
+    const float* xs = valid ? x + pbase + ((int64_t)ta * W + tb) * Cin + c * KC + 4 * bg : g_zero_page + 4 * bg;
+    glds16(xs, Bs + buf * B_ST + (bg * SLP + 64 * (wave & 1)) * 4);
+    glds16(xs + 8, Bs + buf * B_ST + ((bg + 2) * SLP + 64 * (wave & 1)) * 4);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  struct Frag {
+    float a[2][2];   // [mi][row of the lane's channel pair]
+    float2 b[2];     // [ni]
+  };
+  auto read_frag = [&](const float* Ab, const float* Bb, int g) {
+    Frag f;
+    const int r0 = 4 * g + 2 * kh;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      f.a[mi][0] = Ab[r0 * BM + mi * 32];
+      f.a[mi][1] = Ab[(r0 + 1) * BM + mi * 32];
+    }
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) f.b[ni] = *reinterpret_cast<const float2*>(Bb + (g * SLP + ni * 32) * 4);
+    return f;
+  };
+
+  stage(0, 0);
+  __syncthreads();   // (hipcc drains the LDS-DMA with vmcnt(0) here)
+  for (int i = 0; i < nchunks; ++i) {
+    const int buf = i & 1;
+    if (i + 1 < nchunks) stage(buf ^ 1, i + 1);
+    const float* Ab = As + buf * A_ST + wm * 64 + li;
+    const float* Bb = Bs + buf * B_ST + (wn * 64 + li) * 4 + 2 * kh;
+    Frag cur = read_frag(Ab, Bb, 0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      Frag nxt = cur;
+      if (g + 1 < NG) nxt = read_frag(Ab, Bb, g + 1);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const float b0 = e ? cur.b[0].y : cur.b[0].x;
+        const float b1 = e ? cur.b[1].y : cur.b[1].x;
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[0][e], b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[0][e], b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[1][e], b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[1][e], b1, acc[1][1], 0, 0, 0);
+      }
+      cur = nxt;
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: a lane holds 4 consecutive output channels of one pixel per register quad
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int64_t n = n0 + wn * 64 + ni * 32 + li;
+    if (n >= npix) continue;
+    float* orow = out + n * Cout;
+    const float* rrow = residual ? residual + n * Cout : nullptr;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m = m0 + wm * 64 + mi * 32 + 8 * q + 4 * kh;
+        if (m >= Cout) continue;                       // Cout % 4 == 0: a quad is inside or outside
+        float4 v = make_float4(acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2],
+                               acc[mi][ni][4 * q + 3]);
+        if (bias) {
+          const float4 bv = *reinterpret_cast<const float4*>(bias + m);
+          v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        }
+        if (rrow) {
+          const float4 rv = *reinterpret_cast<const float4*>(rrow + m);
+          v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+        }
+        if (relu) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        *reinterpret_cast<float4*>(orow + m) = v;
+      }
+  }
+}
+
+// detectron2 ROIAlign (layers/csrc/ROIAlignRotated is NOT this one; this is ROIAlign/ROIAlign_cpu.cpp's
+// arithmetic, restated in oracle/roi_head_oracle.py): one workgroup per (roi, ph), threads over
+// (pw, 4-channel group).
+__device__ __forceinline__ void bilinear_setup(float y, float x, int H, int W, int& yl, int& yh, int& xl, int& xh,
+                                               float& w1, float& w2, float& w3, float& w4, bool& empty) {
+  empty = y < -1.0f || y > (float)H || x < -1.0f || x > (float)W;
+  y = fmaxf(y, 0.f);
+  x = fmaxf(x, 0.f);
+  yl = (int)y;
+  xl = (int)x;
+  if (yl >= H - 1) { yh = yl = H - 1; y = (float)yl; } else { yh = yl + 1; }
+  if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else { xh = xl + 1; }
+  const float ly = y - (float)yl, lx = x - (float)xl, hy = 1.f - ly, hx = 1.f - lx;
+  w1 = hy * hx; w2 = hy * lx; w3 = ly * hx; w4 = ly * lx;
+}
+
+__global__ __launch_bounds__(256) void roi_align_nhwc_kernel(
+    const float* __restrict__ feat, int NF, int H, int W, int C, const float* __restrict__ rois, int64_t R,
+    int P, float scale, int sampling_ratio, int aligned, float* __restrict__ out) {
+  const int64_t item = blockIdx.x;                 // (roi, ph)
+  const int64_t r = item / P;
+  const int ph = (int)(item - r * P);
+  const float* roi = rois + r * 5;
+  int bi = (int)roi[0];
+  bi = bi < 0 ? 0 : (bi >= NF ? NF - 1 : bi);
+  const float off = aligned ? 0.5f : 0.f;
+  const float sw = roi[1] * scale - off, sh = roi[2] * scale - off;
+  float rw = roi[3] * scale - off - sw, rh = roi[4] * scale - off - sh;
+  if (!aligned) { rw = fmaxf(rw, 1.f); rh = fmaxf(rh, 1.f); }
+  const float bin_h = rh / (float)P, bin_w = rw / (float)P;
+  const int gh = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rh / (float)P);
+  const int gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rw / (float)P);
+  const float count = (float)max(gh * gw, 1);
+  const float* fb = feat + (int64_t)bi * H * W * C;
+  const int c4 = C >> 2;
+  for (int idx = threadIdx.x; idx < P * c4; idx += blockDim.x) {
+    const int pw = idx / c4, cg = idx - pw * c4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int iy = 0; iy < gh; ++iy) {
+      const float y = sh + (float)ph * bin_h + ((float)iy + .5f) * bin_h / (float)gh;
+      for (int ix = 0; ix < gw; ++ix) {
+        const float xx = sw + (float)pw * bin_w + ((float)ix + .5f) * bin_w / (float)gw;
+        int yl, yh, xl, xh;
+        float w1, w2, w3, w4;
+        bool empty;
+        bilinear_setup(y, xx, H, W, yl, yh, xl, xh, w1, w2, w3, w4, empty);
+        if (empty) continue;
+        const float4 v1 = *reinterpret_cast<const float4*>(fb + ((int64_t)yl * W + xl) * C + 4 * cg);
+        const float4 v2 = *reinterpret_cast<const float4*>(fb + ((int64_t)yl * W + xh) * C + 4 * cg);
+        const float4 v3 = *reinterpret_cast<const float4*>(fb + ((int64_t)yh * W + xl) * C + 4 * cg);
+        const float4 v4 = *reinterpret_cast<const float4*>(fb + ((int64_t)yh * W + xh) * C + 4 * cg);
+        acc.x += w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x;
+        acc.y += w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y;
+        acc.z += w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z;
+        acc.w += w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w;
+      }
+    }
+    acc.x /= count; acc.y /= count; acc.z /= count; acc.w /= count;
+    *reinterpret_cast<float4*>(out + ((r * P + ph) * P + pw) * (int64_t)C + 4 * cg) = acc;
+  }
+}
+
+}  // namespace
+
+extern "C" int tspn_pack_conv2d_f32(const float* w, int64_t Cout, int64_t Cin, int64_t KH, int64_t KW,
+                                    float* packed, void* stream) {
+  TSPN_REQUIRE(w && packed, TSPN_EINVAL, "tspn_pack_conv2d_f32: null pointer");
+  TSPN_REQUIRE(Cout > 0 && Cin > 0 && KH > 0 && KW > 0 && KH * KW <= 32, TSPN_EINVAL,
+               "tspn_pack_conv2d_f32: bad sizes");
+  const int64_t total = KH * KW * Cin * Cout;
+  const int blocks = (int)std::min<int64_t>(tspn::ceil_div(total, 256), 8192);
+  hipLaunchKernelGGL(pack_conv2d_kernel, dim3(blocks), dim3(256), 0, TSPN_STREAM(stream), w, Cout, Cin, KH, KW,
+                     packed);
+  return tspn::check_launch("tspn_pack_conv2d_f32");
+}
+
+extern "C" int tspn_conv2d_nhwc_f32(const float* x, int64_t NB, int64_t H, int64_t W, int64_t Cin,
+                                    const float* packed, int64_t Cout, int64_t KH, int64_t KW, int64_t stride,
+                                    int64_t pad, const float* bias, const float* residual, int relu, float* out,
+                                    void* stream) {
+  TSPN_REQUIRE(NB >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0,
+               TSPN_EINVAL, "tspn_conv2d_nhwc_f32: bad sizes");
+  TSPN_REQUIRE(KH * KW <= 32, TSPN_EUNSUPPORTED, "tspn_conv2d_nhwc_f32: at most 32 taps");
+  const int64_t OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+  TSPN_REQUIRE(OH > 0 && OW > 0, TSPN_EINVAL, "tspn_conv2d_nhwc_f32: empty output (H=%lld W=%lld)", (long long)H,
+               (long long)W);
+  if (NB == 0) return TSPN_OK;
+  TSPN_REQUIRE(x && packed && out, TSPN_EINVAL, "tspn_conv2d_nhwc_f32: null pointer");
+  TSPN_REQUIRE(Cin % KC == 0 && Cout % 4 == 0, TSPN_EUNSUPPORTED,
+               "tspn_conv2d_nhwc_f32: needs Cin %% 16 == 0 and Cout %% 4 == 0 (Cin=%lld Cout=%lld)", (long long)Cin,
+               (long long)Cout);
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  TSPN_REQUIRE(al16(x) && al16(packed) && al16(out) && (!bias || al16(bias)) && (!residual || al16(residual)),
+               TSPN_EUNSUPPORTED, "tspn_conv2d_nhwc_f32: operands must be 16-byte aligned");
+  TSPN_REQUIRE(H < (1 << 20) && W < (1 << 20) && Cin < (1 << 24) && Cout < (1 << 24), TSPN_EUNSUPPORTED,
+               "tspn_conv2d_nhwc_f32: dimension too large");
+  const int64_t npix = NB * OH * OW;
+  const int64_t tiles_m = tspn::ceil_div(Cout, BM), tiles_n = tspn::ceil_div(npix, BN);
+  TSPN_REQUIRE(tiles_m * tiles_n < (1LL << 31), TSPN_EUNSUPPORTED, "tspn_conv2d_nhwc_f32: grid too large");
+  hipLaunchKernelGGL(conv2d_nhwc_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(THREADS), SMEM_BYTES,
+                     TSPN_STREAM(stream), x, packed, bias, residual, out, (int)H, (int)W, (int)Cin, (int)Cout,
+                     (int)KH, (int)KW, (int)stride, (int)pad, (int)OH, (int)OW, npix, (int)tiles_m, (int)tiles_n,
+                     relu);
+  return tspn::check_launch("tspn_conv2d_nhwc_f32");
+}
+
+extern "C" int tspn_roi_align_nhwc_f32(const float* feat, int64_t NF, int64_t H, int64_t W, int64_t C,
+                                       const float* rois, int64_t R, int64_t P, float spatial_scale,
+                                       int sampling_ratio, int aligned, float* out, void* stream) {
+  TSPN_REQUIRE(NF > 0 && H > 0 && W > 0 && C > 0 && R >= 0 && P > 0 && sampling_ratio >= 0, TSPN_EINVAL,
+               "tspn_roi_align_nhwc_f32: bad sizes");
+  if (R == 0) return TSPN_OK;
+  TSPN_REQUIRE(feat && rois && out, TSPN_EINVAL, "tspn_roi_align_nhwc_f32: null pointer");
+  TSPN_REQUIRE(C % 4 == 0 && (reinterpret_cast<uintptr_t>(feat) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(out) & 15) == 0,
+               TSPN_EUNSUPPORTED, "tspn_roi_align_nhwc_f32: needs C %% 4 == 0 and 16-byte aligned tensors");
+  TSPN_REQUIRE(R * P < (1LL << 31) && H < (1 << 20) && W < (1 << 20), TSPN_EUNSUPPORTED,
+               "tspn_roi_align_nhwc_f32: problem too large");
+  hipLaunchKernelGGL(roi_align_nhwc_kernel, dim3((unsigned)(R * P)), dim3(256), 0, TSPN_STREAM(stream), feat,
+                     (int)NF, (int)H, (int)W, (int)C, rois, R, (int)P, spatial_scale, sampling_ratio, aligned, out);
+  return tspn::check_launch("tspn_roi_align_nhwc_f32");
+}

@@ -17,6 +17,7 @@ __all__ = [
     "forward_fused", "temporal_encoder_heads", "fused_workspace_bytes", "decode_topk", "decode_spans",
     "cast_bf16", "pack_conv3_bf16", "pack_heads_bf16", "conv3_tc_bf16", "heads_pairgrid_bf16",
     "temporal_mean_bf16", "forward_fused_bf16", "span_predicate",
+    "pack_conv2d", "conv2d_nhwc", "roi_align_nhwc",
 ]
 
 
@@ -681,4 +682,58 @@ def span_predicate(feats, pairs, spans, cls_w, cls_b):
     out = torch.empty((P, K), dtype=torch.float32, device=feats.device)
     _abi.check(l.tspn_span_predicate_f32(_p(feats), NT, T, D, _p(pairs), _p(spans), P, _p(cls_w), _p(cls_b), K,
                                          _p(out), _p(ws), ws.numel(), _stream()))
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# f4 (first slice): RoI feature head operators (csrc/tspn_roi.hip)
+# --------------------------------------------------------------------------- #
+def pack_conv2d(weight):
+    """nn.Conv2d weight [Cout,Cin,KH,KW] -> [KH*KW, Cin, Cout] (tspn_pack_conv2d_f32)."""
+    _dev(weight, "conv2d weight")
+    if weight.dim() != 4:
+        raise ValueError("pack_conv2d: weight must be [Cout,Cin,KH,KW]")
+    Cout, Cin, KH, KW = weight.shape
+    packed = torch.empty((KH * KW, Cin, Cout), dtype=torch.float32, device=weight.device)
+    _abi.check(_abi.lib().tspn_pack_conv2d_f32(_p(weight), Cout, Cin, KH, KW, _p(packed), _stream()))
+    return packed
+
+
+def conv2d_nhwc(x, packed, kernel_size, stride=1, padding=0, bias=None, residual=None, relu=False):
+    """act(conv2d(x) + bias + residual) on channels-last tensors: x [NB,H,W,Cin] -> [NB,OH,OW,Cout];
+    `packed` = pack_conv2d(weight), kernel_size = (KH, KW)."""
+    _dev(x, "x"); _dev(packed, "packed")
+    NB, H, W, Cin = x.shape
+    KH, KW = kernel_size
+    if packed.dim() != 3 or packed.shape[0] != KH * KW or packed.shape[1] != Cin:
+        raise ValueError(f"conv2d_nhwc: packed weights {tuple(packed.shape)} do not match taps={KH * KW}, Cin={Cin}")
+    Cout = packed.shape[2]
+    OH, OW = (H + 2 * padding - KH) // stride + 1, (W + 2 * padding - KW) // stride + 1
+    if OH <= 0 or OW <= 0:
+        raise ValueError("conv2d_nhwc: empty output")
+    if bias is not None:
+        _dev(bias, "bias")
+        if bias.shape != (Cout,):
+            raise ValueError("conv2d_nhwc: bias shape mismatch")
+    if residual is not None:
+        _dev(residual, "residual")
+        if tuple(residual.shape) != (NB, OH, OW, Cout):
+            raise ValueError("conv2d_nhwc: residual shape mismatch")
+    out = torch.empty((NB, OH, OW, Cout), dtype=torch.float32, device=x.device)
+    _abi.check(_abi.lib().tspn_conv2d_nhwc_f32(_p(x), NB, H, W, Cin, _p(packed), Cout, KH, KW, stride, padding,
+                                               _p(bias), _p(residual), 1 if relu else 0, _p(out), _stream()))
+    return out
+
+
+def roi_align_nhwc(feat, rois, output_size, spatial_scale, sampling_ratio=0, aligned=True):
+    """detectron2 ROIAlign on a channels-last map: feat [NF,H,W,C], rois [R,5] = (map index, x1, y1, x2, y2)
+    -> [R,P,P,C]."""
+    _dev(feat, "feat"); _dev(rois, "rois")
+    NF, H, W, C = feat.shape
+    if rois.dim() != 2 or rois.shape[1] != 5:
+        raise ValueError("roi_align_nhwc: rois must be [R,5]")
+    R, P = rois.shape[0], int(output_size)
+    out = torch.empty((R, P, P, C), dtype=torch.float32, device=feat.device)
+    _abi.check(_abi.lib().tspn_roi_align_nhwc_f32(_p(feat), NF, H, W, C, _p(rois), R, P, float(spatial_scale),
+                                                  int(sampling_ratio), 1 if aligned else 0, _p(out), _stream()))
     return out

@@ -1,0 +1,134 @@
+"""RoI feature head on the GPU: res4 feature maps + tracklet boxes -> per-(tracklet, frame) RoI features,
+the `tracklet_feats [N,T,D]` the pair builder consumes (first slice).
+
+The reference obtains these features from detectron2's R101-C4 model (lib/detectron/trainer.py:23-33
+configures it; 35 classes) — it owns no code for the step.  This module mirrors that model's ROI head
+(detectron2 v0.6 `Res5ROIHeads`: ROIAlign 14x14 aligned / adaptive sampling on the stride-16 map -> res5 =
+3 BottleneckBlocks with stride_in_1x1 and FrozenBatchNorm -> mean over 7x7) with the SAME parameter names
+(`res5.{b}.{conv1,conv2,conv3,shortcut}.weight`, `...norm.{weight,bias,running_mean,running_var}`), so the
+`roi_heads.res5.*` entries of a detectron2 checkpoint load with `load_state_dict` after stripping the
+`roi_heads.` prefix.  Every tensor operation runs in the hand-written HIP library (ops.roi_align_nhwc,
+ops.conv2d_nhwc: fp32 MFMA implicit GEMM, channels-last); there is no CPU path.
+
+Not built: the C4 backbone itself (stem, res2-res4 on full frames) — the caller hands over
+res4 maps, channels-last.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .model import _DeviceCache, _compute_device, _f32
+
+BN_EPS = 1e-5   # detectron2 FrozenBatchNorm2d default
+
+
+class FrozenBatchNorm2d(nn.Module):
+    """Parameter holder of detectron2's FrozenBatchNorm2d (layers/batch_norm.py): four buffers."""
+
+    def __init__(self, num_features):
+        super().__init__()
+        self.register_buffer("weight", torch.ones(num_features))
+        self.register_buffer("bias", torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+
+
+class ConvFrozenBN(nn.Module):
+    """detectron2 `Conv2d(bias=False, norm=FrozenBN)`: `weight` [Cout,Cin,k,k] + `norm.*`.  The batch norm is
+    folded into the packed weight and a bias once per parameter version:
+        w' = w * scale[co],  b' = bias - running_mean * scale,  scale = weight * rsqrt(running_var + eps)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, kernel_size, kernel_size))
+        nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")
+        self.norm = FrozenBatchNorm2d(out_channels)
+        self.kernel_size, self.stride, self.padding = kernel_size, stride, padding
+        self._cache = _DeviceCache()
+
+    def folded(self, dev):
+        def build(ts):
+            w, g, b, m, v = ts
+            scale = g * torch.rsqrt(v + BN_EPS)
+            return ops.pack_conv2d((w * scale.reshape(-1, 1, 1, 1)).contiguous()), (b - m * scale).contiguous()
+        n = self.norm
+        return self._cache.get("folded", (self.weight, n.weight, n.bias, n.running_mean, n.running_var), dev, build)
+
+    def forward(self, x, residual=None, relu=False):
+        """x channels-last [NB,H,W,Cin] on the HIP device -> act(bn(conv(x)) + residual)."""
+        packed, bias = self.folded(x.device)
+        return ops.conv2d_nhwc(x, packed, (self.kernel_size, self.kernel_size), self.stride, self.padding,
+                               bias=bias, residual=residual, relu=relu)
+
+
+class BottleneckBlock(nn.Module):
+    """detectron2 BottleneckBlock (modeling/backbone/resnet.py), stride_in_1x1=True: 1x1 (stride) -> 3x3 -> 1x1,
+    projection shortcut when the channel count changes, ReLU after the residual add (fused into conv3)."""
+
+    def __init__(self, in_channels, out_channels, bottleneck_channels, stride=1):
+        super().__init__()
+        self.shortcut = ConvFrozenBN(in_channels, out_channels, 1, stride) if in_channels != out_channels else None
+        self.conv1 = ConvFrozenBN(in_channels, bottleneck_channels, 1, stride)
+        self.conv2 = ConvFrozenBN(bottleneck_channels, bottleneck_channels, 3, 1, 1)
+        self.conv3 = ConvFrozenBN(bottleneck_channels, out_channels, 1)
+        self.stride = stride
+
+    def forward(self, x):
+        out = self.conv1(x, relu=True)
+        out = self.conv2(out, relu=True)
+        if self.shortcut is not None:
+            sc = self.shortcut(x)
+        elif self.stride == 1:
+            sc = x
+        else:
+            raise ValueError("identity shortcut needs stride 1")
+        return self.conv3(out, residual=sc, relu=True)
+
+
+class Res5RoIHead(nn.Module):
+    """ROIAlign + res5 + spatial mean (detectron2 Res5ROIHeads._shared_roi_transform, then .mean([2,3])).
+
+    forward(feature_maps, tracklet_boxes):
+        feature_maps  [T,Hf,Wf,C] channels-last res4 maps, one per frame (use `from_nchw` for NCHW maps)
+        tracklet_boxes [N,T,4] (left, top, right, bottom) in image pixels
+        -> tracklet_feats [N,T,out_channels] on the device of `tracklet_boxes`
+    """
+
+    def __init__(self, in_channels=1024, bottleneck_channels=512, out_channels=2048, num_blocks=3,
+                 pooler_resolution=14, spatial_scale=1.0 / 16, sampling_ratio=0, first_stride=2, roi_chunk=1024):
+        super().__init__()
+        blocks, cin = [], in_channels
+        for b in range(num_blocks):
+            blocks.append(BottleneckBlock(cin, out_channels, bottleneck_channels, first_stride if b == 0 else 1))
+            cin = out_channels
+        self.res5 = nn.Sequential(*blocks)
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.pooler_resolution, self.spatial_scale, self.sampling_ratio = pooler_resolution, spatial_scale, sampling_ratio
+        self.roi_chunk = int(roi_chunk)
+
+    @staticmethod
+    def from_nchw(feature_maps):
+        """[T,C,Hf,Wf] (what a detectron2 backbone returns) -> channels-last [T,Hf,Wf,C]."""
+        return feature_maps.permute(0, 2, 3, 1).contiguous()
+
+    def forward(self, feature_maps, tracklet_boxes):
+        with torch.no_grad():
+            dev = _compute_device(feature_maps, tracklet_boxes, self.res5[0].conv1.weight)
+            fm = _f32(feature_maps, dev)
+            if fm.dim() != 4 or fm.shape[3] != self.in_channels:
+                raise ValueError(f"feature_maps must be channels-last [T,Hf,Wf,{self.in_channels}], got {tuple(fm.shape)}")
+            boxes = _f32(tracklet_boxes, dev)
+            if boxes.dim() != 3 or boxes.shape[2] != 4 or boxes.shape[1] != fm.shape[0]:
+                raise ValueError(f"tracklet_boxes must be [N,T={fm.shape[0]},4], got {tuple(boxes.shape)}")
+            n, t, _ = boxes.shape
+            idx = torch.arange(t, dtype=torch.float32, device=dev).repeat(n)
+            rois = torch.cat([idx[:, None], boxes.reshape(n * t, 4)], dim=1).contiguous()
+            feats = torch.empty((n * t, self.out_channels), dtype=torch.float32, device=dev)
+            for lo in range(0, n * t, self.roi_chunk):
+                x = ops.roi_align_nhwc(fm, rois[lo:lo + self.roi_chunk].contiguous(), self.pooler_resolution,
+                                       self.spatial_scale, self.sampling_ratio, aligned=True)
+                x = self.res5(x)
+                r, h, w, c = x.shape
+                feats[lo:lo + r] = ops.temporal_mean(x.view(r, h * w, c), layout_tc=True)
+            src = tracklet_boxes.device if isinstance(tracklet_boxes, torch.Tensor) else torch.device("cpu")
+            return feats.view(n, t, self.out_channels).to(src)

@@ -1,0 +1,119 @@
+"""RoI feature head (first slice) on the GPU against its CPU restatement
+(oracle/roi_head_oracle.py: detectron2's published ROIAlign / BottleneckBlock / FrozenBN algorithms; the
+reference itself has no runnable counterpart — parity unpinned by the reference)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import roi_head_oracle as ro
+
+pytestmark = pytest.mark.gpu
+
+
+def t(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+@pytest.mark.parametrize("NB,H,W,Cin,Cout,k,stride,pad", [
+    (2, 7, 7, 16, 32, 1, 1, 0), (3, 14, 14, 32, 64, 1, 2, 0), (2, 7, 7, 32, 48, 3, 1, 1),
+    (1, 9, 11, 16, 132, 3, 2, 1), (5, 7, 7, 64, 256, 3, 1, 1), (40, 7, 7, 48, 96, 1, 1, 0),
+    (1, 1, 1, 16, 4, 1, 1, 0), (2, 5, 6, 16, 20, 3, 1, 0)])
+@pytest.mark.parametrize("fused", [False, True])
+def test_conv2d_nhwc_vs_torch(tspn, device, NB, H, W, Cin, Cout, k, stride, pad, fused):
+    """Implicit-GEMM conv2d on channels-last tensors == F.conv2d (float64) for 1x1 / 3x3, stride 1 / 2, with
+    and without padding, partial weight and pixel tiles; fused bias + residual + ReLU epilogue."""
+    x = tspn.hashrng.uniform(71, "x", (NB, H, W, Cin), -1, 1)
+    w = tspn.hashrng.normal(71, "w", (Cout, Cin, k, k), std=0.1)
+    b = tspn.hashrng.normal(71, "b", (Cout,), std=0.1)
+    ref = torch.nn.functional.conv2d(t(x).double().permute(0, 3, 1, 2), t(w).double(), t(b).double() if fused else None,
+                                     stride=stride, padding=pad).permute(0, 2, 3, 1)
+    res = tspn.hashrng.uniform(71, "r", tuple(ref.shape), -1, 1)
+    if fused:
+        ref = torch.relu(ref + t(res).double())
+    packed = tspn.ops.pack_conv2d(t(w).to(device))
+    np.testing.assert_array_equal(packed.cpu().numpy(), w.transpose(2, 3, 1, 0).reshape(k * k, Cin, Cout))
+    y = tspn.ops.conv2d_nhwc(t(x).to(device), packed, (k, k), stride, pad,
+                             bias=t(b).to(device) if fused else None,
+                             residual=t(res).to(device) if fused else None, relu=fused)
+    assert tuple(y.shape) == tuple(ref.shape)
+    np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), rtol=0, atol=2e-5)
+
+
+def test_conv2d_nhwc_errors(tspn, device):
+    x = torch.zeros((1, 4, 4, 8), device=device)
+    with pytest.raises(tspn._abi.TspnError):          # Cin % 16 != 0
+        tspn.ops.conv2d_nhwc(x, torch.zeros((1, 8, 16), device=device), (1, 1))
+    with pytest.raises(ValueError):                   # packed weights for another Cin
+        tspn.ops.conv2d_nhwc(torch.zeros((1, 4, 4, 16), device=device), torch.zeros((1, 32, 16), device=device), (1, 1))
+    with pytest.raises(RuntimeError):                 # CPU tensor: no fallback
+        tspn.ops.conv2d_nhwc(torch.zeros((1, 4, 4, 16)), torch.zeros((1, 16, 16)), (1, 1))
+    y = tspn.ops.conv2d_nhwc(torch.zeros((0, 4, 4, 16), device=device), torch.zeros((1, 16, 16), device=device), (1, 1))
+    assert y.shape == (0, 4, 4, 16)
+
+
+@pytest.mark.parametrize("sampling_ratio,aligned", [(0, True), (2, True), (0, False), (3, False)])
+def test_roi_align_nhwc_vs_oracle(tspn, device, sampling_ratio, aligned):
+    """ROIAlign == the restated detectron2 CPU kernel: boxes inside, touching and beyond the map, tiny and
+    large boxes (adaptive grid 1..4 samples), several maps."""
+    NF, H, W, C, P = 3, 9, 12, 8, 5
+    feat = tspn.hashrng.uniform(72, "f", (NF, H, W, C), -1, 1)
+    rois = np.array([[0, 10, 20, 100, 120], [1, 0, 0, 191, 143], [2, -30, -10, 60, 50], [0, 150, 100, 260, 200],
+                     [1, 40.5, 33.25, 41.0, 34.0], [2, 5, 5, 180, 20], [1, 300, 300, 400, 400]], dtype=np.float32)
+    ref = ro.roi_align_nhwc(feat, rois, P, 1.0 / 16, sampling_ratio, aligned)
+    got = tspn.ops.roi_align_nhwc(t(feat).to(device), t(rois).to(device), P, 1.0 / 16, sampling_ratio, aligned)
+    np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=0, atol=2e-6)
+    const = tspn.ops.roi_align_nhwc(torch.full((1, H, W, C), 3.0, device=device), t(rois[:2] * [0, 1, 1, 1, 1]).float().to(device),
+                                    P, 1.0 / 16, sampling_ratio, aligned)
+    np.testing.assert_allclose(const.cpu().numpy(), 3.0, rtol=1e-6)   # a constant map pools to the constant
+
+
+def _head_and_weights(tspn, device, cin, mid, cout, **kw):
+    u = lambda name, shape, lo, hi: tspn.hashrng.uniform(73, name, shape, lo, hi)
+    nrm = lambda name, shape, std: tspn.hashrng.normal(73, name, shape, std=std)
+    p = ro.make_res5_weights(u, nrm, cin, mid, cout)
+    head = tspn.Res5RoIHead(cin, mid, cout, **kw)
+    missing, unexpected = head.load_state_dict(p, strict=True)
+    assert not missing and not unexpected            # detectron2 key names: res5.{b}.{conv}.weight / .norm.*
+    return head.to(device), p
+
+
+def test_res5_roi_head_matches_oracle(tspn, device):
+    """Tracklet boxes + res4 maps -> [N,T,D] features == ROIAlign + 3 bottleneck blocks (FrozenBN unfused,
+    float64 convs) + spatial mean; then the features go straight into the fused scorer."""
+    N, T, cin, mid, cout = 3, 4, 64, 32, 128
+    head, p = _head_and_weights(tspn, device, cin, mid, cout, roi_chunk=5)      # 12 RoIs in chunks of 5
+    fm = tspn.hashrng.uniform(74, "fm", (T, 10, 12, cin), 0, 1)
+    v = tspn.synth.make_video(75, N, T, 16)
+    boxes = (v["tracklet_boxes"] * np.float32(0.15)).astype(np.float32)          # inside a 192 x 160 image
+    got = head(t(fm), t(boxes))                                                   # CPU in -> CPU out
+    assert got.device.type == "cpu" and tuple(got.shape) == (N, T, cout)
+    ref = ro.res5_roi_head(t(fm), t(boxes), p, dtype=torch.float64)
+    scale = float(ref.abs().max())
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=0, atol=2e-5 * max(scale, 1.0))
+    # NCHW maps (what a detectron2 backbone returns) through the helper
+    got2 = head(tspn.Res5RoIHead.from_nchw(t(fm).permute(0, 3, 1, 2).contiguous()).to(device), t(boxes).to(device))
+    assert got2.is_cuda and torch.equal(got2.cpu(), got)
+    # hand-over to the pair builder: the features are the `tracklet_feats` of PairList.from_tracklets
+    plist = tspn.PairList.from_tracklets(got2, t(boxes).to(device), t(v["track_cls_logits"]).to(device))
+    assert plist.get_field("tracklet_feats").shape == (N, T, cout)
+
+
+def test_res5_roi_head_full_width(tspn, device):
+    """The real widths (1024 -> 512 -> 2048, 14x14 -> 7x7) on a handful of boxes."""
+    N, T = 2, 2
+    head, p = _head_and_weights(tspn, device, 1024, 512, 2048)
+    fm = tspn.hashrng.uniform(76, "fm", (T, 8, 10, 1024), 0, 1)
+    boxes = np.array([[[8, 8, 100, 90], [20, 10, 140, 120]], [[0, 0, 159, 127], [60, 40, 90, 70]]], dtype=np.float32)
+    got = head(t(fm).to(device), t(boxes).to(device)).cpu()
+    ref = ro.res5_roi_head(t(fm), t(boxes), p, dtype=torch.float64)
+    scale = float(ref.abs().max())
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=0, atol=5e-5 * max(scale, 1.0))
+
+
+def test_res5_roi_head_errors(tspn, device):
+    head = tspn.Res5RoIHead(32, 16, 64).to(device)
+    with pytest.raises(ValueError):
+        head(torch.zeros((2, 5, 5, 16), device=device), torch.zeros((1, 2, 4), device=device))   # wrong C
+    with pytest.raises(ValueError):
+        head(torch.zeros((2, 5, 5, 32), device=device), torch.zeros((1, 3, 4), device=device))   # T mismatch

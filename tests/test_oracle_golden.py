@@ -200,3 +200,21 @@ def test_forward_bf16_is_forward_dense_on_rounded_operands_up_to_one_rounding():
         assert out[k].shape == ref[k].shape
         scale = float(ref[k].abs().max())
         assert float((out[k] - ref[k]).abs().max()) <= 2.0 ** -8 * max(scale, 1.0)
+
+
+def test_roi_align_oracle_known_answers():
+    """oracle.roi_head_oracle.roi_align_nhwc (restated detectron2 CPU kernel): hand-computed cases."""
+    from oracle import roi_head_oracle as ro
+    # map value = 10*y + x; legacy (aligned=False) box [0,0,2,2] at scale 1, P=2, one sample per bin:
+    # sample points (0.5,0.5), (0.5,1.5), (1.5,0.5), (1.5,1.5) -> bilinear of a linear map = its value there
+    fmap = np.fromfunction(lambda y, x: 10.0 * y + x, (4, 4), dtype=np.float32)[None, :, :, None]
+    out = ro.roi_align_nhwc(fmap, np.array([[0, 0, 0, 2, 2]], dtype=np.float32), 2, 1.0, 1, False)
+    np.testing.assert_allclose(out[0, :, :, 0].numpy(), [[5.5, 6.5], [15.5, 16.5]], rtol=1e-6)
+    # aligned=True shifts the sampling grid by half a pixel
+    out = ro.roi_align_nhwc(fmap, np.array([[0, 0, 0, 2, 2]], dtype=np.float32), 2, 1.0, 1, True)
+    np.testing.assert_allclose(out[0, :, :, 0].numpy(), [[0.0, 1.0], [10.0, 11.0]], atol=1e-6)
+    # a box entirely outside the map pools to zero; a constant map pools to the constant
+    assert float(ro.roi_align_nhwc(fmap, np.array([[0, 50, 50, 60, 60]], dtype=np.float32), 2, 1.0, 0, True).abs().max()) == 0.0
+    const = ro.roi_align_nhwc(np.full((1, 5, 5, 3), 2.5, dtype=np.float32), np.array([[0, 1, 1, 30, 40]], dtype=np.float32),
+                              3, 0.1, 0, True)
+    np.testing.assert_allclose(const.numpy(), 2.5, rtol=1e-6)
