@@ -377,6 +377,16 @@ int tspn_conv2d_nhwc_f32(const float* x, int64_t NB, int64_t H, int64_t W, int64
                          const float* packed, int64_t Cout, int64_t KH, int64_t KW, int64_t stride,
                          int64_t pad, const float* bias, const float* residual, int relu, float* out,
                          void* stream);
+/* Fast variant for Cout % 32 == 0 (the res5 widths): FRAGMENT-MAJOR weights
+ *   frag[Cout/32][KH*KW][Cin/16][64 lanes = 32 kh + li][8 = (g, r)] = w[32 mb + li][16 c + 4 g + 2 kh + r][tap]
+ * loaded straight into MFMA operand registers (each wave owns 32 output rows; only x goes through LDS).
+ * Same arguments and result as tspn_conv2d_nhwc_f32 (bit-identical: same contraction order). */
+int tspn_pack_conv2d_frag_f32(const float* w, int64_t Cout, int64_t Cin, int64_t KH, int64_t KW,
+                              float* frag, void* stream);
+int tspn_conv2d_nhwc_frag_f32(const float* x, int64_t NB, int64_t H, int64_t W, int64_t Cin,
+                              const float* frag, int64_t Cout, int64_t KH, int64_t KW, int64_t stride,
+                              int64_t pad, const float* bias, const float* residual, int relu, float* out,
+                              void* stream);
 /* tspn_roi_align_nhwc_f32: detectron2 ROIAlign on a channels-last map feat[NF,H,W,C]:
  *   rois[R,5] = (map index, x1, y1, x2, y2) in image coordinates, `spatial_scale` image -> map,
  *   out[R,P,P,C]; sampling_ratio 0 = adaptive grid ceil(roi size / P) (detectron2's POOLER_SAMPLING_RATIO 0);

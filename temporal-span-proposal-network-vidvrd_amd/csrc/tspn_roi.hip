@@ -13,6 +13,7 @@
 //   * roi_align_nhwc_kernel: detectron2's ROIAlign (aligned or legacy, fixed or adaptive sampling grid) on a
 //     channels-last feature map; one workgroup per output bin row, a thread = 4 channels.
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "tspn_common.h"
@@ -20,15 +21,15 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int THREADS = 256;
 constexpr int BM = 128, BN = 128;
-constexpr int KC = 16;                 // channels per K chunk
-constexpr int NG = KC / 4;             // 4-channel groups
 constexpr int SLP = 132;               // padded pixel slots per channel group (128 used)
-constexpr int A_ST = KC * BM;          // floats
-constexpr int B_ST = NG * SLP * 4;     // floats
-constexpr size_t SMEM_BYTES = sizeof(float) * 2 * (A_ST + B_ST);
+// KC = channels per K chunk (template parameter: 32 where Cin allows, else 16): 2 KC MFMAs per wave
+// between two barriers; LDS 2 x (KC x 128 + KC/4 x 132 x 4) floats = 33 / 66 KB
+template <int KC>
+constexpr size_t smem_bytes() { return sizeof(float) * 2 * (KC * BM + (KC / 4) * SLP * 4); }
 
 __device__ float g_zero_page[64];      // source of padding taps (never written)
 
@@ -50,13 +51,18 @@ __global__ void pack_conv2d_kernel(const float* __restrict__ w, int64_t Cout, in
   }
 }
 
+template <int KC>
 __global__ __launch_bounds__(THREADS, 2) void conv2d_nhwc_kernel(
     const float* __restrict__ x, const float* __restrict__ Wp, const float* __restrict__ bias,
     const float* __restrict__ residual, float* __restrict__ out, int H, int W, int Cin, int Cout, int KH,
     int KW, int stride, int pad, int OH, int OW, int64_t npix, int tiles_m, int tiles_n, int relu) {
+  constexpr int NG = KC / 4;             // 4-channel groups per chunk
+  constexpr int A_ST = KC * BM;          // floats
+  constexpr int B_ST = NG * SLP * 4;     // floats
+  constexpr int NP = KC / 8;             // DMA pieces per wave and operand
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* As = reinterpret_cast<float*>(smem_raw);   // [2][16 ch][128 m]
-  float* Bs = As + 2 * A_ST;                         // [2][4 groups][132 slots][4 ch]
+  float* As = reinterpret_cast<float*>(smem_raw);   // [2][KC ch][128 m]
+  float* Bs = As + 2 * A_ST;                         // [2][KC/4 groups][132 slots][4 ch]
 
   // workgroup -> tile: bijective XCD remap, then groups of GM weight panels x all pixel tiles
   const int nwg = gridDim.x;
@@ -80,11 +86,11 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_nhwc_kernel(
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, kh = lane >> 5;
 
-  // ---- weight pieces: wave w stages rows 4w .. 4w+3 of the 16 x 128 tile, two rows per piece
+  // ---- weight pieces: wave w stages rows 2 NP w .. 2 NP (w+1) - 1 of the KC x 128 tile, two rows per piece
   const int am = (lane & 31) * 4;
   const int amc = m0 + am < Cout ? m0 + am : 0;       // columns beyond Cout: re-read column 0, never stored
-  const int arow = 4 * wave + (lane >> 5);            // + 2 i
-  // ---- x pieces: both pieces of a lane belong to ONE output pixel (slot), channel groups g and g + 2
+  const int arow = 2 * NP * wave + (lane >> 5);       // + 2 i
+  // ---- x pieces: all pieces of a lane belong to ONE output pixel (slot), channel groups bg, bg + 2, ...
   const int slot = 64 * (wave & 1) + lane;
   const int bg = wave >> 1;
   int64_t pbase;          // offset (floats) of input pixel (ih0, iw0) of this lane's output pixel, channel 0
@@ -110,12 +116,14 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_nhwc_kernel(
     const int tap = i / cchunks, c = i - tap * cchunks;
     const int ta = tap / KW, tb = tap - ta * KW;
     const float* wsrc = Wp + ((int64_t)tap * Cin + c * KC + arow) * Cout + amc;
-    glds16(wsrc, As + buf * A_ST + (4 * wave) * BM);
-    glds16(wsrc + 2 * (int64_t)Cout, As + buf * A_ST + (4 * wave + 2) * BM);
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+      glds16(wsrc + 2 * p * (int64_t)Cout, As + buf * A_ST + (2 * NP * wave + 2 * p) * BM);
     const bool valid = (tapmask >> tap) & 1u;
     const float* xs = valid ? x + pbase + ((int64_t)ta * W + tb) * Cin + c * KC + 4 * bg : g_zero_page + 4 * bg;
-    glds16(xs, Bs + buf * B_ST + (bg * SLP + 64 * (wave & 1)) * 4);
-    glds16(xs + 8, Bs + buf * B_ST + ((bg + 2) * SLP + 64 * (wave & 1)) * 4);
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+      glds16(xs + 8 * p, Bs + buf * B_ST + ((bg + 2 * p) * SLP + 64 * (wave & 1)) * 4);
   };
 
   f32x16 acc[2][2];
@@ -145,9 +153,13 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_nhwc_kernel(
 
   stage(0, 0);
   __syncthreads();   // (hipcc drains the LDS-DMA with vmcnt(0) here)
-  for (int i = 0; i < nchunks; ++i) {
+  // chunk i: 2 KC MFMAs per wave on buffer i & 1, the DMA pieces of chunk i+1 and the fragment reads of
+  // the next channel group issued between them (1 MFMA : 1 LDS read, a DMA piece behind every other MFMA of
+  // the first groups)
+  auto chunk_body = [&](int i, auto more_tag) {
+    constexpr bool MORE = decltype(more_tag)::value;
     const int buf = i & 1;
-    if (i + 1 < nchunks) stage(buf ^ 1, i + 1);
+    if (MORE) stage(buf ^ 1, i + 1);
     const float* Ab = As + buf * A_ST + wm * 64 + li;
     const float* Bb = Bs + buf * B_ST + (wn * 64 + li) * 4 + 2 * kh;
     Frag cur = read_frag(Ab, Bb, 0);
@@ -164,10 +176,23 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_nhwc_kernel(
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[1][e], b0, acc[1][0], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[1][e], b1, acc[1][1], 0, 0, 0);
       }
+#if !defined(TSPN_CONV2D_NOINTERLEAVE)
+#define TSPN_G(NVM)                                     \
+  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    \
+  __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    \
+  __builtin_amdgcn_sched_group_barrier(0x020, NVM, 0);
+      // (the 2 NP pieces of this wave: four per channel group)
+      if (g < NP / 2 && MORE) { TSPN_G(1) TSPN_G(0) TSPN_G(1) TSPN_G(0) TSPN_G(1) TSPN_G(0) TSPN_G(1) TSPN_G(0) }
+      else { TSPN_G(0) TSPN_G(0) TSPN_G(0) TSPN_G(0) TSPN_G(0) TSPN_G(0) TSPN_G(0) TSPN_G(0) }
+#undef TSPN_G
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       cur = nxt;
     }
     __syncthreads();
-  }
+  };
+  for (int i = 0; i + 1 < nchunks; ++i) chunk_body(i, std::true_type{});
+  chunk_body(nchunks - 1, std::false_type{});
 
   // ---- epilogue: a lane holds 4 consecutive output channels of one pixel per register quad
 #pragma unroll
@@ -197,6 +222,189 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_nhwc_kernel(
         }
         *reinterpret_cast<float4*>(orow + m) = v;
       }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fast variant for Cout % 32 == 0: FRAGMENT-MAJOR weights loaded straight into MFMA operand registers
+// (the recipe of tspn_wino43r.hip).  Tile 128 output channels x 128 pixels; wave w = rows [32 w, 32 w + 32)
+// x all 128 pixels (4 accumulator blocks), so a wave's weight slice is private and never needs LDS:
+//     Wf[Cout / 32][tap][Cin / 16][lane = 32 kh + li][8]  =  w[32 mb + li][16 c + 4 g + 2 kh + r][tap],  8 = (g, r)
+// is two global_load_dwordx4 per lane and chunk (one 2-KiB line per wave), refilled for chunk i+1 as soon
+// as the MFMAs of chunk i have read them (rolling, counted vmcnt).  Only the x tile goes through LDS
+// (2 DMA pieces per wave and chunk, double-buffered, bare s_barrier per chunk).
+template <int OFF>
+__device__ __forceinline__ void load_wfrag(f32x4& dst, unsigned lane_off, const char* base) {
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(lane_off), "s"(base), "n"(OFF) : "memory");
+}
+template <int VM>
+__device__ __forceinline__ void wait_w(f32x4& r) {
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r) : "n"(VM));
+}
+
+// w [Cout][Cin][KH][KW] -> fragment-major [Cout/32][KH*KW][Cin/16][64][8]
+__global__ void pack_conv2d_frag_kernel(const float* __restrict__ w, int64_t Cout, int64_t Cin, int64_t ntaps,
+                                        float* __restrict__ packed) {
+  const int64_t total = ntaps * Cin * Cout;
+  const int64_t cch = Cin / 16;
+  for (int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; o < total;
+       o += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(o & 1), g = (int)((o >> 1) & 3), lane = (int)((o >> 3) & 63);
+    const int64_t q = o >> 9;
+    const int64_t c = q % cch, tap = (q / cch) % ntaps, mb = q / (cch * ntaps);
+    const int64_t co = 32 * mb + (lane & 31), ci = 16 * c + 4 * g + 2 * (lane >> 5) + r;
+    packed[o] = w[(co * Cin + ci) * ntaps + tap];
+  }
+}
+
+constexpr int F_B_ST = 4 * SLP * 4;    // floats per x stage: [4 groups][132 slots][4 ch]
+
+__global__ __launch_bounds__(THREADS, 2) void conv2d_nhwc_frag_kernel(
+    const float* __restrict__ x, const float* __restrict__ Wf, const float* __restrict__ bias,
+    const float* __restrict__ residual, float* __restrict__ out, int H, int W, int Cin, int Cout, int KH,
+    int KW, int stride, int pad, int OH, int OW, int64_t npix, int tiles_m, int tiles_n, int relu) {
+  __shared__ __attribute__((aligned(16))) float Bs[2 * F_B_ST];
+
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  constexpr int GM = 4;
+  const int group_sz = GM * tiles_n;
+  const int group = wg / group_sz;
+  const int first_m = group * GM;
+  const int gm = min(GM, tiles_m - first_m);
+  const int in_group = wg - group * group_sz;
+  const int tile_m = first_m + in_group % gm;
+  const int tile_n = in_group / gm;
+  const int m0 = tile_m * BM;
+  const int64_t n0 = (int64_t)tile_n * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kh = lane >> 5;
+
+  const int cchunks = Cin >> 4;
+  const int nchunks = KH * KW * cchunks;
+  // weight fragment stream of this wave: chunk i = (tap, c) is line i of its block (tap-major like i)
+  const char* wbase;
+  const unsigned woff = lane * 32;
+  {
+    int mb = (m0 >> 5) + wave;
+    mb = mb < (Cout >> 5) ? mb : 0;               // rows beyond Cout: re-read block 0, never stored
+    wbase = reinterpret_cast<const char*>(Wf) + (int64_t)mb * nchunks * 2048;
+  }
+  // x pieces: both pieces of a lane belong to ONE output pixel (slot), channel groups bg and bg + 2
+  const int slot = 64 * (wave & 1) + lane;
+  const int bg = wave >> 1;
+  int64_t pbase;
+  unsigned tapmask = 0;
+  {
+    const int64_t n = n0 + slot;
+    const bool okn = n < npix;
+    const int64_t nc = okn ? n : 0;
+    const int64_t nb = nc / ((int64_t)OH * OW);
+    const int r = (int)(nc - nb * OH * OW);
+    const int oh = r / OW, ow = r - oh * OW;
+    const int ih0 = oh * stride - pad, iw0 = ow * stride - pad;
+    pbase = ((nb * H + ih0) * (int64_t)W + iw0) * Cin;
+    for (int a = 0; a < KH; ++a)
+      for (int b = 0; b < KW; ++b)
+        if (okn && ih0 + a >= 0 && ih0 + a < H && iw0 + b >= 0 && iw0 + b < W) tapmask |= 1u << (a * KW + b);
+  }
+  auto stage_x = [&](int buf, int i) {             // exactly two pieces per wave (padding taps read the zero page)
+    const int tap = i / cchunks, c = i - tap * cchunks;
+    const int ta = tap / KW, tb = tap - ta * KW;
+    const bool valid = (tapmask >> tap) & 1u;
+    const float* xs = valid ? x + pbase + ((int64_t)ta * W + tb) * Cin + c * 16 + 4 * bg : g_zero_page + 4 * bg;
+    glds16(xs, Bs + buf * F_B_ST + (bg * SLP + 64 * (wave & 1)) * 4);
+    glds16(xs + 8, Bs + buf * F_B_ST + ((bg + 2) * SLP + 64 * (wave & 1)) * 4);
+  };
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[ni][e] = 0.f;
+
+  f32x4 a01, a23;       // weights of channel groups (0, 1) and (2, 3): [0..1] / [2..3] = rows r = 0, 1 of a group
+  auto read_b = [&](const float* Bb, int g, float2 (&b)[4]) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) b[ni] = *reinterpret_cast<const float2*>(Bb + (g * SLP + ni * 32) * 4);
+  };
+  auto mfma_group = [&](float a0, float a1, const float2 (&b)[4]) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[ni].x, acc[ni], 0, 0, 0);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[ni].y, acc[ni], 0, 0, 0);
+  };
+
+  // ---- prologue: x_0 landed; the weights of chunk 0 are the two youngest VMEM operations
+  stage_x(0, 0);
+  __syncthreads();
+  load_wfrag<0>(a01, woff, wbase);
+  load_wfrag<16>(a23, woff, wbase);
+  wbase += 2048;
+  __builtin_amdgcn_sched_barrier(0);
+
+  // chunk i.  VMEM issue order: [x_{i+1}: 2 pieces] w01' | w23'; counts = YOUNGER operations at each wait.
+  auto chunk_body = [&](int i, auto more_tag) {
+    constexpr bool MORE = decltype(more_tag)::value;
+    constexpr int NX = MORE ? 2 : 0, NW = MORE ? 1 : 0;
+    const int buf = i & 1;
+    const float* Bb = Bs + buf * F_B_ST + li * 4 + 2 * kh;
+    float2 b0[4], b1[4];
+    wait_w<1>(a01);                                   // younger: w23 of this chunk
+    if (MORE) stage_x(buf ^ 1, i + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    read_b(Bb, 0, b0);
+    read_b(Bb, 1, b1);
+    mfma_group(a01[0], a01[1], b0);
+    read_b(Bb, 2, b0);
+    mfma_group(a01[2], a01[3], b1);
+    if (MORE) load_wfrag<0>(a01, woff, wbase);
+    __builtin_amdgcn_sched_barrier(0);
+    wait_w<NX + NW>(a23);                             // younger: the x pieces and w01' issued above
+    read_b(Bb, 3, b1);
+    mfma_group(a23[0], a23[1], b0);
+    mfma_group(a23[2], a23[3], b1);
+    if (MORE) { load_wfrag<16>(a23, woff, wbase); wbase += 2048; }
+    __builtin_amdgcn_sched_barrier(0);
+    // x_{i+1} has landed (older than the two weight loads), every LDS read of this chunk has returned
+    if (MORE) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  for (int i = 0; i + 1 < nchunks; ++i) chunk_body(i, std::true_type{});
+  chunk_body(nchunks - 1, std::false_type{});
+
+  // ---- epilogue: a lane holds 4 consecutive output channels of one pixel per register quad
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int64_t n = n0 + ni * 32 + li;
+    if (n >= npix) continue;
+    float* orow = out + n * Cout;
+    const float* rrow = residual ? residual + n * Cout : nullptr;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int m = m0 + wave * 32 + 8 * q + 4 * kh;
+      if (m >= Cout) continue;
+      float4 v = make_float4(acc[ni][4 * q], acc[ni][4 * q + 1], acc[ni][4 * q + 2], acc[ni][4 * q + 3]);
+      if (bias) {
+        const float4 bv = *reinterpret_cast<const float4*>(bias + m);
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+      }
+      if (rrow) {
+        const float4 rv = *reinterpret_cast<const float4*>(rrow + m);
+        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+      }
+      if (relu) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      }
+      *reinterpret_cast<float4*>(orow + m) = v;
+    }
   }
 }
 
@@ -288,7 +496,7 @@ extern "C" int tspn_conv2d_nhwc_f32(const float* x, int64_t NB, int64_t H, int64
                (long long)W);
   if (NB == 0) return TSPN_OK;
   TSPN_REQUIRE(x && packed && out, TSPN_EINVAL, "tspn_conv2d_nhwc_f32: null pointer");
-  TSPN_REQUIRE(Cin % KC == 0 && Cout % 4 == 0, TSPN_EUNSUPPORTED,
+  TSPN_REQUIRE(Cin % 16 == 0 && Cout % 4 == 0, TSPN_EUNSUPPORTED,
                "tspn_conv2d_nhwc_f32: needs Cin %% 16 == 0 and Cout %% 4 == 0 (Cin=%lld Cout=%lld)", (long long)Cin,
                (long long)Cout);
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
@@ -299,11 +507,56 @@ extern "C" int tspn_conv2d_nhwc_f32(const float* x, int64_t NB, int64_t H, int64
   const int64_t npix = NB * OH * OW;
   const int64_t tiles_m = tspn::ceil_div(Cout, BM), tiles_n = tspn::ceil_div(npix, BN);
   TSPN_REQUIRE(tiles_m * tiles_n < (1LL << 31), TSPN_EUNSUPPORTED, "tspn_conv2d_nhwc_f32: grid too large");
-  hipLaunchKernelGGL(conv2d_nhwc_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(THREADS), SMEM_BYTES,
-                     TSPN_STREAM(stream), x, packed, bias, residual, out, (int)H, (int)W, (int)Cin, (int)Cout,
+  // (32-channel chunks were measured slower: 92 vs 102 TFLOP/s on the res5 shapes; 16 ships)
+  hipLaunchKernelGGL(conv2d_nhwc_kernel<16>, dim3((unsigned)(tiles_m * tiles_n)), dim3(THREADS),
+                     smem_bytes<16>(), TSPN_STREAM(stream), x, packed, bias, residual, out, (int)H, (int)W,
+                     (int)Cin, (int)Cout, (int)KH, (int)KW, (int)stride, (int)pad, (int)OH, (int)OW, npix,
+                     (int)tiles_m, (int)tiles_n, relu);
+  return tspn::check_launch("tspn_conv2d_nhwc_f32");
+}
+
+extern "C" int tspn_pack_conv2d_frag_f32(const float* w, int64_t Cout, int64_t Cin, int64_t KH, int64_t KW,
+                                         float* packed, void* stream) {
+  TSPN_REQUIRE(w && packed, TSPN_EINVAL, "tspn_pack_conv2d_frag_f32: null pointer");
+  TSPN_REQUIRE(Cout > 0 && Cin > 0 && KH > 0 && KW > 0 && KH * KW <= 32, TSPN_EINVAL,
+               "tspn_pack_conv2d_frag_f32: bad sizes");
+  TSPN_REQUIRE(Cout % 32 == 0 && Cin % 16 == 0, TSPN_EUNSUPPORTED,
+               "tspn_pack_conv2d_frag_f32: needs Cout %% 32 == 0 and Cin %% 16 == 0 (Cout=%lld Cin=%lld)",
+               (long long)Cout, (long long)Cin);
+  const int64_t total = KH * KW * Cin * Cout;
+  const int blocks = (int)std::min<int64_t>(tspn::ceil_div(total, 256), 8192);
+  hipLaunchKernelGGL(pack_conv2d_frag_kernel, dim3(blocks), dim3(256), 0, TSPN_STREAM(stream), w, Cout, Cin,
+                     KH * KW, packed);
+  return tspn::check_launch("tspn_pack_conv2d_frag_f32");
+}
+
+extern "C" int tspn_conv2d_nhwc_frag_f32(const float* x, int64_t NB, int64_t H, int64_t W, int64_t Cin,
+                                         const float* frag, int64_t Cout, int64_t KH, int64_t KW,
+                                         int64_t stride, int64_t pad, const float* bias, const float* residual,
+                                         int relu, float* out, void* stream) {
+  TSPN_REQUIRE(NB >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0,
+               TSPN_EINVAL, "tspn_conv2d_nhwc_frag_f32: bad sizes");
+  TSPN_REQUIRE(KH * KW <= 32, TSPN_EUNSUPPORTED, "tspn_conv2d_nhwc_frag_f32: at most 32 taps");
+  const int64_t OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+  TSPN_REQUIRE(OH > 0 && OW > 0, TSPN_EINVAL, "tspn_conv2d_nhwc_frag_f32: empty output");
+  if (NB == 0) return TSPN_OK;
+  TSPN_REQUIRE(x && frag && out, TSPN_EINVAL, "tspn_conv2d_nhwc_frag_f32: null pointer");
+  TSPN_REQUIRE(Cin % 16 == 0 && Cout % 32 == 0, TSPN_EUNSUPPORTED,
+               "tspn_conv2d_nhwc_frag_f32: needs Cin %% 16 == 0 and Cout %% 32 == 0 (Cin=%lld Cout=%lld)",
+               (long long)Cin, (long long)Cout);
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  TSPN_REQUIRE(al16(x) && al16(frag) && al16(out) && (!bias || al16(bias)) && (!residual || al16(residual)),
+               TSPN_EUNSUPPORTED, "tspn_conv2d_nhwc_frag_f32: operands must be 16-byte aligned");
+  TSPN_REQUIRE(H < (1 << 20) && W < (1 << 20) && Cin < (1 << 24) && Cout < (1 << 24), TSPN_EUNSUPPORTED,
+               "tspn_conv2d_nhwc_frag_f32: dimension too large");
+  const int64_t npix = NB * OH * OW;
+  const int64_t tiles_m = tspn::ceil_div(Cout, BM), tiles_n = tspn::ceil_div(npix, BN);
+  TSPN_REQUIRE(tiles_m * tiles_n < (1LL << 31), TSPN_EUNSUPPORTED, "tspn_conv2d_nhwc_frag_f32: grid too large");
+  hipLaunchKernelGGL(conv2d_nhwc_frag_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(THREADS), 0,
+                     TSPN_STREAM(stream), x, frag, bias, residual, out, (int)H, (int)W, (int)Cin, (int)Cout,
                      (int)KH, (int)KW, (int)stride, (int)pad, (int)OH, (int)OW, npix, (int)tiles_m, (int)tiles_n,
                      relu);
-  return tspn::check_launch("tspn_conv2d_nhwc_f32");
+  return tspn::check_launch("tspn_conv2d_nhwc_frag_f32");
 }
 
 extern "C" int tspn_roi_align_nhwc_f32(const float* feat, int64_t NF, int64_t H, int64_t W, int64_t C,

@@ -17,7 +17,7 @@ __all__ = [
     "forward_fused", "temporal_encoder_heads", "fused_workspace_bytes", "decode_topk", "decode_spans",
     "cast_bf16", "pack_conv3_bf16", "pack_heads_bf16", "conv3_tc_bf16", "heads_pairgrid_bf16",
     "temporal_mean_bf16", "forward_fused_bf16", "span_predicate",
-    "pack_conv2d", "conv2d_nhwc", "roi_align_nhwc",
+    "pack_conv2d", "pack_conv2d_frag", "conv2d_nhwc", "roi_align_nhwc",
 ]
 
 
@@ -699,15 +699,36 @@ def pack_conv2d(weight):
     return packed
 
 
+def pack_conv2d_frag(weight):
+    """nn.Conv2d weight [Cout,Cin,KH,KW] -> fragment-major [Cout/32, KH*KW, Cin/16, 64, 8]
+    (tspn_pack_conv2d_frag_f32; the registers-direct kernel).  Needs Cout % 32 == 0, Cin % 16 == 0."""
+    _dev(weight, "conv2d weight")
+    if weight.dim() != 4:
+        raise ValueError("pack_conv2d_frag: weight must be [Cout,Cin,KH,KW]")
+    Cout, Cin, KH, KW = weight.shape
+    if Cout % 32 or Cin % 16:
+        raise ValueError(f"pack_conv2d_frag: needs Cout % 32 == 0 and Cin % 16 == 0 (Cout={Cout}, Cin={Cin})")
+    frag = torch.empty((Cout // 32, KH * KW, Cin // 16, 64, 8), dtype=torch.float32, device=weight.device)
+    _abi.check(_abi.lib().tspn_pack_conv2d_frag_f32(_p(weight), Cout, Cin, KH, KW, _p(frag), _stream()))
+    return frag
+
+
 def conv2d_nhwc(x, packed, kernel_size, stride=1, padding=0, bias=None, residual=None, relu=False):
     """act(conv2d(x) + bias + residual) on channels-last tensors: x [NB,H,W,Cin] -> [NB,OH,OW,Cout];
-    `packed` = pack_conv2d(weight), kernel_size = (KH, KW)."""
+    `packed` = pack_conv2d(weight) or pack_conv2d_frag(weight) (5-D: fast kernel), kernel_size = (KH, KW)."""
     _dev(x, "x"); _dev(packed, "packed")
     NB, H, W, Cin = x.shape
     KH, KW = kernel_size
-    if packed.dim() != 3 or packed.shape[0] != KH * KW or packed.shape[1] != Cin:
-        raise ValueError(f"conv2d_nhwc: packed weights {tuple(packed.shape)} do not match taps={KH * KW}, Cin={Cin}")
-    Cout = packed.shape[2]
+    frag = packed.dim() == 5
+    if frag:
+        if tuple(packed.shape[1:]) != (KH * KW, Cin // 16, 64, 8) or Cin % 16:
+            raise ValueError(f"conv2d_nhwc: fragment-major weights {tuple(packed.shape)} do not match "
+                             f"taps={KH * KW}, Cin={Cin}")
+        Cout = packed.shape[0] * 32
+    else:
+        if packed.dim() != 3 or packed.shape[0] != KH * KW or packed.shape[1] != Cin:
+            raise ValueError(f"conv2d_nhwc: packed weights {tuple(packed.shape)} do not match taps={KH * KW}, Cin={Cin}")
+        Cout = packed.shape[2]
     OH, OW = (H + 2 * padding - KH) // stride + 1, (W + 2 * padding - KW) // stride + 1
     if OH <= 0 or OW <= 0:
         raise ValueError("conv2d_nhwc: empty output")
@@ -720,8 +741,9 @@ def conv2d_nhwc(x, packed, kernel_size, stride=1, padding=0, bias=None, residual
         if tuple(residual.shape) != (NB, OH, OW, Cout):
             raise ValueError("conv2d_nhwc: residual shape mismatch")
     out = torch.empty((NB, OH, OW, Cout), dtype=torch.float32, device=x.device)
-    _abi.check(_abi.lib().tspn_conv2d_nhwc_f32(_p(x), NB, H, W, Cin, _p(packed), Cout, KH, KW, stride, padding,
-                                               _p(bias), _p(residual), 1 if relu else 0, _p(out), _stream()))
+    fn = _abi.lib().tspn_conv2d_nhwc_frag_f32 if frag else _abi.lib().tspn_conv2d_nhwc_f32
+    _abi.check(fn(_p(x), NB, H, W, Cin, _p(packed), Cout, KH, KW, stride, padding,
+                  _p(bias), _p(residual), 1 if relu else 0, _p(out), _stream()))
     return out
 
 

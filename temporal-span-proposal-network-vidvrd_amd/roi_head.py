@@ -50,7 +50,10 @@ class ConvFrozenBN(nn.Module):
         def build(ts):
             w, g, b, m, v = ts
             scale = g * torch.rsqrt(v + BN_EPS)
-            return ops.pack_conv2d((w * scale.reshape(-1, 1, 1, 1)).contiguous()), (b - m * scale).contiguous()
+            wf = (w * scale.reshape(-1, 1, 1, 1)).contiguous()
+            # fragment-major weights select the registers-direct kernel (Cout % 32 == 0, Cin % 16 == 0)
+            pack = ops.pack_conv2d_frag if (wf.shape[0] % 32 == 0 and wf.shape[1] % 16 == 0) else ops.pack_conv2d
+            return pack(wf), (b - m * scale).contiguous()
         n = self.norm
         return self._cache.get("folded", (self.weight, n.weight, n.bias, n.running_mean, n.running_var), dev, build)
 

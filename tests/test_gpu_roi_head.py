@@ -38,6 +38,14 @@ def test_conv2d_nhwc_vs_torch(tspn, device, NB, H, W, Cin, Cout, k, stride, pad,
                              residual=t(res).to(device) if fused else None, relu=fused)
     assert tuple(y.shape) == tuple(ref.shape)
     np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), rtol=0, atol=2e-5)
+    if Cout % 32 == 0:   # registers-direct kernel on fragment-major weights: same contraction order, same bits
+        fr = tspn.ops.pack_conv2d_frag(t(w).to(device))
+        want = w.reshape(Cout // 32, 32, Cin // 16, 4, 2, 2, k * k).transpose(0, 6, 2, 4, 1, 3, 5)
+        np.testing.assert_array_equal(fr.cpu().numpy().reshape(Cout // 32, k * k, Cin // 16, 2, 32, 4, 2), want)
+        y2 = tspn.ops.conv2d_nhwc(t(x).to(device), fr, (k, k), stride, pad,
+                                  bias=t(b).to(device) if fused else None,
+                                  residual=t(res).to(device) if fused else None, relu=fused)
+        assert torch.equal(y, y2)
 
 
 def test_conv2d_nhwc_errors(tspn, device):
@@ -50,6 +58,8 @@ def test_conv2d_nhwc_errors(tspn, device):
         tspn.ops.conv2d_nhwc(torch.zeros((1, 4, 4, 16)), torch.zeros((1, 16, 16)), (1, 1))
     y = tspn.ops.conv2d_nhwc(torch.zeros((0, 4, 4, 16), device=device), torch.zeros((1, 16, 16), device=device), (1, 1))
     assert y.shape == (0, 4, 4, 16)
+    with pytest.raises(ValueError):                   # fragment-major layout needs Cout % 32 == 0
+        tspn.ops.pack_conv2d_frag(torch.zeros((48, 16, 1, 1), device=device))
 
 
 @pytest.mark.parametrize("sampling_ratio,aligned", [(0, True), (2, True), (0, False), (3, False)])
