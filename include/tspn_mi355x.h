@@ -387,6 +387,17 @@ int tspn_conv2d_nhwc_frag_f32(const float* x, int64_t NB, int64_t H, int64_t W, 
                               const float* frag, int64_t Cout, int64_t KH, int64_t KW, int64_t stride,
                               int64_t pad, const float* bias, const float* residual, int relu, float* out,
                               void* stream);
+/* bf16-operand form (tspn_roi_bf16.hip; v_mfma_f32_32x32x16_bf16): x, residual, out are bf16 (uint16_t
+ * bit patterns), bias fp32; products exact, fp32 accumulation, act(acc + bias + residual) rounded to bf16
+ * once (round to nearest even).  Weights: tspn_pack_conv2d_frag_bf16 rounds the fp32 (BN-folded) weight
+ * once into  frag[Cout/32][KH*KW][Cin/64][4 ks][64 lanes = 32 kh + li][8 j] =
+ * bf16(w[32 mb + li][64 c + 16 ks + 8 kh + j][tap]).  Needs Cin % 64 == 0, Cout % 32 == 0. */
+int tspn_pack_conv2d_frag_bf16(const float* w, int64_t Cout, int64_t Cin, int64_t KH, int64_t KW,
+                               uint16_t* frag, void* stream);
+int tspn_conv2d_nhwc_bf16(const uint16_t* x, int64_t NB, int64_t H, int64_t W, int64_t Cin,
+                          const uint16_t* frag, int64_t Cout, int64_t KH, int64_t KW, int64_t stride,
+                          int64_t pad, const float* bias, const uint16_t* residual, int relu,
+                          uint16_t* out, void* stream);
 /* tspn_roi_align_nhwc_f32: detectron2 ROIAlign on a channels-last map feat[NF,H,W,C]:
  *   rois[R,5] = (map index, x1, y1, x2, y2) in image coordinates, `spatial_scale` image -> map,
  *   out[R,P,P,C]; sampling_ratio 0 = adaptive grid ceil(roi size / P) (detectron2's POOLER_SAMPLING_RATIO 0);
@@ -394,6 +405,10 @@ int tspn_conv2d_nhwc_frag_f32(const float* x, int64_t NB, int64_t H, int64_t W, 
 int tspn_roi_align_nhwc_f32(const float* feat, int64_t NF, int64_t H, int64_t W, int64_t C,
                             const float* rois, int64_t R, int64_t P, float spatial_scale,
                             int sampling_ratio, int aligned, float* out, void* stream);
+/* same interpolation in fp32, result rounded once to bf16 (input of tspn_conv2d_nhwc_bf16) */
+int tspn_roi_align_nhwc_f32_bf16out(const float* feat, int64_t NF, int64_t H, int64_t W, int64_t C,
+                                    const float* rois, int64_t R, int64_t P, float spatial_scale,
+                                    int sampling_ratio, int aligned, uint16_t* out, void* stream);
 
 #ifdef __cplusplus
 }

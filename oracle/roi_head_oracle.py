@@ -19,7 +19,8 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-__all__ = ["roi_align_nhwc", "frozen_bn", "bottleneck_block", "res5_roi_head", "make_res5_weights"]
+__all__ = ["roi_align_nhwc", "frozen_bn", "bottleneck_block", "res5_roi_head", "make_res5_weights",
+           "conv2d_bf16", "res5_roi_head_bf16"]
 
 BN_EPS = 1e-5
 
@@ -140,3 +141,50 @@ def make_res5_weights(rng_uniform, rng_normal, in_channels, bottleneck_channels,
             p[pre + name + ".norm.running_var"] = torch.from_numpy(rng_uniform(pre + name + ".v", (co,), 0.5, 1.5))
         cin = out_channels
     return p
+
+
+def _r16(x):
+    return x.float().to(torch.bfloat16).double()
+
+
+def conv2d_bf16(x, w, bias, stride=1, padding=0, residual=None, relu=False):
+    """bf16-operand conv (build-defined semantics of csrc/tspn_roi_bf16.hip): x, w, residual are bf16
+    VALUES (rounded here), products exact, sums in float64 here (fp32 on the GPU), bias fp32;
+    act(sum + bias + residual) rounded to bf16 once.  x NCHW, returns NCHW float64 holding bf16 values."""
+    y = F.conv2d(_r16(x), _r16(w), bias.double() if bias is not None else None, stride=stride, padding=padding)
+    if residual is not None:
+        y = y + _r16(residual)
+    if relu:
+        y = F.relu(y)
+    return _r16(y)
+
+
+def res5_roi_head_bf16(feat_nhwc, tracklet_boxes, p, num_blocks=3, pooler_resolution=14, spatial_scale=1.0 / 16,
+                       sampling_ratio=0, first_stride=2):
+    """The head with bf16 operands: ROIAlign in fp32 on the bf16 map values -> bf16; every conv as
+    conv2d_bf16 with the batch norm folded in fp32 (w * scale, bias - mean * scale) before the single
+    rounding of the weight; spatial mean rounded to bf16."""
+    N, T, _ = tracklet_boxes.shape
+    idx = torch.arange(T, dtype=torch.float32).repeat(N)
+    rois = torch.cat([idx[:, None], tracklet_boxes.reshape(N * T, 4).float()], dim=1)
+    fm = feat_nhwc.float().to(torch.bfloat16).float()
+    x = _r16(roi_align_nhwc(fm, rois, pooler_resolution, spatial_scale, sampling_ratio, True).permute(0, 3, 1, 2))
+
+    def fold(prefix):
+        scale = p[prefix + "norm.weight"] * (p[prefix + "norm.running_var"] + BN_EPS).rsqrt()
+        return (p[prefix + "weight"] * scale.reshape(-1, 1, 1, 1)), (p[prefix + "norm.bias"] - p[prefix + "norm.running_mean"] * scale)
+
+    for b in range(num_blocks):
+        pre, s = f"res5.{b}.", (first_stride if b == 0 else 1)
+        w1, b1 = fold(pre + "conv1.")
+        w2, b2 = fold(pre + "conv2.")
+        w3, b3 = fold(pre + "conv3.")
+        out = conv2d_bf16(x, w1, b1, stride=s, relu=True)
+        out = conv2d_bf16(out, w2, b2, padding=1, relu=True)
+        if pre + "shortcut.weight" in p:
+            ws, bs = fold(pre + "shortcut.")
+            sc = conv2d_bf16(x, ws, bs, stride=s)
+        else:
+            sc = x
+        x = conv2d_bf16(out, w3, b3, residual=sc, relu=True)
+    return _r16(x.mean(dim=(2, 3))).reshape(N, T, -1).float()

@@ -105,8 +105,13 @@ PROTOTYPES = {
     "tspn_pack_conv2d_frag_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "tspn_conv2d_nhwc_frag_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp,
                                          _int, _vp, _vp]),
+    "tspn_pack_conv2d_frag_bf16": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "tspn_conv2d_nhwc_bf16": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp,
+                                     _int, _vp, _vp]),
     "tspn_roi_align_nhwc_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, ctypes.c_float, _int,
                                        _int, _vp, _vp]),
+    "tspn_roi_align_nhwc_f32_bf16out": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, ctypes.c_float, _int,
+                                               _int, _vp, _vp]),
     "tspn_repack_wino43_frag_f32": (_int, [_vp, _i64, _i64, _vp, _vp]),
     "tspn_conv3_tc_wino43r_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _int, _vp, _vp]),
     "tspn_span_predicate_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),

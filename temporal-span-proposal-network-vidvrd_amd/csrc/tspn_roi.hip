@@ -424,9 +424,12 @@ __device__ __forceinline__ void bilinear_setup(float y, float x, int H, int W, i
   w1 = hy * hx; w2 = hy * lx; w3 = ly * hx; w4 = ly * lx;
 }
 
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+template <bool BF16OUT>
 __global__ __launch_bounds__(256) void roi_align_nhwc_kernel(
     const float* __restrict__ feat, int NF, int H, int W, int C, const float* __restrict__ rois, int64_t R,
-    int P, float scale, int sampling_ratio, int aligned, float* __restrict__ out) {
+    int P, float scale, int sampling_ratio, int aligned, void* __restrict__ out_v) {
   const int64_t item = blockIdx.x;                 // (roi, ph)
   const int64_t r = item / P;
   const int ph = (int)(item - r * P);
@@ -466,7 +469,13 @@ __global__ __launch_bounds__(256) void roi_align_nhwc_kernel(
       }
     }
     acc.x /= count; acc.y /= count; acc.z /= count; acc.w /= count;
-    *reinterpret_cast<float4*>(out + ((r * P + ph) * P + pw) * (int64_t)C + 4 * cg) = acc;
+    const int64_t o = ((r * P + ph) * P + pw) * (int64_t)C + 4 * cg;
+    if constexpr (BF16OUT) {     // the fp32 result rounded once to bf16 (operand of the bf16 conv kernels)
+      const bf16x4 ob = {(__bf16)acc.x, (__bf16)acc.y, (__bf16)acc.z, (__bf16)acc.w};
+      *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(out_v) + o) = ob;
+    } else {
+      *reinterpret_cast<float4*>(static_cast<float*>(out_v) + o) = acc;
+    }
   }
 }
 
@@ -559,9 +568,9 @@ extern "C" int tspn_conv2d_nhwc_frag_f32(const float* x, int64_t NB, int64_t H, 
   return tspn::check_launch("tspn_conv2d_nhwc_frag_f32");
 }
 
-extern "C" int tspn_roi_align_nhwc_f32(const float* feat, int64_t NF, int64_t H, int64_t W, int64_t C,
-                                       const float* rois, int64_t R, int64_t P, float spatial_scale,
-                                       int sampling_ratio, int aligned, float* out, void* stream) {
+static int roi_align_launch(const float* feat, int64_t NF, int64_t H, int64_t W, int64_t C, const float* rois,
+                            int64_t R, int64_t P, float spatial_scale, int sampling_ratio, int aligned,
+                            void* out, bool bf16_out, void* stream) {
   TSPN_REQUIRE(NF > 0 && H > 0 && W > 0 && C > 0 && R >= 0 && P > 0 && sampling_ratio >= 0, TSPN_EINVAL,
                "tspn_roi_align_nhwc_f32: bad sizes");
   if (R == 0) return TSPN_OK;
@@ -571,7 +580,25 @@ extern "C" int tspn_roi_align_nhwc_f32(const float* feat, int64_t NF, int64_t H,
                TSPN_EUNSUPPORTED, "tspn_roi_align_nhwc_f32: needs C %% 4 == 0 and 16-byte aligned tensors");
   TSPN_REQUIRE(R * P < (1LL << 31) && H < (1 << 20) && W < (1 << 20), TSPN_EUNSUPPORTED,
                "tspn_roi_align_nhwc_f32: problem too large");
-  hipLaunchKernelGGL(roi_align_nhwc_kernel, dim3((unsigned)(R * P)), dim3(256), 0, TSPN_STREAM(stream), feat,
-                     (int)NF, (int)H, (int)W, (int)C, rois, R, (int)P, spatial_scale, sampling_ratio, aligned, out);
+  if (bf16_out)
+    hipLaunchKernelGGL(roi_align_nhwc_kernel<true>, dim3((unsigned)(R * P)), dim3(256), 0, TSPN_STREAM(stream),
+                       feat, (int)NF, (int)H, (int)W, (int)C, rois, R, (int)P, spatial_scale, sampling_ratio,
+                       aligned, out);
+  else
+    hipLaunchKernelGGL(roi_align_nhwc_kernel<false>, dim3((unsigned)(R * P)), dim3(256), 0, TSPN_STREAM(stream),
+                       feat, (int)NF, (int)H, (int)W, (int)C, rois, R, (int)P, spatial_scale, sampling_ratio,
+                       aligned, out);
   return tspn::check_launch("tspn_roi_align_nhwc_f32");
+}
+
+extern "C" int tspn_roi_align_nhwc_f32(const float* feat, int64_t NF, int64_t H, int64_t W, int64_t C,
+                                       const float* rois, int64_t R, int64_t P, float spatial_scale,
+                                       int sampling_ratio, int aligned, float* out, void* stream) {
+  return roi_align_launch(feat, NF, H, W, C, rois, R, P, spatial_scale, sampling_ratio, aligned, out, false, stream);
+}
+
+extern "C" int tspn_roi_align_nhwc_f32_bf16out(const float* feat, int64_t NF, int64_t H, int64_t W, int64_t C,
+                                               const float* rois, int64_t R, int64_t P, float spatial_scale,
+                                               int sampling_ratio, int aligned, uint16_t* out, void* stream) {
+  return roi_align_launch(feat, NF, H, W, C, rois, R, P, spatial_scale, sampling_ratio, aligned, out, true, stream);
 }

@@ -1,0 +1,306 @@
+// bf16-operand conv2d for the RoI feature head (the VidOR end-to-end config is bf16).
+//
+// Same operator and structure as conv2d_nhwc_frag_kernel (tspn_roi.hip): implicit GEMM, M = output
+// channels, N = output pixels, K = taps x Cin; tile 128 x 128, wave w = rows [32 w, 32 w + 32) x all 128
+// pixels; FRAGMENT-MAJOR weights loaded straight into MFMA operand registers; x through LDS by DMA with a
+// zero page for padding taps; bare s_barrier + counted vmcnt.  On v_mfma_f32_32x32x16_bf16:
+//   * operands are bf16 values (x, weights with the batch norm folded in fp32 and rounded once, residual),
+//     every product is exact, accumulation is fp32, bias is fp32, the result act(acc + bias + residual) is
+//     rounded to bf16 once (round to nearest even) -- the semantics restated in
+//     oracle/roi_head_oracle.py:conv2d_bf16;
+//   * K chunk = 64 channels of one tap = four MFMA k-steps of 16 channels (16 MFMAs per wave and chunk);
+//     a pixel's 64 channels are one 128-byte line of x, staged as eight 16-byte pieces
+//     [8 channel groups][132 slots][8 bf16];
+//   * weights  Wf[Cout/32][tap][Cin/64][ks = 0..3][lane = 32 kh + li][8] = w[32 mb + li][64 c + 16 ks + 8 kh + j][tap]:
+//     one global_load_dwordx4 per lane and k-step, refilled for the next chunk right after the k-step's MFMAs.
+//   * MI = 32-row blocks per wave (template): MI = 2 (tile 256 x 128, Cout % 64 == 0) shares every x fragment
+//     between two weight fragments -- 0.5 instead of 1 LDS fragment read per MFMA, which is what bounds
+//     the MI = 1 kernel (8 waves x 16 KB of ds_read_b128 per chunk against 1024 MFMA cycles per SIMD).
+// Needs Cin % 64 == 0, Cout % 32 == 0.
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+
+#include "tspn_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int THREADS = 256;
+constexpr int BN = 128;
+constexpr int KC = 64;                  // channels per chunk
+constexpr int SLP = 132;                // padded pixel slots per channel group
+constexpr int B_ST = 8 * SLP * 16;      // bytes per x stage: [8 groups][132 slots][8 bf16]
+
+__device__ __bf16 g_zero_page_bf16[128];   // source of padding taps (never written)
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+template <int OFF>
+__device__ __forceinline__ void load_wfrag(f32x4& dst, unsigned lane_off, const char* base) {
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(lane_off), "s"(base), "n"(OFF) : "memory");
+}
+template <int VM>
+__device__ __forceinline__ void wait_w(f32x4& r) {
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r) : "n"(VM));
+}
+template <int VM>
+__device__ __forceinline__ void wait_w(f32x4& r0, f32x4& r1) {
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r0), "+v"(r1) : "n"(VM));
+}
+
+// w fp32 [Cout][Cin][KH][KW] -> bf16 fragment-major [Cout/32][taps][Cin/64][4][64][8]
+__global__ void pack_conv2d_frag_bf16_kernel(const float* __restrict__ w, int64_t Cout, int64_t Cin, int64_t ntaps,
+                                             __bf16* __restrict__ packed) {
+  const int64_t total = ntaps * Cin * Cout;
+  const int64_t cch = Cin / KC;
+  for (int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; o < total;
+       o += (int64_t)gridDim.x * blockDim.x) {
+    const int j = (int)(o & 7), lane = (int)((o >> 3) & 63), ks = (int)((o >> 9) & 3);
+    const int64_t q = o >> 11;
+    const int64_t c = q % cch, tap = (q / cch) % ntaps, mb = q / (cch * ntaps);
+    const int64_t co = 32 * mb + (lane & 31), ci = KC * c + 16 * ks + 8 * (lane >> 5) + j;
+    packed[o] = (__bf16)w[(co * Cin + ci) * ntaps + tap];
+  }
+}
+
+template <int MI>
+__global__ __launch_bounds__(THREADS, 2) void conv2d_nhwc_bf16_kernel(
+    const __bf16* __restrict__ x, const __bf16* __restrict__ Wf, const float* __restrict__ bias,
+    const __bf16* __restrict__ residual, __bf16* __restrict__ out, int H, int W, int Cin, int Cout, int KH,
+    int KW, int stride, int pad, int OH, int OW, int64_t npix, int tiles_m, int tiles_n, int relu) {
+  constexpr int BM = 128 * MI;
+  __shared__ __attribute__((aligned(16))) char Bs[2 * B_ST];
+
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  constexpr int GM = 4;
+  const int group_sz = GM * tiles_n;
+  const int group = wg / group_sz;
+  const int first_m = group * GM;
+  const int gm = min(GM, tiles_m - first_m);
+  const int in_group = wg - group * group_sz;
+  const int tile_m = first_m + in_group % gm;
+  const int tile_n = in_group / gm;
+  const int m0 = tile_m * BM;
+  const int64_t n0 = (int64_t)tile_n * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kh = lane >> 5;
+
+  const int cchunks = Cin / KC;
+  const int nchunks = KH * KW * cchunks;
+  const char* wbase[MI];                           // per 32-row block: 4 KiB per chunk, [4 ks][64 lanes][16 B]
+  const unsigned woff = lane * 16;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    int mb = (m0 >> 5) + MI * wave + mi;
+    mb = mb < (Cout >> 5) ? mb : 0;
+    wbase[mi] = reinterpret_cast<const char*>(Wf) + (int64_t)mb * nchunks * 4096;
+  }
+  // x pieces: the four pieces of a lane belong to ONE output pixel (slot), channel groups bg, bg + 2, bg + 4, bg + 6
+  const int slot = 64 * (wave & 1) + lane;
+  const int bg = wave >> 1;
+  int64_t pbase;
+  unsigned tapmask = 0;
+  {
+    const int64_t n = n0 + slot;
+    const bool okn = n < npix;
+    const int64_t nc = okn ? n : 0;
+    const int64_t nb = nc / ((int64_t)OH * OW);
+    const int r = (int)(nc - nb * OH * OW);
+    const int oh = r / OW, ow = r - oh * OW;
+    const int ih0 = oh * stride - pad, iw0 = ow * stride - pad;
+    pbase = ((nb * H + ih0) * (int64_t)W + iw0) * Cin;
+    for (int a = 0; a < KH; ++a)
+      for (int b = 0; b < KW; ++b)
+        if (okn && ih0 + a >= 0 && ih0 + a < H && iw0 + b >= 0 && iw0 + b < W) tapmask |= 1u << (a * KW + b);
+  }
+  auto stage_x = [&](int buf, int i) {             // exactly four pieces per wave
+    const int tap = i / cchunks, c = i - tap * cchunks;
+    const int ta = tap / KW, tb = tap - ta * KW;
+    const bool valid = (tapmask >> tap) & 1u;
+    const __bf16* xs = valid ? x + pbase + ((int64_t)ta * W + tb) * Cin + c * KC + 8 * bg : g_zero_page_bf16 + 8 * bg;
+    char* dst = Bs + buf * B_ST + (bg * SLP + 64 * (wave & 1)) * 16;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) glds16(xs + 16 * p, dst + 2 * p * SLP * 16);
+  };
+
+  f32x16 acc[MI][4];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  f32x4 a[4][MI];      // weight fragments of the four k-steps (8 bf16 each, carried as 4 dwords)
+  auto read_b = [&](const char* Bb, int ks, bf16x8 (&b)[4]) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+      b[ni] = *reinterpret_cast<const bf16x8*>(Bb + ((2 * ks) * SLP + ni * 32) * 16);
+  };
+  auto mfma_step = [&](const f32x4 (&aw)[MI], const bf16x8 (&b)[4]) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const bf16x8 av = __builtin_bit_cast(bf16x8, aw[mi]);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b[ni], acc[mi][ni], 0, 0, 0);
+    }
+  };
+  auto load_step = [&](auto ks_tag) {               // the MI fragments of k-step ks of the chunk at wbase
+    constexpr int KS = decltype(ks_tag)::value;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) load_wfrag<1024 * KS>(a[KS][mi], woff, wbase[mi]);
+  };
+  auto wait_step = [&](auto vm_tag, int ks) {
+    constexpr int VM = decltype(vm_tag)::value;
+    if constexpr (MI == 1) wait_w<VM>(a[ks][0]); else wait_w<VM>(a[ks][0], a[ks][1]);
+  };
+  using K0 = std::integral_constant<int, 0>;
+  using K1 = std::integral_constant<int, 1>;
+  using K2 = std::integral_constant<int, 2>;
+  using K3 = std::integral_constant<int, 3>;
+  auto bump = [&]() {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) wbase[mi] += 4096;
+  };
+
+  // ---- prologue: x_0 landed; the weights of chunk 0 are the youngest VMEM operations
+  stage_x(0, 0);
+  __syncthreads();
+  load_step(K0{}); load_step(K1{}); load_step(K2{}); load_step(K3{});
+  bump();
+  __builtin_amdgcn_sched_barrier(0);
+
+  // chunk i.  VMEM issue order: [x_{i+1}: 4 pieces] a0' | a1' | a2' | a3' (MI loads each); counts = YOUNGER
+  // operations at each wait.
+  auto chunk_body = [&](int i, auto more_tag) {
+    constexpr bool MORE = decltype(more_tag)::value;
+    constexpr int NX = MORE ? 4 : 0, R = MORE ? MI : 0, L = MI;
+    const int buf = i & 1;
+    const char* Bb = Bs + buf * B_ST + (kh * SLP + li) * 16;
+    bf16x8 b0[4], b1[4];
+    wait_step(std::integral_constant<int, 3 * L>{}, 0);            // younger: a1 a2 a3 of this chunk
+    if (MORE) stage_x(buf ^ 1, i + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    read_b(Bb, 0, b0);
+    read_b(Bb, 1, b1);
+    mfma_step(a[0], b0);
+    if (MORE) load_step(K0{});
+    __builtin_amdgcn_sched_barrier(0);
+    wait_step(std::integral_constant<int, 2 * L + NX + R>{}, 1);   // younger: a2 a3, the x pieces, a0'
+    read_b(Bb, 2, b0);
+    mfma_step(a[1], b1);
+    if (MORE) load_step(K1{});
+    __builtin_amdgcn_sched_barrier(0);
+    wait_step(std::integral_constant<int, L + NX + 2 * R>{}, 2);
+    read_b(Bb, 3, b1);
+    mfma_step(a[2], b0);
+    if (MORE) load_step(K2{});
+    __builtin_amdgcn_sched_barrier(0);
+    wait_step(std::integral_constant<int, NX + 3 * R>{}, 3);
+    mfma_step(a[3], b1);
+    if (MORE) { load_step(K3{}); bump(); }
+    __builtin_amdgcn_sched_barrier(0);
+    // x_{i+1} has landed (older than the 4 MI weight loads), every LDS read of this chunk has returned
+    if (MORE) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * MI) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  for (int i = 0; i + 1 < nchunks; ++i) chunk_body(i, std::true_type{});
+  chunk_body(nchunks - 1, std::false_type{});
+
+  // ---- epilogue: a lane holds 4 consecutive output channels of one pixel per register quad
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int64_t n = n0 + ni * 32 + li;
+    if (n >= npix) continue;
+    __bf16* orow = out + n * Cout;
+    const __bf16* rrow = residual ? residual + n * Cout : nullptr;
+#pragma unroll
+    for (int mq = 0; mq < 4 * MI; ++mq) {
+      const int mi = mq >> 2, q = mq & 3;
+      const int m = m0 + (MI * wave + mi) * 32 + 8 * q + 4 * kh;
+      if (m >= Cout) continue;
+      float v[4] = {acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
+      if (bias) {
+        const float4 bv = *reinterpret_cast<const float4*>(bias + m);
+        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+      }
+      if (rrow) {
+        const bf16x4 rv = *reinterpret_cast<const bf16x4*>(rrow + m);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] += (float)rv[k];
+      }
+      bf16x4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = (__bf16)(relu ? fmaxf(v[k], 0.f) : v[k]);
+      *reinterpret_cast<bf16x4*>(orow + m) = o;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int tspn_pack_conv2d_frag_bf16(const float* w, int64_t Cout, int64_t Cin, int64_t KH, int64_t KW,
+                                          uint16_t* frag, void* stream) {
+  TSPN_REQUIRE(w && frag, TSPN_EINVAL, "tspn_pack_conv2d_frag_bf16: null pointer");
+  TSPN_REQUIRE(Cout > 0 && Cin > 0 && KH > 0 && KW > 0 && KH * KW <= 32, TSPN_EINVAL,
+               "tspn_pack_conv2d_frag_bf16: bad sizes");
+  TSPN_REQUIRE(Cout % 32 == 0 && Cin % KC == 0, TSPN_EUNSUPPORTED,
+               "tspn_pack_conv2d_frag_bf16: needs Cout %% 32 == 0 and Cin %% 64 == 0 (Cout=%lld Cin=%lld)",
+               (long long)Cout, (long long)Cin);
+  const int64_t total = KH * KW * Cin * Cout;
+  const int blocks = (int)std::min<int64_t>(tspn::ceil_div(total, 256), 8192);
+  hipLaunchKernelGGL(pack_conv2d_frag_bf16_kernel, dim3(blocks), dim3(256), 0, TSPN_STREAM(stream), w, Cout, Cin,
+                     KH * KW, reinterpret_cast<__bf16*>(frag));
+  return tspn::check_launch("tspn_pack_conv2d_frag_bf16");
+}
+
+extern "C" int tspn_conv2d_nhwc_bf16(const uint16_t* x, int64_t NB, int64_t H, int64_t W, int64_t Cin,
+                                     const uint16_t* frag, int64_t Cout, int64_t KH, int64_t KW, int64_t stride,
+                                     int64_t pad, const float* bias, const uint16_t* residual, int relu,
+                                     uint16_t* out, void* stream) {
+  TSPN_REQUIRE(NB >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0,
+               TSPN_EINVAL, "tspn_conv2d_nhwc_bf16: bad sizes");
+  TSPN_REQUIRE(KH * KW <= 32, TSPN_EUNSUPPORTED, "tspn_conv2d_nhwc_bf16: at most 32 taps");
+  const int64_t OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+  TSPN_REQUIRE(OH > 0 && OW > 0, TSPN_EINVAL, "tspn_conv2d_nhwc_bf16: empty output");
+  if (NB == 0) return TSPN_OK;
+  TSPN_REQUIRE(x && frag && out, TSPN_EINVAL, "tspn_conv2d_nhwc_bf16: null pointer");
+  TSPN_REQUIRE(Cin % KC == 0 && Cout % 32 == 0, TSPN_EUNSUPPORTED,
+               "tspn_conv2d_nhwc_bf16: needs Cin %% 64 == 0 and Cout %% 32 == 0 (Cin=%lld Cout=%lld)", (long long)Cin,
+               (long long)Cout);
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  TSPN_REQUIRE(al16(x) && al16(frag) && al16(out) && (!bias || al16(bias)) && (!residual || al16(residual)),
+               TSPN_EUNSUPPORTED, "tspn_conv2d_nhwc_bf16: operands must be 16-byte aligned");
+  TSPN_REQUIRE(H < (1 << 20) && W < (1 << 20) && Cin < (1 << 24) && Cout < (1 << 24), TSPN_EUNSUPPORTED,
+               "tspn_conv2d_nhwc_bf16: dimension too large");
+  const int64_t npix = NB * OH * OW;
+  static const bool allow2 = getenv("TSPN_CONV2D_BF16_MI1") == nullptr;   // A/B switch
+  const int mi = (allow2 && Cout % 64 == 0) ? 2 : 1;   // 64 rows per wave where Cout allows
+  const int64_t tiles_m = tspn::ceil_div(Cout, 128 * mi), tiles_n = tspn::ceil_div(npix, BN);
+  TSPN_REQUIRE(tiles_m * tiles_n < (1LL << 31), TSPN_EUNSUPPORTED, "tspn_conv2d_nhwc_bf16: grid too large");
+  auto launch = [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n)), dim3(THREADS), 0, TSPN_STREAM(stream),
+                       reinterpret_cast<const __bf16*>(x), reinterpret_cast<const __bf16*>(frag), bias,
+                       reinterpret_cast<const __bf16*>(residual), reinterpret_cast<__bf16*>(out), (int)H, (int)W,
+                       (int)Cin, (int)Cout, (int)KH, (int)KW, (int)stride, (int)pad, (int)OH, (int)OW, npix,
+                       (int)tiles_m, (int)tiles_n, relu);
+  };
+  if (mi == 2) launch(conv2d_nhwc_bf16_kernel<2>); else launch(conv2d_nhwc_bf16_kernel<1>);
+  return tspn::check_launch("tspn_conv2d_nhwc_bf16");
+}

@@ -17,7 +17,7 @@ __all__ = [
     "forward_fused", "temporal_encoder_heads", "fused_workspace_bytes", "decode_topk", "decode_spans",
     "cast_bf16", "pack_conv3_bf16", "pack_heads_bf16", "conv3_tc_bf16", "heads_pairgrid_bf16",
     "temporal_mean_bf16", "forward_fused_bf16", "span_predicate",
-    "pack_conv2d", "pack_conv2d_frag", "conv2d_nhwc", "roi_align_nhwc",
+    "pack_conv2d", "pack_conv2d_frag", "conv2d_nhwc", "roi_align_nhwc", "pack_conv2d_frag_bf16", "conv2d_nhwc_bf16",
 ]
 
 
@@ -747,15 +747,57 @@ def conv2d_nhwc(x, packed, kernel_size, stride=1, padding=0, bias=None, residual
     return out
 
 
-def roi_align_nhwc(feat, rois, output_size, spatial_scale, sampling_ratio=0, aligned=True):
+def roi_align_nhwc(feat, rois, output_size, spatial_scale, sampling_ratio=0, aligned=True, out_bf16=False):
     """detectron2 ROIAlign on a channels-last map: feat [NF,H,W,C], rois [R,5] = (map index, x1, y1, x2, y2)
-    -> [R,P,P,C]."""
+    -> [R,P,P,C]; `out_bf16`: the fp32 result rounded once to bf16."""
     _dev(feat, "feat"); _dev(rois, "rois")
     NF, H, W, C = feat.shape
     if rois.dim() != 2 or rois.shape[1] != 5:
         raise ValueError("roi_align_nhwc: rois must be [R,5]")
     R, P = rois.shape[0], int(output_size)
-    out = torch.empty((R, P, P, C), dtype=torch.float32, device=feat.device)
-    _abi.check(_abi.lib().tspn_roi_align_nhwc_f32(_p(feat), NF, H, W, C, _p(rois), R, P, float(spatial_scale),
-                                                  int(sampling_ratio), 1 if aligned else 0, _p(out), _stream()))
+    out = torch.empty((R, P, P, C), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=feat.device)
+    fn = _abi.lib().tspn_roi_align_nhwc_f32_bf16out if out_bf16 else _abi.lib().tspn_roi_align_nhwc_f32
+    _abi.check(fn(_p(feat), NF, H, W, C, _p(rois), R, P, float(spatial_scale),
+                  int(sampling_ratio), 1 if aligned else 0, _p(out), _stream()))
+    return out
+
+
+def pack_conv2d_frag_bf16(weight):
+    """fp32 nn.Conv2d weight [Cout,Cin,KH,KW] -> bf16 fragment-major [Cout/32, KH*KW, Cin/64, 4, 64, 8]
+    (tspn_pack_conv2d_frag_bf16; rounded once, to nearest even).  Needs Cout % 32 == 0, Cin % 64 == 0."""
+    _dev(weight, "conv2d weight")
+    if weight.dim() != 4:
+        raise ValueError("pack_conv2d_frag_bf16: weight must be [Cout,Cin,KH,KW]")
+    Cout, Cin, KH, KW = weight.shape
+    if Cout % 32 or Cin % 64:
+        raise ValueError(f"pack_conv2d_frag_bf16: needs Cout % 32 == 0 and Cin % 64 == 0 (Cout={Cout}, Cin={Cin})")
+    frag = torch.empty((Cout // 32, KH * KW, Cin // 64, 4, 64, 8), dtype=torch.bfloat16, device=weight.device)
+    _abi.check(_abi.lib().tspn_pack_conv2d_frag_bf16(_p(weight), Cout, Cin, KH, KW, _p(frag), _stream()))
+    return frag
+
+
+def conv2d_nhwc_bf16(x, frag, kernel_size, stride=1, padding=0, bias=None, residual=None, relu=False):
+    """bf16-operand conv2d on channels-last tensors (tspn_conv2d_nhwc_bf16): x bf16 [NB,H,W,Cin], frag =
+    pack_conv2d_frag_bf16(weight), bias fp32 [Cout], residual bf16 -> bf16 [NB,OH,OW,Cout]
+    = bf16(act(fp32 sum of exact products + bias + residual))."""
+    _dev(x, "x", torch.bfloat16); _dev(frag, "frag", torch.bfloat16)
+    NB, H, W, Cin = x.shape
+    KH, KW = kernel_size
+    if frag.dim() != 6 or tuple(frag.shape[1:]) != (KH * KW, Cin // 64, 4, 64, 8) or Cin % 64:
+        raise ValueError(f"conv2d_nhwc_bf16: weights {tuple(frag.shape)} do not match taps={KH * KW}, Cin={Cin}")
+    Cout = frag.shape[0] * 32
+    OH, OW = (H + 2 * padding - KH) // stride + 1, (W + 2 * padding - KW) // stride + 1
+    if OH <= 0 or OW <= 0:
+        raise ValueError("conv2d_nhwc_bf16: empty output")
+    if bias is not None:
+        _dev(bias, "bias")
+        if bias.shape != (Cout,):
+            raise ValueError("conv2d_nhwc_bf16: bias shape mismatch")
+    if residual is not None:
+        _dev(residual, "residual", torch.bfloat16)
+        if tuple(residual.shape) != (NB, OH, OW, Cout):
+            raise ValueError("conv2d_nhwc_bf16: residual shape mismatch")
+    out = torch.empty((NB, OH, OW, Cout), dtype=torch.bfloat16, device=x.device)
+    _abi.check(_abi.lib().tspn_conv2d_nhwc_bf16(_p(x), NB, H, W, Cin, _p(frag), Cout, KH, KW, stride, padding,
+                                                _p(bias), _p(residual), 1 if relu else 0, _p(out), _stream()))
     return out

@@ -57,11 +57,26 @@ class ConvFrozenBN(nn.Module):
         n = self.norm
         return self._cache.get("folded", (self.weight, n.weight, n.bias, n.running_mean, n.running_var), dev, build)
 
+    def folded_bf16(self, dev):
+        """bf16 operand set: the folded fp32 weight rounded once to bf16 (fragment-major), fp32 bias."""
+        def build(ts):
+            w, g, b, m, v = ts
+            scale = g * torch.rsqrt(v + BN_EPS)
+            return (ops.pack_conv2d_frag_bf16((w * scale.reshape(-1, 1, 1, 1)).contiguous()),
+                    (b - m * scale).contiguous())
+        n = self.norm
+        return self._cache.get("folded_bf16", (self.weight, n.weight, n.bias, n.running_mean, n.running_var),
+                               dev, build)
+
     def forward(self, x, residual=None, relu=False):
-        """x channels-last [NB,H,W,Cin] on the HIP device -> act(bn(conv(x)) + residual)."""
+        """x channels-last [NB,H,W,Cin] on the HIP device -> act(bn(conv(x)) + residual); bf16 x selects
+        the bf16-operand kernel (bf16 out)."""
+        k = (self.kernel_size, self.kernel_size)
+        if x.dtype == torch.bfloat16:
+            frag, bias = self.folded_bf16(x.device)
+            return ops.conv2d_nhwc_bf16(x, frag, k, self.stride, self.padding, bias=bias, residual=residual, relu=relu)
         packed, bias = self.folded(x.device)
-        return ops.conv2d_nhwc(x, packed, (self.kernel_size, self.kernel_size), self.stride, self.padding,
-                               bias=bias, residual=residual, relu=relu)
+        return ops.conv2d_nhwc(x, packed, k, self.stride, self.padding, bias=bias, residual=residual, relu=relu)
 
 
 class BottleneckBlock(nn.Module):
@@ -95,10 +110,13 @@ class Res5RoIHead(nn.Module):
         feature_maps  [T,Hf,Wf,C] channels-last res4 maps, one per frame (use `from_nchw` for NCHW maps)
         tracklet_boxes [N,T,4] (left, top, right, bottom) in image pixels
         -> tracklet_feats [N,T,out_channels] on the device of `tracklet_boxes`
+    bf16 feature maps select the bf16-operand kernels (bf16 MFMA, fp32 accumulation; every layer's output
+    rounded to bf16 once) and return bf16 features — what the bf16 scorer path consumes (BASELINE cfg3 / cfg5).
+    Needs channel counts that are multiples of 64.
     """
 
     def __init__(self, in_channels=1024, bottleneck_channels=512, out_channels=2048, num_blocks=3,
-                 pooler_resolution=14, spatial_scale=1.0 / 16, sampling_ratio=0, first_stride=2, roi_chunk=1024):
+                 pooler_resolution=14, spatial_scale=1.0 / 16, sampling_ratio=0, first_stride=2, roi_chunk=2400):
         super().__init__()
         blocks, cin = [], in_channels
         for b in range(num_blocks):
@@ -117,7 +135,8 @@ class Res5RoIHead(nn.Module):
     def forward(self, feature_maps, tracklet_boxes):
         with torch.no_grad():
             dev = _compute_device(feature_maps, tracklet_boxes, self.res5[0].conv1.weight)
-            fm = _f32(feature_maps, dev)
+            bf16 = isinstance(feature_maps, torch.Tensor) and feature_maps.dtype == torch.bfloat16
+            fm = _f32(feature_maps, dev)       # RoIAlign interpolates in fp32 (bf16 values are exact in fp32)
             if fm.dim() != 4 or fm.shape[3] != self.in_channels:
                 raise ValueError(f"feature_maps must be channels-last [T,Hf,Wf,{self.in_channels}], got {tuple(fm.shape)}")
             boxes = _f32(tracklet_boxes, dev)
@@ -129,9 +148,13 @@ class Res5RoIHead(nn.Module):
             feats = torch.empty((n * t, self.out_channels), dtype=torch.float32, device=dev)
             for lo in range(0, n * t, self.roi_chunk):
                 x = ops.roi_align_nhwc(fm, rois[lo:lo + self.roi_chunk].contiguous(), self.pooler_resolution,
-                                       self.spatial_scale, self.sampling_ratio, aligned=True)
+                                       self.spatial_scale, self.sampling_ratio, aligned=True, out_bf16=bf16)
                 x = self.res5(x)
                 r, h, w, c = x.shape
-                feats[lo:lo + r] = ops.temporal_mean(x.view(r, h * w, c), layout_tc=True)
+                if bf16:
+                    feats[lo:lo + r] = ops.temporal_mean_bf16(x.view(r, h * w, c))   # bf16-rounded means
+                else:
+                    feats[lo:lo + r] = ops.temporal_mean(x.view(r, h * w, c), layout_tc=True)
             src = tracklet_boxes.device if isinstance(tracklet_boxes, torch.Tensor) else torch.device("cpu")
-            return feats.view(n, t, self.out_channels).to(src)
+            feats = feats.view(n, t, self.out_channels)
+            return (ops.cast_bf16(feats) if bf16 else feats).to(src)

@@ -127,3 +127,58 @@ def test_res5_roi_head_errors(tspn, device):
         head(torch.zeros((2, 5, 5, 16), device=device), torch.zeros((1, 2, 4), device=device))   # wrong C
     with pytest.raises(ValueError):
         head(torch.zeros((2, 5, 5, 32), device=device), torch.zeros((1, 3, 4), device=device))   # T mismatch
+
+
+@pytest.mark.parametrize("NB,H,W,Cin,Cout,k,stride,pad", [
+    (2, 7, 7, 64, 32, 1, 1, 0), (3, 14, 14, 128, 64, 1, 2, 0), (2, 7, 7, 64, 96, 3, 1, 1),
+    (1, 9, 11, 64, 160, 3, 2, 1), (5, 7, 7, 192, 256, 3, 1, 1), (40, 7, 7, 64, 128, 1, 1, 0), (1, 1, 1, 64, 32, 1, 1, 0)])
+@pytest.mark.parametrize("fused", [False, True])
+def test_conv2d_nhwc_bf16_vs_fp64(tspn, device, NB, H, W, Cin, Cout, k, stride, pad, fused):
+    """bf16-operand conv2d: exact products, fp32 accumulation (vs float64 on the same bf16 operands), one
+    rounding of the result to bf16; the fragment-major bf16 weight layout is the documented permutation."""
+    r16 = lambda a: t(a).to(torch.bfloat16)
+    x = tspn.hashrng.uniform(77, "x", (NB, H, W, Cin), -1, 1)
+    w = tspn.hashrng.normal(77, "w", (Cout, Cin, k, k), std=0.1)
+    b = tspn.hashrng.normal(77, "b", (Cout,), std=0.1)
+    xb, wb = r16(x), r16(w)
+    ref = torch.nn.functional.conv2d(xb.double().permute(0, 3, 1, 2), wb.double(), t(b).double() if fused else None,
+                                     stride=stride, padding=pad).permute(0, 2, 3, 1)
+    res = r16(tspn.hashrng.uniform(77, "r", tuple(ref.shape), -1, 1))
+    if fused:
+        ref = torch.relu(ref + res.double())
+    frag = tspn.ops.pack_conv2d_frag_bf16(t(w).to(device))
+    want = wb.view(torch.int16).numpy().reshape(Cout // 32, 32, Cin // 64, 4, 2, 8, k * k).transpose(0, 6, 2, 3, 4, 1, 5)
+    np.testing.assert_array_equal(frag.cpu().view(torch.int16).numpy().reshape(Cout // 32, k * k, Cin // 64, 4, 2, 32, 8), want)
+    y = tspn.ops.conv2d_nhwc_bf16(xb.to(device), frag, (k, k), stride, pad, bias=t(b).to(device) if fused else None,
+                                  residual=res.to(device) if fused else None, relu=fused)
+    assert y.dtype == torch.bfloat16 and tuple(y.shape) == tuple(ref.shape)
+    got = y.cpu().double()
+    # the result is the bf16 rounding of an fp32 sum that is within 2e-5 of the float64 one: half a bf16 ulp
+    # of the value plus that slack
+    tol = ref.abs() * 2.0 ** -8 + 3e-5
+    assert bool(((got - ref).abs() <= tol).all()), float(((got - ref).abs() - tol).max())
+    # and on the vast majority of elements it IS the correctly rounded float64 result
+    exact = (got == ref.float().to(torch.bfloat16).double()).double().mean()
+    assert float(exact) > 0.99
+
+
+def test_res5_roi_head_bf16_matches_oracle(tspn, device):
+    """bf16 feature maps select the bf16 kernels; output = bf16 features within a few bf16 ulps of the
+    float64 restatement with the same rounding points, and close to the fp32 head."""
+    N, T, cin, mid, cout = 3, 4, 128, 64, 256
+    head, p = _head_and_weights(tspn, device, cin, mid, cout, roi_chunk=7)
+    fm = t(tspn.hashrng.uniform(78, "fm", (T, 10, 12, cin), 0, 1)).to(torch.bfloat16)
+    v = tspn.synth.make_video(79, N, T, 16)
+    boxes = (v["tracklet_boxes"] * np.float32(0.15)).astype(np.float32)
+    got = head(fm.to(device), t(boxes).to(device))
+    assert got.dtype == torch.bfloat16 and got.is_cuda and tuple(got.shape) == (N, T, cout)
+    ref = ro.res5_roi_head_bf16(fm, t(boxes), p)
+    scale = float(ref.abs().max())
+    err = (got.cpu().float() - ref).abs()
+    assert float(err.max()) <= 4 * 2.0 ** -8 * scale, (float(err.max()), scale)   # a few bf16 ulps of the range
+    assert float((err <= 2.0 ** -8 * ref.abs() + 1e-6).double().mean()) > 0.97     # mostly within one ulp
+    f32 = head(fm.float().to(device), t(boxes).to(device)).cpu()
+    assert float((got.cpu().float() - f32).abs().max()) <= 0.05 * float(f32.abs().max())
+    # the bf16 features feed the bf16 scorer path unchanged
+    plist = tspn.PairList.from_tracklets(got, t(boxes).to(device), t(v["track_cls_logits"]).to(device))
+    assert plist.get_field("tracklet_feats").dtype == torch.bfloat16
