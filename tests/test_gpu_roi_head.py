@@ -182,3 +182,52 @@ def test_res5_roi_head_bf16_matches_oracle(tspn, device):
     # the bf16 features feed the bf16 scorer path unchanged
     plist = tspn.PairList.from_tracklets(got, t(boxes).to(device), t(v["track_cls_logits"]).to(device))
     assert plist.get_field("tracklet_feats").dtype == torch.bfloat16
+
+
+def test_end_to_end_maps_to_relations(tspn, device):
+    """res4 maps + tracklet boxes -> RoI head -> pair builder / temporal encoder / heads -> triplet decode, all on
+    the GPU, against the oracle chain (RoI-head restatement -> oracle.forward_dense -> oracle.decode_topk)."""
+    import cases
+    N, T, cin, mid, D = 4, 6, 64, 32, 32
+    head, p = _head_and_weights(tspn, device, cin, mid, D)
+    cfg = cases.baseline_cfg(**{"RELPN.USE_PPN": False, "RELPN.USE_DPN": True, "RELPN.DPN.IN_CHANNELS": 2 * D,
+                                "PREDICT.FEATURE_DIM": 2 * D})
+    sd = tspn.synth.make_weights(5, c=2 * D, bias_std=0.05)
+    model = tspn.BaseModel(cfg)
+    own = model.state_dict()
+    model.load_state_dict({k: t(v) for k, v in sd.items() if k in own})
+    model.eval()
+    fm = tspn.hashrng.uniform(81, "fm", (T, 10, 12, cin), 0, 1)
+    v = tspn.synth.make_video(82, N, T, 16)
+    boxes = (v["tracklet_boxes"] * np.float32(0.15)).astype(np.float32)
+    # --- GPU pipeline
+    feats = head(t(fm).to(device), t(boxes).to(device))
+    plist = tspn.PairList.from_tracklets(feats, t(boxes).to(device), t(v["track_cls_logits"]).to(device))
+    with torch.no_grad():
+        _, dur, logits = model([plist], None)
+    trip = model.decode([plist], logits, topk_per_pair=5, topk_per_seg=20)[0]
+    # --- oracle chain
+    pre = "relpn.duration_proposal_network.dpn_head."
+    w = {"conv_w": t(sd[pre + "conv.weight"]), "conv_b": t(sd[pre + "conv.bias"]),
+         "dur_w": t(sd[pre + "duration_pred.weight"]), "dur_b": t(sd[pre + "duration_pred.bias"]),
+         "rel_w": t(sd[pre + "relness_pred.weight"]), "rel_b": t(sd[pre + "relness_pred.bias"]),
+         "cls_w": t(sd["classifier.rel_predictor.weight"]), "cls_b": t(sd["classifier.rel_predictor.bias"])}
+    ofeats = ro.res5_roi_head(t(fm), t(boxes), p, dtype=torch.float64)
+    ref = oracle.forward_dense(ofeats, t(boxes), oracle.pair_index(N), w)
+    scale = max(1.0, float(ofeats.abs().max()))
+    np.testing.assert_allclose(feats.cpu().numpy(), ofeats.numpy(), rtol=0, atol=2e-5 * scale)
+    np.testing.assert_allclose(dur[0].duration.cpu().numpy(), ref["duration"].numpy(), rtol=0, atol=1e-4)
+    np.testing.assert_allclose(dur[0].relness.cpu().numpy(), ref["relness"].numpy(), rtol=0, atol=1e-4)
+    np.testing.assert_allclose(logits[0].cpu().numpy(), ref["rel_logits"].numpy(), rtol=0, atol=1e-4)
+    # decode of the GPU logits == predict.py:66-106 restated on the same logits (tracklet segments take the
+    # classes from track_cls_logits): indices bit-exact
+    lg = logits[0].cpu()
+    sc, idx = torch.sort(lg, descending=True, dim=-1, stable=True)
+    sc, idx = sc[:, :5], idx[:, :5]
+    order = torch.sort(sc.flatten(), descending=True, stable=True)[1][:20]
+    pi, ki = order // 5, order % 5
+    tids = oracle.pair_index(N)[pi]
+    cls = t(v["track_cls_logits"])
+    want = torch.stack([cls[tids[:, 0]].argmax(1), idx[pi, ki], cls[tids[:, 1]].argmax(1)]).t()
+    assert torch.equal(trip[1].cpu(), want) and torch.equal(trip[2].cpu(), tids)
+    assert torch.equal(trip[0].cpu(), sc[pi, ki])
