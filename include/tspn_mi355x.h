@@ -366,7 +366,7 @@ int tspn_temporal_encoder_heads_f32(const float* x, int64_t P, int64_t C, int64_
  * channels-last (NHWC) fp32 tensors; `temporal-span-proposal-network-vidvrd_amd/roi_head.py`
  * assembles them and hands [N,T,2048] straight to the pair builder.
  *
- * tspn_pack_conv2d_f32: Conv2d weight [Cout][Cin][KH][KW] -> [KH*KW][Cin][Cout] (KH*KW <= 32).
+ * tspn_pack_conv2d_f32: Conv2d weight [Cout][Cin][KH][KW] -> [KH*KW][Cin][Cout] (KH*KW <= 64).
  * tspn_conv2d_nhwc_f32: out[NB,OH,OW,Cout] = act( conv(x[NB,H,W,Cin]) + bias[Cout] + residual[NB,OH,OW,Cout] ),
  *   zero padding `pad`, `stride`, OH = (H + 2 pad - KH) / stride + 1; bias / residual may be NULL;
  *   relu != 0 applies max(.,0).  BatchNorm is folded into (packed, bias) by the caller.  Implicit GEMM
@@ -387,6 +387,14 @@ int tspn_conv2d_nhwc_frag_f32(const float* x, int64_t NB, int64_t H, int64_t W, 
                               const float* frag, int64_t Cout, int64_t KH, int64_t KW, int64_t stride,
                               int64_t pad, const float* bias, const float* residual, int relu, float* out,
                               void* stream);
+/* Stem form for Cin <= 4 (RGB): x[NB,H,W,4] (channels zero-padded to 4); one K chunk = four taps x 4 channels,
+ * so a 7x7 stem runs 13 chunks instead of 49 on 16-channel padding.
+ *   frag[Cout/32][ceil(KH*KW/4)][64 lanes][8 = (g, r)] = w[32 mb + li][2 kh + r][tap = 4 c + g] (0 beyond Cin / taps) */
+int tspn_pack_conv2d_frag_cin4_f32(const float* w, int64_t Cout, int64_t Cin, int64_t KH, int64_t KW,
+                                   float* frag, void* stream);
+int tspn_conv2d_nhwc_cin4_f32(const float* x, int64_t NB, int64_t H, int64_t W, const float* frag,
+                              int64_t Cout, int64_t KH, int64_t KW, int64_t stride, int64_t pad,
+                              const float* bias, int relu, float* out, void* stream);
 /* bf16-operand form (tspn_roi_bf16.hip; v_mfma_f32_32x32x16_bf16): x, residual, out are bf16 (uint16_t
  * bit patterns), bias fp32; products exact, fp32 accumulation, act(acc + bias + residual) rounded to bf16
  * once (round to nearest even).  Weights: tspn_pack_conv2d_frag_bf16 rounds the fp32 (BN-folded) weight
@@ -409,6 +417,12 @@ int tspn_roi_align_nhwc_f32(const float* feat, int64_t NF, int64_t H, int64_t W,
 int tspn_roi_align_nhwc_f32_bf16out(const float* feat, int64_t NF, int64_t H, int64_t W, int64_t C,
                                     const float* rois, int64_t R, int64_t P, float spatial_scale,
                                     int sampling_ratio, int aligned, uint16_t* out, void* stream);
+
+/* max_pool2d(k, stride, pad) on a channels-last fp32 map x[NB,H,W,C] -> out[NB,OH,OW,C], fp32 (out_bf16 == 0)
+ * or bf16 (rounded once); padding positions do not take part.  detectron2 BasicStem uses 3 / 2 / 1.
+ * Needs C % 4 == 0. */
+int tspn_max_pool_nhwc_f32(const float* x, int64_t NB, int64_t H, int64_t W, int64_t C, int64_t k,
+                           int64_t stride, int64_t pad, void* out, int out_bf16, void* stream);
 
 #ifdef __cplusplus
 }

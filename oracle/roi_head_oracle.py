@@ -20,7 +20,7 @@ import torch
 import torch.nn.functional as F
 
 __all__ = ["roi_align_nhwc", "frozen_bn", "bottleneck_block", "res5_roi_head", "make_res5_weights",
-           "conv2d_bf16", "res5_roi_head_bf16"]
+           "conv2d_bf16", "res5_roi_head_bf16", "resnet_c4", "resnet_c4_bf16", "make_backbone_weights"]
 
 BN_EPS = 1e-5
 
@@ -188,3 +188,83 @@ def res5_roi_head_bf16(feat_nhwc, tracklet_boxes, p, num_blocks=3, pooler_resolu
             sc = x
         x = conv2d_bf16(out, w3, b3, residual=sc, relu=True)
     return _r16(x.mean(dim=(2, 3))).reshape(N, T, -1).float()
+
+
+def _make_stage(p, rng_uniform, rng_normal, name, nblocks, cin, cout, gamma3=(0.5, 1.5)):
+    for b in range(nblocks):
+        pre = f"{name}.{b}."
+        mid = cout // 4
+        convs = [("conv1", mid, cin, 1, (0.5, 1.5)), ("conv2", mid, mid, 3, (0.5, 1.5)), ("conv3", cout, mid, 1, gamma3)]
+        if cin != cout:
+            convs.append(("shortcut", cout, cin, 1, (0.5, 1.5)))
+        for cname, co, ci, k, gam in convs:
+            std = math.sqrt(2.0 / (ci * k * k))
+            p[pre + cname + ".weight"] = torch.from_numpy(rng_normal(pre + cname + ".w", (co, ci, k, k), std))
+            p[pre + cname + ".norm.weight"] = torch.from_numpy(rng_uniform(pre + cname + ".g", (co,), gam[0], gam[1]))
+            p[pre + cname + ".norm.bias"] = torch.from_numpy(rng_uniform(pre + cname + ".b", (co,), -0.2, 0.2))
+            p[pre + cname + ".norm.running_mean"] = torch.from_numpy(rng_uniform(pre + cname + ".m", (co,), -0.2, 0.2))
+            p[pre + cname + ".norm.running_var"] = torch.from_numpy(rng_uniform(pre + cname + ".v", (co,), 0.5, 1.5))
+        cin = cout
+    return cin
+
+
+def make_backbone_weights(rng_uniform, rng_normal, stem_out, res2_out, blocks):
+    """Deterministic random C4-backbone parameters with detectron2 key names (stem.conv1.*, res2..res4.*); the
+    last batch norm of every block is damped (gamma in [0.1, 0.4]) so that activations stay O(1) over depth."""
+    p = {}
+    std = math.sqrt(2.0 / (3 * 49))
+    p["stem.conv1.weight"] = torch.from_numpy(rng_normal("stem.w", (stem_out, 3, 7, 7), std))
+    p["stem.conv1.norm.weight"] = torch.from_numpy(rng_uniform("stem.g", (stem_out,), 0.5, 1.5))
+    p["stem.conv1.norm.bias"] = torch.from_numpy(rng_uniform("stem.b", (stem_out,), -0.2, 0.2))
+    p["stem.conv1.norm.running_mean"] = torch.from_numpy(rng_uniform("stem.m", (stem_out,), -0.2, 0.2))
+    p["stem.conv1.norm.running_var"] = torch.from_numpy(rng_uniform("stem.v", (stem_out,), 0.5, 1.5))
+    cin, cout = stem_out, res2_out
+    for i, nb in enumerate(blocks):
+        cin = _make_stage(p, rng_uniform, rng_normal, f"res{i + 2}", nb, cin, cout, gamma3=(0.1, 0.4))
+        cout *= 2
+    return p
+
+
+def resnet_c4(images_nhwc, p, blocks, dtype=torch.float64):
+    """detectron2 ResNet.forward up to res4 (modeling/backbone/resnet.py: BasicStem = conv 7x7/2 + FrozenBN +
+    ReLU + max_pool2d(3, 2, 1); stages of BottleneckBlocks, stride 2 in the first block of res3 and res4).
+    images [T,H,W,3] -> res4 map [T,H/16,W/16,C] channels-last."""
+    pp = {k: v.to(dtype) for k, v in p.items()}
+    x = images_nhwc.permute(0, 3, 1, 2).to(dtype)
+    x = F.relu(frozen_bn(F.conv2d(x, pp["stem.conv1.weight"], stride=2, padding=3), pp, "stem.conv1.norm."))
+    x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+    for i, nb in enumerate(blocks):
+        for b in range(nb):
+            x = bottleneck_block(x, pp, f"res{i + 2}.{b}.", 2 if (b == 0 and i > 0) else 1)
+    return x.permute(0, 2, 3, 1).contiguous().float()
+
+
+def _fold(p, prefix):
+    scale = p[prefix + "norm.weight"] * (p[prefix + "norm.running_var"] + BN_EPS).rsqrt()
+    return (p[prefix + "weight"] * scale.reshape(-1, 1, 1, 1)), (p[prefix + "norm.bias"] - p[prefix + "norm.running_mean"] * scale)
+
+
+def _bottleneck_bf16(x, p, pre, s):
+    w1, b1 = _fold(p, pre + "conv1.")
+    w2, b2 = _fold(p, pre + "conv2.")
+    w3, b3 = _fold(p, pre + "conv3.")
+    out = conv2d_bf16(x, w1, b1, stride=s, relu=True)
+    out = conv2d_bf16(out, w2, b2, padding=1, relu=True)
+    if pre + "shortcut.weight" in p:
+        ws, bs = _fold(p, pre + "shortcut.")
+        sc = conv2d_bf16(x, ws, bs, stride=s)
+    else:
+        sc = x
+    return conv2d_bf16(out, w3, b3, residual=sc, relu=True)
+
+
+def resnet_c4_bf16(images_nhwc, p, blocks):
+    """The backbone as the GPU runs it with bf16=True: stem conv + FrozenBN + ReLU + max pool in fp32 (float64
+    here), the pooled map rounded once to bf16, res2-res4 as conv2d_bf16 chains."""
+    w, b = _fold(p, "stem.conv1.")
+    x = F.relu(F.conv2d(images_nhwc.permute(0, 3, 1, 2).double(), w.double(), b.double(), stride=2, padding=3))
+    x = _r16(F.max_pool2d(x, kernel_size=3, stride=2, padding=1))
+    for i, nb in enumerate(blocks):
+        for bidx in range(nb):
+            x = _bottleneck_bf16(x, p, f"res{i + 2}.{bidx}.", 2 if (bidx == 0 and i > 0) else 1)
+    return x.permute(0, 2, 3, 1).contiguous().float()

@@ -19,6 +19,6 @@ from .sampler import BalancedPositiveNegativePairSampler  # noqa: F401
 from .anchor_generator import AnchorGenerator, generate_anchors, make_anchor_generator  # noqa: F401
 from . import dist  # noqa: F401
 from . import roi_head  # noqa: F401
-from .roi_head import Res5RoIHead  # noqa: F401
+from .roi_head import Res5RoIHead, ResNetC4  # noqa: F401
 
 __version__ = "0.1.0"

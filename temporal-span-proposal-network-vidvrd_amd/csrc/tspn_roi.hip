@@ -94,7 +94,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_nhwc_kernel(
   const int slot = 64 * (wave & 1) + lane;
   const int bg = wave >> 1;
   int64_t pbase;          // offset (floats) of input pixel (ih0, iw0) of this lane's output pixel, channel 0
-  unsigned tapmask = 0;   // bit (kh * KW + kw): the tap lies inside the image
+  unsigned long long tapmask = 0;   // bit (kh * KW + kw): the tap lies inside the image
   {
     const int64_t n = n0 + slot;
     const bool okn = n < npix;
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_nhwc_kernel(
     pbase = ((nb * H + ih0) * (int64_t)W + iw0) * Cin;
     for (int a = 0; a < KH; ++a)
       for (int b = 0; b < KW; ++b)
-        if (okn && ih0 + a >= 0 && ih0 + a < H && iw0 + b >= 0 && iw0 + b < W) tapmask |= 1u << (a * KW + b);
+        if (okn && ih0 + a >= 0 && ih0 + a < H && iw0 + b >= 0 && iw0 + b < W) tapmask |= 1ull << (a * KW + b);
   }
 
   const int cchunks = Cin / KC;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_nhwc_kernel(
 #pragma unroll
     for (int p = 0; p < NP; ++p)
       glds16(wsrc + 2 * p * (int64_t)Cout, As + buf * A_ST + (2 * NP * wave + 2 * p) * BM);
-    const bool valid = (tapmask >> tap) & 1u;
+    const bool valid = (tapmask >> tap) & 1ull;
     const float* xs = valid ? x + pbase + ((int64_t)ta * W + tb) * Cin + c * KC + 4 * bg : g_zero_page + 4 * bg;
 #pragma unroll
     for (int p = 0; p < NP; ++p)
@@ -257,8 +257,26 @@ __global__ void pack_conv2d_frag_kernel(const float* __restrict__ w, int64_t Cou
   }
 }
 
+// Stem form (Cin <= 4, e.g. RGB): the image has 4 channels per pixel (zero padded) and one K chunk spans FOUR
+// TAPS x 4 channels -- a 16-byte DMA piece is exactly one (pixel, tap) -- so a 7x7 stem needs 13 chunks, not 49:
+//   frag[Cout/32][ceil(taps/4)][64 lanes][8 = (g, r)] = w[32 mb + li][2 kh + r][tap = 4 c + g]   (0 beyond Cin / taps)
+__global__ void pack_conv2d_frag_cin4_kernel(const float* __restrict__ w, int64_t Cout, int64_t Cin, int64_t ntaps,
+                                             float* __restrict__ packed) {
+  const int64_t nch = (ntaps + 3) / 4;
+  const int64_t total = (Cout / 32) * nch * 512;
+  for (int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; o < total;
+       o += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(o & 1), g = (int)((o >> 1) & 3), lane = (int)((o >> 3) & 63);
+    const int64_t q = o >> 9;
+    const int64_t c = q % nch, mb = q / nch;
+    const int64_t co = 32 * mb + (lane & 31), ci = 2 * (lane >> 5) + r, tap = 4 * c + g;
+    packed[o] = (ci < Cin && tap < ntaps) ? w[(co * Cin + ci) * ntaps + tap] : 0.f;
+  }
+}
+
 constexpr int F_B_ST = 4 * SLP * 4;    // floats per x stage: [4 groups][132 slots][4 ch]
 
+template <bool CIN4>
 __global__ __launch_bounds__(THREADS, 2) void conv2d_nhwc_frag_kernel(
     const float* __restrict__ x, const float* __restrict__ Wf, const float* __restrict__ bias,
     const float* __restrict__ residual, float* __restrict__ out, int H, int W, int Cin, int Cout, int KH,
@@ -286,7 +304,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_nhwc_frag_kernel(
   const int li = lane & 31, kh = lane >> 5;
 
   const int cchunks = Cin >> 4;
-  const int nchunks = KH * KW * cchunks;
+  const int nchunks = CIN4 ? (KH * KW + 3) / 4 : KH * KW * cchunks;
   // weight fragment stream of this wave: chunk i = (tap, c) is line i of its block (tap-major like i)
   const char* wbase;
   const unsigned woff = lane * 32;
@@ -299,7 +317,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_nhwc_frag_kernel(
   const int slot = 64 * (wave & 1) + lane;
   const int bg = wave >> 1;
   int64_t pbase;
-  unsigned tapmask = 0;
+  unsigned long long tapmask = 0;
   {
     const int64_t n = n0 + slot;
     const bool okn = n < npix;
@@ -308,18 +326,29 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_nhwc_frag_kernel(
     const int r = (int)(nc - nb * OH * OW);
     const int oh = r / OW, ow = r - oh * OW;
     const int ih0 = oh * stride - pad, iw0 = ow * stride - pad;
-    pbase = ((nb * H + ih0) * (int64_t)W + iw0) * Cin;
+    pbase = ((nb * H + ih0) * (int64_t)W + iw0) * (CIN4 ? 4 : Cin);
     for (int a = 0; a < KH; ++a)
       for (int b = 0; b < KW; ++b)
-        if (okn && ih0 + a >= 0 && ih0 + a < H && iw0 + b >= 0 && iw0 + b < W) tapmask |= 1u << (a * KW + b);
+        if (okn && ih0 + a >= 0 && ih0 + a < H && iw0 + b >= 0 && iw0 + b < W) tapmask |= 1ull << (a * KW + b);
   }
   auto stage_x = [&](int buf, int i) {             // exactly two pieces per wave (padding taps read the zero page)
-    const int tap = i / cchunks, c = i - tap * cchunks;
-    const int ta = tap / KW, tb = tap - ta * KW;
-    const bool valid = (tapmask >> tap) & 1u;
-    const float* xs = valid ? x + pbase + ((int64_t)ta * W + tb) * Cin + c * 16 + 4 * bg : g_zero_page + 4 * bg;
-    glds16(xs, Bs + buf * F_B_ST + (bg * SLP + 64 * (wave & 1)) * 4);
-    glds16(xs + 8, Bs + buf * F_B_ST + ((bg + 2) * SLP + 64 * (wave & 1)) * 4);
+    if constexpr (CIN4) {                          // group g of chunk i = tap 4 i + g, the pixel's 4 channels
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int tap = 4 * i + bg + 2 * p;
+        const int ta = tap / KW, tb = tap - ta * KW;
+        const bool valid = tap < KH * KW && ((tapmask >> tap) & 1ull);
+        const float* xs = valid ? x + pbase + ((int64_t)ta * W + tb) * 4 : g_zero_page;
+        glds16(xs, Bs + buf * F_B_ST + ((bg + 2 * p) * SLP + 64 * (wave & 1)) * 4);
+      }
+    } else {
+      const int tap = i / cchunks, c = i - tap * cchunks;
+      const int ta = tap / KW, tb = tap - ta * KW;
+      const bool valid = (tapmask >> tap) & 1ull;
+      const float* xs = valid ? x + pbase + ((int64_t)ta * W + tb) * Cin + c * 16 + 4 * bg : g_zero_page + 4 * bg;
+      glds16(xs, Bs + buf * F_B_ST + (bg * SLP + 64 * (wave & 1)) * 4);
+      glds16(xs + 8, Bs + buf * F_B_ST + ((bg + 2) * SLP + 64 * (wave & 1)) * 4);
+    }
   };
 
   f32x16 acc[4];
@@ -479,12 +508,47 @@ __global__ __launch_bounds__(256) void roi_align_nhwc_kernel(
   }
 }
 
+// max_pool2d(kernel k, stride s, padding p) on a channels-last fp32 map (detectron2 BasicStem: 3 / 2 / 1);
+// padding positions do not take part (-inf).  A thread = 4 channels of one output pixel.
+template <bool BF16OUT>
+__global__ __launch_bounds__(256) void max_pool_nhwc_kernel(const float* __restrict__ x, int64_t NB, int H, int W,
+                                                            int C, int k, int stride, int pad, int OH, int OW,
+                                                            void* __restrict__ out_v) {
+  const int c4 = C >> 2;
+  const int64_t total = NB * OH * OW * c4;
+  for (int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(o % c4);
+    const int64_t pix = o / c4;
+    const int ow = (int)(pix % OW);
+    const int oh = (int)((pix / OW) % OH);
+    const int64_t nb = pix / ((int64_t)OW * OH);
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    for (int a = 0; a < k; ++a) {
+      const int ih = oh * stride - pad + a;
+      if (ih < 0 || ih >= H) continue;
+      for (int b = 0; b < k; ++b) {
+        const int iw = ow * stride - pad + b;
+        if (iw < 0 || iw >= W) continue;
+        const float4 v = *reinterpret_cast<const float4*>(x + ((nb * H + ih) * (int64_t)W + iw) * C + 4 * cg);
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+      }
+    }
+    const int64_t oo = pix * C + 4 * cg;
+    if constexpr (BF16OUT) {
+      const bf16x4 ob = {(__bf16)m.x, (__bf16)m.y, (__bf16)m.z, (__bf16)m.w};
+      *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(out_v) + oo) = ob;
+    } else {
+      *reinterpret_cast<float4*>(static_cast<float*>(out_v) + oo) = m;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int tspn_pack_conv2d_f32(const float* w, int64_t Cout, int64_t Cin, int64_t KH, int64_t KW,
                                     float* packed, void* stream) {
   TSPN_REQUIRE(w && packed, TSPN_EINVAL, "tspn_pack_conv2d_f32: null pointer");
-  TSPN_REQUIRE(Cout > 0 && Cin > 0 && KH > 0 && KW > 0 && KH * KW <= 32, TSPN_EINVAL,
+  TSPN_REQUIRE(Cout > 0 && Cin > 0 && KH > 0 && KW > 0 && KH * KW <= 64, TSPN_EINVAL,
                "tspn_pack_conv2d_f32: bad sizes");
   const int64_t total = KH * KW * Cin * Cout;
   const int blocks = (int)std::min<int64_t>(tspn::ceil_div(total, 256), 8192);
@@ -499,7 +563,7 @@ extern "C" int tspn_conv2d_nhwc_f32(const float* x, int64_t NB, int64_t H, int64
                                     void* stream) {
   TSPN_REQUIRE(NB >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0,
                TSPN_EINVAL, "tspn_conv2d_nhwc_f32: bad sizes");
-  TSPN_REQUIRE(KH * KW <= 32, TSPN_EUNSUPPORTED, "tspn_conv2d_nhwc_f32: at most 32 taps");
+  TSPN_REQUIRE(KH * KW <= 64, TSPN_EUNSUPPORTED, "tspn_conv2d_nhwc_f32: at most 64 taps");
   const int64_t OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
   TSPN_REQUIRE(OH > 0 && OW > 0, TSPN_EINVAL, "tspn_conv2d_nhwc_f32: empty output (H=%lld W=%lld)", (long long)H,
                (long long)W);
@@ -527,7 +591,7 @@ extern "C" int tspn_conv2d_nhwc_f32(const float* x, int64_t NB, int64_t H, int64
 extern "C" int tspn_pack_conv2d_frag_f32(const float* w, int64_t Cout, int64_t Cin, int64_t KH, int64_t KW,
                                          float* packed, void* stream) {
   TSPN_REQUIRE(w && packed, TSPN_EINVAL, "tspn_pack_conv2d_frag_f32: null pointer");
-  TSPN_REQUIRE(Cout > 0 && Cin > 0 && KH > 0 && KW > 0 && KH * KW <= 32, TSPN_EINVAL,
+  TSPN_REQUIRE(Cout > 0 && Cin > 0 && KH > 0 && KW > 0 && KH * KW <= 64, TSPN_EINVAL,
                "tspn_pack_conv2d_frag_f32: bad sizes");
   TSPN_REQUIRE(Cout % 32 == 0 && Cin % 16 == 0, TSPN_EUNSUPPORTED,
                "tspn_pack_conv2d_frag_f32: needs Cout %% 32 == 0 and Cin %% 16 == 0 (Cout=%lld Cin=%lld)",
@@ -545,7 +609,7 @@ extern "C" int tspn_conv2d_nhwc_frag_f32(const float* x, int64_t NB, int64_t H, 
                                          int relu, float* out, void* stream) {
   TSPN_REQUIRE(NB >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0,
                TSPN_EINVAL, "tspn_conv2d_nhwc_frag_f32: bad sizes");
-  TSPN_REQUIRE(KH * KW <= 32, TSPN_EUNSUPPORTED, "tspn_conv2d_nhwc_frag_f32: at most 32 taps");
+  TSPN_REQUIRE(KH * KW <= 64, TSPN_EUNSUPPORTED, "tspn_conv2d_nhwc_frag_f32: at most 64 taps");
   const int64_t OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
   TSPN_REQUIRE(OH > 0 && OW > 0, TSPN_EINVAL, "tspn_conv2d_nhwc_frag_f32: empty output");
   if (NB == 0) return TSPN_OK;
@@ -561,11 +625,48 @@ extern "C" int tspn_conv2d_nhwc_frag_f32(const float* x, int64_t NB, int64_t H, 
   const int64_t npix = NB * OH * OW;
   const int64_t tiles_m = tspn::ceil_div(Cout, BM), tiles_n = tspn::ceil_div(npix, BN);
   TSPN_REQUIRE(tiles_m * tiles_n < (1LL << 31), TSPN_EUNSUPPORTED, "tspn_conv2d_nhwc_frag_f32: grid too large");
-  hipLaunchKernelGGL(conv2d_nhwc_frag_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(THREADS), 0,
+  hipLaunchKernelGGL(conv2d_nhwc_frag_kernel<false>, dim3((unsigned)(tiles_m * tiles_n)), dim3(THREADS), 0,
                      TSPN_STREAM(stream), x, frag, bias, residual, out, (int)H, (int)W, (int)Cin, (int)Cout,
                      (int)KH, (int)KW, (int)stride, (int)pad, (int)OH, (int)OW, npix, (int)tiles_m, (int)tiles_n,
                      relu);
   return tspn::check_launch("tspn_conv2d_nhwc_frag_f32");
+}
+
+extern "C" int tspn_pack_conv2d_frag_cin4_f32(const float* w, int64_t Cout, int64_t Cin, int64_t KH, int64_t KW,
+                                              float* packed, void* stream) {
+  TSPN_REQUIRE(w && packed, TSPN_EINVAL, "tspn_pack_conv2d_frag_cin4_f32: null pointer");
+  TSPN_REQUIRE(Cout > 0 && Cin > 0 && Cin <= 4 && KH > 0 && KW > 0 && KH * KW <= 64 && Cout % 32 == 0, TSPN_EUNSUPPORTED,
+               "tspn_pack_conv2d_frag_cin4_f32: needs Cin <= 4, Cout %% 32 == 0, at most 64 taps");
+  const int64_t total = (Cout / 32) * ((KH * KW + 3) / 4) * 512;
+  const int blocks = (int)std::min<int64_t>(tspn::ceil_div(total, 256), 8192);
+  hipLaunchKernelGGL(pack_conv2d_frag_cin4_kernel, dim3(blocks), dim3(256), 0, TSPN_STREAM(stream), w, Cout, Cin,
+                     KH * KW, packed);
+  return tspn::check_launch("tspn_pack_conv2d_frag_cin4_f32");
+}
+
+extern "C" int tspn_conv2d_nhwc_cin4_f32(const float* x, int64_t NB, int64_t H, int64_t W, const float* frag,
+                                         int64_t Cout, int64_t KH, int64_t KW, int64_t stride, int64_t pad,
+                                         const float* bias, int relu, float* out, void* stream) {
+  TSPN_REQUIRE(NB >= 0 && H > 0 && W > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0, TSPN_EINVAL,
+               "tspn_conv2d_nhwc_cin4_f32: bad sizes");
+  TSPN_REQUIRE(KH * KW <= 64 && Cout % 32 == 0, TSPN_EUNSUPPORTED,
+               "tspn_conv2d_nhwc_cin4_f32: needs at most 64 taps and Cout %% 32 == 0");
+  const int64_t OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+  TSPN_REQUIRE(OH > 0 && OW > 0, TSPN_EINVAL, "tspn_conv2d_nhwc_cin4_f32: empty output");
+  if (NB == 0) return TSPN_OK;
+  TSPN_REQUIRE(x && frag && out, TSPN_EINVAL, "tspn_conv2d_nhwc_cin4_f32: null pointer");
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  TSPN_REQUIRE(al16(x) && al16(frag) && al16(out) && (!bias || al16(bias)), TSPN_EUNSUPPORTED,
+               "tspn_conv2d_nhwc_cin4_f32: operands must be 16-byte aligned");
+  const int64_t npix = NB * OH * OW;
+  const int64_t tiles_m = tspn::ceil_div(Cout, BM), tiles_n = tspn::ceil_div(npix, BN);
+  TSPN_REQUIRE(tiles_m * tiles_n < (1LL << 31) && H < (1 << 20) && W < (1 << 20), TSPN_EUNSUPPORTED,
+               "tspn_conv2d_nhwc_cin4_f32: problem too large");
+  hipLaunchKernelGGL(conv2d_nhwc_frag_kernel<true>, dim3((unsigned)(tiles_m * tiles_n)), dim3(THREADS), 0,
+                     TSPN_STREAM(stream), x, frag, bias, static_cast<const float*>(nullptr), out, (int)H, (int)W, 4,
+                     (int)Cout, (int)KH, (int)KW, (int)stride, (int)pad, (int)OH, (int)OW, npix, (int)tiles_m,
+                     (int)tiles_n, relu);
+  return tspn::check_launch("tspn_conv2d_nhwc_cin4_f32");
 }
 
 static int roi_align_launch(const float* feat, int64_t NF, int64_t H, int64_t W, int64_t C, const float* rois,
@@ -601,4 +702,25 @@ extern "C" int tspn_roi_align_nhwc_f32_bf16out(const float* feat, int64_t NF, in
                                                const float* rois, int64_t R, int64_t P, float spatial_scale,
                                                int sampling_ratio, int aligned, uint16_t* out, void* stream) {
   return roi_align_launch(feat, NF, H, W, C, rois, R, P, spatial_scale, sampling_ratio, aligned, out, true, stream);
+}
+
+extern "C" int tspn_max_pool_nhwc_f32(const float* x, int64_t NB, int64_t H, int64_t W, int64_t C, int64_t k,
+                                      int64_t stride, int64_t pad, void* out, int out_bf16, void* stream) {
+  TSPN_REQUIRE(NB >= 0 && H > 0 && W > 0 && C > 0 && k > 0 && stride > 0 && pad >= 0 && 2 * pad <= k, TSPN_EINVAL,
+               "tspn_max_pool_nhwc_f32: bad sizes");
+  const int64_t OH = (H + 2 * pad - k) / stride + 1, OW = (W + 2 * pad - k) / stride + 1;
+  TSPN_REQUIRE(OH > 0 && OW > 0, TSPN_EINVAL, "tspn_max_pool_nhwc_f32: empty output");
+  if (NB == 0) return TSPN_OK;
+  TSPN_REQUIRE(x && out, TSPN_EINVAL, "tspn_max_pool_nhwc_f32: null pointer");
+  TSPN_REQUIRE(C % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0,
+               TSPN_EUNSUPPORTED, "tspn_max_pool_nhwc_f32: needs C %% 4 == 0 and 16-byte aligned tensors");
+  const int64_t total = NB * OH * OW * (C / 4);
+  const int blocks = (int)std::min<int64_t>(tspn::ceil_div(total, 256), 1 << 20);
+  if (out_bf16)
+    hipLaunchKernelGGL(max_pool_nhwc_kernel<true>, dim3(blocks), dim3(256), 0, TSPN_STREAM(stream), x, NB, (int)H,
+                       (int)W, (int)C, (int)k, (int)stride, (int)pad, (int)OH, (int)OW, out);
+  else
+    hipLaunchKernelGGL(max_pool_nhwc_kernel<false>, dim3(blocks), dim3(256), 0, TSPN_STREAM(stream), x, NB, (int)H,
+                       (int)W, (int)C, (int)k, (int)stride, (int)pad, (int)OH, (int)OW, out);
+  return tspn::check_launch("tspn_max_pool_nhwc_f32");
 }

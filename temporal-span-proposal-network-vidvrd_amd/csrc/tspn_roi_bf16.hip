@@ -112,7 +112,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_nhwc_bf16_kernel(
   const int slot = 64 * (wave & 1) + lane;
   const int bg = wave >> 1;
   int64_t pbase;
-  unsigned tapmask = 0;
+  unsigned long long tapmask = 0;
   {
     const int64_t n = n0 + slot;
     const bool okn = n < npix;
@@ -124,12 +124,12 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_nhwc_bf16_kernel(
     pbase = ((nb * H + ih0) * (int64_t)W + iw0) * Cin;
     for (int a = 0; a < KH; ++a)
       for (int b = 0; b < KW; ++b)
-        if (okn && ih0 + a >= 0 && ih0 + a < H && iw0 + b >= 0 && iw0 + b < W) tapmask |= 1u << (a * KW + b);
+        if (okn && ih0 + a >= 0 && ih0 + a < H && iw0 + b >= 0 && iw0 + b < W) tapmask |= 1ull << (a * KW + b);
   }
   auto stage_x = [&](int buf, int i) {             // exactly four pieces per wave
     const int tap = i / cchunks, c = i - tap * cchunks;
     const int ta = tap / KW, tb = tap - ta * KW;
-    const bool valid = (tapmask >> tap) & 1u;
+    const bool valid = (tapmask >> tap) & 1ull;
     const __bf16* xs = valid ? x + pbase + ((int64_t)ta * W + tb) * Cin + c * KC + 8 * bg : g_zero_page_bf16 + 8 * bg;
     char* dst = Bs + buf * B_ST + (bg * SLP + 64 * (wave & 1)) * 16;
 #pragma unroll
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_nhwc_bf16_kernel(
 extern "C" int tspn_pack_conv2d_frag_bf16(const float* w, int64_t Cout, int64_t Cin, int64_t KH, int64_t KW,
                                           uint16_t* frag, void* stream) {
   TSPN_REQUIRE(w && frag, TSPN_EINVAL, "tspn_pack_conv2d_frag_bf16: null pointer");
-  TSPN_REQUIRE(Cout > 0 && Cin > 0 && KH > 0 && KW > 0 && KH * KW <= 32, TSPN_EINVAL,
+  TSPN_REQUIRE(Cout > 0 && Cin > 0 && KH > 0 && KW > 0 && KH * KW <= 64, TSPN_EINVAL,
                "tspn_pack_conv2d_frag_bf16: bad sizes");
   TSPN_REQUIRE(Cout % 32 == 0 && Cin % KC == 0, TSPN_EUNSUPPORTED,
                "tspn_pack_conv2d_frag_bf16: needs Cout %% 32 == 0 and Cin %% 64 == 0 (Cout=%lld Cin=%lld)",
@@ -276,7 +276,7 @@ extern "C" int tspn_conv2d_nhwc_bf16(const uint16_t* x, int64_t NB, int64_t H, i
                                      uint16_t* out, void* stream) {
   TSPN_REQUIRE(NB >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0,
                TSPN_EINVAL, "tspn_conv2d_nhwc_bf16: bad sizes");
-  TSPN_REQUIRE(KH * KW <= 32, TSPN_EUNSUPPORTED, "tspn_conv2d_nhwc_bf16: at most 32 taps");
+  TSPN_REQUIRE(KH * KW <= 64, TSPN_EUNSUPPORTED, "tspn_conv2d_nhwc_bf16: at most 64 taps");
   const int64_t OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
   TSPN_REQUIRE(OH > 0 && OW > 0, TSPN_EINVAL, "tspn_conv2d_nhwc_bf16: empty output");
   if (NB == 0) return TSPN_OK;

@@ -17,7 +17,7 @@ __all__ = [
     "forward_fused", "temporal_encoder_heads", "fused_workspace_bytes", "decode_topk", "decode_spans",
     "cast_bf16", "pack_conv3_bf16", "pack_heads_bf16", "conv3_tc_bf16", "heads_pairgrid_bf16",
     "temporal_mean_bf16", "forward_fused_bf16", "span_predicate",
-    "pack_conv2d", "pack_conv2d_frag", "conv2d_nhwc", "roi_align_nhwc", "pack_conv2d_frag_bf16", "conv2d_nhwc_bf16",
+    "pack_conv2d", "pack_conv2d_frag", "conv2d_nhwc", "roi_align_nhwc", "pack_conv2d_frag_bf16", "conv2d_nhwc_bf16", "max_pool_nhwc", "pack_conv2d_frag_cin4", "conv2d_nhwc_cin4",
 ]
 
 
@@ -800,4 +800,45 @@ def conv2d_nhwc_bf16(x, frag, kernel_size, stride=1, padding=0, bias=None, resid
     out = torch.empty((NB, OH, OW, Cout), dtype=torch.bfloat16, device=x.device)
     _abi.check(_abi.lib().tspn_conv2d_nhwc_bf16(_p(x), NB, H, W, Cin, _p(frag), Cout, KH, KW, stride, padding,
                                                 _p(bias), _p(residual), 1 if relu else 0, _p(out), _stream()))
+    return out
+
+
+def max_pool_nhwc(x, kernel_size=3, stride=2, padding=1, out_bf16=False):
+    """max_pool2d on a channels-last fp32 map [NB,H,W,C] -> [NB,OH,OW,C] (fp32, or bf16 rounded once)."""
+    _dev(x, "x")
+    NB, H, W, C = x.shape
+    OH, OW = (H + 2 * padding - kernel_size) // stride + 1, (W + 2 * padding - kernel_size) // stride + 1
+    if OH <= 0 or OW <= 0:
+        raise ValueError("max_pool_nhwc: empty output")
+    out = torch.empty((NB, OH, OW, C), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
+    _abi.check(_abi.lib().tspn_max_pool_nhwc_f32(_p(x), NB, H, W, C, kernel_size, stride, padding, _p(out),
+                                                 1 if out_bf16 else 0, _stream()))
+    return out
+
+
+def pack_conv2d_frag_cin4(weight):
+    """Stem weights [Cout, Cin <= 4, KH, KW] -> [Cout/32, ceil(KH*KW/4), 64, 8] (tspn_pack_conv2d_frag_cin4_f32)."""
+    _dev(weight, "conv2d weight")
+    Cout, Cin, KH, KW = weight.shape
+    if Cin > 4 or Cout % 32:
+        raise ValueError(f"pack_conv2d_frag_cin4: needs Cin <= 4 and Cout % 32 == 0 (Cin={Cin}, Cout={Cout})")
+    frag = torch.empty((Cout // 32, (KH * KW + 3) // 4, 64, 8), dtype=torch.float32, device=weight.device)
+    _abi.check(_abi.lib().tspn_pack_conv2d_frag_cin4_f32(_p(weight), Cout, Cin, KH, KW, _p(frag), _stream()))
+    return frag
+
+
+def conv2d_nhwc_cin4(x, frag, kernel_size, stride=1, padding=0, bias=None, relu=False):
+    """Stem conv on a 4-channel channels-last image x [NB,H,W,4] (RGB + one zero channel) -> [NB,OH,OW,Cout]."""
+    _dev(x, "x"); _dev(frag, "frag")
+    NB, H, W, C4 = x.shape
+    KH, KW = kernel_size
+    if C4 != 4 or frag.dim() != 4 or tuple(frag.shape[1:]) != ((KH * KW + 3) // 4, 64, 8):
+        raise ValueError("conv2d_nhwc_cin4: x must be [NB,H,W,4] and frag = pack_conv2d_frag_cin4(weight)")
+    Cout = frag.shape[0] * 32
+    OH, OW = (H + 2 * padding - KH) // stride + 1, (W + 2 * padding - KW) // stride + 1
+    if bias is not None:
+        _dev(bias, "bias")
+    out = torch.empty((NB, OH, OW, Cout), dtype=torch.float32, device=x.device)
+    _abi.check(_abi.lib().tspn_conv2d_nhwc_cin4_f32(_p(x), NB, H, W, _p(frag), Cout, KH, KW, stride, padding,
+                                                    _p(bias), 1 if relu else 0, _p(out), _stream()))
     return out

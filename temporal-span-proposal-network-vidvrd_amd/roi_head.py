@@ -38,12 +38,13 @@ class ConvFrozenBN(nn.Module):
     folded into the packed weight and a bias once per parameter version:
         w' = w * scale[co],  b' = bias - running_mean * scale,  scale = weight * rsqrt(running_var + eps)."""
 
-    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, pad_cin_to=0):
         super().__init__()
         self.weight = nn.Parameter(torch.empty(out_channels, in_channels, kernel_size, kernel_size))
         nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")
         self.norm = FrozenBatchNorm2d(out_channels)
         self.kernel_size, self.stride, self.padding = kernel_size, stride, padding
+        self.pad_cin_to = pad_cin_to      # the kernels take Cin % 16 == 0: the RGB stem runs on zero-padded channels
         self._cache = _DeviceCache()
 
     def folded(self, dev):
@@ -51,6 +52,8 @@ class ConvFrozenBN(nn.Module):
             w, g, b, m, v = ts
             scale = g * torch.rsqrt(v + BN_EPS)
             wf = (w * scale.reshape(-1, 1, 1, 1)).contiguous()
+            if self.pad_cin_to > wf.shape[1]:
+                wf = torch.nn.functional.pad(wf, (0, 0, 0, 0, 0, self.pad_cin_to - wf.shape[1])).contiguous()
             # fragment-major weights select the registers-direct kernel (Cout % 32 == 0, Cin % 16 == 0)
             pack = ops.pack_conv2d_frag if (wf.shape[0] % 32 == 0 and wf.shape[1] % 16 == 0) else ops.pack_conv2d
             return pack(wf), (b - m * scale).contiguous()
@@ -158,3 +161,75 @@ class Res5RoIHead(nn.Module):
             src = tracklet_boxes.device if isinstance(tracklet_boxes, torch.Tensor) else torch.device("cpu")
             feats = feats.view(n, t, self.out_channels)
             return (ops.cast_bf16(feats) if bf16 else feats).to(src)
+
+
+class BasicStem(nn.Module):
+    """detectron2 BasicStem (modeling/backbone/resnet.py): 7x7 stride-2 conv + FrozenBN + ReLU, then
+    max_pool2d(3, 2, 1).  The RGB input runs on 16 zero-padded channels (fp32 kernel); the pool emits bf16 when
+    the rest of the backbone runs in bf16."""
+
+    def __init__(self, in_channels=3, out_channels=64):
+        super().__init__()
+        self.conv1 = ConvFrozenBN(in_channels, out_channels, 7, 2, 3, pad_cin_to=16)
+        self.in_channels = in_channels
+
+    def _folded_cin4(self, dev):
+        c = self.conv1
+
+        def build(ts):
+            w, g, b, m, v = ts
+            scale = g * torch.rsqrt(v + BN_EPS)
+            return ops.pack_conv2d_frag_cin4((w * scale.reshape(-1, 1, 1, 1)).contiguous()), (b - m * scale).contiguous()
+        n = c.norm
+        return c._cache.get("folded_cin4", (c.weight, n.weight, n.bias, n.running_mean, n.running_var), dev, build)
+
+    def forward(self, x, out_bf16=False):
+        c = self.conv1
+        if self.in_channels <= 4 and c.weight.shape[0] % 32 == 0:
+            # stem form: RGB + zero channel, one K chunk = four taps (13 chunks for 7x7 instead of 49)
+            frag, bias = self._folded_cin4(x.device)
+            x = torch.nn.functional.pad(x, (0, 4 - self.in_channels)).contiguous()    # [NB,H,W,4]
+            y = ops.conv2d_nhwc_cin4(x, frag, (c.kernel_size, c.kernel_size), c.stride, c.padding, bias=bias, relu=True)
+        else:
+            x = torch.nn.functional.pad(x, (0, 16 - self.in_channels)).contiguous()   # [NB,H,W,16]
+            y = c(x, relu=True)
+        return ops.max_pool_nhwc(y, 3, 2, 1, out_bf16=out_bf16)
+
+
+class ResNetC4(nn.Module):
+    """The C4 backbone of detectron2's R-50/101-C4 models (build_resnet_backbone with OUT_FEATURES = res4):
+    stem -> res2 -> res3 -> res4, bottleneck blocks with stride_in_1x1 and FrozenBN, parameter names as in a
+    detectron2 checkpoint after stripping `backbone.` (`stem.conv1.weight`, `res4.22.conv3.norm.running_var`, ...).
+
+    forward(images): channels-last frames [T,H,W,3] float (already mean-subtracted, BGR for the MSRA weights the
+    reference's config uses) -> res4 maps [T,H/16,W/16,1024] channels-last on the HIP device, fp32 or — with
+    `bf16=True` — bf16 (stem in fp32, res2-res4 on the bf16 MFMA kernels): the input of Res5RoIHead."""
+
+    BLOCKS = {50: (3, 4, 6), 101: (3, 4, 23)}
+
+    def __init__(self, depth=101, stem_out=64, res2_out=256, blocks=None, frame_chunk=4):
+        super().__init__()
+        blocks = tuple(blocks) if blocks is not None else self.BLOCKS[depth]
+        self.stem = BasicStem(3, stem_out)
+        cin, cout = stem_out, res2_out
+        for i, nb in enumerate(blocks):
+            stage = []
+            for b in range(nb):
+                stage.append(BottleneckBlock(cin, cout, cout // 4, 2 if (b == 0 and i > 0) else 1))
+                cin = cout
+            setattr(self, f"res{i + 2}", nn.Sequential(*stage))
+            cout *= 2
+        self.out_channels = cin
+        self.frame_chunk = int(frame_chunk)
+
+    def forward(self, images, bf16=False):
+        with torch.no_grad():
+            dev = _compute_device(images, self.stem.conv1.weight)
+            if images.dim() != 4 or images.shape[3] != 3:
+                raise ValueError(f"images must be channels-last [T,H,W,3], got {tuple(images.shape)}")
+            out = []
+            for lo in range(0, images.shape[0], self.frame_chunk):
+                x = self.stem(_f32(images[lo:lo + self.frame_chunk], dev), out_bf16=bf16)
+                x = self.res4(self.res3(self.res2(x)))
+                out.append(x)
+            return torch.cat(out)

@@ -231,3 +231,71 @@ def test_end_to_end_maps_to_relations(tspn, device):
     want = torch.stack([cls[tids[:, 0]].argmax(1), idx[pi, ki], cls[tids[:, 1]].argmax(1)]).t()
     assert torch.equal(trip[1].cpu(), want) and torch.equal(trip[2].cpu(), tids)
     assert torch.equal(trip[0].cpu(), sc[pi, ki])
+
+
+def test_max_pool_nhwc(tspn, device):
+    x = tspn.hashrng.uniform(83, "x", (2, 9, 12, 8), -1, 1)
+    ref = torch.nn.functional.max_pool2d(t(x).permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
+    got = tspn.ops.max_pool_nhwc(t(x).to(device), 3, 2, 1)
+    np.testing.assert_array_equal(got.cpu().numpy(), ref.numpy())
+    got16 = tspn.ops.max_pool_nhwc(t(x).to(device), 3, 2, 1, out_bf16=True)
+    assert got16.dtype == torch.bfloat16 and torch.equal(got16.cpu(), ref.to(torch.bfloat16))
+
+
+def _backbone_and_weights(tspn, device, stem_out, res2_out, blocks):
+    u = lambda name, shape, lo, hi: tspn.hashrng.uniform(84, name, shape, lo, hi)
+    nrm = lambda name, shape, std: tspn.hashrng.normal(84, name, shape, std=std)
+    p = ro.make_backbone_weights(u, nrm, stem_out, res2_out, blocks)
+    net = tspn.ResNetC4(stem_out=stem_out, res2_out=res2_out, blocks=blocks, frame_chunk=2)
+    missing, unexpected = net.load_state_dict(p, strict=True)     # detectron2 key names
+    assert not missing and not unexpected
+    return net.to(device), p
+
+
+def test_resnet_c4_backbone_matches_oracle(tspn, device):
+    """Frames -> stem (7x7/2 on zero-padded RGB, FrozenBN, ReLU, max pool) -> res2 -> res3 -> res4 == the float64
+    restatement of detectron2's ResNet; odd image sizes, three frames in chunks of two."""
+    blocks = (2, 2, 3)
+    net, p = _backbone_and_weights(tspn, device, 16, 64, blocks)
+    img = tspn.hashrng.uniform(85, "img", (3, 70, 100, 3), -1, 1)
+    got = net(t(img).to(device))
+    ref = ro.resnet_c4(t(img), p, blocks)
+    assert tuple(got.shape) == tuple(ref.shape) == (3, 5, 7, 256)
+    scale = max(1.0, float(ref.abs().max()))
+    np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=0, atol=5e-5 * scale)
+
+
+def test_resnet_c4_backbone_bf16_and_pixels_to_features(tspn, device):
+    """bf16=True: stem in fp32, res2-res4 on the bf16 MFMA kernels, within a few bf16 ulps of the restatement
+    with the same rounding points; its maps feed the RoI head (frames -> per-tracklet RoI features)."""
+    blocks = (1, 1, 2)
+    net, p = _backbone_and_weights(tspn, device, 64, 256, blocks)
+    img = tspn.hashrng.uniform(86, "img", (2, 64, 96, 3), -1, 1)
+    got = net(t(img).to(device), bf16=True)
+    ref = ro.resnet_c4_bf16(t(img), p, blocks)
+    assert got.dtype == torch.bfloat16 and tuple(got.shape) == tuple(ref.shape) == (2, 4, 6, 1024)
+    scale = float(ref.abs().max())
+    err = (got.cpu().float() - ref).abs()
+    assert float(err.max()) <= 6 * 2.0 ** -8 * scale, (float(err.max()), scale)
+    assert float((err <= 2.0 ** -7 * ref.abs() + 1e-3 * scale).double().mean()) > 0.97
+    head = tspn.Res5RoIHead(1024, 64, 128).to(device)
+    boxes = torch.tensor([[[4.0, 4, 60, 50], [10, 8, 90, 60]], [[0, 0, 95, 63], [30, 20, 50, 40]]], device=device)
+    feats = head(got, boxes)
+    assert feats.dtype == torch.bfloat16 and tuple(feats.shape) == (2, 2, 128) and bool(torch.isfinite(feats.float()).all())
+
+
+@pytest.mark.parametrize("NB,H,W,Cin,Cout,k,stride,pad", [(2, 30, 41, 3, 64, 7, 2, 3), (1, 9, 9, 3, 32, 3, 1, 1),
+                                                           (3, 16, 20, 4, 96, 5, 2, 2), (1, 7, 7, 1, 32, 7, 1, 3)])
+def test_conv2d_stem_form_vs_torch(tspn, device, NB, H, W, Cin, Cout, k, stride, pad):
+    """Stem form (Cin <= 4: one K chunk = four taps x 4 channels) == F.conv2d in float64, including tap counts
+    that are not a multiple of 4 (49, 9, 25) and fewer than 4 input channels."""
+    x = tspn.hashrng.uniform(87, "x", (NB, H, W, Cin), -1, 1)
+    w = tspn.hashrng.normal(87, "w", (Cout, Cin, k, k), std=0.1)
+    b = tspn.hashrng.normal(87, "b", (Cout,), std=0.1)
+    ref = torch.relu(torch.nn.functional.conv2d(t(x).double().permute(0, 3, 1, 2), t(w).double(), t(b).double(),
+                                                stride=stride, padding=pad)).permute(0, 2, 3, 1)
+    frag = tspn.ops.pack_conv2d_frag_cin4(t(w).to(device))
+    x4 = torch.nn.functional.pad(t(x), (0, 4 - Cin)).contiguous().to(device)
+    y = tspn.ops.conv2d_nhwc_cin4(x4, frag, (k, k), stride, pad, bias=t(b).to(device), relu=True)
+    assert tuple(y.shape) == tuple(ref.shape)
+    np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), rtol=0, atol=2e-5)

@@ -17,6 +17,7 @@ ap.add_argument("--n", type=int, default=32)
 ap.add_argument("--t", type=int, default=150)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--fp32", action="store_true")
+ap.add_argument("--pixels", action="store_true", help="start from 720p frames: run the ResNet-101-C4 backbone too")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev).manual_seed(0)
@@ -28,14 +29,22 @@ head = tspn.Res5RoIHead().to(dev)
 fm = torch.rand((args.t, 45, 80, 1024), device=dev, generator=g)
 if not args.fp32:
     fm = fm.to(torch.bfloat16)
+net, img = None, None
+if args.pixels:
+    net = tspn.ResNetC4(depth=101, frame_chunk=16).to(dev)
+    img = torch.rand((args.t, 720, 1280, 3), device=dev, generator=g) - 0.5
 xy = torch.rand((args.n, args.t, 2), device=dev, generator=g) * torch.tensor([900.0, 400.0], device=dev)
 wh = 40 + torch.rand((args.n, args.t, 2), device=dev, generator=g) * 260
 boxes = torch.cat([xy, xy + wh], dim=2).contiguous()
 cls = torch.rand((args.n, 35), device=dev, generator=g)
 
 
+def maps():
+    return net(img, bf16=not args.fp32) if args.pixels else fm
+
+
 def run():
-    feats = head(fm, boxes)
+    feats = head(maps(), boxes)
     plist = tspn.PairList.from_tracklets(feats, boxes, cls)
     with torch.no_grad():
         pp, dur, logits = model([plist], None)
@@ -44,11 +53,13 @@ def run():
 
 run()
 torch.cuda.synchronize()
-evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-       for _ in range(args.iters)]
-for a, m, b in evs:
+evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
+        torch.cuda.Event(enable_timing=True)) for _ in range(args.iters)]
+for a0, a, m, b in evs:
+    a0.record()
+    cur = maps()
     a.record()
-    feats = head(fm, boxes)
+    feats = head(cur, boxes)
     m.record()
     plist = tspn.PairList.from_tracklets(feats, boxes, cls)
     with torch.no_grad():
@@ -56,10 +67,13 @@ for a, m, b in evs:
     trip = model.decode([plist], logits)[0]
     b.record()
 torch.cuda.synchronize()
-tot = sorted(a.elapsed_time(b) for a, m, b in evs)[len(evs) // 2]
-roi = sorted(a.elapsed_time(m) for a, m, b in evs)[len(evs) // 2]
+tot = sorted(a0.elapsed_time(b) for a0, a, m, b in evs)[len(evs) // 2]
+bb = sorted(a0.elapsed_time(a) for a0, a, m, b in evs)[len(evs) // 2]
+roi = sorted(a.elapsed_time(m) for a0, a, m, b in evs)[len(evs) // 2]
 P = args.n * (args.n - 1)
-print(f"end to end [{'fp32' if args.fp32 else 'bf16'}], one video (N={args.n}, T={args.t}): {tot:.1f} ms "
-      f"(RoI head {roi:.1f} ms, scoring + decode {tot - roi:.1f} ms) -> {1e3 / tot:.1f} videos/s, "
+print(f"end to end [{'fp32' if args.fp32 else 'bf16'}{', from 720p frames' if args.pixels else ', from res4 maps'}], one video "
+      f"(N={args.n}, T={args.t}): {tot:.1f} ms ("
+      + (f"ResNet-101-C4 backbone {bb:.1f} ms, " if args.pixels else "") +
+      f"RoI head {roi:.1f} ms, scoring + decode {tot - bb - roi:.1f} ms) -> {1e3 / tot:.1f} videos/s, "
       f"{P * 1e3 / tot:.0f} tracklet-pairs/s, {args.n * args.t * 1e3 / tot:.0f} RoIs/s; "
       f"feats {tuple(feats.shape)} {feats.dtype}, {trip[0].shape[0]} triplets", flush=True)
