@@ -76,7 +76,8 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_nhwc_bf16_kernel(
     const __bf16* __restrict__ residual, __bf16* __restrict__ out, int H, int W, int Cin, int Cout, int KH,
     int KW, int stride, int pad, int OH, int OW, int64_t npix, int tiles_m, int tiles_n, int relu) {
   constexpr int BM = 128 * MI;
-  __shared__ __attribute__((aligned(16))) char Bs[2 * B_ST];
+  constexpr int EPI_BYTES = 4 * 32 * (32 * MI + 4) * 4;   // epilogue transpose: 4 waves x 32 pixels x padded row
+  __shared__ __attribute__((aligned(16))) char Bs[2 * B_ST > EPI_BYTES ? 2 * B_ST : EPI_BYTES];
 
   const int nwg = gridDim.x;
   const int bid = blockIdx.x;
@@ -223,7 +224,13 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_nhwc_bf16_kernel(
   for (int i = 0; i + 1 < nchunks; ++i) chunk_body(i, std::true_type{});
   chunk_body(nchunks - 1, std::false_type{});
 
-  // ---- epilogue: a lane holds 4 consecutive output channels of one pixel per register quad
+  // ---- epilogue.  A lane holds 4 consecutive channels of ONE pixel per register quad, so direct stores would
+  // write 8-byte fragments to 32 different rows per instruction (measured: the 1x1 convs of the backbone ran at
+  // 2.2-2.8 TB/s of effective traffic).  Each wave instead transposes its 32-pixel x (32 MI)-channel blocks
+  // through the now idle stage memory -- fp32 (acc + bias), rows padded by 16 bytes: conflict-free 16-byte
+  // writes -- and every lane then handles 8 consecutive channels of a pixel: residual read, ReLU, the single
+  // rounding to bf16 and the store are 16 bytes per lane, whole 64 MI-byte row segments per pixel.
+#if defined(TSPN_CONV2D_BF16_DIRECT_EPILOGUE)
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni) {
     const int64_t n = n0 + ni * 32 + li;
@@ -251,6 +258,57 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_nhwc_bf16_kernel(
       *reinterpret_cast<bf16x4*>(orow + m) = o;
     }
   }
+#else
+  {
+    constexpr int CW = 32 * MI;                 // channels of this wave
+    constexpr int PITCH = CW + 4;               // floats per pixel row in LDS (16 bytes of padding)
+    constexpr int CPL = CW / 8;                 // 8-channel groups per pixel row = lanes per pixel
+    constexpr int PPP = 64 / CPL;               // pixels per pass
+    float* tw = reinterpret_cast<float*>(Bs) + wave * (32 * PITCH);
+    const int mw = m0 + MI * wave * 32;         // first channel of this wave
+    float4 bv[MI][4];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m = mw + mi * 32 + 8 * q + 4 * kh;
+        bv[mi][q] = (bias && m < Cout) ? *reinterpret_cast<const float4*>(bias + m) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    const int pl = lane / CPL, cg = lane - pl * CPL;
+    const int mc = mw + 8 * cg;                 // this lane's 8 channels in the read phase
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 v = make_float4(acc[mi][ni][4 * q] + bv[mi][q].x, acc[mi][ni][4 * q + 1] + bv[mi][q].y,
+                                       acc[mi][ni][4 * q + 2] + bv[mi][q].z, acc[mi][ni][4 * q + 3] + bv[mi][q].w);
+          *reinterpret_cast<float4*>(tw + li * PITCH + mi * 32 + 8 * q + 4 * kh) = v;
+        }
+      // (same wave wrote and reads: LDS operations of a wave execute in order)
+#pragma unroll
+      for (int pass = 0; pass < 32 / PPP; ++pass) {
+        const int px = pass * PPP + pl;
+        const float4 v0 = *reinterpret_cast<const float4*>(tw + px * PITCH + 8 * cg);
+        const float4 v1 = *reinterpret_cast<const float4*>(tw + px * PITCH + 8 * cg + 4);
+        const int64_t n = n0 + ni * 32 + px;
+        if (n < npix && mc < Cout) {
+          float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+          if (residual) {
+            const bf16x8 rv = *reinterpret_cast<const bf16x8*>(residual + n * Cout + mc);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += (float)rv[k];
+          }
+          bf16x8 o;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) o[k] = (__bf16)(relu ? fmaxf(v[k], 0.f) : v[k]);
+          *reinterpret_cast<bf16x8*>(out + n * Cout + mc) = o;
+        }
+      }
+    }
+  }
+#endif
 }
 
 }  // namespace
