@@ -38,8 +38,7 @@ constexpr int QT = 32;                 // quads per workgroup
 constexpr int KC = 8;
 constexpr int NSLOT = 4 * QT + 2;      // frame rows of the x tile (one halo row on each side)
 constexpr int XROW = 9;                // 16-byte units per row of an x super-stage: 8 channel groups + 1 pad
-constexpr int XS_UNITS = NSLOT * XROW; // 1170
-constexpr int XP_UNITS = 59;           // units per DMA piece: 20 pieces (5 per wave) cover 1180 >= 1170
+constexpr int XP_UNITS = 59;           // units per DMA piece: 20 pieces (5 per wave) cover 1180 >= NSLOT * XROW = 1170
 constexpr int XS_ST = 20 * XP_UNITS * 4 + 32;   // floats per super-stage buffer
 constexpr int V_ST = 2 * 7 * QT * 4;   // [2 g][6 j + 1 scratch plane][32 quads][4 ch]
 constexpr int NXS = 2, NVS = 4;       // V stage of chunk k: k % 4 (static in the unrolled loop)
