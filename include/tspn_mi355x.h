@@ -413,6 +413,10 @@ int tspn_conv2d_nhwc_bf16(const uint16_t* x, int64_t NB, int64_t H, int64_t W, i
 int tspn_roi_align_nhwc_f32(const float* feat, int64_t NF, int64_t H, int64_t W, int64_t C,
                             const float* rois, int64_t R, int64_t P, float spatial_scale,
                             int sampling_ratio, int aligned, float* out, void* stream);
+/* bf16 map in (values exact in fp32, interpolation in fp32), bf16 out */
+int tspn_roi_align_nhwc_bf16(const uint16_t* feat, int64_t NF, int64_t H, int64_t W, int64_t C,
+                             const float* rois, int64_t R, int64_t P, float spatial_scale,
+                             int sampling_ratio, int aligned, uint16_t* out, void* stream);
 /* same interpolation in fp32, result rounded once to bf16 (input of tspn_conv2d_nhwc_bf16) */
 int tspn_roi_align_nhwc_f32_bf16out(const float* feat, int64_t NF, int64_t H, int64_t W, int64_t C,
                                     const float* rois, int64_t R, int64_t P, float spatial_scale,

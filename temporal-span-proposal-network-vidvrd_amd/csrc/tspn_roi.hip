@@ -455,9 +455,20 @@ __device__ __forceinline__ void bilinear_setup(float y, float x, int H, int W, i
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-template <bool BF16OUT>
+// four channels of a map pixel as fp32 (bf16 values are exact in fp32)
+template <bool BF16IN>
+__device__ __forceinline__ float4 load4(const void* base, int64_t idx) {
+  if constexpr (BF16IN) {
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>(static_cast<const __bf16*>(base) + idx);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+  } else {
+    return *reinterpret_cast<const float4*>(static_cast<const float*>(base) + idx);
+  }
+}
+
+template <bool BF16IN, bool BF16OUT>
 __global__ __launch_bounds__(256) void roi_align_nhwc_kernel(
-    const float* __restrict__ feat, int NF, int H, int W, int C, const float* __restrict__ rois, int64_t R,
+    const void* __restrict__ feat, int NF, int H, int W, int C, const float* __restrict__ rois, int64_t R,
     int P, float scale, int sampling_ratio, int aligned, void* __restrict__ out_v) {
   const int64_t item = blockIdx.x;                 // (roi, ph)
   const int64_t r = item / P;
@@ -473,7 +484,7 @@ __global__ __launch_bounds__(256) void roi_align_nhwc_kernel(
   const int gh = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rh / (float)P);
   const int gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rw / (float)P);
   const float count = (float)max(gh * gw, 1);
-  const float* fb = feat + (int64_t)bi * H * W * C;
+  const int64_t fb = (int64_t)bi * H * W * C;
   const int c4 = C >> 2;
   for (int idx = threadIdx.x; idx < P * c4; idx += blockDim.x) {
     const int pw = idx / c4, cg = idx - pw * c4;
@@ -487,10 +498,10 @@ __global__ __launch_bounds__(256) void roi_align_nhwc_kernel(
         bool empty;
         bilinear_setup(y, xx, H, W, yl, yh, xl, xh, w1, w2, w3, w4, empty);
         if (empty) continue;
-        const float4 v1 = *reinterpret_cast<const float4*>(fb + ((int64_t)yl * W + xl) * C + 4 * cg);
-        const float4 v2 = *reinterpret_cast<const float4*>(fb + ((int64_t)yl * W + xh) * C + 4 * cg);
-        const float4 v3 = *reinterpret_cast<const float4*>(fb + ((int64_t)yh * W + xl) * C + 4 * cg);
-        const float4 v4 = *reinterpret_cast<const float4*>(fb + ((int64_t)yh * W + xh) * C + 4 * cg);
+        const float4 v1 = load4<BF16IN>(feat, fb + ((int64_t)yl * W + xl) * C + 4 * cg);
+        const float4 v2 = load4<BF16IN>(feat, fb + ((int64_t)yl * W + xh) * C + 4 * cg);
+        const float4 v3 = load4<BF16IN>(feat, fb + ((int64_t)yh * W + xl) * C + 4 * cg);
+        const float4 v4 = load4<BF16IN>(feat, fb + ((int64_t)yh * W + xh) * C + 4 * cg);
         acc.x += w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x;
         acc.y += w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y;
         acc.z += w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z;
@@ -669,9 +680,9 @@ extern "C" int tspn_conv2d_nhwc_cin4_f32(const float* x, int64_t NB, int64_t H, 
   return tspn::check_launch("tspn_conv2d_nhwc_cin4_f32");
 }
 
-static int roi_align_launch(const float* feat, int64_t NF, int64_t H, int64_t W, int64_t C, const float* rois,
-                            int64_t R, int64_t P, float spatial_scale, int sampling_ratio, int aligned,
-                            void* out, bool bf16_out, void* stream) {
+static int roi_align_launch(const void* feat, bool bf16_in, int64_t NF, int64_t H, int64_t W, int64_t C,
+                            const float* rois, int64_t R, int64_t P, float spatial_scale, int sampling_ratio,
+                            int aligned, void* out, bool bf16_out, void* stream) {
   TSPN_REQUIRE(NF > 0 && H > 0 && W > 0 && C > 0 && R >= 0 && P > 0 && sampling_ratio >= 0, TSPN_EINVAL,
                "tspn_roi_align_nhwc_f32: bad sizes");
   if (R == 0) return TSPN_OK;
@@ -681,27 +692,35 @@ static int roi_align_launch(const float* feat, int64_t NF, int64_t H, int64_t W,
                TSPN_EUNSUPPORTED, "tspn_roi_align_nhwc_f32: needs C %% 4 == 0 and 16-byte aligned tensors");
   TSPN_REQUIRE(R * P < (1LL << 31) && H < (1 << 20) && W < (1 << 20), TSPN_EUNSUPPORTED,
                "tspn_roi_align_nhwc_f32: problem too large");
-  if (bf16_out)
-    hipLaunchKernelGGL(roi_align_nhwc_kernel<true>, dim3((unsigned)(R * P)), dim3(256), 0, TSPN_STREAM(stream),
-                       feat, (int)NF, (int)H, (int)W, (int)C, rois, R, (int)P, spatial_scale, sampling_ratio,
-                       aligned, out);
-  else
-    hipLaunchKernelGGL(roi_align_nhwc_kernel<false>, dim3((unsigned)(R * P)), dim3(256), 0, TSPN_STREAM(stream),
-                       feat, (int)NF, (int)H, (int)W, (int)C, rois, R, (int)P, spatial_scale, sampling_ratio,
-                       aligned, out);
-  return tspn::check_launch("tspn_roi_align_nhwc_f32");
+  auto launch = [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3((unsigned)(R * P)), dim3(256), 0, TSPN_STREAM(stream), feat, (int)NF, (int)H,
+                       (int)W, (int)C, rois, R, (int)P, spatial_scale, sampling_ratio, aligned, out);
+  };
+  if (bf16_in) launch(roi_align_nhwc_kernel<true, true>);
+  else if (bf16_out) launch(roi_align_nhwc_kernel<false, true>);
+  else launch(roi_align_nhwc_kernel<false, false>);
+  return tspn::check_launch("tspn_roi_align_nhwc");
 }
 
 extern "C" int tspn_roi_align_nhwc_f32(const float* feat, int64_t NF, int64_t H, int64_t W, int64_t C,
                                        const float* rois, int64_t R, int64_t P, float spatial_scale,
                                        int sampling_ratio, int aligned, float* out, void* stream) {
-  return roi_align_launch(feat, NF, H, W, C, rois, R, P, spatial_scale, sampling_ratio, aligned, out, false, stream);
+  return roi_align_launch(feat, false, NF, H, W, C, rois, R, P, spatial_scale, sampling_ratio, aligned, out, false,
+                          stream);
 }
 
 extern "C" int tspn_roi_align_nhwc_f32_bf16out(const float* feat, int64_t NF, int64_t H, int64_t W, int64_t C,
                                                const float* rois, int64_t R, int64_t P, float spatial_scale,
                                                int sampling_ratio, int aligned, uint16_t* out, void* stream) {
-  return roi_align_launch(feat, NF, H, W, C, rois, R, P, spatial_scale, sampling_ratio, aligned, out, true, stream);
+  return roi_align_launch(feat, false, NF, H, W, C, rois, R, P, spatial_scale, sampling_ratio, aligned, out, true,
+                          stream);
+}
+
+extern "C" int tspn_roi_align_nhwc_bf16(const uint16_t* feat, int64_t NF, int64_t H, int64_t W, int64_t C,
+                                        const float* rois, int64_t R, int64_t P, float spatial_scale,
+                                        int sampling_ratio, int aligned, uint16_t* out, void* stream) {
+  return roi_align_launch(feat, true, NF, H, W, C, rois, R, P, spatial_scale, sampling_ratio, aligned, out, true,
+                          stream);
 }
 
 extern "C" int tspn_max_pool_nhwc_f32(const float* x, int64_t NB, int64_t H, int64_t W, int64_t C, int64_t k,

@@ -139,7 +139,8 @@ class Res5RoIHead(nn.Module):
         with torch.no_grad():
             dev = _compute_device(feature_maps, tracklet_boxes, self.res5[0].conv1.weight)
             bf16 = isinstance(feature_maps, torch.Tensor) and feature_maps.dtype == torch.bfloat16
-            fm = _f32(feature_maps, dev)       # RoIAlign interpolates in fp32 (bf16 values are exact in fp32)
+            # RoIAlign interpolates in fp32 and reads a bf16 map as it is (bf16 values are exact in fp32)
+            fm = feature_maps.to(dev).contiguous() if bf16 else _f32(feature_maps, dev)
             if fm.dim() != 4 or fm.shape[3] != self.in_channels:
                 raise ValueError(f"feature_maps must be channels-last [T,Hf,Wf,{self.in_channels}], got {tuple(fm.shape)}")
             boxes = _f32(tracklet_boxes, dev)

@@ -73,6 +73,12 @@ def test_roi_align_nhwc_vs_oracle(tspn, device, sampling_ratio, aligned):
     ref = ro.roi_align_nhwc(feat, rois, P, 1.0 / 16, sampling_ratio, aligned)
     got = tspn.ops.roi_align_nhwc(t(feat).to(device), t(rois).to(device), P, 1.0 / 16, sampling_ratio, aligned)
     np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=0, atol=2e-6)
+    if aligned and sampling_ratio == 0:   # bf16 map read directly == the fp32 kernel on the same (exact) values, rounded
+        f16 = t(feat).to(torch.bfloat16)
+        a = tspn.ops.roi_align_nhwc(f16.to(device), t(rois).to(device), P, 1.0 / 16, sampling_ratio, aligned)
+        b = tspn.ops.roi_align_nhwc(f16.float().to(device), t(rois).to(device), P, 1.0 / 16, sampling_ratio, aligned,
+                                    out_bf16=True)
+        assert a.dtype == torch.bfloat16 and torch.equal(a, b)
     const = tspn.ops.roi_align_nhwc(torch.full((1, H, W, C), 3.0, device=device), t(rois[:2] * [0, 1, 1, 1, 1]).float().to(device),
                                     P, 1.0 / 16, sampling_ratio, aligned)
     np.testing.assert_allclose(const.cpu().numpy(), 3.0, rtol=1e-6)   # a constant map pools to the constant
