@@ -33,7 +33,10 @@
 extern "C" {
 #endif
 
-#define TSPN_ABI_VERSION 1
+/* Bumped whenever a struct layout or a signature changes (2: tspn_fused_desc gained conv_algo /
+ * canonical_pairs in round 1 without a bump; round 2 adds the struct-size exports below, which the
+ * host checks against its own view of the descriptors at load time).                              */
+#define TSPN_ABI_VERSION 2
 
 enum {
   TSPN_OK = 0,
@@ -46,6 +49,10 @@ enum {
 #define TSPN_GEOM_CHANNELS 8
 
 int tspn_version(void);
+/* sizeof(tspn_fused_desc) / sizeof(tspn_fused_bf16_desc) as this library was compiled: a host whose
+ * view of the descriptors differs (stale .so, stale binding) must refuse to call the library.      */
+size_t tspn_fused_desc_size(void);
+size_t tspn_fused_bf16_desc_size(void);
 const char* tspn_last_error(void);
 const char* tspn_error_string(int code);
 
@@ -81,6 +88,27 @@ int tspn_predicate_head_norm_f32(const float* x, int64_t P, int64_t F, int64_t l
 int tspn_feature_preprocess_f32(float* feats, int64_t P, int64_t F, int64_t ld,
                                 int64_t first, int64_t block, int64_t nblocks,
                                 void* stream);
+
+/* ---- a15: proposal pair filter ------------------------------------------
+ * Replaces VRDataset._get_proposal_idx + _get_num_tracklet_proposals
+ * (lib/dataset/vrdataset.py:140-148) for S segments stored back to back:
+ *   segment s owns pair rows [pair_off[s], pair_off[s+1]) of `pairs` [sum P_s, 2] (track indices LOCAL
+ *   to the segment, as in the `pairs` dataset of its -relation.h5 file) and tracks
+ *   [track_off[s], track_off[s+1]) of `trackid` (-1 = proposal, >= 0 = ground-truth track).
+ *   out_idx[pair_off[s] + r], r < out_count[s]: local indices of the kept pairs (both tracks are
+ *       proposals), ascending = the order of the reference's list comprehension;
+ *   out_count[s]      number kept, or -1 if a pair of the segment names a track outside it
+ *                     (the reference raises IndexError there);
+ *   out_num_tracks[s] = sum(trackid < 0).
+ * All pointers are device pointers; one workgroup per segment, order-preserving compaction.        */
+int tspn_proposal_pair_filter_i64(const int64_t* pairs, const int64_t* pair_off,
+                                  const int64_t* trackid, const int64_t* track_off, int64_t S,
+                                  int64_t* out_idx, int64_t* out_count, int64_t* out_num_tracks,
+                                  void* stream);
+/* out[r, 0:F] = src[idx_base + idx[r], 0:F] (src row stride ld): feats[proposal_idx] of
+ * vrdataset.py:66-67.                                                                              */
+int tspn_gather_rows_f32(const float* src, int64_t ld, int64_t F, const int64_t* idx,
+                         int64_t idx_base, int64_t R, float* out, void* stream);
 
 /* ---- a5/a6: PPN pair matrix + top-k pair indices ------------------------
  * Replaces PPNHead.forward + the sort in PPN._forward_test

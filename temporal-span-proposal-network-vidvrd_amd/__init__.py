@@ -10,7 +10,7 @@ The directory name is not a valid Python identifier; import it through the
 repo-root shim:  `import tspn_mi355x`  (see tspn_mi355x.py), or
 `importlib.import_module("temporal-span-proposal-network-vidvrd_amd")`.
 """
-from . import _abi, association, config, hashrng, ops, predict, synth  # noqa: F401
+from . import _abi, association, config, dataset, hashrng, ops, predict, synth  # noqa: F401
 from .config import Cfg, default_cfg, load_cfg, merge_from_file  # noqa: F401
 from .model import (BaseModel, DPN, DPNHead, PPN, PPNHead, RelOIPool, RelPN,  # noqa: F401
                     RelationPredictor, TemporalProposals, make_relpn)

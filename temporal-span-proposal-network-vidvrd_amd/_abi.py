@@ -15,6 +15,7 @@ ROOT = os.path.dirname(HERE)
 LIB_PATH = os.environ.get("TSPN_LIB_PATH") or os.path.join(HERE, "libtspn_mi355x.so")
 HEADER_PATH = os.path.join(ROOT, "include", "tspn_mi355x.h")
 
+ABI_VERSION = 2   # TSPN_ABI_VERSION of include/tspn_mi355x.h
 TSPN_OK = 0
 TSPN_EINVAL = -1
 TSPN_EUNSUPPORTED = -2
@@ -63,6 +64,8 @@ class FusedBf16Desc(ctypes.Structure):
 # name -> (restype, argtypes); mirrors the header one-to-one
 PROTOTYPES = {
     "tspn_version": (_int, []),
+    "tspn_fused_desc_size": (_sz, []),
+    "tspn_fused_bf16_desc_size": (_sz, []),
     "tspn_last_error": (ctypes.c_char_p, []),
     "tspn_error_string": (ctypes.c_char_p, [_int]),
     "tspn_predicate_head_workspace_bytes": (_sz, [_i64, _i64, _i64]),
@@ -71,6 +74,8 @@ PROTOTYPES = {
     "tspn_predicate_head_norm_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _int,
                                             _vp, _sz, _vp]),
     "tspn_feature_preprocess_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp]),
+    "tspn_proposal_pair_filter_i64": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "tspn_gather_rows_f32": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp]),
     "tspn_ppn_pair_matrix_topk_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _i64,
                                              _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                              _i64, _vp, _vp, _vp]),
@@ -163,8 +168,14 @@ def lib():
                 raise RuntimeError(f"TSPN HIP library {LIB_PATH} does not export {name}") from exc
             fn.restype = res
             fn.argtypes = args
-        if handle.tspn_version() != 1:
-            raise RuntimeError(f"TSPN ABI version mismatch: library reports {handle.tspn_version()}, host expects 1")
+        if handle.tspn_version() != ABI_VERSION:
+            raise RuntimeError(f"TSPN ABI version mismatch: library {LIB_PATH} reports "
+                               f"{handle.tspn_version()}, host expects {ABI_VERSION} (stale build? run "
+                               "__graft_entry__.build())")
+        for fn, struct in (("tspn_fused_desc_size", FusedDesc), ("tspn_fused_bf16_desc_size", FusedBf16Desc)):
+            if getattr(handle, fn)() != ctypes.sizeof(struct):
+                raise RuntimeError(f"TSPN ABI mismatch: {fn}() = {getattr(handle, fn)()} but the host binding "
+                                   f"has {ctypes.sizeof(struct)} bytes (stale {LIB_PATH}?)")
         _lib = handle
     return _lib
 

@@ -19,35 +19,70 @@ LIB_PATH = os.path.join(HERE, LIB_NAME)
 ARCH = "gfx950"
 
 FLAGS = [
-    f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
+    f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC",
     "-ffp-contract=off",          # keep mul/add unfused where the reference's numpy does (tspn_iou.hip)
     "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
     f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}",
 ]
+OBJ_DIR = os.path.join(HERE, "build", "obj")   # git-ignored and gpurun-ignored: only the .so travels
 
 
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def _headers():
+    return glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h")) + \
+        [os.path.abspath(__file__)]
+
+
 def needs_build():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
-    deps.append(os.path.abspath(__file__))
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.getmtime(d) > t for d in sources() + _headers())
 
 
-def build(force=False, verbose=True):
-    """Compile every HIP source into one shared library; returns its path."""
+def _obj_of(src):
+    return os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
+
+
+def _compile_one(hipcc, src, verbose):
+    cmd = [hipcc] + FLAGS + ["-c", src, "-o", _obj_of(src)]
+    if verbose:
+        print("[tspn build]", " ".join(cmd), flush=True)
+    res = subprocess.run(cmd, cwd=CSRC, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    return src, res.returncode, res.stdout
+
+
+def build(force=False, verbose=True, jobs=None):
+    """Compile every HIP source for gfx950 (one object per source, stale ones only, in parallel) and link
+    them into one shared library; returns its path."""
     if not force and not needs_build():
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build the TSPN HIP library")
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    newest_header = max(os.path.getmtime(h) for h in _headers())
+    stale = [s for s in sources()
+             if force or not os.path.exists(_obj_of(s))
+             or os.path.getmtime(_obj_of(s)) < max(os.path.getmtime(s), newest_header)]
+    from concurrent.futures import ThreadPoolExecutor
+    jobs = jobs or min(len(stale) or 1, os.cpu_count() or 1, 8)
+    with ThreadPoolExecutor(max_workers=jobs) as pool:
+        results = list(pool.map(lambda s: _compile_one(hipcc, s, verbose), stale))
+    for src, rc, log in results:
+        if log.strip() and (verbose or rc):
+            print(log, flush=True)
+        if rc:
+            raise RuntimeError(f"hipcc failed on {src} (exit {rc})")
+    wanted = {_obj_of(s) for s in sources()}
+    for o in glob.glob(os.path.join(OBJ_DIR, "*.o")):   # objects of deleted sources must not be linked
+        if o not in wanted:
+            os.remove(o)
     tmp = LIB_PATH + ".tmp"
-    cmd = [hipcc] + FLAGS + sources() + ["-o", tmp]
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-fno-gpu-rdc"] + sorted(wanted) + ["-o", tmp]
     if verbose:
         print("[tspn build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=CSRC)

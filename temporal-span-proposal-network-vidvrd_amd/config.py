@@ -42,8 +42,8 @@ def _wrap(obj):
 
 _DEFAULTS = {
     "MODEL": {"NAME": "baseline"},
-    "DATASET": {"TRAIN_BATCH_SIZE": 1024, "TEST_BATCH_SIZE": 1, "LOGIT_ONLY": False,
-                "USE_GT_OBJ_TRAJS": False},
+    "DATASET": {"TRAIN_BATCH_SIZE": 1024, "TEST_BATCH_SIZE": 1, "TRAIN_NUM_WORKERS": 0,
+                "TEST_NUM_WORKERS": 4, "LOGIT_ONLY": False, "USE_GT_OBJ_TRAJS": False},
     "PREDICT": {"OBJECT_NUM": 35, "PREDICATE_NUM": 132, "TOPK_PER_PAIR": 20, "TOPK_PER_SEG": 200,
                 "FEATURE_DIM": 11070},
     "RELPN": {

@@ -34,7 +34,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int THREADS = 256;
 
 __device__ __forceinline__ void glds16(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -118,204 +117,24 @@ __global__ __launch_bounds__(256) void temporal_mean_bf16_kernel(const __bf16* _
 //   x       [2 channel groups][BN + 4 column slots][8 ch]   read at 3 shifts (halo columns are ordinary
 //                                                      units of the same DMA; no im2col)
 constexpr int BM = 128, BN = 128;
-constexpr int SLP = 132;
 
 // ------------------------------------------------------------------------------------------------
-// 128 x 128 tile, 4 waves x (2 x 2 blocks of 32 x 32), kept for A/B timing (TSPN_BF16_CONV=2).  A chunk
-// is ONE k-step (16 input channels x 3 taps = 12 MFMAs per wave) and the LDS holds a ring of 4 stages
-// (16.1 KB each, 64.5 KB -> 2 workgroups/CU): the DMA of chunk c+3 is issued while chunk c is computed,
-// `s_waitcnt vmcnt(N)` counts only the pieces of chunk c+1 out, and the barrier is a bare s_barrier
-// (no fence, which would drain the whole DMA queue).
+// Ring constants shared with the shipped 256 x 256 kernel below: a chunk is ONE k-step (16 input
+// channels x 3 taps) and the LDS holds a ring of 4 stages; the DMA of chunk c+3 is issued while
+// chunk c is computed, `s_waitcnt vmcnt(N)` counts only the pieces of chunk c+1 out, and the barrier
+// is a bare s_barrier (no fence, which would drain the whole DMA queue).  (A 128 x 128 tile with
+// this ring reached 0.9 PFLOP/s and was removed: see DESIGN.md §4b.)
 constexpr int R_KC = 16, R_KG = 2, R_NST = 4;
-constexpr int R_A_ST = 3 * R_KG * BM * 16;  // 12288
-constexpr int R_X_ST = R_KG * SLP * 16;     // 4224
-constexpr int R_ST = R_A_ST + R_X_ST;       // 16512
-constexpr int R_X_UNITS = R_KG * SLP;       // 264 -> 5 pieces
-constexpr size_t R_SMEM = (size_t)R_NST * R_ST;
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-__global__ __launch_bounds__(THREADS, 2) void conv3_bf16_ring_kernel(
-    const __bf16* __restrict__ x, const __bf16* __restrict__ Wp, const float* __restrict__ bias,
-    float* __restrict__ y, int Cin, int T, int M, int64_t ncols, int tiles_m, int tiles_n, int ldm) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int nwg = gridDim.x;
-  const int bid = blockIdx.x;
-  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  constexpr int GM = 2;
-  const int group_sz = GM * tiles_n;
-  const int group = wg / group_sz;
-  const int first_m = group * GM;
-  const int gm = min(GM, tiles_m - first_m);
-  const int in_group = wg - group * group_sz;
-  const int tile_m = first_m + in_group % gm;
-  const int tile_n = in_group / gm;
-  const int m0 = tile_m * BM;
-  const int64_t n0 = (int64_t)tile_n * BN;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int li = lane & 31, kh = lane >> 5;
-
-  // weight pieces: pa = (tap*2 + group)*2 + half; wave w stages pa = 3w .. 3w+2
-  const __bf16* asrc[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int pa = wave * 3 + i;
-    const int tap = pa >> 2, kg = (pa >> 1) & 1, half = pa & 1;
-    int m = m0 + 64 * half + lane;
-    m = m < M ? m : 0;
-    asrc[i] = Wp + (((int64_t)tap * (Cin >> 3) + kg) * M + m) * 8;
-  }
-  const int64_t a_step = (int64_t)R_KG * M * 8;
-  // x pieces: wave w stages units [64w, 64w+64); wave 0 also the 8 units of piece 4
-  const __bf16* bsrc[2];
-  bool bval[2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int u = 64 * (wave + 4 * q) + lane;
-    const int g = u / SLP, slot = u - g * SLP;
-    bval[q] = u < R_X_UNITS && slot < BN + 2 && (q == 0 || wave == 0);
-    int64_t n = n0 + slot - 1;
-    n = n < 0 ? 0 : (n < ncols ? n : ncols - 1);
-    bsrc[q] = x + n * Cin + 8 * (g < R_KG ? g : 0);
-  }
-  auto stage_chunk = [&](int st) {
-#if defined(TSPN_BF16_ABL_NODMA)
-    return;
-#endif
-    char* sa = smem + st * R_ST;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      glds16(asrc[i], sa + (wave * 3 + i) * 1024);
-      asrc[i] += a_step;
-    }
-    if (bval[0]) glds16(bsrc[0], sa + R_A_ST + 64 * wave * 16);
-    bsrc[0] += R_KC;
-    if (wave == 0) {
-      if (bval[1]) glds16(bsrc[1], sa + R_A_ST + 64 * 4 * 16);
-      bsrc[1] += R_KC;
-    }
-  };
-  // pieces in flight per chunk: 4 (waves 1-3) or 5 (wave 0)
-  auto wait_keep = [&](auto chunks_tag) {
-    constexpr int CH = decltype(chunks_tag)::value;
-    if (wave == 0) wait_vmcnt<5 * CH>(); else wait_vmcnt<4 * CH>();
-  };
-  using K0 = std::integral_constant<int, 0>;
-  using K1 = std::integral_constant<int, 1>;
-  using K2 = std::integral_constant<int, 2>;
-
-  bool mask_l[2], mask_r[2];
-#pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int64_t n = n0 + wn * 64 + ni * 32 + li;
-    const int t = (int)(n % T);
-    mask_l[ni] = t != 0;
-    mask_r[ni] = t != T - 1;
-  }
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
-
-  const int nchunks = Cin / R_KC;
-  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-  auto compute = [&](int st) {
-    const char* Ab = smem + st * R_ST + (kh * BM + wm * 64 + li) * 16;
-    const char* Xb = smem + st * R_ST + R_A_ST + (kh * SLP + wn * 64 + li) * 16;
-    bf16x8 a[3][2], b[2][3];
-#if defined(TSPN_BF16_ABL_NOLDS)
-#pragma unroll
-    for (int tap = 0; tap < 3; ++tap)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        a[tap][i] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)st, (unsigned)tap, (unsigned)i, (unsigned)lane});
-        b[i][tap] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)lane, (unsigned)i, (unsigned)tap, (unsigned)st});
-      }
-    (void)Ab; (void)Xb;
-#else
-#pragma unroll
-    for (int tap = 0; tap < 3; ++tap)
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-        a[tap][mi] = *reinterpret_cast<const bf16x8*>(Ab + (tap * R_KG * BM + mi * 32) * 16);
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int tap = 0; tap < 3; ++tap)
-        b[ni][tap] = *reinterpret_cast<const bf16x8*>(Xb + (ni * 32 + tap) * 16);
-#endif
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      b[ni][0] = mask_l[ni] ? b[ni][0] : zero8;
-      b[ni][2] = mask_r[ni] ? b[ni][2] : zero8;
-    }
-#pragma unroll
-    for (int tap = 0; tap < 3; ++tap) {
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tap][0], b[0][tap], acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tap][0], b[1][tap], acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tap][1], b[0][tap], acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tap][1], b[1][tap], acc[1][1], 0, 0, 0);
-    }
-  };
-
-  // prologue: chunks 0..2 in flight, chunk 0 landed
-  stage_chunk(0);
-  if (nchunks > 1) stage_chunk(1);
-  if (nchunks > 2) stage_chunk(2);
-  if (nchunks > 2) wait_keep(K2{}); else if (nchunks > 1) wait_keep(K1{}); else wait_keep(K0{});
-  __builtin_amdgcn_s_barrier();
-
-  int c = 0;
-  for (; c + 3 < nchunks; ++c) {        // steady state: chunk c+3 exists
-    stage_chunk((c + 3) & 3);
-    compute(c & 3);
-    wait_keep(K2{});                    // chunks c+2, c+3 may still fly; c+1 has landed
-    __builtin_amdgcn_s_barrier();
-  }
-  for (; c < nchunks; ++c) {            // tail: nothing left to issue
-    compute(c & 3);
-    wait_keep(K0{});
-    __builtin_amdgcn_s_barrier();
-  }
-
-#pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int64_t n = n0 + wn * 64 + ni * 32 + li;
-    if (n >= ncols) continue;
-    float* yrow = y + n * (int64_t)ldm;
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-      for (int eq = 0; eq < 4; ++eq) {
-        const int m = m0 + wm * 64 + mi * 32 + 8 * eq + 4 * kh;
-        if (m < M) {
-          f32x4 v = {acc[mi][ni][4 * eq], acc[mi][ni][4 * eq + 1], acc[mi][ni][4 * eq + 2],
-                     acc[mi][ni][4 * eq + 3]};
-          if (bias != nullptr) v += *reinterpret_cast<const f32x4*>(bias + m);
-          *reinterpret_cast<f32x4*>(yrow + m) = v;
-        }
-      }
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
-// conv3 bf16, third structure (shipped): 256 x 256 tile, 8 waves (2 x 4, wave tile 128 m x 64 n =
+// conv3 bf16 (shipped structure): 256 x 256 tile, 8 waves (2 x 4, wave tile 128 m x 64 n =
 // 4 x 2 blocks), ring of 4 stages of one k-step each (32.1 KB per stage, 128.5 KB, 1 workgroup/CU with
-// 2 waves per SIMD).  Ablation of the 128 x 128 kernels above at the config-3 shape: MFMA + epilogue
+// 2 waves per SIMD).  Ablation of the earlier 128 x 128 kernels at the config-3 shape: MFMA + epilogue
 // 3.1 ms, + LDS fragment reads 4.1, + LDS-DMA 6.5 -- the operand stream from L2 (61 GB per launch,
 // 9.4 TB/s) and one ds_read_b128 per MFMA are the limiters, both set by the tile: 256 x 256 halves the
 // bytes per MFMA from L2 and needs 0.75 fragment reads per MFMA.
@@ -738,12 +557,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void heads_pairgrid_bf16_
   }
 }
 
-int set_smem(const void* fn, size_t bytes, const char* what) {
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  if (e != hipSuccess) return tspn::fail(TSPN_ELAUNCH, "%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
-  return TSPN_OK;
-}
-
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -815,14 +628,10 @@ extern "C" int tspn_conv3_tc_bf16(const uint16_t* x, int64_t B, int64_t T, int64
   const int64_t ncols = B * T;
   const int64_t tiles_m = tspn::ceil_div(M, BM), tiles_n = tspn::ceil_div(ncols, BN);
   TSPN_REQUIRE(tiles_m * tiles_n < (1LL << 31), TSPN_EUNSUPPORTED, "tspn_conv3_tc_bf16: grid too large");
-  const char* variant = getenv("TSPN_BF16_CONV");
-  if (variant == nullptr || atoi(variant) == 3) {
-    static thread_local bool attr3 = false;
-    if (!attr3) {
-      int rc = set_smem(reinterpret_cast<const void*>(conv3_bf16_big_kernel), G_SMEM, "tspn_conv3_tc_bf16");
-      if (rc) return rc;
-      attr3 = true;
-    }
+  {
+    static tspn::LdsLimit lds;
+    if (int rc = lds.ensure(reinterpret_cast<const void*>(conv3_bf16_big_kernel), G_SMEM, "tspn_conv3_tc_bf16"))
+      return rc;
     const int64_t tm = tspn::ceil_div(M, G_BM), tn = tspn::ceil_div(ncols, G_BN);
     hipLaunchKernelGGL(conv3_bf16_big_kernel, dim3((unsigned)(tm * tn)), dim3(G_THREADS), G_SMEM,
                        TSPN_STREAM(stream), reinterpret_cast<const __bf16*>(x),
@@ -830,17 +639,6 @@ extern "C" int tspn_conv3_tc_bf16(const uint16_t* x, int64_t B, int64_t T, int64
                        (int)tm, (int)tn, (int)ldm);
     return tspn::check_launch("tspn_conv3_tc_bf16");
   }
-  static thread_local bool attr2 = false;
-  if (!attr2) {
-    int rc = set_smem(reinterpret_cast<const void*>(conv3_bf16_ring_kernel), R_SMEM, "tspn_conv3_tc_bf16");
-    if (rc) return rc;
-    attr2 = true;
-  }
-  hipLaunchKernelGGL(conv3_bf16_ring_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(THREADS), R_SMEM,
-                     TSPN_STREAM(stream), reinterpret_cast<const __bf16*>(x),
-                     reinterpret_cast<const __bf16*>(packed), bias, y, (int)Cin, (int)T, (int)M, ncols,
-                     (int)tiles_m, (int)tiles_n, (int)ldm);
-  return tspn::check_launch("tspn_conv3_tc_bf16");
 }
 
 extern "C" int tspn_heads_pairgrid_bf16(const float* y, int64_t ldm, int64_t B, int64_t N, int64_t C,
@@ -853,23 +651,19 @@ extern "C" int tspn_heads_pairgrid_bf16(const float* y, int64_t ldm, int64_t B, 
   TSPN_REQUIRE(y && head_packed && head_b && out, TSPN_EINVAL, "tspn_heads_pairgrid_bf16: null pointer");
   TSPN_REQUIRE(C % HP_KC == 0 && ldm % 4 == 0 && aligned16(y) && aligned16(head_packed), TSPN_EUNSUPPORTED,
                "tspn_heads_pairgrid_bf16: needs C %% 32 == 0, ldm %% 4 == 0, 16-byte aligned y / weights");
-  const bool big = N > 12 && getenv("TSPN_BF16_HEADS_SMALL") == nullptr;
+  const bool big = N > 12;
   const int64_t sblk = big ? 16 : 8;
   const int64_t nsb = tspn::ceil_div(N, sblk), nfb = tspn::ceil_div(T, HP_FB);
   const int64_t grid = B * nsb * nsb * nfb;
   TSPN_REQUIRE(grid < (1LL << 31) && N < (1 << 20) && T < (1 << 24) && C < (1 << 24), TSPN_EUNSUPPORTED,
                "tspn_heads_pairgrid_bf16: problem too large");
   const size_t smem = 2 * ((size_t)(2 * sblk) * HP_ROW + 1024);
-  static thread_local bool attr = false;
-  if (!attr) {
-    int rc = set_smem(reinterpret_cast<const void*>(heads_pairgrid_bf16_kernel<4, 8>), 2 * (16 * HP_ROW + 1024),
-                      "tspn_heads_pairgrid_bf16");
-    if (rc) return rc;
-    rc = set_smem(reinterpret_cast<const void*>(heads_pairgrid_bf16_kernel<8, 16>), 2 * (32 * HP_ROW + 1024),
-                  "tspn_heads_pairgrid_bf16");
-    if (rc) return rc;
-    attr = true;
-  }
+  static tspn::LdsLimit lds[2];
+  if (int rc = big ? lds[1].ensure(reinterpret_cast<const void*>(heads_pairgrid_bf16_kernel<8, 16>), smem,
+                                   "tspn_heads_pairgrid_bf16")
+                   : lds[0].ensure(reinterpret_cast<const void*>(heads_pairgrid_bf16_kernel<4, 8>), smem,
+                                   "tspn_heads_pairgrid_bf16"))
+    return rc;
   if (big)
     hipLaunchKernelGGL((heads_pairgrid_bf16_kernel<8, 16>), dim3((unsigned)grid), dim3(512), smem,
                        TSPN_STREAM(stream), y, ldm, (int)B, (int)N, (int)C, (int)T,

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -29,6 +30,35 @@ inline int check_launch(const char* what) {
 }
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel.  One static
+// LdsLimit per launch site remembers, per device ordinal, the largest limit already set there, so the
+// attribute call is paid once per (kernel, device) — not once per thread, which left every device but
+// the first one a thread used without the raised limit.
+struct LdsLimit {
+  static constexpr int kMaxDevices = 64;
+  std::atomic<size_t> set[kMaxDevices] = {};
+  int ensure(const void* fn, size_t bytes, const char* what) {
+    int dev = -1;
+    (void)hipGetDevice(&dev);
+    const bool tracked = dev >= 0 && dev < kMaxDevices;
+    if (tracked && set[dev].load(std::memory_order_relaxed) >= bytes) return TSPN_OK;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess)
+      return fail(TSPN_ELAUNCH, "%s: hipFuncSetAttribute(%zu bytes of LDS): %s", what, bytes,
+                  hipGetErrorString(e));
+    if (tracked) set[dev].store(bytes, std::memory_order_relaxed);
+    return TSPN_OK;
+  }
+};
+
+// Weight panels (128 output rows) per tile group of the Winograd conv kernels' XCD-aware tile map:
+// a group sweeps all frame tiles, so x is re-read from beyond L2 once per group.  Measured minimum of
+// the fabric traffic (profiles/r1/conv3_ablation.md); a build-time probe knob, not a run-time switch.
+#ifndef TSPN_WINO_GM
+#define TSPN_WINO_GM 2
+#endif
+constexpr int kWinoPanelGroup = TSPN_WINO_GM;
 
 // Internal (not exported) forms with explicit row strides, shared between translation units.
 // y[b][m][ldy]: the fused driver pads rows of the tracklet projections to a multiple of 4 frames so

@@ -853,10 +853,6 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_mfma_cl_kernel(
 // Requires T even (frame pairs never straddle sequences), Cin % 8 == 0, M % 4 == 0.
 constexpr int WN_KC = 8;
 constexpr int WN_SLP = 132;
-constexpr int WN_A_ST = 4 * WN_KC * BM;        // floats: [4 j][8 ch][128 m]
-constexpr int WN_B_ST = 2 * WN_SLP * 4;        // floats: [2 groups][132 slots][4 ch]
-constexpr int WN_UNITS = 2 * WN_SLP;
-constexpr size_t WN_SMEM_BYTES = sizeof(float) * 2 * (WN_A_ST + WN_B_ST);
 
 __global__ void pack_conv3_wino_kernel(const float* __restrict__ W, int64_t M, int64_t Cin,
                                        int64_t split, float* __restrict__ packed) {
@@ -878,207 +874,11 @@ __global__ void pack_conv3_wino_kernel(const float* __restrict__ W, int64_t M, i
   }
 }
 
-__global__ __launch_bounds__(THREADS, 2) void conv3_wino_cl_kernel(
-    const float* __restrict__ x, const float* __restrict__ Wp, const float* __restrict__ bias,
-    float* __restrict__ y, int Cin, int T, int M, int64_t ncols, int tiles_m, int tiles_n,
-    int relu, int ldy) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* As = reinterpret_cast<float*>(smem_raw);  // [2][4][8][BM]
-  float* Bs = As + 2 * WN_A_ST;                     // [2][2][132][4]
-
-  const int nwg = gridDim.x;
-  const int bid = blockIdx.x;
-  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  constexpr int GM = 8;
-  const int group_sz = GM * tiles_n;
-  const int group = wg / group_sz;
-  const int first_m = group * GM;
-  const int gm = min(GM, tiles_m - first_m);
-  const int in_group = wg - group * group_sz;
-  const int tile_m = first_m + in_group % gm;
-  const int tile_n = in_group / gm;
-  const int m0 = tile_m * BM;
-  const int64_t n0 = (int64_t)tile_n * BN;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 31, kh = lane >> 5;
-
-  // ---- DMA sources.  A: wave w stages U_w (8 channel rows x 128 m = 4 pieces of 2 rows).
-  const float* asrc[4];
-  {
-    const int am = (lane & 31) * 4;
-    const int amc = m0 + am < M ? m0 + am : 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int ch = 2 * i + (lane >> 5);
-      asrc[i] = Wp + ((int64_t)wave * Cin + ch) * M + amc;
-    }
-  }
-  const float* bsrc[2];
-  bool bval[2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int u = 64 * (wave + 4 * q) + lane;
-    const int g = u / WN_SLP, slot = u - g * WN_SLP;
-    bval[q] = u < WN_UNITS && slot < BN + 2;
-    int64_t n = n0 + slot - 1;
-    n = n < 0 ? 0 : (n < ncols ? n : ncols - 1);
-    bsrc[q] = x + n * Cin + 4 * (g < 2 ? g : 0);
-  }
-  const int64_t a_step = (int64_t)WN_KC * M;
-
-  auto stage_one = [&](int buf, auto d_tag) {
-    constexpr int d = decltype(d_tag)::value;
-#if defined(TSPN_ABLATE_NODMA)
-    return;
-#endif
-    if constexpr (d < 4) {
-      glds16(asrc[d], As + buf * WN_A_ST + (wave * WN_KC + 2 * d) * BM);
-#if !defined(TSPN_ABLATE_HOTDMA)
-      asrc[d] += a_step;
-#endif
-    } else {
-      constexpr int q = d - 4;
-      if (bval[q]) glds16(bsrc[q], Bs + buf * WN_B_ST + 64 * (wave + 4 * q) * 4);
-#if !defined(TSPN_ABLATE_HOTDMA)
-      bsrc[q] += WN_KC;
-#endif
-    }
-  };
-
-  // frame pair q of the tile <-> frames (2q, 2q+1): d0 = x[2q-1] is outside the sequence when the
-  // first frame is t = 0, d3 = x[2q+2] when the second frame is t = T-1.
-  bool mask0[2], mask3[2];
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    const int64_t n = n0 + 2 * (qb * 32 + li);
-    const int t = (int)(n % T);
-    mask0[qb] = t != 0;
-    mask3[qb] = t != T - 2;
-  }
-
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[j][qb][e] = 0.f;
-
-  const int nchunks = Cin / WN_KC;
-  stage_one(0, std::integral_constant<int, 0>{});
-  stage_one(0, std::integral_constant<int, 1>{});
-  stage_one(0, std::integral_constant<int, 2>{});
-  stage_one(0, std::integral_constant<int, 3>{});
-  stage_one(0, std::integral_constant<int, 4>{});
-  stage_one(0, std::integral_constant<int, 5>{});
-  __syncthreads();
-
-  auto chunk_body = [&](int buf, auto more_tag) {
-    constexpr bool MORE = decltype(more_tag)::value;
-    const float* Ab = As + buf * WN_A_ST + (4 * kh) * BM + wave * 32 + li;
-    const float* Bb = Bs + buf * WN_B_ST + (kh * WN_SLP + 2 * li) * 4;
-    float4 d[2][4];
-    float a[4][4];
-#if defined(TSPN_ABLATE_NOLDS)
-    for (int qb = 0; qb < 2; ++qb) for (int pos = 0; pos < 4; ++pos) d[qb][pos] = make_float4(1.f + pos, 2.f, 3.f * kh, 4.f);
-    for (int j = 0; j < 4; ++j) for (int e = 0; e < 4; ++e) a[j][e] = 0.25f * (j + e);
-    asm volatile("" : "+v"(d[0][0].x), "+v"(a[0][0]));
-#else
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-      for (int pos = 0; pos < 4; ++pos)
-        d[qb][pos] = *reinterpret_cast<const float4*>(Bb + (qb * 64 + pos) * 4);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) a[j][e] = Ab[(j * WN_KC + e) * BM];
-#endif
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb) {
-        const float* d0p = reinterpret_cast<const float*>(&d[qb][0]);
-        const float* d1p = reinterpret_cast<const float*>(&d[qb][1]);
-        const float* d2p = reinterpret_cast<const float*>(&d[qb][2]);
-        const float* d3p = reinterpret_cast<const float*>(&d[qb][3]);
-        const float d0 = mask0[qb] ? d0p[e] : 0.f;
-        const float d1 = d1p[e], d2 = d2p[e];
-        const float d3 = mask3[qb] ? d3p[e] : 0.f;
-        const float v0 = d0 - d2, v1 = d1 + d2, v2 = d2 - d1, v3 = d1 - d3;
-        acc[0][qb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][e], v0, acc[0][qb], 0, 0, 0);
-        acc[1][qb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][e], v1, acc[1][qb], 0, 0, 0);
-        acc[2][qb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2][e], v2, acc[2][qb], 0, 0, 0);
-        acc[3][qb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3][e], v3, acc[3][qb], 0, 0, 0);
-        if (MORE) {
-          if (e == 0 && qb == 0) stage_one(buf ^ 1, std::integral_constant<int, 0>{});
-          if (e == 0 && qb == 1) stage_one(buf ^ 1, std::integral_constant<int, 1>{});
-          if (e == 1 && qb == 0) stage_one(buf ^ 1, std::integral_constant<int, 2>{});
-          if (e == 1 && qb == 1) stage_one(buf ^ 1, std::integral_constant<int, 3>{});
-          if (e == 2 && qb == 0) stage_one(buf ^ 1, std::integral_constant<int, 4>{});
-          if (e == 2 && qb == 1) stage_one(buf ^ 1, std::integral_constant<int, 5>{});
-        }
-      }
-    }
-#if !defined(TSPN_WINO_NOSCHED)
-    // Issue pattern: the fragments of (e = 0, first pair block) up front, then behind every MFMA
-    // one LDS read, two VALU (Winograd input transform / masks) and, every fourth, a DMA piece.
-    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-#define TSPN_G(NVM)                                     \
-  __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);    \
-  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    \
-  __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    \
-  __builtin_amdgcn_sched_group_barrier(0x020, NVM, 0);
-    TSPN_G(0) TSPN_G(0) TSPN_G(0) TSPN_G(1) TSPN_G(0) TSPN_G(0) TSPN_G(0) TSPN_G(1)
-    TSPN_G(0) TSPN_G(0) TSPN_G(0) TSPN_G(1) TSPN_G(0) TSPN_G(0) TSPN_G(0) TSPN_G(1)
-    TSPN_G(0) TSPN_G(0) TSPN_G(0) TSPN_G(1) TSPN_G(0) TSPN_G(0) TSPN_G(0) TSPN_G(1)
-    TSPN_G(0) TSPN_G(0) TSPN_G(0) TSPN_G(0) TSPN_G(0) TSPN_G(0) TSPN_G(0) TSPN_G(0)
-#undef TSPN_G
-#endif
-    __syncthreads();
-  };
-  for (int c = 0; c + 1 < nchunks; ++c) chunk_body(c & 1, std::true_type{});
-  chunk_body((nchunks - 1) & 1, std::false_type{});
-
-  // ---- output transform + store: lane column = frame pair q -> frames (t, t+1), float2 per row
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    const int64_t n = n0 + 2 * (qb * 32 + li);
-    if (n >= ncols) continue;
-    const int64_t b = n / T;
-    const int64_t t = n - b * T;
-    float* ycol = y + (b * M) * (int64_t)ldy + t;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int m = m0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-      if (m < M) {
-        float v0 = acc[0][qb][e] + acc[1][qb][e] + acc[2][qb][e];
-        float v1 = acc[1][qb][e] - acc[2][qb][e] - acc[3][qb][e];
-        if (bias != nullptr) {
-          const float bb = bias[m];
-          v0 += bb;
-          v1 += bb;
-        }
-        if (relu) {
-          v0 = fmaxf(v0, 0.f);
-          v1 = fmaxf(v1, 0.f);
-        }
-        *reinterpret_cast<float2*>(ycol + (int64_t)m * ldy) = make_float2(v0, v1);
-      }
-    }
-  }
-}
-
-
 // ---------------------------------------------------------------------------------------------
-// Winograd F(2,3), second structure: the input transform V = B^T d is computed ONCE per workgroup
+// Winograd F(2,3) kernel: the input transform V = B^T d is computed ONCE per workgroup
 // (one (group, pair, half) item per thread, written to an LDS V tile) instead of once per wave —
-// the four waves of a workgroup cover different output channels of the SAME columns, so the v1
-// kernel above repeats the transform (48 VALU per wave and chunk = 8 % of its time) four times.
+// the four waves of a workgroup cover different output channels of the SAME columns (a first
+// version repeated the transform, 48 VALU per wave and chunk = 8 % of its time, four times).
 // The transform of chunk c+1 runs under the MFMAs of chunk c: x tiles are DMA'd two chunks ahead
 // (two x stages), V tiles are double-buffered, one barrier per chunk as before.
 constexpr int W2_A_ST = 4 * WN_KC * BM;       // [4 j][8 ch][128 m]
@@ -1322,24 +1122,15 @@ extern "C" int tspn_conv3_f32(const float* x, int64_t B, int64_t Cin, int64_t T,
   const int64_t tiles_n = tspn::ceil_div(ncols, BN);
   TSPN_REQUIRE(tiles_m * tiles_n < (1LL << 31), TSPN_EUNSUPPORTED, "tspn_conv3_f32: grid too large");
   const bool vec = (M % 4 == 0) && ((reinterpret_cast<uintptr_t>(packed) & 15) == 0);
-  const bool dma = vec && (Cin % 8 == 0) && getenv("TSPN_CONV3_NO_DMA") == nullptr;
-  const char* kc_env = getenv("TSPN_CONV3_KC");
-  const int kcd = (Cin % 16 != 0) ? 8 : (kc_env ? atoi(kc_env) : 16);
+  const bool dma = vec && (Cin % 8 == 0);
+  const int kcd = (Cin % 16 != 0) ? 8 : 16;
   const bool dma8 = dma && kcd == 8;
   auto kern = dma ? (dma8 ? conv3_mfma_dma_kernel<8> : conv3_mfma_dma_kernel<16>)
                   : (vec ? conv3_mfma_kernel<true> : conv3_mfma_kernel<false>);
   const int which = dma ? (dma8 ? 3 : 2) : (vec ? 1 : 0);
   const size_t smem = dma8 ? sizeof(float) * 2 * (3 * 8 * BM + 8 * BNP) : SMEM_BYTES;
-  static thread_local bool attr_set[4] = {false, false, false, false};
-  if (!attr_set[which]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)smem);
-    if (e != hipSuccess)
-      return tspn::fail(TSPN_ELAUNCH, "tspn_conv3_f32: hipFuncSetAttribute: %s",
-                        hipGetErrorString(e));
-    attr_set[which] = true;
-  }
+  static tspn::LdsLimit lds[4];
+  if (int rc = lds[which].ensure(reinterpret_cast<const void*>(kern), smem, "tspn_conv3_f32")) return rc;
   hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n)), dim3(THREADS), smem,
                      TSPN_STREAM(stream), x, packed, bias, y, (int)Cin, (int)T, (int)M, ncols,
                      (int)tiles_m, (int)tiles_n, relu, (int)T);
@@ -1375,16 +1166,10 @@ int tspn::conv3_tc_direct(const float* x, int64_t B, int64_t T, int64_t Cin, con
   const int64_t tiles_m = tspn::ceil_div(M, BM);
   const int64_t tiles_n = tspn::ceil_div(ncols, BN);
   TSPN_REQUIRE(tiles_m * tiles_n < (1LL << 31), TSPN_EUNSUPPORTED, "tspn_conv3_tc_f32: grid too large");
-  static thread_local bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_mfma_cl_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)CL_SMEM_BYTES);
-    if (e != hipSuccess)
-      return tspn::fail(TSPN_ELAUNCH, "tspn_conv3_tc_f32: hipFuncSetAttribute: %s",
-                        hipGetErrorString(e));
-    attr_set = true;
-  }
+  static tspn::LdsLimit lds;
+  if (int rc = lds.ensure(reinterpret_cast<const void*>(conv3_mfma_cl_kernel), CL_SMEM_BYTES,
+                          "tspn_conv3_tc_f32"))
+    return rc;
   hipLaunchKernelGGL(conv3_mfma_cl_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(THREADS),
                      CL_SMEM_BYTES, TSPN_STREAM(stream), x, packed, bias, y, (int)Cin, (int)T, (int)M,
                      ncols, (int)tiles_m, (int)tiles_n, relu, (int)ldy);
@@ -1435,19 +1220,12 @@ int tspn::conv3_tc_wino(const float* x, int64_t B, int64_t T, int64_t Cin, const
   const int64_t tiles_n = tspn::ceil_div(ncols, BN);
   TSPN_REQUIRE(tiles_m * tiles_n < (1LL << 31), TSPN_EUNSUPPORTED,
                "tspn_conv3_tc_wino_f32: grid too large");
-  if (getenv("TSPN_WINO_V1") != nullptr) {
-    hipLaunchKernelGGL(conv3_wino_cl_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(THREADS),
-                       WN_SMEM_BYTES, TSPN_STREAM(stream), x, packed4, bias, y, (int)Cin, (int)T, (int)M,
-                       ncols, (int)tiles_m, (int)tiles_n, relu, (int)ldy);
-  } else {
-    static const int gm_tiles = [] {
-      const char* e = getenv("TSPN_WINO_GM");
-      const int v = e ? atoi(e) : 2;
-      return v > 0 ? v : 2;
-    }();
-    hipLaunchKernelGGL(conv3_wino2_cl_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(THREADS),
-                       W2_SMEM_BYTES, TSPN_STREAM(stream), x, packed4, bias, y, (int)Cin, (int)T, (int)M,
-                       ncols, (int)tiles_m, (int)tiles_n, relu, (int)ldy, gm_tiles);
-  }
+  static tspn::LdsLimit lds;
+  if (int rc = lds.ensure(reinterpret_cast<const void*>(conv3_wino2_cl_kernel), W2_SMEM_BYTES,
+                          "tspn_conv3_tc_wino_f32"))
+    return rc;
+  hipLaunchKernelGGL(conv3_wino2_cl_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(THREADS),
+                     W2_SMEM_BYTES, TSPN_STREAM(stream), x, packed4, bias, y, (int)Cin, (int)T, (int)M,
+                     ncols, (int)tiles_m, (int)tiles_n, relu, (int)ldy, tspn::kWinoPanelGroup);
   return tspn::check_launch("tspn_conv3_tc_wino_f32");
 }

@@ -9,6 +9,8 @@ char* err_buf() {
 }  // namespace tspn
 
 extern "C" int tspn_version(void) { return TSPN_ABI_VERSION; }
+extern "C" size_t tspn_fused_desc_size(void) { return sizeof(tspn_fused_desc); }
+extern "C" size_t tspn_fused_bf16_desc_size(void) { return sizeof(tspn_fused_bf16_desc); }
 
 extern "C" const char* tspn_last_error(void) { return tspn::err_buf(); }
 

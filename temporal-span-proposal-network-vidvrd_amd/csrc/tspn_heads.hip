@@ -581,7 +581,7 @@ int tspn::heads_pairgrid(const float* y, int64_t ldt, int64_t B, int64_t N, int6
   // pairs in the output; anything else runs the register-staged kernel
   const bool v3 = (ldt % 4 == 0) && ldt >= 4 && (C % PG_CK == 0) && (T % 2 == 0) &&
                   ((reinterpret_cast<uintptr_t>(y) & 15) == 0) &&
-                  ((reinterpret_cast<uintptr_t>(out) & 7) == 0) && getenv("TSPN_HEADS_V2") == nullptr;
+                  ((reinterpret_cast<uintptr_t>(out) & 7) == 0);
   const bool vec2 = (T % 2 == 0) && (ldt % 2 == 0) && ((reinterpret_cast<uintptr_t>(y) & 7) == 0) &&
                     ((reinterpret_cast<uintptr_t>(out) & 7) == 0);
   TSPN_REQUIRE(v3 || ldt == T, TSPN_EUNSUPPORTED,
@@ -590,14 +590,8 @@ int tspn::heads_pairgrid(const float* y, int64_t ldt, int64_t B, int64_t N, int6
                       : (vec2 ? reinterpret_cast<const void*>(heads_pairgrid_kernel<true>)
                               : reinterpret_cast<const void*>(heads_pairgrid_kernel<false>));
   const int which = v3 ? 2 : (vec2 ? 1 : 0);
-  static thread_local bool attr_set[3] = {false, false, false};
-  if (!attr_set[which]) {
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess)
-      return tspn::fail(TSPN_ELAUNCH, "tspn_heads_pairgrid_f32: hipFuncSetAttribute: %s",
-                        hipGetErrorString(e));
-    attr_set[which] = true;
-  }
+  static tspn::LdsLimit lds[3];
+  if (int rc = lds[which].ensure(fn, smem, "tspn_heads_pairgrid_f32")) return rc;
   hipStream_t st = TSPN_STREAM(stream);
   if (v3) {
     hipLaunchKernelGGL(heads_pairgrid3_kernel, dim3((unsigned)nwg), dim3(256), smem, st, y, ldt, (int)C,

@@ -134,13 +134,10 @@ extern "C" int tspn_ppn_pair_matrix_topk_f32(const float* cls, int64_t B, int64_
                       (sizeof(float) + sizeof(int)) * (size_t)n2p;
   TSPN_REQUIRE(smem <= 160 * 1024, TSPN_EUNSUPPORTED,
                "tspn_ppn_pair_matrix_topk_f32: needs %zu B of LDS (> 160 KiB)", smem);
-  if (smem > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ppn_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess)
-      return tspn::fail(TSPN_ELAUNCH, "tspn_ppn_pair_matrix_topk_f32: hipFuncSetAttribute: %s",
-                        hipGetErrorString(e));
-  }
+  static tspn::LdsLimit lds;
+  if (smem > 48 * 1024)
+    if (int rc = lds.ensure(reinterpret_cast<const void*>(ppn_kernel), smem, "tspn_ppn_pair_matrix_topk_f32"))
+      return rc;
   TSPN_REQUIRE(B < (1LL << 31), TSPN_EUNSUPPORTED, "tspn_ppn_pair_matrix_topk_f32: B too large");
   hipLaunchKernelGGL(ppn_kernel, dim3((unsigned)B), dim3(PPN_THREADS), smem, TSPN_STREAM(stream),
                      cls, (int)N, (int)Cin, (int)H, (int)Cout, ws1, bs1, ws2, bs2, wo1, bo1, wo2,

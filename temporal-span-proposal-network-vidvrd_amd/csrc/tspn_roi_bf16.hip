@@ -348,8 +348,7 @@ extern "C" int tspn_conv2d_nhwc_bf16(const uint16_t* x, int64_t NB, int64_t H, i
   TSPN_REQUIRE(H < (1 << 20) && W < (1 << 20) && Cin < (1 << 24) && Cout < (1 << 24), TSPN_EUNSUPPORTED,
                "tspn_conv2d_nhwc_bf16: dimension too large");
   const int64_t npix = NB * OH * OW;
-  static const bool allow2 = getenv("TSPN_CONV2D_BF16_MI1") == nullptr;   // A/B switch
-  const int mi = (allow2 && Cout % 64 == 0) ? 2 : 1;   // 64 rows per wave where Cout allows
+  const int mi = (Cout % 64 == 0) ? 2 : 1;   // 64 rows per wave where Cout allows
   const int64_t tiles_m = tspn::ceil_div(Cout, 128 * mi), tiles_n = tspn::ceil_div(npix, BN);
   TSPN_REQUIRE(tiles_m * tiles_n < (1LL << 31), TSPN_EUNSUPPORTED, "tspn_conv2d_nhwc_bf16: grid too large");
   auto launch = [&](auto kern) {

@@ -203,15 +203,10 @@ extern "C" int tspn_decode_spans_f32(const float* heads, int64_t P, int64_t A, i
                "tspn_decode_spans_f32: needs %zu B of LDS", smem);
   SpanSizes sz{};
   for (int a = 0; a < A; ++a) sz.v[a] = sizes_host[a];
-  static thread_local size_t attr_bytes = 0;
-  if (smem > 48 * 1024 && smem > attr_bytes) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(decode_spans_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess)
-      return tspn::fail(TSPN_ELAUNCH, "tspn_decode_spans_f32: hipFuncSetAttribute: %s",
-                        hipGetErrorString(e));
-    attr_bytes = smem;
-  }
+  static tspn::LdsLimit lds;
+  if (smem > 48 * 1024)
+    if (int rc = lds.ensure(reinterpret_cast<const void*>(decode_spans_kernel), smem, "tspn_decode_spans_f32"))
+      return rc;
   TSPN_REQUIRE(P < (1LL << 31), TSPN_EUNSUPPORTED, "tspn_decode_spans_f32: P too large");
   // the kernel writes top_k columns; with top_k > m the tail is the "unused" filler
   hipLaunchKernelGGL(decode_spans_kernel, dim3((unsigned)P), dim3(SP_THREADS), smem,

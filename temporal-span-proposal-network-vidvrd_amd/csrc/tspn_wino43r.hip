@@ -474,19 +474,11 @@ int tspn::conv3_tc_wino43r(const float* x, int64_t B, int64_t T, int64_t Cin, co
   const int64_t tiles_m = tspn::ceil_div(M, BM), tiles_n = tspn::ceil_div(nquads, QT);
   TSPN_REQUIRE(tiles_m * tiles_n < (1LL << 31), TSPN_EUNSUPPORTED, "tspn_conv3_tc_wino43r_f32: grid too large");
   const int vec4 = (ldy % 4 == 0) && (ldy >= 4 * nq) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
-  static thread_local bool attr = false;   // 66.7 KB of dynamic LDS: above the 64 KB default limit
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wino43r_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_BYTES);
-    if (e != hipSuccess)
-      return tspn::fail(TSPN_ELAUNCH, "tspn_conv3_tc_wino43r_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr = true;
-  }
-  static const int gm_tiles = [] {
-    const char* e = getenv("TSPN_WINO_GM");
-    const int v = e ? atoi(e) : 2;
-    return v > 0 ? v : 2;
-  }();
+  static tspn::LdsLimit lds;   // 66.7 KB of dynamic LDS: above the 64 KB default limit
+  if (int rc = lds.ensure(reinterpret_cast<const void*>(conv3_wino43r_kernel), SMEM_BYTES,
+                          "tspn_conv3_tc_wino43r_f32"))
+    return rc;
+  const int gm_tiles = tspn::kWinoPanelGroup;
   hipLaunchKernelGGL(conv3_wino43r_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(THREADS), SMEM_BYTES,
                      TSPN_STREAM(stream), x, frag, bias, y, (int)Cin, (int)T, (int)M, (int)nq, nquads, B * T,
                      (int)tiles_m, (int)tiles_n, relu, (int)ldy, gm_tiles, vec4);

@@ -45,6 +45,33 @@ def _compute_device(*tensors):
     return torch.device("cuda", torch.cuda.current_device())
 
 
+def invalidate_caches(module):
+    """Drop every packed / device-resident weight copy held under `module` (see _DeviceCache)."""
+    for m in module.modules():
+        for cache in vars(m).values():
+            if isinstance(cache, _DeviceCache):
+                cache.clear()
+
+
+class _CachedWeightsMixin:
+    """nn.Module mix-in: anything that can replace parameter values wholesale clears the weight caches."""
+
+    def invalidate_caches(self):
+        invalidate_caches(self)
+
+    def train(self, mode=True):
+        invalidate_caches(self)
+        return super().train(mode)
+
+    def _apply(self, fn, *args, **kwargs):
+        invalidate_caches(self)
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        invalidate_caches(self)
+        return super().load_state_dict(*args, **kwargs)
+
+
 def _f32(t, device):
     if isinstance(t, np.ndarray):
         t = torch.from_numpy(t)
@@ -65,7 +92,12 @@ def _segment_pairs(plist, n, device):
 
 
 class _DeviceCache:
-    """Device-resident (and packed) copies of parameters, refreshed when a parameter changes."""
+    """Device-resident (and packed) copies of parameters, refreshed when a parameter changes.
+
+    Contract: a change is seen through the parameter's storage pointer, its autograd version counter and
+    its device — optimiser steps, `load_state_dict`, `.to()` / `.cuda()` and `train()` all refresh the
+    cache (the last three through `invalidate_caches`).  In-place edits through `.data` (`p.data.copy_`,
+    EMA updates, legacy loaders) bump none of these: call `model.invalidate_caches()` after them."""
 
     def __init__(self):
         self._store = {}
@@ -284,7 +316,8 @@ class PPN(nn.Module):
             n = int(plist.get_field("num_tracklets"))
             pos = (tlist.target.detach().sum(dim=1) > 0).cpu()
             gt = torch.zeros(n, n)
-            sel = pairs[: len(pos)][pos]
+            m = min(len(pairs), len(pos))   # zip(track_pair, pred_label) stops at the shorter one (ppn.py:44)
+            sel = pairs[:m][pos[:m]]
             gt[sel[:, 0], sel[:, 1]] = 1
             out.append(gt)
         return out
@@ -484,7 +517,7 @@ def make_relpn(cfg):
     return RelPN(cfg)
 
 
-class BaseModel(nn.Module):
+class BaseModel(_CachedWeightsMixin, nn.Module):
     """RelPN -> RelOIPool -> predicate classifier (reference lib/modeling/model.py:7-65)."""
 
     def __init__(self, cfg):
@@ -689,8 +722,14 @@ class BaseModel(nn.Module):
                 if plist.has_field("tracklet_pairs") and plist.get_field("tracklet_pairs") is not None:
                     p = plist.get_field("tracklet_pairs")
                     p = p.detach().long() if isinstance(p, torch.Tensor) else torch.as_tensor(np.asarray(p)).long()
+                    if tuple(p.shape) != (rel_logits[i].shape[0], 2):
+                        raise ValueError(f"decode: segment {i}: 'tracklet_pairs' must be [P,2] with one row per "
+                                         f"rel_logits row (P={rel_logits[i].shape[0]}), got {tuple(p.shape)}")
                     pairs.append(p.to(dev))
                 else:
+                    if n * (n - 1) != rel_logits[i].shape[0]:
+                        raise ValueError(f"decode: segment {i}: rel_logits has {rel_logits[i].shape[0]} rows but "
+                                         f"{n} tracklets give {n * (n - 1)} pairs and no 'tracklet_pairs' field is set")
                     pairs.append(ops.pair_index(n, dev))
             pairs = torch.stack(pairs).contiguous()
             if quirk:

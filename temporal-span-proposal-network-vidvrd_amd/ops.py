@@ -17,12 +17,57 @@ __all__ = [
     "forward_fused", "temporal_encoder_heads", "fused_workspace_bytes", "decode_topk", "decode_spans",
     "cast_bf16", "pack_conv3_bf16", "pack_heads_bf16", "conv3_tc_bf16", "heads_pairgrid_bf16",
     "temporal_mean_bf16", "forward_fused_bf16", "span_predicate",
+    "proposal_pair_filter", "gather_rows",
     "pack_conv2d", "pack_conv2d_frag", "conv2d_nhwc", "roi_align_nhwc", "pack_conv2d_frag_bf16", "conv2d_nhwc_bf16", "max_pool_nhwc", "pack_conv2d_frag_cin4", "conv2d_nhwc_cin4",
 ]
 
 
 def _stream():
+    """Current stream of the CURRENT device; every public op runs under `_on_tensor_device`, which makes
+    the device of its tensor arguments current for the duration of the call."""
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _first_hip_device(obj, depth=0):
+    if isinstance(obj, torch.Tensor):
+        return obj.device if obj.is_cuda else None
+    if depth < 2:
+        if isinstance(obj, (list, tuple)):
+            for v in obj:
+                d = _first_hip_device(v, depth + 1)
+                if d is not None:
+                    return d
+        elif isinstance(obj, dict):
+            for v in obj.values():
+                d = _first_hip_device(v, depth + 1)
+                if d is not None:
+                    return d
+    return None
+
+
+def _on_tensor_device(fn):
+    """The C ABI launches on the stream it is handed and never calls hipSetDevice; kernels, the
+    per-device LDS limits and the workspace allocations of an op must all belong to the device that
+    holds its operands.  This wrapper makes that device current (a no-op when it already is) and
+    refuses operands spread over several devices."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        dev = None
+        for a in list(args) + list(kwargs.values()):
+            d = _first_hip_device(a)
+            if d is None:
+                continue
+            if dev is None:
+                dev = d
+            elif d != dev:
+                raise RuntimeError(f"{fn.__name__}: operands live on different devices ({dev} and {d})")
+        if dev is None or dev.index == torch.cuda.current_device():
+            return fn(*args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(*args, **kwargs)
+    return wrapper
 
 
 def _dev(t, name, dtype=torch.float32):
@@ -89,6 +134,55 @@ def feature_preprocess_(feats, first=70, block=1000, nblocks=8):
     return feats
 
 
+def proposal_pair_filter(pairs, trackid, pair_off=None, track_off=None):
+    """VRDataset._get_proposal_idx + _get_num_tracklet_proposals (lib/dataset/vrdataset.py:140-148).
+
+    One segment: pairs int64 [P,2] (track indices as stored in the -relation.h5 file), trackid int64 [M]
+    (-1 = proposal, >= 0 = ground truth) -> (proposal_idx int64 [P'], num_tracks int).
+    Several segments stored back to back: pass int64 offsets pair_off [S+1], track_off [S+1] (device
+    tensors) -> (idx int64 [P_total] with segment s's kept local indices at idx[pair_off[s]:pair_off[s]
+    + count[s]], count int64 [S], num_tracks int64 [S]) as device tensors (no host sync).
+    A pair naming a track outside its segment raises IndexError (single-segment form) or yields
+    count -1 (batched form)."""
+    _dev(pairs, "pairs", torch.int64); _dev(trackid, "trackid", torch.int64)
+    if pairs.dim() != 2 or pairs.shape[1] != 2 or trackid.dim() != 1:
+        raise ValueError("proposal_pair_filter: pairs must be [P,2] and trackid [M]")
+    dev = pairs.device
+    single = pair_off is None
+    if single:
+        pair_off = torch.tensor([0, pairs.shape[0]], dtype=torch.int64, device=dev)
+        track_off = torch.tensor([0, trackid.shape[0]], dtype=torch.int64, device=dev)
+    _dev(pair_off, "pair_off", torch.int64); _dev(track_off, "track_off", torch.int64)
+    if pair_off.shape != track_off.shape or pair_off.dim() != 1 or pair_off.numel() < 1:
+        raise ValueError("proposal_pair_filter: pair_off / track_off must be int64 [S+1]")
+    S = pair_off.numel() - 1
+    idx = torch.empty((pairs.shape[0],), dtype=torch.int64, device=dev)
+    count = torch.empty((S,), dtype=torch.int64, device=dev)
+    ntr = torch.empty((S,), dtype=torch.int64, device=dev)
+    _abi.check(_abi.lib().tspn_proposal_pair_filter_i64(_p(pairs), _p(pair_off), _p(trackid), _p(track_off), S,
+                                                        _p(idx), _p(count), _p(ntr), _stream()))
+    if not single:
+        return idx, count, ntr
+    c = int(count[0])
+    if c < 0:
+        raise IndexError("proposal_pair_filter: a pair names a track index outside trackid")
+    return idx[:c], int(ntr[0])
+
+
+def gather_rows(src, idx):
+    """out[r] = src[idx[r]] for a 2-D fp32 matrix (feats[proposal_idx], lib/dataset/vrdataset.py:66-67)."""
+    _dev(src, "src"); _dev(idx, "idx", torch.int64)
+    if src.dim() != 2 or idx.dim() != 1:
+        raise ValueError("gather_rows: src must be [R,F] and idx [R']")
+    if idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= src.shape[0]):
+        raise IndexError("gather_rows: row index out of range")
+    out = torch.empty((idx.numel(), src.shape[1]), dtype=torch.float32, device=src.device)
+    if src.shape[1]:
+        _abi.check(_abi.lib().tspn_gather_rows_f32(_p(src), src.shape[1], src.shape[1], _p(idx), 0, idx.numel(),
+                                                   _p(out), _stream()))
+    return out
+
+
 def ppn_pair_matrix_topk(cls_logits, w, topk):
     """PPNHead + top-k (lib/modeling/relpn/ppn.py:107-112, 84-85).
 
@@ -139,8 +233,10 @@ def pair_index(n, device, base=0):
     dev = torch.device(device)
     if dev.type != "cuda":
         raise RuntimeError("pair_index: needs a HIP device (no CPU fallback)")
-    out = torch.empty((max(n * (n - 1), 0), 2), dtype=torch.int64, device=dev)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
     with torch.cuda.device(dev):
+        out = torch.empty((max(n * (n - 1), 0), 2), dtype=torch.int64, device=dev)
         _abi.check(_abi.lib().tspn_pair_index_i64(n, base, _p(out), _stream()))
     return out
 
@@ -846,3 +942,10 @@ def conv2d_nhwc_cin4(x, frag, kernel_size, stride=1, padding=0, bias=None, relu=
     _abi.check(_abi.lib().tspn_conv2d_nhwc_cin4_f32(_p(x), NB, H, W, _p(frag), Cout, KH, KW, stride, padding,
                                                     _p(bias), 1 if relu else 0, _p(out), _stream()))
     return out
+
+
+# every public operator runs with the device of its operands made current (see _on_tensor_device)
+for _name in __all__:
+    if _name not in ("pair_index", "fused_workspace_bytes"):
+        globals()[_name] = _on_tensor_device(globals()[_name])
+del _name

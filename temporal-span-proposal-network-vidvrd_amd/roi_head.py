@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .model import _DeviceCache, _compute_device, _f32
+from .model import _CachedWeightsMixin, _DeviceCache, _compute_device, _f32
 
 BN_EPS = 1e-5   # detectron2 FrozenBatchNorm2d default
 
@@ -106,7 +106,7 @@ class BottleneckBlock(nn.Module):
         return self.conv3(out, residual=sc, relu=True)
 
 
-class Res5RoIHead(nn.Module):
+class Res5RoIHead(_CachedWeightsMixin, nn.Module):
     """ROIAlign + res5 + spatial mean (detectron2 Res5ROIHeads._shared_roi_transform, then .mean([2,3])).
 
     forward(feature_maps, tracklet_boxes):
@@ -197,7 +197,7 @@ class BasicStem(nn.Module):
         return ops.max_pool_nhwc(y, 3, 2, 1, out_bf16=out_bf16)
 
 
-class ResNetC4(nn.Module):
+class ResNetC4(_CachedWeightsMixin, nn.Module):
     """The C4 backbone of detectron2's R-50/101-C4 models (build_resnet_backbone with OUT_FEATURES = res4):
     stem -> res2 -> res3 -> res4, bottleneck blocks with stride_in_1x1 and FrozenBN, parameter names as in a
     detectron2 checkpoint after stripping `backbone.` (`stem.conv1.weight`, `res4.22.conv3.norm.running_var`, ...).

@@ -88,6 +88,46 @@ def g6_inputs():
     return {"n": n, "rel_logit": rel_logit, "feat70": feat70, "pairs": ref_pairs(n)}
 
 
+def full_pairs(m):
+    """All ordered pairs among m tracks, i-major — the `pairs` dataset of a -relation.h5 file
+    (vrdataset.py:203-212: "all possible pairs among N+M object trajectories")."""
+    return ref_pairs(m)
+
+
+def g10_tables():
+    """(pairs, trackid) cases for VRDataset._get_proposal_idx / _get_num_tracklet_proposals:
+    proposals first then ground truth (the layout of the h5 files), interleaved, all proposals, no
+    proposals, a single proposal, and a shuffled pair table."""
+    out = []
+    out.append((full_pairs(10), np.array([-1] * 8 + [0, 1], dtype=np.int64)))
+    out.append((full_pairs(9), np.array([-1, 3, -1, -1, 0, -1, 2, -1, -1], dtype=np.int64)))
+    out.append((full_pairs(6), -np.ones(6, dtype=np.int64)))
+    out.append((full_pairs(4), np.arange(4, dtype=np.int64)))
+    out.append((full_pairs(3), np.array([-1, 0, 1], dtype=np.int64)))
+    perm = np.argsort(tspn.hashrng.bits(10, "pair_perm", 12 * 11), kind="stable")
+    out.append((full_pairs(12)[perm], np.array([-1, -1, 5, -1, -1, -1, 0, -1, -1, 2, -1, -1], dtype=np.int64)))
+    return out
+
+
+def g10_segments():
+    """Three cfg1-shaped segments as the -relation.h5 files hold them (N proposals followed by G
+    ground-truth tracks, all ordered pairs, RAW 11070-d features), plus the cfg1 weights."""
+    f, k = 11070, 132
+    sd = tspn.synth.make_weights(0, c=1024, k=k, feat_dim=f, bias_std=0.02)
+    segs, indexs = [], []
+    for s, (n, g) in enumerate(((8, 2), (5, 1), (1, 2))):
+        m = n + g
+        pairs = full_pairs(m)
+        raw = tspn.synth.make_baseline_features(20 + s, pairs.shape[0], f)
+        raw[1, 1070:2070] = 0.0
+        trackid = np.array([-1] * n + list(range(g)), dtype=np.int64)
+        cls = tspn.synth.make_video(20 + s, n, 2, 2)["track_cls_logits"]
+        iou = tspn.hashrng.uniform(20 + s, "iou", (m, m))
+        segs.append({"n": n, "pairs": pairs, "raw": raw, "trackid": trackid, "cls": cls, "iou": iou})
+        indexs.append((f"vid{s}", 15 * s, 15 * s + 30))
+    return {"state_dict": sd, "segments": segs, "indexs": indexs}
+
+
 def g9_scenario(seed=11, n_seg=5, n_trk=7, n_pred=40):
     """Synthetic multi-segment video for the association: 30-frame segments with stride 15
     (lib/modeling/__init__.py:35-41), tracklets that mostly continue from segment to segment (so the

@@ -13,15 +13,17 @@ What is imported from the reference (torch + numpy only):
     lib.modeling.relpn.anchor_generator   AnchorGenerator
     lib.modeling.relpn.sampler    BalancedPositiveNegativePairSampler
     lib.modeling.trajectory       cubic_iou
-    lib.dataset.vrdataset         VRDataset._feature_preprocess
+    lib.dataset.vrdataset         VRDataset._feature_preprocess, _get_proposal_idx,
+                                  _get_num_tracklet_proposals
+    lib.modeling.predict          predict   (the whole prediction loop + top-k decode)
     lib.dataset.list_pair / list_target   PairList, TargetList
     lib.modeling                  segment_video
 Third-party modules the reference imports but does not use on these code paths
-(dlib, h5py, IPython) are absent here; empty module objects stand in for the
+(dlib, h5py, IPython, torchvision) are absent here; empty module objects stand in for the
 *import statement only*.  `np.float` (removed in numpy 1.24, used by
-anchor_generator.py:72,80) is aliased to `float`.  The decode golden restates
-lib/modeling/predict.py:66-106 line by line because predict.py cannot run
-without the dataset.
+anchor_generator.py:72,80) is aliased to `float`.  The decode goldens (g6, g10) come from the reference's own
+`lib.modeling.predict.predict()` run as a whole: only its checkpoint directory and its
+data loader (the h5py / dataset side) are replaced, see `run_ref_predict`.
 
 Usage:  python tests/golden/make_golden.py        (writes tests/golden/*.npz)
 """
@@ -73,12 +75,14 @@ class _Rect:
         return self._v[3] - self._v[1] + 1
 
 
-for _name, _attrs in (("dlib", ("drectangle", "correlation_tracker")), ("h5py", ()), ("IPython", ())):
+for _name, _attrs in (("dlib", ("drectangle", "correlation_tracker")), ("h5py", ()), ("IPython", ()),
+                      ("torchvision", ()), ("torchvision.transforms", ("functional",))):
     if _name not in sys.modules:
         _m = types.ModuleType(_name)
         for _a in _attrs:
             setattr(_m, _a, _Rect if _a == "drectangle" else object)
         sys.modules[_name] = _m
+sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
 
 from lib.modeling import segment_video  # noqa: E402
 from lib.modeling.model import BaseModel as RefBaseModel  # noqa: E402
@@ -92,6 +96,7 @@ import lib.modeling.association as ref_association  # noqa: E402
 from lib.dataset.list_pair import PairList as RefPairList  # noqa: E402
 from lib.dataset.list_target import TargetList as RefTargetList  # noqa: E402
 from lib.dataset.vrdataset import VRDataset as RefVRDataset  # noqa: E402
+import lib.modeling.predict as ref_predict  # noqa: E402
 
 torch.manual_seed(0)
 torch.set_num_threads(8)
@@ -217,36 +222,118 @@ def g5_anchors():
     save("g5_anchors.npz", **out)
 
 
+class _Log:
+    def info(self, *a, **k):
+        pass
+
+
+def run_ref_predict(cfg, state_dict, batches, model_factory=None):
+    """Run the reference's own `predict()` (lib/modeling/predict.py:14-123) as a whole.  Replaced,
+    and nothing else: the checkpoint directory (`get_model_path`, a temporary directory holding a real
+    `torch.save`d checkpoint that the reference's `torch.load` + `load_checkpoint` read) and the data
+    loader (`build_data_loader`, which would open the h5py dataset) — `batches` is a list of
+    `(pair_list, target_list, indexs)` as the reference's collate yields them.  `model_factory`
+    replaces `BaseModel` when the golden needs the decode on given logits (g6)."""
+    import shutil
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="tspn_golden_")
+    saved = (ref_predict.get_model_path, ref_predict.build_data_loader, ref_predict.BaseModel)
+    try:
+        torch.save({"model": state_dict, "iter": 0, "loss": 0.0}, os.path.join(tmp, cfg.ETC.MODEL_DUMP_FILE))
+        ref_predict.get_model_path = lambda: tmp
+        ref_predict.build_data_loader = lambda *a, **k: batches
+        if model_factory is not None:
+            ref_predict.BaseModel = model_factory
+        return ref_predict.predict(cfg, None, _Log())
+    finally:
+        ref_predict.get_model_path, ref_predict.build_data_loader, ref_predict.BaseModel = saved
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def _predictions_arrays(preds):
+    return (np.array([np.asarray(s) for s, _, _ in preds], dtype=np.float32),
+            np.array([np.asarray(tr) for _, tr, _ in preds], dtype=np.int64).reshape(-1, 3),
+            np.array([np.asarray(p) for _, _, p in preds], dtype=np.int64).reshape(-1, 2))
+
+
 def g6_decode():
-    """Top-k triplet decode, restated from reference predict.py:66-106 (cannot be imported without
-    the dataset): tie-free inputs, N=12."""
+    """Top-k triplet decode = the reference's own predict() loop (predict.py:39-123) on tie-free
+    logits, N=12.  The model is a stand-in that returns the given logits (the decode is what g6 pins;
+    g10 runs the loop with the reference's BaseModel)."""
     c = cases.g6_inputs()
-    rel_logit, feature, tracklet_pair = t(c["rel_logit"]), t(c["feat70"]), t(c["pairs"])
-    num_tracklet = c["n"]
-    topk_per_pair, topk_per_seg = 20, 200
+    rel_logit = t(c["rel_logit"])
     assert min_gap_desc(rel_logit.numpy()) > 0, "ties in decode input"
-    # ---- begin restatement of predict.py:66-106
-    sub_logit = feature[:, :35]
-    obj_logit = feature[:, 35:70]
-    topk_pred_per_pair = torch.sort(rel_logit, descending=True, dim=-1)
-    topk_score_per_pair = topk_pred_per_pair[0][:, :topk_per_pair]
-    topk_idx_per_pair = topk_pred_per_pair[1][:, :topk_per_pair]
-    r, c_ = topk_score_per_pair.shape
-    topk_pred_per_seg = torch.sort(topk_score_per_pair.flatten(), descending=True, dim=-1)
-    topk_idx_per_seg = topk_pred_per_seg[1][:topk_per_seg]
-    topk_idx = torch.tensor([(idx // c_, idx % c_) for idx in topk_idx_per_seg])
-    top_pair_idx = topk_idx[:, 0]
-    top_pair_tid = tracklet_pair[top_pair_idx]
-    top_sub_logit = sub_logit[(num_tracklet - 1) * top_pair_tid[:, 0]]
-    top_obj_logit = obj_logit[(num_tracklet - 1) * top_pair_tid[:, 1]]
-    top_sub_label = torch.argmax(top_sub_logit, dim=1)
-    top_obj_label = torch.argmax(top_obj_logit, dim=1)
-    top_rel_label = torch.tensor([topk_idx_per_pair[idx[0], idx[1]] for idx in topk_idx])
-    top_triplet_label = torch.stack([top_sub_label, top_rel_label, top_obj_label]).t()
-    top_rel_score = torch.tensor([topk_score_per_pair[idx[0], idx[1]] for idx in topk_idx])
-    # ---- end restatement
-    save("g6_decode.npz", scores=top_rel_score.numpy(), triplets=top_triplet_label.numpy(),
-         pair_tids=top_pair_tid.numpy())
+
+    class GivenLogits(torch.nn.Module):
+        def __init__(self, cfg):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(1))
+
+        def forward(self, pair_list, _):
+            return None, None, [rel_logit]
+
+    feat = torch.zeros(rel_logit.shape[0], 70)
+    feat[:, :70] = t(c["feat70"])
+    plist = RefPairList(feat)
+    plist.add_field("tracklet_pairs", t(c["pairs"]))
+    plist.add_field("track_cls_logits", torch.zeros(c["n"], 35))
+    plist.add_field("num_tracklets", np.int64(c["n"]))
+    plist.add_field("ious", np.zeros((c["n"], c["n"]), dtype=np.float32))
+    plist.add_field("track_ids", -np.ones(c["n"], dtype=np.int64))
+    index = ("g6", 0, 30)
+    res = run_ref_predict(ref_cfg(), {"w": torch.zeros(1)}, [([plist], None, [index])], model_factory=GivenLogits)
+    scores, trip, tids = _predictions_arrays(res[index][0])
+    assert scores.shape == (200,)
+    save("g6_decode.npz", scores=scores, triplets=trip, pair_tids=tids)
+
+
+def g10_dataset_and_predict():
+    """(a) VRDataset._get_proposal_idx / _get_num_tracklet_proposals (lib/dataset/vrdataset.py:140-148)
+    on the pair tables of cases.g10_tables (proposal + ground-truth tracks mixed).
+    (b) the reference's whole prediction path on cfg1-shaped segments: VRDataset's own pair filter and
+    _feature_preprocess -> reference BaseModel (configs/baseline.yaml) -> predict()'s decode, for three
+    segments (N = 8, 5 and 1 proposal tracklets; the last is skipped by predict.py:61-64)."""
+    out = {}
+    for i, (pairs, trackid) in enumerate(cases.g10_tables()):
+        out[f"proposal_idx_{i}"] = np.array(RefVRDataset._get_proposal_idx(None, pairs, trackid), dtype=np.int64)
+        out[f"num_tracks_{i}"] = np.array(int(RefVRDataset._get_num_tracklet_proposals(None, trackid)))
+    cfg = ref_cfg()
+    segs = cases.g10_segments()
+    sd = {k: t(v) for k, v in segs["state_dict"].items()}
+    own = RefBaseModel(cfg).state_dict()
+    sd = {"module." + k: v for k, v in sd.items() if k in own}      # checkpoints are saved from DDP (train.py:114)
+    batches = []
+    for index, seg in zip(segs["indexs"], segs["segments"]):
+        pairs, trackid, raw = seg["pairs"], seg["trackid"], seg["raw"]
+        keep = RefVRDataset._get_proposal_idx(None, pairs, trackid)
+        feats = RefVRDataset._feature_preprocess(None, torch.tensor(raw, dtype=torch.float32)[keep])
+        plist = RefPairList(feats)
+        plist.add_field("tracklet_pairs", pairs[keep])
+        plist.add_field("track_cls_logits", t(seg["cls"]))
+        plist.add_field("num_tracklets", RefVRDataset._get_num_tracklet_proposals(None, trackid))
+        plist.add_field("ious", seg["iou"])
+        plist.add_field("track_ids", trackid)
+        batches.append(([plist], None, [index]))
+    captured = []
+
+    class Recording(RefBaseModel):           # the reference's model; only records what it returns
+        def forward(self, pair_list, target_list=None):
+            res = super().forward(pair_list, target_list)
+            captured.append(res[2][0].clone())
+            return res
+
+    res = run_ref_predict(cfg, sd, batches, model_factory=Recording)
+    assert len(captured) == 3 and captured[2].shape[0] == 0
+    assert set(res.keys()) == set(segs["indexs"][:2]), res.keys()
+    for i, index in enumerate(segs["indexs"][:2]):
+        scores, trip, tids = _predictions_arrays(res[index][0])
+        gaps = scores[:-1] - scores[1:]
+        assert gaps.min() > 0, "ties in the g10 decode"
+        out[f"seg{i}_scores"], out[f"seg{i}_triplets"], out[f"seg{i}_pair_tids"] = scores, trip, tids
+        out[f"seg{i}_min_gap"] = np.array(float(gaps.min()))
+        out[f"seg{i}_rel_logits"] = captured[i].numpy()
+        np.testing.assert_array_equal(res[index][2], segs["segments"][i]["trackid"])
+    save("g10_dataset_predict.npz", **out)
 
 
 def g7_misc():
@@ -339,6 +426,7 @@ def main():
     g7_misc()
     g8_bf16()
     g9_association()
+    g10_dataset_and_predict()
 
 
 if __name__ == "__main__":

@@ -103,7 +103,9 @@ def test_abi_library_exports_every_declared_symbol(tspn):
     for n in names:
         assert hasattr(raw, n), f"library does not export {n}"
     lib = tspn._abi.lib()
-    assert lib.tspn_version() == 1
+    assert lib.tspn_version() == tspn._abi.ABI_VERSION == 2
+    assert lib.tspn_fused_desc_size() == ctypes.sizeof(tspn._abi.FusedDesc)
+    assert lib.tspn_fused_bf16_desc_size() == ctypes.sizeof(tspn._abi.FusedBf16Desc)
     assert lib.tspn_error_string(-3) == b"workspace too small"
 
 
@@ -199,3 +201,34 @@ def test_anchor_generator_matches_reference(tspn):
         assert set(gen.state_dict()) == {"cell_anchors_0"}
     gen = tspn.make_anchor_generator(tspn.load_cfg(None))
     assert gen.grid_anchors(60)[0].shape == (len(range(0, 61, 132)) * 4, 2)
+
+
+def test_weight_caches_are_invalidated(tspn):
+    """packed / device copies must not survive load_state_dict, train(), .to() — and
+    `invalidate_caches()` exists for in-place `.data` edits that bump no version counter."""
+    model = tspn.BaseModel(tspn.load_cfg(None, **{"PREDICT.FEATURE_DIM": 16}))
+    cache = model.classifier._cache
+    marker = object()
+    for action in (lambda: model.load_state_dict(model.state_dict()), lambda: model.train(), lambda: model.eval(),
+                   lambda: model.float(), lambda: model.invalidate_caches()):
+        cache._store["cls"] = (("stale",), marker)
+        action()
+        assert "cls" not in cache._store
+    p = model.classifier.rel_predictor.weight
+    v0 = p._version
+    p.data.mul_(2.0)
+    assert p._version == v0    # the documented blind spot: .data edits need invalidate_caches()
+
+
+def test_gt_matrices_truncate_like_zip(tspn):
+    """ppn.py:44 zips pairs with labels: the shorter one wins."""
+    pl = tspn.PairList(torch.zeros(3, 4))
+    pl.add_field("tracklet_pairs", np.array([[0, 1], [1, 2], [2, 0]]))
+    pl.add_field("num_tracklets", 3)
+    tgt = torch.zeros(5, 6)
+    tgt[1, 2] = 1
+    tgt[4, 0] = 1            # beyond the pair table: ignored
+    gt = tspn.PPN._gt_matrices([pl], [tspn.TargetList(tgt)])[0]
+    assert gt.sum() == 1 and gt[1, 2] == 1
+    gt = tspn.PPN._gt_matrices([pl], [tspn.TargetList(tgt[:2])])[0]   # fewer labels than pairs
+    assert gt.sum() == 1 and gt[1, 2] == 1

@@ -94,6 +94,34 @@ def test_g6_decode():
     np.testing.assert_array_equal(tids.numpy(), g["pair_tids"])
 
 
+def test_g10_proposal_filter_and_predict_pipeline():
+    """g10 = the reference's own VRDataset._get_proposal_idx / _get_num_tracklet_proposals, and its whole
+    predict() run (dataset filter + _feature_preprocess + BaseModel + top-k decode) on three segments."""
+    g = cases.load("g10_dataset_predict.npz")
+    for i, (pairs, trackid) in enumerate(cases.g10_tables()):
+        np.testing.assert_array_equal(oracle.proposal_pair_idx(pairs, trackid), g[f"proposal_idx_{i}"])
+        assert oracle.num_tracklet_proposals(trackid) == int(g[f"num_tracks_{i}"])
+    segs = cases.g10_segments()
+    sd = sd_t(segs["state_dict"])
+    for i, seg in enumerate(segs["segments"][:2]):
+        keep = oracle.proposal_pair_idx(seg["pairs"], seg["trackid"])
+        n = oracle.num_tracklet_proposals(seg["trackid"])
+        assert n == seg["n"] and len(keep) == n * (n - 1)
+        feats = oracle.feature_preprocess(t(seg["raw"])[keep])
+        logits = oracle.predicate_head(feats, sd["classifier.rel_predictor.weight"],
+                                       sd["classifier.rel_predictor.bias"])
+        np.testing.assert_allclose(logits.numpy(), g[f"seg{i}_rel_logits"], rtol=0, atol=1e-6)
+        # the decode itself on the reference's own logits: exact
+        sc, trip, tids = oracle.decode_topk(t(g[f"seg{i}_rel_logits"]), feats[:, :70], t(seg["pairs"][keep]), n)
+        np.testing.assert_array_equal(sc.numpy(), g[f"seg{i}_scores"])
+        np.testing.assert_array_equal(trip.numpy(), g[f"seg{i}_triplets"])
+        np.testing.assert_array_equal(tids.numpy(), g[f"seg{i}_pair_tids"])
+    # third segment: one proposal among ground-truth tracks -> no proposal pair, skipped by predict()
+    seg = segs["segments"][2]
+    assert len(oracle.proposal_pair_idx(seg["pairs"], seg["trackid"])) == 0
+    assert oracle.num_tracklet_proposals(seg["trackid"]) == 1
+
+
 def test_g7_known_answers():
     g = cases.load("g7_misc.npz")
     for a, b in ((0, 30), (0, 45), (0, 150), (0, 29)):
