@@ -51,3 +51,52 @@ def gather_results(local, num_items, group=None, force=False):
     if all(c == mx for c in counts):
         return out
     return torch.cat([out[r * mx: r * mx + c] for r, c in enumerate(counts)])
+
+
+# ---- the payload of the final gather: decoded results, not logits ------------------------------
+# Per video the prediction loop keeps the top-200 (score, triplet, pair) rows (reference
+# lib/modeling/predict.py:106-116) and, with PPN, the top-k pair indices: ~9-11 KB per video instead of
+# 524 KB of logits (SURVEY.md §8e).  The fields are packed into ONE byte row per video so that the
+# exchange stays a single collective; `unpack_decoded` restores the typed views.
+_DECODED_FIELDS = (("scores", torch.float32, 1), ("triplets", torch.int64, 3), ("pair_tids", torch.int64, 2))
+
+
+def pack_decoded(scores, triplets, pair_tids, pair_proposals=None):
+    """[B,M] fp32, [B,M,3] int64, [B,M,2] int64 (+ [B,k] int64) -> uint8 [B, row_bytes]."""
+    b = scores.shape[0]
+
+    def as_bytes(x):   # explicit row width: reshape(b, -1) is ambiguous for an empty shard (b == 0)
+        x = x.contiguous()
+        row = (x.numel() // b if b else int(torch.tensor(x.shape[1:]).prod())) * x.element_size()
+        return x.view(torch.uint8).reshape(b, row)
+
+    parts = [as_bytes(scores), as_bytes(triplets), as_bytes(pair_tids)]
+    if pair_proposals is not None:
+        parts.append(as_bytes(pair_proposals))
+    return torch.cat(parts, dim=1)
+
+
+def unpack_decoded(packed, m, k=0):
+    """Inverse of pack_decoded for M = m rows per video and k pair proposals."""
+    b = packed.shape[0]
+    out, off = {}, 0
+    for name, dtype, width in _DECODED_FIELDS:
+        nbytes = m * width * torch.empty((), dtype=dtype).element_size()
+        out[name] = packed[:, off:off + nbytes].contiguous().view(dtype).reshape((b, m) if width == 1 else (b, m, width))
+        off += nbytes
+    if k:
+        out["pair_proposals"] = packed[:, off:off + 8 * k].contiguous().view(torch.int64).reshape(b, k)
+        off += 8 * k
+    if off != packed.shape[1]:
+        raise ValueError(f"unpack_decoded: row has {packed.shape[1]} bytes, fields need {off}")
+    return out
+
+
+def gather_decoded(scores, triplets, pair_tids, num_items, pair_proposals=None, group=None, force=False):
+    """The one collective of the path: all-gather of the decoded per-video results in global video order.
+    Returns the dict of `unpack_decoded` over all `num_items` videos."""
+    m = scores.shape[1]
+    k = pair_proposals.shape[1] if pair_proposals is not None else 0
+    packed = gather_results(pack_decoded(scores, triplets, pair_tids, pair_proposals), num_items, group=group,
+                            force=force)
+    return unpack_decoded(packed, m, k)

@@ -29,7 +29,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("src")
     ap.add_argument("dst")
-    ap.add_argument("--videos", type=int, default=8)
+    ap.add_argument("--videos", type=int, default=16)
+    ap.add_argument("--workload", default="cfg2")
     args = ap.parse_args()
     rows, per_kernel = [], collections.defaultdict(dict)
     for sub, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
@@ -48,19 +49,30 @@ def main():
             rows.append((ctr, k, n, val, dur))
             per_kernel[k][ctr] = val * 1024.0
     os.makedirs(args.dst, exist_ok=True)
-    with open(os.path.join(args.dst, "pmc_hbm_traffic.csv"), "w") as fh:
+    csv_name = "pmc_hbm_traffic.csv" if args.workload == "cfg2" else f"pmc_hbm_traffic_{args.workload}.csv"
+    with open(os.path.join(args.dst, csv_name), "w") as fh:
         fh.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py "
-                 f"--videos {args.videos}; KiB per dispatch as reported (reads x2 on gfx950, see tools/pmc_summary.py)\n")
+                 f"--workload {args.workload} --videos {args.videos}; KiB per dispatch as reported (reads x2 on gfx950, see tools/pmc_summary.py)\n")
         fh.write("counter,kernel,dispatches,avg_value_KiB,avg_duration_us\n")
         for r in rows:
             fh.write("%s,%s,%d,%.1f,%.1f\n" % r)
-    out = {"videos_per_launch": args.videos, "source": os.path.join(args.dst, "pmc_hbm_traffic.csv"), "kernels": {}}
+    out = {"videos_per_launch": args.videos, "workload": args.workload,
+           "source": os.path.join(args.dst, csv_name), "kernels": {}}
     for k, d in per_kernel.items():
         if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
             out["kernels"][k] = {"fetch_bytes_corrected": 2.0 * d["FETCH_SIZE"], "write_bytes": d["WRITE_SIZE"],
                                  "hbm_bytes": 2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]}
-    with open(os.path.join(os.path.dirname(args.dst.rstrip("/")), "pmc_traffic.json"), "w") as fh:
-        json.dump(out, fh, indent=1, sort_keys=True)
+    # profiles/pmc_traffic.json holds one measurement set per "<workload>:<videos per launch>"
+    path = os.path.join(os.path.dirname(args.dst.rstrip("/")), "pmc_traffic.json")
+    try:
+        allsets = json.load(open(path))
+        if "sets" not in allsets:
+            allsets = {"sets": {}}
+    except (OSError, ValueError):
+        allsets = {"sets": {}}
+    allsets["sets"][f"{args.workload}:{args.videos}"] = out
+    with open(path, "w") as fh:
+        json.dump(allsets, fh, indent=1, sort_keys=True)
     print(json.dumps(out["kernels"], indent=1)[:1500])
 
 
