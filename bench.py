@@ -30,7 +30,7 @@ Printed JSON (rank 0): see the task contract; extras:
                clock_mhz = shader clock sampled from the driver while the timed steps ran (box-to-box
                variance of `frac` is mostly the clock the chip holds under this kernel).
   cpu_baseline the oracle's reference-faithful dense forward on a FIXED sample of pairs (all 31 objects
-               of 2 subjects), median of 5 runs after a warm-up, on the cores this process may use.
+               of 8 subjects = 248 pairs), median of 5 runs after a warm-up, on the cores this process may use.
 """
 import argparse
 import json
@@ -49,6 +49,7 @@ PEAK_CLOCK_MHZ = 2400.0  # the clock the 157.3 TFLOP/s figure is quoted at
 CFG3 = (64, 900, 1024)
 DPN_PRE = "relpn.duration_proposal_network.dpn_head."
 PPN_PRE = "relpn.pair_proposal_network.ppn_head."
+CPU_SUBJECTS = 8   # cpu_baseline sample: all 31 objects of this many subjects
 TOPK_PAIR, TOPK_SEG, TOPK_PPN = 20, 200, 256   # PREDICT.TOPK_PER_PAIR / TOPK_PER_SEG, PPN.NUM_PAIR_PROPOSALS
 
 
@@ -126,8 +127,8 @@ def cpu_model():
 
 def cpu_baseline(weights, runs):
     """Reference-faithful dense forward (oracle.forward_dense: materialise [P,4096,150] -> DPNHead -> heads;
-    RelOIPool; predicate head) on a FIXED sample of one cfg2 video: all 31 objects of subjects 0 and 1
-    (62 pairs, 0.94 TFLOP).  One warm-up run, then `runs` timed runs; the median is reported."""
+    RelOIPool; predicate head) on a FIXED sample of one cfg2 video: all 31 objects of subjects 0..7
+    (248 pairs, 3.75 TFLOP).  One warm-up run, then `runs` timed runs; the median is reported."""
     import numpy as np
     import torch
 
@@ -138,7 +139,7 @@ def cpu_baseline(weights, runs):
     v = tspn.synth.make_video(1, N_TRK, T_FRAMES, D_ROI)
     feats, boxes = torch.from_numpy(v["tracklet_feats"]), torch.from_numpy(v["tracklet_boxes"])
     w = {k: torch.from_numpy(x) for k, x in weights.items()}
-    pairs = oracle.pair_index(N_TRK)[: 2 * (N_TRK - 1)]
+    pairs = oracle.pair_index(N_TRK)[: CPU_SUBJECTS * (N_TRK - 1)]
     p = pairs.shape[0]
 
     def run():
@@ -153,7 +154,7 @@ def cpu_baseline(weights, runs):
     return {"value": p / med, "unit": "tracklet-pairs/s", "cores": cores, "kind": "port",
             "cpu": cpu_model(), "runs": len(times),
             "spread": [p / times[-1], p / times[0]],
-            "sample": f"all {N_TRK - 1} objects of 2 subjects = {p} of 992 pairs of one cfg2 video, dense reference "
+            "sample": f"all {N_TRK - 1} objects of {CPU_SUBJECTS} subjects = {p} of 992 pairs of one cfg2 video, dense reference "
                       f"formulation (oracle.forward_dense), median of {len(times)} runs after 1 warm-up "
                       f"({med:.2f} s per run), torch {torch.__version__} CPU, {cores} threads"}
 
@@ -179,10 +180,16 @@ class ClockSampler:
     """Shader clock (MHz) of the device while the timed steps run, read from the amdgpu hwmon node
     (`freq1_input`, Hz) by a background thread every few ms.  None when the node is not readable."""
 
-    def __init__(self, local_rank):
+    def __init__(self, pci_address):
+        """`pci_address` "dddd:bb:dd.f" of the HIP device (the box shows the hwmon nodes of every GPU of
+        the host, the process sees one of them)."""
         import glob
-        nodes = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input"))
-        self.path = nodes[min(local_rank, len(nodes) - 1)] if nodes else None
+        self.path = None
+        for node in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input")):
+            card_dev = node.split("/hwmon/")[0]
+            if os.path.basename(os.path.realpath(card_dev)).lower() == pci_address.lower():
+                self.path = node
+                break
         self.samples = []
         self._stop = False
         self._thread = None
@@ -366,7 +373,9 @@ def main():
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
-    clock = ClockSampler(local_rank)
+    props = torch.cuda.get_device_properties(dev)
+    clock = ClockSampler("%04x:%02x:%02x.0" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0),
+                                               getattr(props, "pci_device_id", 0)))
     clock.start()
     t0 = time.perf_counter()
     for i in range(args.warmup, total_steps):

@@ -26,7 +26,7 @@ def dev_sd(sd, device):
 def test_library_is_the_hip_build(tspn, device):
     import ctypes
     lib = tspn._abi.lib()
-    assert isinstance(lib, ctypes.CDLL) and lib.tspn_version() == 1
+    assert isinstance(lib, ctypes.CDLL) and lib.tspn_version() == tspn._abi.ABI_VERSION
 
 
 # ------------------------------------------------------------------ predicate head
