@@ -359,7 +359,7 @@ def main():
         _, idx = tspn.ops.ppn_pair_matrix_topk(cls, ppn_w, TOPK_PPN)
         # top-k triplet decode (predict.py:66-106): per pair top-20 of 132, per video top-200
         sc, trip, tid = tspn.ops.decode_topk(lg.view(B, P_vid, K_PRED), local_pairs, cls, row_mul=1,
-                                             topk_per_pair=TOPK_PAIR, topk_per_seg=TOPK_SEG)
+                                             topk_per_pair=TOPK_PAIR, topk_per_seg=TOPK_SEG, check_pairs=False)
         if use_dist:  # the one collective of the path: final result gather over RCCL
             if args.gather == "decoded":
                 state["gathered"] = tspn.dist.gather_decoded(sc, trip, tid, world * B, pair_proposals=idx, force=True)

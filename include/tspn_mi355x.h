@@ -206,6 +206,17 @@ int tspn_conv3_tc_wino43_f32(const float* x, int64_t B, int64_t T, int64_t Cin, 
 int tspn_repack_wino43_frag_f32(const float* packed6, int64_t Cin, int64_t M, float* frag, void* stream);
 int tspn_conv3_tc_wino43r_f32(const float* x, int64_t B, int64_t T, int64_t Cin, const float* frag,
                               int64_t M, const float* bias, int relu, float* y, void* stream);
+/* The same convolution with the input transform V = B^T d taken OUT of the MFMA kernel (on
+ * gfx950 fp32 MFMA and VALU instructions do not overlap on a SIMD, so the 24 VALU per chunk of the in-kernel
+ * transform cost 6 % of the launch): a first HBM-bound kernel writes V [Cin/4][6][quads padded to 32][4] into
+ * `workspace` (tspn_conv3_tc_wino43v_workspace_bytes), the MFMA kernel stages it by LDS-DMA.  Bit-identical
+ * to tspn_conv3_tc_wino43r_f32 / tspn_conv3_tc_wino43_f32.  Needs Cin % 32 == 0, M % 32 == 0, 16-byte
+ * aligned x / frag / workspace.  This is what tspn_forward_fused_f32 runs for conv_algo 3 when Cin % 32 == 0. */
+size_t tspn_conv3_tc_wino43v_workspace_bytes(int64_t B, int64_t T, int64_t Cin);
+int tspn_conv3_tc_wino43v_f32(const float* x, int64_t B, int64_t T, int64_t Cin, const float* frag,
+                              int64_t M, const float* bias, int relu, float* y,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
 
 /* ---- a8/a10: relationness + span-regression heads -----------------------
  * Replaces duration_pred (lib/modeling/relpn/dpn.py:71) and relness_pred

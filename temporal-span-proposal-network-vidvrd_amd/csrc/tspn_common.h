@@ -73,6 +73,16 @@ int conv3_tc_wino43(const float* x, int64_t B, int64_t T, int64_t Cin, const flo
 bool wino43_frag_supported(int64_t Cin, int64_t M);
 int conv3_tc_wino43r(const float* x, int64_t B, int64_t T, int64_t Cin, const float* frag, int64_t M,
                      const float* bias, int relu, float* y, int64_t ldy, void* stream);
+// pre-transformed-input form (tspn_wino43v.hip): Cin % 32 == 0, M % 32 == 0; `workspace` holds V
+bool wino43v_supported(int64_t Cin, int64_t M);
+size_t wino43v_workspace_bytes(int64_t B, int64_t T, int64_t Cin);
+int wino43v_input_transform(const float* x, int64_t B, int64_t T, int64_t Cin, void* workspace,
+                            size_t workspace_bytes, void* stream);
+int wino43v_contract(const void* workspace, int64_t B, int64_t T, int64_t Cin, const float* frag, int64_t M,
+                     const float* bias, int relu, float* y, int64_t ldy, void* stream);
+int conv3_tc_wino43v(const float* x, int64_t B, int64_t T, int64_t Cin, const float* frag, int64_t M,
+                     const float* bias, int relu, float* y, int64_t ldy, void* workspace,
+                     size_t workspace_bytes, void* stream);
 int heads_pairgrid(const float* y, int64_t ldt, int64_t B, int64_t N, int64_t C, int64_t T,
                    const float* Wh, const float* bh, int64_t H, float* out, void* stream);
 inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }

@@ -20,7 +20,8 @@
 namespace {
 
 struct FusedLayout {
-  size_t xt, y, bias2, fbar, pooled, lin, total;
+  size_t xt, y, bias2, fbar, pooled, lin, vt, total;
+  size_t vt_bytes;
   size_t lin_bytes;
 };
 
@@ -41,6 +42,9 @@ FusedLayout layout_of(const tspn_fused_desc* d) {
   L.pooled = take(256);  // (unused since the predicate head is evaluated per tracklet)
   L.lin_bytes = tspn::pair_predicate_workspace_bytes((int64_t)NT, (int64_t)D, d->K);
   L.lin = take(L.lin_bytes);
+  // pre-transformed input of the F(4,3) kernel of tspn_wino43v.hip (conv_algo 3 with D % 32 == 0)
+  L.vt_bytes = (D % 32 == 0) ? tspn::wino43v_workspace_bytes((int64_t)NT, (int64_t)T, (int64_t)D) : 0;
+  L.vt = take(L.vt_bytes);
   L.total = off;
   return L;
 }
@@ -113,8 +117,14 @@ extern "C" int tspn_forward_fused_f32(const tspn_fused_desc* d, void* stream) {
   const int64_t ldy =
       (tc && d->canonical_pairs && T % 2 == 0) ? (int64_t)tspn::align_up((size_t)T, 4) : T;
   if (!tc && (rc = tspn_transpose_td_f32(d->feats, NT, T, D, xt, stream))) return rc;
+  // conv_algo 3 with D % 32 == 0: the Winograd input transform runs as its own HBM-bound pass (tspn_wino43v.hip);
+  // the profiling events bracket the MFMA kernel only
+  const bool pre_v = d->conv_algo == 3 && tspn::wino43v_supported(D, 2 * C);
+  if (pre_v && (rc = tspn::wino43v_input_transform(d->feats, NT, T, D, ws + L.vt, L.vt_bytes, stream))) return rc;
   if (d->ev_conv_begin) (void)hipEventRecord(static_cast<hipEvent_t>(d->ev_conv_begin), s);
-  if (d->conv_algo == 3)
+  if (pre_v)
+    rc = tspn::wino43v_contract(ws + L.vt, NT, T, D, d->conv_packed, 2 * C, bias2, 0, y, ldy, stream);
+  else if (d->conv_algo == 3)
     rc = tspn::conv3_tc_wino43r(d->feats, NT, T, D, d->conv_packed, 2 * C, bias2, 0, y, ldy, stream);
   else if (d->conv_algo == 2)
     rc = tspn::conv3_tc_wino43(d->feats, NT, T, D, d->conv_packed, 2 * C, bias2, 0, y, ldy, stream);

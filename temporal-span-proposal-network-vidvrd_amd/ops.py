@@ -13,7 +13,7 @@ from . import _abi
 
 __all__ = [
     "predicate_head", "feature_preprocess_", "ppn_pair_matrix_topk", "traj_iou", "pair_index",
-    "pair_gather", "pack_conv3", "conv3", "conv3_tc", "pack_conv3_wino", "conv3_tc_wino", "pack_conv3_wino43", "conv3_tc_wino43", "repack_wino43_frag", "conv3_tc_wino43r", "heads", "heads_pairgrid", "temporal_mean", "pair_rows", "transpose_td",
+    "pair_gather", "pack_conv3", "conv3", "conv3_tc", "pack_conv3_wino", "conv3_tc_wino", "pack_conv3_wino43", "conv3_tc_wino43", "repack_wino43_frag", "conv3_tc_wino43r", "conv3_tc_wino43v", "heads", "heads_pairgrid", "temporal_mean", "pair_rows", "transpose_td",
     "forward_fused", "temporal_encoder_heads", "fused_workspace_bytes", "decode_topk", "decode_spans",
     "cast_bf16", "pack_conv3_bf16", "pack_heads_bf16", "conv3_tc_bf16", "heads_pairgrid_bf16",
     "temporal_mean_bf16", "forward_fused_bf16", "span_predicate",
@@ -409,6 +409,29 @@ def conv3_tc_wino43r(x, frag, bias=None, relu=False):
     return y
 
 
+def conv3_tc_wino43v(x, frag, bias=None, relu=False, workspace=None):
+    """Winograd F(4,3) conv3 with the input transform as a separate HBM-bound pass (tspn_wino43v.hip):
+    channels-last x[B,T,Cin] with fragment-major weights -> y[B,M,T], bit-identical to conv3_tc_wino43r.
+    Needs Cin % 32 == 0; `workspace` (uint8, >= tspn_conv3_tc_wino43v_workspace_bytes) holds V."""
+    _dev(x, "x"); _dev(frag, "frag")
+    if bias is not None:
+        _dev(bias, "bias")
+    B, T, Cin = x.shape
+    cin_w, M = wino43_frag_dims(frag)
+    if cin_w != Cin:
+        raise ValueError(f"conv3_tc_wino43v: weights are for Cin={cin_w}, x has Cin={Cin}")
+    l = _abi.lib()
+    need = l.tspn_conv3_tc_wino43v_workspace_bytes(B, T, Cin)
+    if workspace is None:
+        workspace = _ws(need, x.device)
+    elif workspace.numel() * workspace.element_size() < need:
+        raise ValueError(f"conv3_tc_wino43v: workspace too small ({workspace.numel()} < {need})")
+    y = torch.empty((B, M, T), dtype=torch.float32, device=x.device)
+    _abi.check(l.tspn_conv3_tc_wino43v_f32(_p(x), B, T, Cin, _p(frag), M, _p(bias), 1 if relu else 0, _p(y),
+                                           _p(workspace), workspace.numel() * workspace.element_size(), _stream()))
+    return y
+
+
 def heads(a, head_w, head_b, b=None, ia=None, ib=None, bias=None, channels=None, num_pairs=None):
     """out[P,H,T] = head_b + head_w @ h_p; h_p = a[ia[p]] (dense) or relu(a[ia[p]] + b[ib[p]] + bias)."""
     _dev(a, "a"); _dev(head_w, "head_w")
@@ -478,7 +501,7 @@ def transpose_td(x):
 
 
 def decode_topk(rel_logit, pairs, cls_sub, cls_obj=None, row_mul=1, num_obj=35,
-                topk_per_pair=20, topk_per_seg=200):
+                topk_per_pair=20, topk_per_seg=200, check_pairs=True):
     """Top-k triplet decode (lib/modeling/predict.py:66-106) for a batch of equal-shape segments.
 
     rel_logit [S,P,K] (or [P,K]); pairs int64 [S,P,2] local tracklet ids; class logits:
@@ -508,7 +531,7 @@ def decode_topk(rel_logit, pairs, cls_sub, cls_obj=None, row_mul=1, num_obj=35,
         if cls_obj.shape != cls_sub.shape:
             raise ValueError("decode_topk: cls_obj shape mismatch")
         obj_ptr = cls_obj.data_ptr()
-    if P and (int(pairs.min()) < 0 or int(pairs.max()) * row_mul >= seg_rows):
+    if check_pairs and P and (int(pairs.min()) < 0 or int(pairs.max()) * row_mul >= seg_rows):
         raise IndexError("decode_topk: row_mul * tracklet id exceeds the class-logit rows")
     R = min(topk_per_pair, K)
     M = min(topk_per_seg, P * R)

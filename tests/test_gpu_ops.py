@@ -683,3 +683,41 @@ def test_fused_fragment_major_equals_canonical(tspn, device, B, N, T, D):
     with pytest.raises(ValueError):   # weights for another D
         tspn.ops.forward_fused(d(feats), d(pairs), B, N, tspn.ops.repack_wino43_frag(
             torch.zeros((6, 2 * D, 8 * D), device=device)), d(w["conv_b"]), hw, hb, d(w["cls_w"]), d(w["cls_b"]))
+
+
+@pytest.mark.parametrize("B,Cin,T,M", [(1, 32, 1, 32), (2, 32, 5, 32), (3, 64, 30, 128), (5, 96, 33, 160),
+                                       (7, 64, 150, 64), (2, 160, 257, 288), (40, 32, 30, 96), (3, 32, 7, 32),
+                                       (33, 128, 13, 128), (1, 32, 4, 32), (9, 256, 150, 256)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_conv3_winograd43_pretransformed_input_kernel(tspn, device, B, Cin, T, M, relu):
+    """F(4,3) with the input transform as a separate pass (tspn_wino43v.hip: V by LDS-DMA, ring of three
+    32-channel super-stages, one barrier per super-stage): BIT-IDENTICAL to the canonical and to the
+    fragment-major kernels for 1, 2, 3 and many super-stages, ragged T (quads masked at tracklet ends, tiles
+    that straddle tracklets), partial weight / quad tiles; within the F(4,3) tolerance of the fp64 conv."""
+    x = tspn.hashrng.uniform(51, "x", (B, T, Cin), -1, 1)
+    w = tspn.hashrng.normal(51, "w", (M, Cin, 3), std=0.1)
+    b = tspn.hashrng.normal(51, "b", (M,), std=0.1)
+    p6 = tspn.ops.pack_conv3_wino43(t(w).to(device))
+    fr = tspn.ops.repack_wino43_frag(p6)
+    for bias in (t(b).to(device), None):
+        y0 = tspn.ops.conv3_tc_wino43(t(x).to(device), p6, bias, relu=relu)
+        y1 = tspn.ops.conv3_tc_wino43r(t(x).to(device), fr, bias, relu=relu)
+        y2 = tspn.ops.conv3_tc_wino43v(t(x).to(device), fr, bias, relu=relu)
+        assert torch.equal(y0, y1) and torch.equal(y0, y2)
+    ref = conv_ref(np.ascontiguousarray(x.transpose(0, 2, 1)), w, b, relu)
+    y = tspn.ops.conv3_tc_wino43v(t(x).to(device), fr, t(b).to(device), relu=relu)
+    np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=0, atol=6e-5)
+
+
+def test_conv3_winograd43_pretransformed_errors(tspn, device):
+    fr = tspn.ops.repack_wino43_frag(torch.zeros((6, 24, 64), device=device))
+    with pytest.raises(tspn._abi.TspnError) as e:    # Cin % 32 != 0: this kernel refuses, the r kernel takes it
+        tspn.ops.conv3_tc_wino43v(torch.zeros((2, 9, 24), device=device), fr)
+    assert e.value.code == tspn._abi.TSPN_EUNSUPPORTED
+    fr = tspn.ops.repack_wino43_frag(torch.zeros((6, 32, 64), device=device))
+    with pytest.raises(ValueError):                  # workspace too small
+        tspn.ops.conv3_tc_wino43v(torch.zeros((2, 9, 32), device=device), fr,
+                                  workspace=torch.zeros(16, dtype=torch.uint8, device=device))
+    y = tspn.ops.conv3_tc_wino43v(torch.zeros((0, 9, 32), device=device), fr)   # empty batch
+    assert y.shape == (0, 64, 9)
+    assert tspn._abi.lib().tspn_conv3_tc_wino43v_workspace_bytes(16 * 32, 150, 2048) == 2048 // 4 * 6 * 19456 * 16
