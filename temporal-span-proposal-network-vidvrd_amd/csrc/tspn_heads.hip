@@ -356,25 +356,26 @@ __global__ __launch_bounds__(256, 2) void heads_pairgrid3_kernel(
   const int t0 = tb * PG_T;
   const int64_t rowlen = 2 * (int64_t)C * ldt;
 
-  // ---- DMA sources: wave w stages tile rows 4w..4w+3; lane -> (channel line lane>>3, 4 frames)
-  const float* src[4];
-  {
-    const int64_t tsrc = min((int64_t)t0 + (lane & 7) * 4, ldt - 4);  // groups past the row end are never stored
-    const int line = lane >> 3;
+  // ---- DMA sources: wave w stages tile rows 4w..4w+3; lane -> (channel line lane>>3, 4 frames).
+  // The row base is wave-uniform (SGPRs, advanced by scalar adds); only the (line, frame group) offset of the
+  // lane lives in a VGPR: fp32 MFMA and VALU do not overlap on gfx950 (profiles/r2/mfma_valu_overlap.txt), so the
+  // 17 per-lane 64-bit pointer updates per chunk of the first version cost 1.7 % of the kernel.
+  const float* srow[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = 4 * wave + r;
-      const int local = row < PG_S ? sb * PG_S + row : ob * PG_O + (row - PG_S);
-      const int64_t trk = b * N + min(local, N - 1);
-      src[r] = y + trk * rowlen + (row < PG_S ? 0 : (int64_t)C * ldt) + line * ldt + tsrc;
-    }
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * wave + r;
+    const int local = row < PG_S ? sb * PG_S + row : ob * PG_O + (row - PG_S);
+    const int64_t trk = b * N + min(local, N - 1);
+    srow[r] = y + trk * rowlen + (row < PG_S ? 0 : (int64_t)C * ldt);
   }
+  // groups past the row end are never stored
+  const unsigned loff = (unsigned)((lane >> 3) * ldt + min((int64_t)t0 + (lane & 7) * 4, ldt - 4));
   const int64_t half_step = 8 * ldt, chunk_step = 16 * ldt;
   auto stage_piece = [&](int buf, auto p_tag) {  // piece p = 2*r + hh of this wave
     constexpr int p = decltype(p_tag)::value;
     constexpr int r = p >> 1, hh = p & 1;
-    hglds16(src[r] + hh * half_step, S + buf * PG_STAGE + ((4 * wave + r) * PG_CK + 8 * hh) * PG_T);
-    if (hh == 1) src[r] += chunk_step;
+    hglds16(srow[r] + hh * half_step + loff, S + buf * PG_STAGE + ((4 * wave + r) * PG_CK + 8 * hh) * PG_T);
+    if (hh == 1) srow[r] += chunk_step;
   };
   const int o_a = lane & 15;
   const float* wsrc = Wh + (int64_t)min(o_a, H - 1) * C + kq;

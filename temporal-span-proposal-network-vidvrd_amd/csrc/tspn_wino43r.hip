@@ -103,7 +103,11 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_wino43r_kernel(
   const int gm = min(GM, tiles_m - first_m);
   const int in_group = wg - group * group_sz;
   const int tile_m = first_m + in_group % gm;
+#if defined(TSPN_W43R_ROT)   // probe: every XCD sweeps the quad tiles from a different starting tile
+  const int tile_n = (in_group / gm + xcd * (tiles_n / 8)) % tiles_n;
+#else
   const int tile_n = in_group / gm;
+#endif
   const int m0 = tile_m * BM;
   const int64_t Q0 = (int64_t)tile_n * QT;
 

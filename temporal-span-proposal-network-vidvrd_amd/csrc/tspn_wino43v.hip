@@ -14,7 +14,7 @@
 //   * conv3_wino43v_kernel stages V by LDS-DMA in super-stages of 32 channels (four 8-channel chunks):
 //     a (channel group, position) row of the tile is 32 quads x 16 B = 512 contiguous bytes of Vg, a DMA
 //     piece (1 KiB per wave-instruction) is two such rows, six pieces per wave and super-stage, issued as
-//     one burst TWO super-stages ahead (ring of 3 buffers, 72 KB: two workgroups per CU).  In-order VMEM
+//     one burst TWO super-stages ahead (ring of 3 buffers of 2 x 24 KB = 144 KB: one workgroup per CU).  In-order VMEM
 //     return makes every piece land before younger weight loads are consumed, so the burst needs no wait
 //     of its own, and ONE bare s_barrier per super-stage (not per chunk) orders the ring.
 //   * weights: fragment-major, one global_load_dwordx4 per lane and (chunk, position) straight into the MFMA
@@ -31,15 +31,44 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int THREADS = 256;
-constexpr int BM = 128;
-constexpr int QT = 32;                    // quads per workgroup
+// Workgroup shape (build-time, -DTSPN_W43V_WAVES=4|8, -DTSPN_W43V_ROWSPLIT; measured in profiles/r2/conv_traffic_sweep.md):
+//   8 waves, tile 128 rows x 64 quads (SHIPPED): waves w and w + 4 — the two waves of one SIMD — take the SAME 32
+//     weight rows on the two 32-quad halves of the tile, so the second wave's weight loads hit the CU's L1: the
+//     weight stream from L2 halves, and so does the fabric traffic (FETCH_SIZE 17.1 M KiB per launch against 30.6
+//     for the 4-wave form and 18.0 for conv3_wino43r_kernel), 3 % faster than either.  One workgroup per CU
+//     (144 KB of LDS), both waves of a SIMD in the same workgroup: hence one barrier per super-stage, not per chunk.
+//   4 waves, tile 128 rows x 32 quads, two workgroups per CU (72 KB each): the round-1 tiling.
+//   8 waves + ROWSPLIT, tile 256 rows x 32 quads: shares the V tile instead of the weights; no gain (V is the small stream).
+#ifndef TSPN_W43V_WAVES
+#define TSPN_W43V_WAVES 8
+#endif
+constexpr int NW = TSPN_W43V_WAVES;
+#if TSPN_W43V_WAVES == 8 && !defined(TSPN_W43V_ROWSPLIT)
+constexpr int QH = 2;                     // 32-quad halves per workgroup
+#else
+constexpr int QH = 1;
+#endif
+constexpr int THREADS = 64 * NW;
+constexpr int BM = 32 * NW / QH;
+constexpr int QT = 32;                    // quads per wave (and per V half-tile)
+constexpr int QWG = QT * QH;              // quads per workgroup
 constexpr int KC = 8;                     // channels per chunk
 constexpr int VROW = QT * 4;              // floats per (channel group, position) row: 512 B
 constexpr int VCH = 12 * VROW;            // floats per chunk: [2 g][6 j][32 quads][4 ch] = 6 KB
-constexpr int VSS = 4 * VCH;              // floats per super-stage (4 chunks): 24 KB
+constexpr int VSS = 4 * VCH * QH;         // floats per super-stage (4 chunks, QH half-tiles): 24 KB x QH
 constexpr int NVB = 3;                    // ring of super-stage buffers
+constexpr int NPIECE = 24 * QH / NW;      // DMA pieces (1 KiB) per wave and super-stage
 constexpr size_t SMEM_BYTES = sizeof(float) * NVB * VSS;
+static_assert(NW == 4 || NW == 8, "TSPN_W43V_WAVES must be 4 or 8");
+// Weight panels (128 rows) per tile group: a group sweeps all quad tiles, so V is re-read from beyond L2 once
+// per group and a panel's weights once per 32 concurrent workgroups of an XCD.  Measured for the shipped shape
+// at 16 videos of config 2: 1 / 2 / 3 / 4 / 5 / 6 / 8 panels -> 30.3 / 30.2 / 30.0 / 29.2-29.6 / 30.2 / 30.1 / 30.3 ms and
+// FETCH_SIZE 32.7 / 16.6 / 16.6 / 17.1 / 16.1 / 17.0 / 19.9 M KiB.  Build-time knob (-DTSPN_WINO_GM=n).
+#if TSPN_WINO_GM != 2
+constexpr int kPanelGroupV = TSPN_WINO_GM;
+#else
+constexpr int kPanelGroupV = QH == 2 ? 4 : 3;
+#endif
 
 __device__ __forceinline__ void glds16(const float* g, float* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -135,13 +164,19 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_wino43v_kernel(
   const int gm = min(GM, tiles_m - first_m);
   const int in_group = wg - group * group_sz;
   const int tile_m = first_m + in_group % gm;
+#if defined(TSPN_W43V_ROT)   // probe: every XCD sweeps the quad tiles from a different starting tile
+  const int tile_n = (in_group / gm + xcd * (tiles_n / 8)) % tiles_n;
+#else
   const int tile_n = in_group / gm;
+#endif
   const int m0 = tile_m * BM;
-  const int64_t Q0 = (int64_t)tile_n * QT;
+  const int64_t Q0 = (int64_t)tile_n * QWG;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wrow = QH == 2 ? (wave & 3) : wave;  // 32-row block of the tile
+  const int wq = QH == 2 ? (wave >> 2) : 0;      // 32-quad half of the tile
   const int li = lane & 31, kh = lane >> 5;
   const int nsuper = Cin >> 5;                  // super-stages of 32 channels (Cin % 32 == 0)
 
@@ -149,26 +184,27 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_wino43v_kernel(
   const char* abase;            // wave-uniform; advanced by one chunk (6 KiB) per refill round
   const unsigned aoff = lane * 16;
   {
-    int mb = (m0 >> 5) + wave;
+    int mb = (m0 >> 5) + wrow;
     mb = mb < (M >> 5) ? mb : 0;
     abase = reinterpret_cast<const char*>(Wf) + (int64_t)mb * (Cin / KC) * (6 * 64 * 16);
   }
 
   // ---- V super-stage DMA: piece p = 6 wave + k holds tile rows 2p (lanes 0..31) and 2p + 1 (lanes 32..63);
   // row rr = chunk-in-super-stage * 12 + g * 6 + j  <->  Vg[(8 S + 2 cl + g)][j][Q0 .. Q0 + 31][0..3]
-  const float* vsrc[6];
+  const float* vsrc[NPIECE];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    const int rr = 2 * (6 * wave + k) + kh;
+  for (int k = 0; k < NPIECE; ++k) {
+    const int pp = NPIECE * wave + k;              // piece of the workgroup: half-tile pp / 24, rows 2 (pp % 24) + kh
+    const int rr = 2 * (pp % 24) + kh;
     const int cl = rr / 12, rem = rr - cl * 12;
     const int g = rem / 6, j = rem - g * 6;
-    vsrc[k] = Vg + (((int64_t)(2 * cl + g) * 6 + j) * nqp + Q0 + li) * 4;
+    vsrc[k] = Vg + (((int64_t)(2 * cl + g) * 6 + j) * nqp + Q0 + QT * (pp / 24) + li) * 4;
   }
   const int64_t super_step = (int64_t)8 * 6 * nqp * 4;     // floats between super-stages
   auto stage_burst = [&](int S) {                // super-stage S -> ring buffer S % 3
-    float* dst = Vs + (S % NVB) * VSS + 6 * wave * 256;
+    float* dst = Vs + (S % NVB) * VSS + NPIECE * wave * 256;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
+    for (int k = 0; k < NPIECE; ++k) {
 #if !defined(TSPN_W43V_ABL_NODMA)
       glds16(vsrc[k], dst + k * 256);
 #endif
@@ -190,7 +226,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_wino43v_kernel(
   // HBM no longer parks the wave (one chunk ahead, as in tspn_wino43r.hip, the waves were parked 11 % of
   // their time on these waits).  V comes from LDS and stays one chunk ahead.
   f32x4 a[2][6], v[6];
-  const float* vlane = Vs + (kh * 6 * QT + li) * 4;      // + buffer + chunk-in-super-stage + position offsets
+  const float* vlane = Vs + wq * (4 * VCH) + (kh * 6 * QT + li) * 4;   // + buffer + chunk + position offsets
   auto load_v = [&](const float* vbuf, int cl, int j) {
 #if !defined(TSPN_W43V_ABL_NOVLOAD)
     v[j] = *reinterpret_cast<const f32x4*>(vbuf + cl * VCH + j * VROW);
@@ -247,7 +283,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_wino43v_kernel(
     constexpr bool BURST = decltype(burst_tag)::value;   // CL == 0 and super-stage S+2 exists
     constexpr bool PBURST = decltype(pburst_tag)::value; // the previous chunk issued a burst (CL == 1)
     constexpr int SET = CL & 1;
-    constexpr int N1 = HAS1 ? 6 : 0, NA = HAS2 ? 2 : 0, NDC = BURST ? 6 : 0, NDP = PBURST ? 6 : 0;
+    constexpr int N1 = HAS1 ? 6 : 0, NA = HAS2 ? 2 : 0, NDC = BURST ? NPIECE : 0, NDP = PBURST ? NPIECE : 0;
     const float* vn = CL == 3 ? vnext : vcur;            // where V of chunk c+1 lives
     constexpr int NCL = (CL + 1) & 3;
     wait_a<4 + N1 + NDP>(a[SET][0], a[SET][1]);
@@ -320,7 +356,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_wino43v_kernel(
 
   // ---- output transform + store: lane column = quad -> frames 4q .. 4q+3
   {
-    const int64_t Q = Q0 + li;
+    const int64_t Q = Q0 + QT * wq + li;
     if (Q < nquads) {
       const int64_t b = Q / nq;
       const int q = (int)(Q - b * nq);
@@ -328,7 +364,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_wino43v_kernel(
       float* ycol = y + (b * M) * (int64_t)ldy + t;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        const int m = m0 + wrow * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
         if (m < M) {
           const float p12 = acc[1][e] + acc[2][e], m12 = acc[1][e] - acc[2][e];
           const float p34 = acc[3][e] + acc[4][e], m34 = acc[3][e] - acc[4][e];
@@ -358,7 +394,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_wino43v_kernel(
   }
 }
 
-int64_t padded_quads(int64_t B, int64_t T) { return tspn::ceil_div(B * tspn::ceil_div(T, 4), QT) * QT; }
+int64_t padded_quads(int64_t B, int64_t T) { return tspn::ceil_div(B * tspn::ceil_div(T, 4), QWG) * QWG; }
 
 }  // namespace
 
@@ -417,14 +453,14 @@ int tspn::wino43v_contract(const void* workspace, int64_t B, int64_t T, int64_t 
                TSPN_EUNSUPPORTED, "%s: frag must be 16-byte aligned", what);
   const int64_t nq = tspn::ceil_div(T, 4);
   const int64_t nquads = B * nq, nqp = padded_quads(B, T);
-  const int64_t tiles_m = tspn::ceil_div(M, BM), tiles_n = nqp / QT;
+  const int64_t tiles_m = tspn::ceil_div(M, BM), tiles_n = nqp / QWG;
   TSPN_REQUIRE(tiles_m * tiles_n < (1LL << 31), TSPN_EUNSUPPORTED, "%s: grid too large", what);
   const int vec4 = (ldy % 4 == 0) && (ldy >= 4 * nq) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
   static tspn::LdsLimit lds;   // 72 KB of dynamic LDS: above the 64 KB default limit
   if (int rc = lds.ensure(reinterpret_cast<const void*>(conv3_wino43v_kernel), SMEM_BYTES, what)) return rc;
   hipLaunchKernelGGL(conv3_wino43v_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(THREADS), SMEM_BYTES,
                      TSPN_STREAM(stream), static_cast<const float*>(workspace), frag, bias, y, (int)Cin, (int)T, (int)M,
-                     (int)nq, nquads, nqp, (int)tiles_m, (int)tiles_n, relu, (int)ldy, tspn::kWinoPanelGroup, vec4);
+                     (int)nq, nquads, nqp, (int)tiles_m, (int)tiles_n, relu, (int)ldy, kPanelGroupV, vec4);
   return tspn::check_launch(what);
 }
 
