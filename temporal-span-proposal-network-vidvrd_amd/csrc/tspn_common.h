@@ -84,7 +84,7 @@ int conv3_tc_wino43v(const float* x, int64_t B, int64_t T, int64_t Cin, const fl
                      const float* bias, int relu, float* y, int64_t ldy, void* workspace,
                      size_t workspace_bytes, void* stream);
 int heads_pairgrid(const float* y, int64_t ldt, int64_t B, int64_t N, int64_t C, int64_t T,
-                   const float* Wh, const float* bh, int64_t H, float* out, void* stream);
+                   const float* Wh, const float* bh, int64_t H, float* out, void* stream, float* Wp12 = nullptr);
 inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 int linear(const float* x, int64_t P, int64_t F, int64_t ldx, const float* W, int64_t ldw,
            const float* b, int64_t K, float* out, int apply_sigmoid, void* workspace,

@@ -20,7 +20,7 @@
 namespace {
 
 struct FusedLayout {
-  size_t xt, y, bias2, fbar, pooled, lin, vt, total;
+  size_t xt, y, bias2, fbar, pooled, lin, vt, hwp, total;
   size_t vt_bytes;
   size_t lin_bytes;
 };
@@ -45,6 +45,7 @@ FusedLayout layout_of(const tspn_fused_desc* d) {
   // pre-transformed input of the F(4,3) kernel of tspn_wino43v.hip (conv_algo 3 with D % 32 == 0)
   L.vt_bytes = (D % 32 == 0) ? tspn::wino43v_workspace_bytes((int64_t)NT, (int64_t)T, (int64_t)D) : 0;
   L.vt = take(L.vt_bytes);
+  L.hwp = take(C * 12 * sizeof(float));   // head weights packed [C][12] for the scalar-weight pair stage (H == 12)
   L.total = off;
   return L;
 }
@@ -140,7 +141,7 @@ extern "C" int tspn_forward_fused_f32(const tspn_fused_desc* d, void* stream) {
     TSPN_REQUIRE(d->P == d->B * d->N * (d->N - 1), TSPN_EINVAL,
                  "tspn_forward_fused: canonical_pairs needs P == B*N*(N-1) (P=%lld)", (long long)d->P);
     if ((rc = tspn::heads_pairgrid(y, ldy, d->B, d->N, C, T, d->head_w, d->head_b, H, d->out_heads,
-                                   stream)))
+                                   stream, reinterpret_cast<float*>(ws + L.hwp))))
       return rc;
   } else if ((rc = tspn_heads_f32(1, y, y + C * T, 2 * C, d->pairs, d->pairs + 1, 2, nullptr,
                                   d->head_w, d->head_b, H, d->P, C, T, d->out_heads, stream))) {

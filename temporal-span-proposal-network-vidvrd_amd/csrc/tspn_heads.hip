@@ -515,6 +515,190 @@ __global__ __launch_bounds__(256, 2) void heads_pairgrid3_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fourth structure of the blocked pair stage: NO matrix instruction.
+// Measured on gfx950 (tools/probes/mfma_valu_overlap_probe.hip, profiles/r2/mfma_valu_overlap.txt): an fp32 MFMA
+// runs at exactly the vector FMA rate (64 FLOP / clk / SIMD) and does not overlap with VALU instructions on its
+// SIMD.  The head GEMM has only H = 12 output rows, so on v_mfma_f32_16x16x4_f32 a quarter of the rows is
+// padding and the two VALU of relu(U[s] + V[o]) per activation come on top (kernel above: MFMA busy 67 %, VALU
+// 20 %, 3.28 ms per 16 videos of config 2).  Here a lane owns one (subject, frame) column and keeps the H head
+// sums of its eight objects in registers; the head weights are wave-uniform, so they travel in SGPRs and every
+// multiply-add pair is one  v_pk_fma_f32 acc2, s_w, v_act2 : 2 + H / 2 VALU per activation, no padding, no fragment layout,
+// and the sum over channels is one fmaf chain in channel order (deterministic, = a plain fp32 dot product).
+// Same tiling and LDS staging as the kernel above (8 subjects x 8 objects x 32 frames per workgroup, 16-channel
+// chunks by LDS-DMA, double-buffered); wave w = subjects {2w, 2w+1}, lane = (subject lane >> 5, frame lane & 31).
+// Weights: packed once per call as Wp[chunk][16 ch][12 h] (pack_heads12_kernel), read by s_load_dwordx4 (inline
+// asm: hipcc turns loads it cannot prove un-clobbered — the LDS-DMA builtin counts as a store — into per-lane
+// VMEM loads, and SLP-vectorises the multiply-adds into v_pk_fma_f32 on VGPR copies of the weights).  SMEM data
+// returns out of order, so every use is behind an `s_waitcnt lgkmcnt(0)` tied to the registers.
+__global__ void pack_heads12_kernel(const float* __restrict__ Wh, int C, float* __restrict__ Wp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;    // i = c * 12 + h
+  if (i < C * 12) Wp[i] = Wh[(int64_t)(i % 12) * C + i / 12];
+}
+
+template <int OFF>
+__device__ __forceinline__ void sload4(f32x4& d, const float* base) {
+  asm volatile("s_load_dwordx4 %0, %1, %2" : "=s"(d) : "s"(base), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void swait6(f32x4& a, f32x4& b, f32x4& c, f32x4& d, f32x4& e, f32x4& f) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(c), "+s"(d), "+s"(e), "+s"(f));
+}
+// (acc.x, acc.y) += w * (act.x, act.y): v_pk_fma_f32 with the weight broadcast from the low (even head) or the
+// high (odd head) dword of an SGPR pair.  A plain v_fma_f32 issues once per 4 cycles and SIMD like every VALU
+// instruction (measured: 4.3), i.e. at HALF the fp32 peak; only the packed form reaches 64 FLOP / clk / SIMD.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void pkfma_lo(f32x2& acc, f32x2 w_sgpr, f32x2 act) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(w_sgpr), "v"(act));
+}
+__device__ __forceinline__ void pkfma_hi(f32x2& acc, f32x2 w_sgpr, f32x2 act) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(w_sgpr), "v"(act));
+}
+
+__global__ __launch_bounds__(256, 2) void heads_pairgrid4_kernel(
+    const float* __restrict__ y, int64_t ldt, int C, int T, int N, const float* __restrict__ Wp,
+    const float* __restrict__ bh, float* __restrict__ out, int ntb, int nob, int nsb, int64_t ngroups) {
+  constexpr int H = 12;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* S = reinterpret_cast<float*>(smem_raw);  // [2][16 rows][16 ch][32 t]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int si = lane >> 5, tl = lane & 31;
+  const int per_group = nsb * nob;
+  const int id = blockIdx.x;
+  const int xcd = id & 7, k = id >> 3;
+  const int64_t G = (int64_t)(k / per_group) * 8 + xcd;
+  if (G >= ngroups) return;
+  const int member = k % per_group;
+  const int sb = member / nob, ob = member - sb * nob;
+  const int64_t b = G / ntb;
+  const int tb = (int)(G - b * ntb);
+  const int t0 = tb * PG_T;
+  const int64_t rowlen = 2 * (int64_t)C * ldt;
+
+  // ---- DMA sources (as in heads_pairgrid3_kernel): wave w stages tile rows 4w..4w+3
+  const float* srow[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * wave + r;
+    const int local = row < PG_S ? sb * PG_S + row : ob * PG_O + (row - PG_S);
+    const int64_t trk = b * N + min(local, N - 1);
+    srow[r] = y + trk * rowlen + (row < PG_S ? 0 : (int64_t)C * ldt);
+  }
+  const unsigned loff = (unsigned)((lane >> 3) * ldt + min((int64_t)t0 + (lane & 7) * 4, ldt - 4));
+  const int64_t half_step = 8 * ldt, chunk_step = 16 * ldt;
+  auto stage_chunk = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+        hglds16(srow[r] + hh * half_step + loff, S + buf * PG_STAGE + ((4 * wave + r) * PG_CK + 8 * hh) * PG_T);
+      srow[r] += chunk_step;
+    }
+  };
+
+  f32x2 acc[PG_O / 2][H];     // (object 2 op, object 2 op + 1) x head
+#pragma unroll
+  for (int op = 0; op < PG_O / 2; ++op)
+#pragma unroll
+    for (int h = 0; h < H; ++h) acc[op][h] = f32x2{0.f, 0.f};
+
+  // A step = two channels: 2 x 9 LDS values per lane and 2 x 12 weights (six SGPR quads), fetched while the
+  // 2 x 8 x (2 + 12) VALU of the previous step run.
+  struct Step {
+    float u[2];
+    float v[PG_O][2];
+  };
+  auto fetch_uv = [&](Step& st, const float* ub, const float* vb, int kk) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int ch = 2 * kk + e;
+      st.u[e] = ub[ch * PG_T];
+#pragma unroll
+      for (int oj = 0; oj < PG_O; ++oj) st.v[oj][e] = vb[(oj * PG_CK + ch) * PG_T];
+    }
+  };
+  auto compute = [&](const Step& st, const f32x4 (&w)[6]) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+#pragma unroll
+      for (int op = 0; op < PG_O / 2; ++op) {
+        const f32x2 a{fmaxf(st.u[e] + st.v[2 * op][e], 0.f), fmaxf(st.u[e] + st.v[2 * op + 1][e], 0.f)};
+#pragma unroll
+        for (int h = 0; h < H; h += 2) {
+          const f32x4& wq = w[3 * e + (h >> 2)];
+          const f32x2 wp = (h & 2) ? f32x2{wq[2], wq[3]} : f32x2{wq[0], wq[1]};
+          pkfma_lo(acc[op][h], wp, a);
+          pkfma_hi(acc[op][h + 1], wp, a);
+        }
+      }
+    }
+  };
+#define TSPN_WLOAD(W, KK, BASE)                                                                        \
+  sload4<(2 * (KK)) * 48>(W[0], BASE); sload4<(2 * (KK)) * 48 + 16>(W[1], BASE);                       \
+  sload4<(2 * (KK)) * 48 + 32>(W[2], BASE); sload4<(2 * (KK) + 1) * 48>(W[3], BASE);                   \
+  sload4<(2 * (KK) + 1) * 48 + 16>(W[4], BASE); sload4<(2 * (KK) + 1) * 48 + 32>(W[5], BASE);
+#define TSPN_WWAIT(W) swait6(W[0], W[1], W[2], W[3], W[4], W[5]);
+
+  const int nchunks = C / PG_CK;
+  stage_chunk(0);
+  __syncthreads();
+  const float* urow = S + ((2 * wave + si) * PG_CK) * PG_T + tl;   // + buffer + channel * 32
+  const float* vrow = S + (PG_S * PG_CK) * PG_T + tl;              // + buffer + (object * 16 + channel) * 32
+  const float* wbase = Wp;                                         // wave-uniform: weights of the current chunk
+  Step s0, s1;
+  f32x4 w0[6], w1[6];
+  fetch_uv(s0, urow, vrow, 0);
+  TSPN_WLOAD(w0, 0, wbase)
+  for (int c = 0; c < nchunks; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nchunks) stage_chunk(buf ^ 1);
+    const float* ub = urow + buf * PG_STAGE;
+    const float* vb = vrow + buf * PG_STAGE;
+    __builtin_amdgcn_sched_barrier(0);
+#define TSPN_STEP2(KK)                                           \
+    fetch_uv(s1, ub, vb, (KK) + 1);                              \
+    TSPN_WLOAD(w1, (KK) + 1, wbase)                              \
+    __builtin_amdgcn_sched_barrier(0);                           \
+    compute(s0, w0);                                             \
+    __builtin_amdgcn_sched_barrier(0);                           \
+    TSPN_WWAIT(w1)                                               \
+    if ((KK) + 2 < PG_CK / 2) {                                  \
+      fetch_uv(s0, ub, vb, (KK) + 2);                            \
+      TSPN_WLOAD(w0, ((KK) + 2) & 7, wbase)                      \
+    }                                                            \
+    __builtin_amdgcn_sched_barrier(0);                           \
+    compute(s1, w1);                                             \
+    __builtin_amdgcn_sched_barrier(0);                           \
+    if ((KK) + 2 < PG_CK / 2) { TSPN_WWAIT(w0) }
+    TSPN_WWAIT(w0)
+    TSPN_STEP2(0) TSPN_STEP2(2) TSPN_STEP2(4) TSPN_STEP2(6)
+#undef TSPN_STEP2
+    wbase += PG_CK * H;
+    if (c + 1 < nchunks) { TSPN_WLOAD(w0, 0, wbase) }   // weights do not depend on the barrier
+    __syncthreads();
+    if (c + 1 < nchunks)      // first step of the next chunk: its tile landed before the barrier
+      fetch_uv(s0, urow + (buf ^ 1) * PG_STAGE, vrow + (buf ^ 1) * PG_STAGE, 0);
+  }
+#undef TSPN_WLOAD
+#undef TSPN_WWAIT
+
+  const int t = t0 + tl;
+  const int s = sb * PG_S + 2 * wave + si;
+  if (t < T && s < N) {
+#pragma unroll
+    for (int oj = 0; oj < PG_O; ++oj) {
+      const int o = ob * PG_O + oj;
+      if (o >= N || s == o) continue;
+      const int64_t p = b * N * (int64_t)(N - 1) + (int64_t)s * (N - 1) + o - (o > s ? 1 : 0);
+#pragma unroll
+      for (int h = 0; h < H; ++h)
+        out[(p * H + h) * (int64_t)T + t] = acc[oj >> 1][h][oj & 1] + (bh ? bh[h] : 0.f);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int tspn_heads_f32(int mode, const float* a, const float* b, int64_t lda,
@@ -561,8 +745,9 @@ extern "C" int tspn_heads_pairgrid_f32(const float* y, int64_t B, int64_t N, int
 }
 
 // y[B*N][2C][ldt] (ldt >= T frames per row)
+// `Wp12` (optional, C * 12 floats of scratch): with it and H == 12 the scalar-weight VALU kernel runs
 int tspn::heads_pairgrid(const float* y, int64_t ldt, int64_t B, int64_t N, int64_t C, int64_t T,
-                         const float* Wh, const float* bh, int64_t H, float* out, void* stream) {
+                         const float* Wh, const float* bh, int64_t H, float* out, void* stream, float* Wp12) {
   TSPN_REQUIRE(B >= 0 && N >= 0 && C > 0 && T > 0 && ldt >= T, TSPN_EINVAL,
                "tspn_heads_pairgrid_f32: bad sizes B=%lld N=%lld C=%lld T=%lld ldt=%lld", (long long)B,
                (long long)N, (long long)C, (long long)T, (long long)ldt);
@@ -587,6 +772,16 @@ int tspn::heads_pairgrid(const float* y, int64_t ldt, int64_t B, int64_t N, int6
                     ((reinterpret_cast<uintptr_t>(out) & 7) == 0);
   TSPN_REQUIRE(v3 || ldt == T, TSPN_EUNSUPPORTED,
                "tspn_heads_pairgrid_f32: padded rows (ldt != T) need the DMA kernel's preconditions");
+  if (v3 && H == 12 && Wp12 != nullptr) {   // scalar-weight VALU form (no 12 -> 16 row padding, no MFMA / VALU serialisation)
+    hipLaunchKernelGGL(pack_heads12_kernel, dim3((unsigned)tspn::ceil_div(C * 12, 256)), dim3(256), 0,
+                       TSPN_STREAM(stream), Wh, (int)C, Wp12);
+    static tspn::LdsLimit lds4;
+    if (int rc = lds4.ensure(reinterpret_cast<const void*>(heads_pairgrid4_kernel), smem, "tspn_heads_pairgrid_f32"))
+      return rc;
+    hipLaunchKernelGGL(heads_pairgrid4_kernel, dim3((unsigned)nwg), dim3(256), smem, TSPN_STREAM(stream), y, ldt,
+                       (int)C, (int)T, (int)N, Wp12, bh, out, ntb, nob, nsb, ngroups);
+    return tspn::check_launch("tspn_heads_pairgrid_f32");
+  }
   const void* fn = v3 ? reinterpret_cast<const void*>(heads_pairgrid3_kernel)
                       : (vec2 ? reinterpret_cast<const void*>(heads_pairgrid_kernel<true>)
                               : reinterpret_cast<const void*>(heads_pairgrid_kernel<false>));
