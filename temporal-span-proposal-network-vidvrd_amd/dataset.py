@@ -13,16 +13,28 @@ What the reference does on the host per segment, and where it runs here:
     num_tracks = sum(trackid < 0)                           -> same kernel
     feats = _feature_preprocess(feats)                      -> tspn_feature_preprocess_f32 (in place), or
                                                                left RAW for PREDICT.FUSE_PREPROCESS
-Reading the HDF5 / JSON files (h5py, vrdataset.py:190-217) and the label construction
-(vrdataset.py:85-138) stay outside this build (dataset I/O is out of scope).
+The label construction (vrdataset.py:85-138) stays outside this build (dataset I/O is out of scope).
+
+On-disk side (the formats a feature-extraction front end has to honour): the small helpers
+at the end of this file read and write the two per-segment files the reference's dataset opens —
+`<vsig>-traj_cls.json` (a list of `Trajectory.serialize()` dicts, lib/modeling/trajectory.py:72-82, read at
+vrdataset.py:162-188) and `<vsig>-relation.h5` (datasets `trackid`, `pairs`, `feats`, `iou`, read at
+vrdataset.py:190-217) — under the reference's own naming (`get_segment_signature`, `get_feature_path`,
+lib/modeling/__init__.py:5-24).  JSON needs nothing; HDF5 needs `h5py`, which is an optional import (absent in
+the build image: the functions then raise ImportError, nothing is emulated).
 """
+import json
+import os
+
 import numpy as np
 import torch
 
 from . import ops
 from .pair_list import PairList, TargetList
 
-__all__ = ["proposal_pair_list", "select_proposal_pairs"]
+__all__ = ["proposal_pair_list", "select_proposal_pairs", "segment_signature", "feature_path",
+           "write_traj_cls_json", "read_traj_cls_json", "tracklets_to_traj_cls", "write_relation_h5",
+           "read_relation_h5"]
 
 
 def _to_dev(x, device, dtype):
@@ -75,3 +87,88 @@ def proposal_pair_list(pairs, feats, iou, trackid, cls_logits, pred_labels=None,
             raise ValueError("pred_labels must be [P,K] with one row per pair")
         tlist = TargetList(ops.gather_rows(lab, idx))
     return plist, tlist
+
+
+# ---------------------------------------------------------------------------------------------------------
+# on-disk formats of the reference's per-segment files
+# ---------------------------------------------------------------------------------------------------------
+def segment_signature(vid, fstart, fend):
+    """'<vid>-<fstart:04d>-<fend:04d>' — lib/modeling/__init__.py:5-9."""
+    return "{}-{:04d}-{:04d}".format(vid, int(fstart), int(fend))
+
+
+def feature_path(root, name, vid, vsig=None, ext=None, create=False):
+    """<root>/features/<name>/<vid>[/<vsig>-<name>.<ext>] — the layout of `get_feature_path` + the file names of
+    vrdataset.py:168-170, 194-196 (`root` = './vidvrd-baseline-output' in the reference)."""
+    d = os.path.join(root, "features", name, vid)
+    if create:
+        os.makedirs(d, exist_ok=True)
+    return d if vsig is None else os.path.join(d, "{}-{}.{}".format(vsig, name, ext or "json"))
+
+
+def tracklets_to_traj_cls(tracklet_boxes, track_cls_logits, fstart, vsig=None, scores=None, gt_trackids=None):
+    """[N,T,4] boxes (l,t,r,b) + [N,35] classeme logits of one segment -> the list of `Trajectory.serialize()`
+    dicts (trajectory.py:72-82) that `<vsig>-traj_cls.json` holds: what a feature-extraction front end writes
+    for the dataset to read (`track_cls_logits` = the 'classeme' entries, vrdataset.py:150-160)."""
+    boxes = np.asarray(tracklet_boxes.detach().cpu() if isinstance(tracklet_boxes, torch.Tensor) else tracklet_boxes,
+                       dtype=np.float64)
+    cls = np.asarray(track_cls_logits.detach().cpu() if isinstance(track_cls_logits, torch.Tensor) else track_cls_logits,
+                     dtype=np.float64)
+    n, t = boxes.shape[:2]
+    if boxes.shape != (n, t, 4) or cls.shape[0] != n:
+        raise ValueError("tracklets_to_traj_cls: boxes must be [N,T,4] and logits [N,K]")
+    out = []
+    for i in range(n):
+        out.append({"pstart": int(fstart), "pend": int(fstart) + t,
+                    "rois": [tuple(float(v) for v in b) for b in boxes[i]],
+                    "score": float(scores[i]) if scores is not None else float(cls[i].max()),
+                    "category": int(cls[i].argmax()),
+                    "classeme": [float(x) for x in cls[i]],
+                    "vsig": vsig,
+                    "gt_trackid": int(gt_trackids[i]) if gt_trackids is not None else -1})
+    return out
+
+
+def write_traj_cls_json(path, trajs):
+    with open(path, "w") as fout:
+        json.dump([dict(t, rois=[list(r) for r in t["rois"]]) for t in trajs], fout)
+
+
+def read_traj_cls_json(path, logit_only=True):
+    """`VRDataset._get_object_trajectory_proposal` (vrdataset.py:162-188): the classeme rows as a float32
+    [N,35] array (`logit_only`, what configs/baseline.yaml uses), or the list of dicts; [] if the file is absent."""
+    if not os.path.exists(path):
+        return np.zeros((0, 0), dtype=np.float32) if logit_only else []
+    with open(path, "r") as fin:
+        trajs = json.load(fin)
+    if not logit_only:
+        return trajs
+    return np.asarray([t["classeme"] for t in trajs], dtype=np.float32)
+
+
+def _h5py():
+    try:
+        import h5py
+    except ImportError as exc:
+        raise ImportError("the -relation.h5 files need h5py, which is not installed here; nothing emulates it") from exc
+    return h5py
+
+
+def write_relation_h5(path, trackid, pairs, feats, iou):
+    """One segment's `-relation.h5` with the four datasets the reference reads (vrdataset.py:203-212)."""
+    h5py = _h5py()
+    with h5py.File(path, "w") as fout:
+        fout.create_dataset("trackid", data=np.asarray(trackid))
+        fout.create_dataset("pairs", data=np.asarray(pairs))
+        fout.create_dataset("feats", data=np.asarray(feats, dtype=np.float32))
+        fout.create_dataset("iou", data=np.asarray(iou, dtype=np.float32))
+
+
+def read_relation_h5(path):
+    """(pairs, feats, iou, trackid) as `VRDataset._get_rel_feature` returns them (vrdataset.py:190-217), or
+    None if the file is absent; feed them to `proposal_pair_list`."""
+    if not os.path.exists(path):
+        return None
+    h5py = _h5py()
+    with h5py.File(path, "r") as fin:
+        return fin["pairs"][:], fin["feats"][:], fin["iou"][:], fin["trackid"][:]

@@ -232,3 +232,36 @@ def test_gt_matrices_truncate_like_zip(tspn):
     assert gt.sum() == 1 and gt[1, 2] == 1
     gt = tspn.PPN._gt_matrices([pl], [tspn.TargetList(tgt[:2])])[0]   # fewer labels than pairs
     assert gt.sum() == 1 and gt[1, 2] == 1
+
+
+def test_on_disk_formats_of_the_reference(tspn, tmp_path):
+    """traj_cls JSON (trajectory.py:72-82 / vrdataset.py:162-188) round trip, the reference's file naming, and the
+    h5py gate of the -relation.h5 helpers."""
+    ds = tspn.dataset
+    assert ds.segment_signature("ILSVRC2015_train_00005003", 0, 30) == "ILSVRC2015_train_00005003-0000-0030"
+    vsig = ds.segment_signature("v1", 15, 45)
+    p = ds.feature_path(str(tmp_path), "traj_cls", "v1", vsig, "json", create=True)
+    assert p.endswith(os.path.join("features", "traj_cls", "v1", "v1-0015-0045-traj_cls.json"))
+    boxes = np.arange(2 * 30 * 4, dtype=np.float32).reshape(2, 30, 4)
+    cls = tspn.hashrng.uniform(3, "cls", (2, 35))
+    trajs = ds.tracklets_to_traj_cls(torch.from_numpy(boxes), cls, fstart=15, vsig=vsig)
+    assert set(trajs[0]) == {"pstart", "pend", "rois", "score", "category", "classeme", "vsig", "gt_trackid"}
+    assert trajs[1]["pend"] - trajs[1]["pstart"] == 30 == len(trajs[1]["rois"]) and trajs[0]["gt_trackid"] == -1
+    assert trajs[0]["category"] == int(cls[0].argmax())
+    ds.write_traj_cls_json(p, trajs)
+    got = ds.read_traj_cls_json(p)                       # logit_only: the [N,35] matrix of vrdataset.py:150-160
+    assert got.dtype == np.float32 and np.array_equal(got, cls.astype(np.float32))
+    full = ds.read_traj_cls_json(p, logit_only=False)
+    assert full[1]["rois"][29] == [float(v) for v in boxes[1, 29]]
+    assert ds.read_traj_cls_json(p + ".missing").shape == (0, 0)
+    h5 = ds.feature_path(str(tmp_path), "relation", "v1", vsig, "h5", create=True)
+    assert ds.read_relation_h5(h5) is None               # absent file: like the reference
+    try:
+        import h5py  # noqa: F401
+    except ImportError:
+        with pytest.raises(ImportError, match="h5py"):
+            ds.write_relation_h5(h5, [-1, 0], [[0, 1], [1, 0]], np.zeros((2, 8)), np.eye(2))
+    else:
+        ds.write_relation_h5(h5, [-1, 0], [[0, 1], [1, 0]], np.ones((2, 8)), np.eye(2))
+        pairs, feats, iou, tid = ds.read_relation_h5(h5)
+        assert pairs.tolist() == [[0, 1], [1, 0]] and feats.dtype == np.float32 and tid.tolist() == [-1, 0]
