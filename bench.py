@@ -16,8 +16,8 @@ Workloads (`--workload`):
 
 A "step" = one pass of the hot path over one batch of synthetic videos per GPU (inputs resident in HBM, a
 rotation of `--batches` different batches): tracklet tensors -> [pair builder + temporal encoder +
-relationness/span heads + RelOIPool + predicate head] (tspn_forward_fused_f32) + PPN pair-matrix/top-k +
-top-k triplet decode (tspn_decode_topk_f32, the reference's predict.py:66-106).  Videos shard across ranks
+relationness/span heads + RelOIPool + predicate head] (tspn_forward_fused_f32) + pair geometry [P,8,T] from the
+boxes (tspn_pair_gather_f32) + PPN pair-matrix/top-k + top-k triplet decode (tspn_decode_topk_f32, the reference's predict.py:66-106).  Videos shard across ranks
 (weak scaling, no collective in the forward); with N>1 each step ends with ONE RCCL all-gather of the
 DECODED per-video results — top-200 (score, triplet, pair) + top-256 pair proposals, 10.8 KB per video
 (`--gather logits` gathers the 524 KB of predicate logits per video instead, as round 1 did).
@@ -315,15 +315,21 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     hashed = min(B, 16)
     vids = [tspn.synth.make_video(1 + rank * B + b, N, T, D) for b in range(hashed)]
-    feats_all, cls_all = [], []
+    feats_all, cls_all, boxes_all = [], [], []
     for k in range(nb):
         f = torch.rand((B * N, T, D), device=dev, generator=gen)
         c = torch.rand((B, N, 35), device=dev, generator=gen)
+        # integer-valued boxes (l, t, r, b) as in SURVEY.md §8d: x, y in [0, 900), w, h in [10, 300)
+        xy = torch.floor(torch.rand((B * N, T, 2), device=dev, generator=gen) * 900.0)
+        wh = torch.floor(10.0 + torch.rand((B * N, T, 2), device=dev, generator=gen) * 290.0)
+        bx = torch.cat([xy, xy + wh], dim=2).contiguous()
         if k == 0:
             f[: hashed * N] = d(np.concatenate([v["tracklet_feats"] for v in vids]))
             c[:hashed] = d(np.stack([v["track_cls_logits"] for v in vids]))
+            bx[: hashed * N] = d(np.concatenate([v["tracklet_boxes"] for v in vids]))
         feats_all.append(tspn.ops.cast_bf16(f) if bf16 else f)
         cls_all.append(c)
+        boxes_all.append(bx)
     del vids
     pairs = torch.cat([tspn.ops.pair_index(N, dev, base=b * N) for b in range(B)]).contiguous()
     local_pairs = tspn.ops.pair_index(N, dev).unsqueeze(0).expand(B, -1, -1).contiguous()
@@ -342,7 +348,7 @@ def main():
     torch.cuda.synchronize()
 
     def step(i):
-        feats, cls = feats_all[i % nb], cls_all[i % nb]
+        feats, cls, boxes = feats_all[i % nb], cls_all[i % nb], boxes_all[i % nb]
         if bf16:
             if "ws" not in state:   # allocate the workspace once (first warm-up step), then reuse it
                 d16 = tspn._abi.FusedBf16Desc()
@@ -356,6 +362,9 @@ def main():
                                    workspace=ws, out_heads=out_heads, out_logits=out_logits,
                                    check_pairs=False, conv_events=events[i], canonical_pairs=True)
             lg = out_logits
+        # the bbox half of the N^2 pair builder: relative geometry [P, 8, T] of every pair (one lane per
+        # (pair, frame), motion channels by wavefront shuffle)
+        _, state["geom"] = tspn.ops.pair_gather(None, boxes, pairs, want_feat=False, check_pairs=False)
         _, idx = tspn.ops.ppn_pair_matrix_topk(cls, ppn_w, TOPK_PPN)
         # top-k triplet decode (predict.py:66-106): per pair top-20 of 132, per video top-200
         sc, trip, tid = tspn.ops.decode_topk(lg.view(B, P_vid, K_PRED), local_pairs, cls, row_mul=1,
@@ -429,7 +438,7 @@ def main():
                        "videos_per_gpu_per_step": B, "pairs_per_video": P_vid, "resident_input_batches": nb,
                        "path": ("fused/factorised (tspn_forward_fused_bf16)" if bf16 else
                                 "fused/factorised (tspn_forward_fused_f32)")
-                               + " + PPN top-k + top-k triplet decode" + gather_txt,
+                               + " + pair geometry + PPN top-k + top-k triplet decode" + gather_txt,
                        "dense_equivalent_gflop_per_pair": (2.0 * T * C * (3 * C + 3 * A_ANCH) + 2.0 * C * K_PRED) / 1e9,
                        "conv_algo": "direct" if bf16 else args.conv,
                        "executed_gflop_per_pair": (conv_flop + 2.0 * P * T * C * 16 + 2.0 * P * C * K_PRED) / P / 1e9},

@@ -29,9 +29,11 @@ import torch.nn.functional as F
 from . import ops
 from .sampler import BalancedPositiveNegativePairSampler
 
-TemporalProposals = namedtuple("TemporalProposals", ["relness", "duration", "heads"])
+TemporalProposals = namedtuple("TemporalProposals", ["relness", "duration", "heads", "geom"], defaults=[None])
 TemporalProposals.__doc__ = """Per-segment output of the temporal branch:
-relness [P,A,T] relationness logits, duration [P,2A,T] span regression (views of heads [P,3A,T])."""
+relness [P,A,T] relationness logits, duration [P,2A,T] span regression (views of heads [P,3A,T]);
+geom [P,8,T]: the bbox half of the pair builder (relative box geometry per pair and frame, DESIGN.md §2) when
+the segment carries 'tracklet_boxes', else None."""
 
 
 def _compute_device(*tensors):
@@ -422,9 +424,9 @@ class DPN(nn.Module):
                     rnd(torch.cat([rb, db])))
         return self._cache.get("bf16", (c.weight, c.bias) + tuple(self.dpn_head.head_params()), dev, build)
 
-    def _wrap(self, heads):
+    def _wrap(self, heads, geom=None):
         a = self.dpn_head.num_windows
-        return TemporalProposals(heads[:, :a], heads[:, a:], heads)
+        return TemporalProposals(heads[:, :a], heads[:, a:], heads, geom)
 
     def forward_dense(self, feats):
         """feats: list of materialised [P,C,T] pair tensors (the layout DPNHead consumes)."""
@@ -589,7 +591,7 @@ class BaseModel(_CachedWeightsMixin, nn.Module):
                  for f in feats], duration_proposals)
             rel_logits = [self.classifier(r).to(f.device) for r, f in zip(reloi_feats, feats)]
             if duration_proposals is not None:
-                duration_proposals = [TemporalProposals(*(t.to(f.device) for t in d))
+                duration_proposals = [TemporalProposals(*(t.to(f.device) if t is not None else None for t in d))
                                       for d, f in zip(duration_proposals, feats)]
             return pair_proposals, duration_proposals, rel_logits
 
@@ -649,9 +651,11 @@ class BaseModel(_CachedWeightsMixin, nn.Module):
                 heads, lg = ops.forward_fused_bf16(feats, allp, len(members), n, packed, cbias, hpk, hb16,
                                                    cw16, cb16)
                 per = n * (n - 1)
+                geom = self._pair_geometry_batch(pair_list, members, allp, dev)
                 for k, i in enumerate(members):
                     src_dev = pair_list[i].get_field("tracklet_feats").device
-                    durations[i] = dpn._wrap(heads[k * per:(k + 1) * per].to(src_dev))
+                    durations[i] = dpn._wrap(heads[k * per:(k + 1) * per].to(src_dev),
+                                             None if geom is None else geom[k * per:(k + 1) * per].to(src_dev))
                     logits[i] = lg[k * per:(k + 1) * per].to(src_dev)
                 continue
             feats = torch.cat([_f32(pair_list[i].get_field("tracklet_feats"), dev) for i in members])
@@ -682,14 +686,27 @@ class BaseModel(_CachedWeightsMixin, nn.Module):
                 # RelOIPool over each pair's best span (decode + NMS, top-1) instead of the whole segment
                 top = ops.decode_spans(heads, self.anchor_sizes(t), top_k=1)["span"][:, 0].contiguous()
                 lg = ops.span_predicate(feats, allp, top, cw, cb)
+            geom = self._pair_geometry_batch(pair_list, members, allp, dev)
             off = 0
             for k, i in enumerate(members):
                 src_dev = pair_list[i].get_field("tracklet_feats").device
                 h = heads[off:off + counts[k]].to(src_dev)
-                durations[i] = dpn._wrap(h)
+                durations[i] = dpn._wrap(h, None if geom is None else geom[off:off + counts[k]].to(src_dev))
                 logits[i] = lg[off:off + counts[k]].to(src_dev)
                 off += counts[k]
         return pair_proposals, durations, logits
+
+    @staticmethod
+    def _pair_geometry_batch(pair_list, members, allp, dev):
+        """The bbox half of the N^2 pair builder for one group of equal-shape segments, ONE launch: relative
+        box geometry [P_total, 8, T] of every scored pair (pair_geometry_kernel: one lane per (pair, frame),
+        the motion channels through a wavefront shuffle).  None unless every segment carries 'tracklet_boxes'."""
+        if not all(pair_list[i].has_field("tracklet_boxes") and pair_list[i].get_field("tracklet_boxes") is not None
+                   for i in members) or allp.shape[0] == 0:
+            return None
+        boxes = torch.cat([_f32(pair_list[i].get_field("tracklet_boxes"), dev) for i in members])
+        _, geom = ops.pair_gather(None, boxes, allp, want_feat=False, check_pairs=False)   # allp was validated above
+        return geom
 
     def decode(self, pair_list, rel_logits, topk_per_pair=20, topk_per_seg=200, num_obj=35):
         """Top-k triplet decode of `forward`'s rel_logits on the GPU (replaces the Python of

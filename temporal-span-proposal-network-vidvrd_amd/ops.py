@@ -241,7 +241,7 @@ def pair_index(n, device, base=0):
     return out
 
 
-def pair_gather(tracklet_feats, tracklet_boxes, pairs, want_feat=True, want_geom=True):
+def pair_gather(tracklet_feats, tracklet_boxes, pairs, want_feat=True, want_geom=True, check_pairs=True):
     """N^2 pair builder: -> (pair_feats [P,2D,T] | None, pair_geom [P,8,T] | None)."""
     _dev(pairs, "pairs", torch.int64)
     P = pairs.shape[0]
@@ -264,7 +264,7 @@ def pair_gather(tracklet_feats, tracklet_boxes, pairs, want_feat=True, want_geom
         D = D or 1
     if NT is None:
         return None, None
-    if P and (int(pairs.min()) < 0 or int(pairs.max()) >= NT):
+    if check_pairs and P and (int(pairs.min()) < 0 or int(pairs.max()) >= NT):   # host sync: skip for tables built here
         raise IndexError("pair_gather: pair index out of range")
     _abi.check(_abi.lib().tspn_pair_gather_f32(
         _p(tracklet_feats if want_feat else None), _p(tracklet_boxes if want_geom else None),

@@ -130,6 +130,15 @@ def test_temporal_forward_tracklets_fused(tspn, device):
     geo = model.pair_geometry(plists)
     ref_g = oracle.pair_geometry(t(vids[1]["tracklet_boxes"]), oracle.pair_index(4))
     np.testing.assert_allclose(geo[1].numpy(), ref_g.numpy(), rtol=2e-6, atol=2e-6)
+    # the bbox half of the pair builder is part of forward's output: one launch per group of segments
+    for i, v in enumerate(vids):
+        n = shapes[i][0]
+        assert dp[i].geom.shape == (n * (n - 1), 8, shapes[i][1]) and dp[i].geom.device.type == "cpu"
+        np.testing.assert_allclose(dp[i].geom.numpy(), oracle.pair_geometry(t(v["tracklet_boxes"]), oracle.pair_index(n)).numpy(),
+                                   rtol=2e-6, atol=2e-6)
+        assert torch.equal(dp[i].geom, geo[i])
+    no_boxes = tspn.PairList.from_tracklets(t(vids[0]["tracklet_feats"]), None, t(vids[0]["track_cls_logits"]))
+    assert model([no_boxes], None)[1][0].geom is None
 
 
 def test_temporal_forward_materialised_features_dense(tspn, device):
