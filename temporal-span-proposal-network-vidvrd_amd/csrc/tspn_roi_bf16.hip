@@ -70,8 +70,12 @@ __global__ void pack_conv2d_frag_bf16_kernel(const float* __restrict__ w, int64_
   }
 }
 
+// waves per SIMD the 32-row form is compiled for (112 VGPRs): the memory-bound short-K 1x1 layers run on it
+#ifndef TSPN_ROI_BF16_MI1_WAVES
+#define TSPN_ROI_BF16_MI1_WAVES 3
+#endif
 template <int MI>
-__global__ __launch_bounds__(THREADS, 2) void conv2d_nhwc_bf16_kernel(
+__global__ __launch_bounds__(THREADS, (MI == 1 ? TSPN_ROI_BF16_MI1_WAVES : 2)) void conv2d_nhwc_bf16_kernel(
     const __bf16* __restrict__ x, const __bf16* __restrict__ Wf, const float* __restrict__ bias,
     const __bf16* __restrict__ residual, __bf16* __restrict__ out, int H, int W, int Cin, int Cout, int KH,
     int KW, int stride, int pad, int OH, int OW, int64_t npix, int tiles_m, int tiles_n, int relu) {
@@ -348,7 +352,14 @@ extern "C" int tspn_conv2d_nhwc_bf16(const uint16_t* x, int64_t NB, int64_t H, i
   TSPN_REQUIRE(H < (1 << 20) && W < (1 << 20) && Cin < (1 << 24) && Cout < (1 << 24), TSPN_EUNSUPPORTED,
                "tspn_conv2d_nhwc_bf16: dimension too large");
   const int64_t npix = NB * OH * OW;
-  const int mi = (Cout % 64 == 0) ? 2 : 1;   // 64 rows per wave where Cout allows
+  // 64 rows per wave where Cout allows — except the 1x1 layers with K <= 256 (res2 - res4 expand convs): four K
+  // chunks of MFMAs between a 64 KB operand prologue and a residual + store epilogue are latency-bound, and
+  // the 32-row form at three workgroups per CU hides more of it (backbone conv time 8.59 -> 8.12 ms per 16
+  // frames; 1024 <- 256 + residual 3.1 -> 3.3 TB/s, 256 <- 64 + residual 3.9 -> 4.9 TB/s; K = 1024 layers lose)
+#ifndef TSPN_ROI_BF16_SHORTK_MI1
+#define TSPN_ROI_BF16_SHORTK_MI1 256
+#endif
+  const int mi = (Cout % 64 == 0 && !(KH * KW == 1 && Cin <= TSPN_ROI_BF16_SHORTK_MI1)) ? 2 : 1;
   const int64_t tiles_m = tspn::ceil_div(Cout, 128 * mi), tiles_n = tspn::ceil_div(npix, BN);
   TSPN_REQUIRE(tiles_m * tiles_n < (1LL << 31), TSPN_EUNSUPPORTED, "tspn_conv2d_nhwc_bf16: grid too large");
   auto launch = [&](auto kern) {
