@@ -17,7 +17,11 @@ Workloads (`--workload`):
 A "step" = one pass of the hot path over one batch of synthetic videos per GPU (inputs resident in HBM, a
 rotation of `--batches` different batches): tracklet tensors -> [pair builder + temporal encoder +
 relationness/span heads + RelOIPool + predicate head] (tspn_forward_fused_f32) + pair geometry [P,8,T] from the
-boxes (tspn_pair_gather_f32) + PPN pair-matrix/top-k + top-k triplet decode (tspn_decode_topk_f32, the reference's predict.py:66-106).  Videos shard across ranks
+boxes (tspn_pair_gather_f32) + PPN pair-matrix/top-k + top-k triplet decode (tspn_decode_topk_f32, the reference's predict.py:66-106).  The predicate logits are ready
+before the encoder starts (they depend on the tracklet means only; tspn_fused_desc.ev_logits_ready), so with
+`--overlap` geometry, PPN, decode and the result gather run on a second HIP stream under the encoder of the same
+step — on one GPU that buys nothing (the encoder fills the chip), so it is off by default.
+Videos shard across ranks
 (weak scaling, no collective in the forward); with N>1 each step ends with ONE RCCL all-gather of the
 DECODED per-video results — top-200 (score, triplet, pair) + top-256 pair proposals, 10.8 KB per video
 (`--gather logits` gathers the 524 KB of predicate logits per video instead, as round 1 did).
@@ -77,6 +81,10 @@ def parse():
                     help="payload of the N>1 result gather: decoded top-k results (default) or raw logits")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the RCCL result gather even with one rank (exercises the N>1 code path)")
+    ap.add_argument("--overlap", action="store_true",
+                    help="pair geometry, PPN, decode and the result gather on a second HIP stream behind the logits-ready "
+                         "event, under the encoder of the same step (measured on one GPU: 32.70 vs 32.65 ms per step, the "
+                         "encoder leaves no idle units to fill, so the default keeps one stream)")
     ap.add_argument("--launch-check", action="store_true",
                     help="rehearse only the rank launch + rendezvous on the CPU (gloo), no GPU work")
     return ap.parse_args()
@@ -338,30 +346,22 @@ def main():
     ws = None if bf16 else torch.empty(tspn.ops.fused_workspace_bytes(B, N, T, D, A_ANCH, K_PRED, P),
                                        dtype=torch.uint8, device=dev)
     out_heads = torch.empty((P, 3 * A_ANCH, T), dtype=torch.float32, device=dev)
-    out_logits = torch.empty((P, K_PRED), dtype=torch.float32, device=dev)
+    # two logits buffers: the second stream may still be decoding step i - 1 while step i writes its logits
+    out_logits2 = [torch.empty((P, K_PRED), dtype=torch.float32, device=dev) for _ in range(2)]
     state = {}
     total_steps = args.warmup + args.steps
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
               for _ in range(total_steps)]
-    for a, b in events:  # create the HIP event handles
-        a.record(); b.record()
+    overlap = args.overlap and not bf16
+    side = torch.cuda.Stream(device=dev) if overlap else None
+    ev_logits = [torch.cuda.Event() for _ in range(total_steps)]
+    ev_side = [torch.cuda.Event() for _ in range(total_steps)]
+    for i, (a, b) in enumerate(events):  # create the HIP event handles
+        a.record(); b.record(); ev_logits[i].record(); ev_side[i].record()
     torch.cuda.synchronize()
 
-    def step(i):
-        feats, cls, boxes = feats_all[i % nb], cls_all[i % nb], boxes_all[i % nb]
-        if bf16:
-            if "ws" not in state:   # allocate the workspace once (first warm-up step), then reuse it
-                d16 = tspn._abi.FusedBf16Desc()
-                d16.B, d16.N, d16.T, d16.D, d16.A, d16.K, d16.P = B, N, T, D, A_ANCH, K_PRED, P
-                state["ws"] = torch.empty(tspn._abi.lib().tspn_forward_fused_bf16_workspace_bytes(d16),
-                                          dtype=torch.uint8, device=dev)
-            _, lg = tspn.ops.forward_fused_bf16(feats, pairs, B, N, packed, conv_b, head_pk, head_b, cls_w,
-                                                cls_b, workspace=state["ws"], conv_events=events[i])
-        else:
-            tspn.ops.forward_fused(feats, pairs, B, N, packed, conv_b, head_w, head_b, cls_w, cls_b,
-                                   workspace=ws, out_heads=out_heads, out_logits=out_logits,
-                                   check_pairs=False, conv_events=events[i], canonical_pairs=True)
-            lg = out_logits
+    def tail(i, lg, cls, boxes):
+        """What only needs the logits (and the boxes): pair geometry, PPN, top-k decode, result gather."""
         # the bbox half of the N^2 pair builder: relative geometry [P, 8, T] of every pair (one lane per
         # (pair, frame), motion channels by wavefront shuffle)
         _, state["geom"] = tspn.ops.pair_gather(None, boxes, pairs, want_feat=False, check_pairs=False)
@@ -376,6 +376,36 @@ def main():
                 tspn.dist.gather_results(lg.view(B, P_vid, K_PRED), world * B, force=True)
                 tspn.dist.gather_results(idx, world * B, force=True)
         state["last"] = (sc, trip, tid, idx)
+
+    def step(i):
+        feats, cls, boxes = feats_all[i % nb], cls_all[i % nb], boxes_all[i % nb]
+        if bf16:
+            if "ws" not in state:   # allocate the workspace once (first warm-up step), then reuse it
+                d16 = tspn._abi.FusedBf16Desc()
+                d16.B, d16.N, d16.T, d16.D, d16.A, d16.K, d16.P = B, N, T, D, A_ANCH, K_PRED, P
+                state["ws"] = torch.empty(tspn._abi.lib().tspn_forward_fused_bf16_workspace_bytes(d16),
+                                          dtype=torch.uint8, device=dev)
+            _, lg = tspn.ops.forward_fused_bf16(feats, pairs, B, N, packed, conv_b, head_pk, head_b, cls_w,
+                                                cls_b, workspace=state["ws"], conv_events=events[i])
+            tail(i, lg, cls, boxes)
+            return
+        lg = out_logits2[i % 2]
+        main = torch.cuda.current_stream()
+        if overlap and i >= 2:
+            main.wait_event(ev_side[i - 2])      # the second stream has finished reading this logits buffer
+        # the logits are computed first inside the call (they depend on the tracklet means only) and the
+        # event fires there: the second stream decodes and gathers under this step's encoder
+        tspn.ops.forward_fused(feats, pairs, B, N, packed, conv_b, head_w, head_b, cls_w, cls_b,
+                               workspace=ws, out_heads=out_heads, out_logits=lg, check_pairs=False,
+                               conv_events=events[i], canonical_pairs=True,
+                               logits_event=ev_logits[i] if overlap else None)
+        if not overlap:
+            tail(i, lg, cls, boxes)
+            return
+        with torch.cuda.stream(side):
+            side.wait_event(ev_logits[i])
+            tail(i, lg, cls, boxes)
+            ev_side[i].record(side)
 
     for i in range(args.warmup):
         step(i)
@@ -438,7 +468,9 @@ def main():
                        "videos_per_gpu_per_step": B, "pairs_per_video": P_vid, "resident_input_batches": nb,
                        "path": ("fused/factorised (tspn_forward_fused_bf16)" if bf16 else
                                 "fused/factorised (tspn_forward_fused_f32)")
-                               + " + pair geometry + PPN top-k + top-k triplet decode" + gather_txt,
+                               + " + pair geometry + PPN top-k + top-k triplet decode" + gather_txt
+                               + (" (geometry, PPN, decode and gather on a second stream under the encoder)" if overlap
+                                  else ""),
                        "dense_equivalent_gflop_per_pair": (2.0 * T * C * (3 * C + 3 * A_ANCH) + 2.0 * C * K_PRED) / 1e9,
                        "conv_algo": "direct" if bf16 else args.conv,
                        "executed_gflop_per_pair": (conv_flop + 2.0 * P * T * C * 16 + 2.0 * P * C * K_PRED) / P / 1e9},

@@ -35,8 +35,8 @@ extern "C" {
 
 /* Bumped whenever a struct layout or a signature changes (2: tspn_fused_desc gained conv_algo /
  * canonical_pairs in round 1 without a bump; round 2 adds the struct-size exports below, which the
- * host checks against its own view of the descriptors at load time).                              */
-#define TSPN_ABI_VERSION 2
+ * host checks against its own view of the descriptors at load time; 3: tspn_fused_desc.ev_logits_ready). */
+#define TSPN_ABI_VERSION 3
 
 enum {
   TSPN_OK = 0,
@@ -324,6 +324,10 @@ typedef struct tspn_fused_desc {
    * dominant kernel (the tracklet-projection implicit GEMM); NULL = off */
   void* ev_conv_begin;
   void* ev_conv_end;
+  /* optional: hipEvent_t recorded on `stream` as soon as out_logits is complete.  The predicate logits depend
+   * only on the tracklet means, so the driver computes them FIRST; a caller can start the top-k decode, the PPN
+   * and the result gather on a second stream behind this event while the encoder is still running. */
+  void* ev_logits_ready;
 } tspn_fused_desc;
 
 size_t tspn_forward_fused_workspace_bytes(const tspn_fused_desc* d);

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(HERE)
 LIB_PATH = os.environ.get("TSPN_LIB_PATH") or os.path.join(HERE, "libtspn_mi355x.so")
 HEADER_PATH = os.path.join(ROOT, "include", "tspn_mi355x.h")
 
-ABI_VERSION = 2   # TSPN_ABI_VERSION of include/tspn_mi355x.h
+ABI_VERSION = 3   # TSPN_ABI_VERSION of include/tspn_mi355x.h
 TSPN_OK = 0
 TSPN_EINVAL = -1
 TSPN_EUNSUPPORTED = -2
@@ -42,7 +42,7 @@ class FusedDesc(ctypes.Structure):
         ("cls_w", _vp), ("cls_b", _vp),
         ("out_heads", _vp), ("out_logits", _vp),
         ("workspace", _vp), ("workspace_bytes", _sz),
-        ("ev_conv_begin", _vp), ("ev_conv_end", _vp),
+        ("ev_conv_begin", _vp), ("ev_conv_end", _vp), ("ev_logits_ready", _vp),
     ]
 
 

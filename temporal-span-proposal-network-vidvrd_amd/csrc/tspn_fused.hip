@@ -98,6 +98,16 @@ extern "C" int tspn_forward_fused_f32(const tspn_fused_desc* d, void* stream) {
   if (e != hipSuccess)
     return tspn::fail(TSPN_ELAUNCH, "tspn_forward_fused: bias staging: %s", hipGetErrorString(e));
 
+  // 0. RelOIPool over the segment on the pair feats (= cat of the two tracklet means) + predicate head;
+  // linear in the two halves, so evaluated per tracklet and combined per pair.  Done FIRST: the logits do not
+  // depend on the encoder, and a caller may decode / gather them on another stream behind ev_logits_ready.
+  if ((rc = tspn_temporal_mean_f32(d->feats, NT, T, D, 1, fbar, stream))) return rc;
+  (void)pooled;
+  if ((rc = tspn::pair_predicate(fbar, NT, D, d->pairs, d->P, d->cls_w, d->cls_b, d->K, d->out_logits, lin,
+                                 L.lin_bytes, stream)))
+    return rc;
+  if (d->ev_logits_ready) (void)hipEventRecord(static_cast<hipEvent_t>(d->ev_logits_ready), s);
+
   // 1+2. per-tracklet projections  y[NT, 2C, T]: rows [0,C) = U (+bias), rows [C,2C) = V.
   // The channels-last kernel consumes the tracklet layout [NT,T,D] directly; ragged shapes go
   // through a transpose to channels-first [NT,D,T] and the general kernel.
@@ -147,12 +157,7 @@ extern "C" int tspn_forward_fused_f32(const tspn_fused_desc* d, void* stream) {
                                   d->head_w, d->head_b, H, d->P, C, T, d->out_heads, stream))) {
     return rc;
   }
-  // 4. RelOIPool over the segment on the pair feats (= cat of the two tracklet means) + predicate
-  // head; linear in the two halves, so evaluated per tracklet and combined per pair
-  if ((rc = tspn_temporal_mean_f32(d->feats, NT, T, D, 1, fbar, stream))) return rc;
-  (void)pooled;
-  return tspn::pair_predicate(fbar, NT, D, d->pairs, d->P, d->cls_w, d->cls_b, d->K, d->out_logits, lin,
-                              L.lin_bytes, stream);
+  return TSPN_OK;
 }
 
 extern "C" int tspn_temporal_encoder_heads_f32(const float* x, int64_t P, int64_t C, int64_t T,

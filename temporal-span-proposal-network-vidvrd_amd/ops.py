@@ -613,7 +613,7 @@ def fused_workspace_bytes(B, N, T, D, A, K, P):
 
 def forward_fused(feats, pairs, B, N, conv_packed, conv_bias, head_w, head_b, cls_w, cls_b,
                   workspace=None, out_heads=None, out_logits=None, check_pairs=True,
-                  conv_events=None, canonical_pairs=False):
+                  conv_events=None, canonical_pairs=False, logits_event=None):
     """Whole scoring pass on tracklet tensors (tspn_forward_fused_f32).
 
     feats [B*N,T,D]; pairs int64 [P,2] global tracklet ids.
@@ -621,6 +621,8 @@ def forward_fused(feats, pairs, B, N, conv_packed, conv_bias, head_w, head_b, cl
     pair_index — which lets the pair stage use the blocked kernel with computed output slots.
     `conv_events`: optional (begin, end) torch.cuda.Event pair (enable_timing=True, already
     recorded once so the handles exist) re-recorded around the dominant kernel.
+    `logits_event`: optional torch.cuda.Event (already recorded once) re-recorded as soon as `rel_logits` is
+    complete — the logits are computed first, so decode / PPN / gather can run on another stream behind it.
     Returns (heads [P,3A,T], rel_logits [P,K]).
     """
     d = _fused_desc(feats, pairs, B, N, conv_packed, conv_bias, head_w, head_b, cls_w, cls_b)
@@ -644,6 +646,8 @@ def forward_fused(feats, pairs, B, N, conv_packed, conv_bias, head_w, head_b, cl
         raise ValueError("forward_fused: canonical_pairs needs P == B*N*(N-1)")
     if conv_events is not None:
         d.ev_conv_begin, d.ev_conv_end = conv_events[0].cuda_event, conv_events[1].cuda_event
+    if logits_event is not None:
+        d.ev_logits_ready = logits_event.cuda_event
     _abi.check(l.tspn_forward_fused_f32(ctypes.byref(d), _stream()))
     return out_heads, out_logits
 
