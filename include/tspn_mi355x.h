@@ -217,6 +217,23 @@ int tspn_conv3_tc_wino43v_f32(const float* x, int64_t B, int64_t T, int64_t Cin,
                               int64_t M, const float* bias, int relu, float* y,
                               void* workspace, size_t workspace_bytes, void* stream);
 
+/* Winograd F(6,3) over time (tspn_wino63.hip): six output frames from eight inputs, 8 channel-GEMMs on a sixth of
+ * the columns = 4/9 of the direct MFMA work, 12 % less than F(4,3) (and T = 150 tiles exactly: no quad padding).
+ * Same structure as tspn_conv3_tc_wino43v_f32: the input transform V = B^T d (points 0, +-1, +-2, +-1/2, inf) is its
+ * own pass into `workspace` (tspn_conv3_tc_wino63_workspace_bytes), the MFMA kernel stages it by LDS-DMA.
+ *   frag = tspn_pack_conv3_wino63_frag_f32(conv.weight [M, Cin, 3], split): U_j = G g computed in double, rounded
+ *          once, stored fragment-major [M'/32][Cin'/8][8][64 lanes][4] (split as in tspn_pack_conv3_f32)
+ * In the K = 2048-deep contraction of the headline config its fp32 error is that of F(4,3) (the accumulation over
+ * the channels dominates; tests/test_gpu_wino63.py).  Needs Cin % 32 == 0, M % 32 == 0, 16-byte aligned operands.
+ * tspn_forward_fused_f32 runs it for conv_algo 4.                                                           */
+int tspn_pack_conv3_wino63_frag_f32(const float* W, int64_t M, int64_t Cin, int64_t split, float* frag,
+                                    void* stream);
+size_t tspn_conv3_tc_wino63_workspace_bytes(int64_t B, int64_t T, int64_t Cin);
+int tspn_conv3_tc_wino63_f32(const float* x, int64_t B, int64_t T, int64_t Cin, const float* frag,
+                             int64_t M, const float* bias, int relu, float* y,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
+
 
 /* ---- a8/a10: relationness + span-regression heads -----------------------
  * Replaces duration_pred (lib/modeling/relpn/dpn.py:71) and relness_pred
@@ -310,7 +327,9 @@ typedef struct tspn_fused_desc {
   int64_t conv_algo;           /* 0 = direct k=3 taps; 1 = Winograd F(2,3) (needs T even, D % 16 == 0);
                                   2 = Winograd F(4,3): conv_packed = tspn_pack_conv3_wino43_f32(..., split=D): [6][D][2C]
                                   3 = Winograd F(4,3) on fragment-major weights: conv_packed =
-                                      tspn_repack_wino43_frag_f32(packed6 of algo 2, D, 2C) */
+                                      tspn_repack_wino43_frag_f32(packed6 of algo 2, D, 2C)
+                                  4 = Winograd F(6,3): conv_packed = tspn_pack_conv3_wino63_frag_f32(conv.weight,
+                                      C, C, split = D) (needs D % 32 == 0) */
   const float* conv_bias;      /* [C] */
   const float* head_w;         /* [3A, C]: rows [0,A) relness_pred, [A,3A) duration_pred */
   const float* head_b;         /* [3A] */

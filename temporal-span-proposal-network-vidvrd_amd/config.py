@@ -58,8 +58,9 @@ _DEFAULTS = {
                 # pair's top temporal span instead of the whole segment (model.py:68-73 is a stub)
                 "POOL_TOP_SPAN": False,
                 # build extension: algorithm of the k=3 temporal conv on the GPU (all exact fp32 MFMA):
+                # "winograd6" = F(6,3) (4/9 of the direct MFMA work; falls back to F(4,3) unless D % 32 == 0),
                 # "winograd4" = F(4,3), "winograd2" = F(2,3), "direct"
-                "CONV_ALGO": "winograd4"},
+                "CONV_ALGO": "winograd6"},
     },
     "ETC": {"RANDOM_SEED": 0, "MODEL_DUMP_FILE": "baseline_weights_epoch_100.pt"},
 }

@@ -83,6 +83,16 @@ int wino43v_contract(const void* workspace, int64_t B, int64_t T, int64_t Cin, c
 int conv3_tc_wino43v(const float* x, int64_t B, int64_t T, int64_t Cin, const float* frag, int64_t M,
                      const float* bias, int relu, float* y, int64_t ldy, void* workspace,
                      size_t workspace_bytes, void* stream);
+// Winograd F(6,3) (tspn_wino63.hip): same structure, 8 positions per 6 output frames
+bool wino63_supported(int64_t Cin, int64_t M);
+size_t wino63_workspace_bytes(int64_t B, int64_t T, int64_t Cin);
+int wino63_input_transform(const float* x, int64_t B, int64_t T, int64_t Cin, void* workspace,
+                           size_t workspace_bytes, void* stream);
+int wino63_contract(const void* workspace, int64_t B, int64_t T, int64_t Cin, const float* frag, int64_t M,
+                    const float* bias, int relu, float* y, int64_t ldy, void* stream);
+int conv3_tc_wino63(const float* x, int64_t B, int64_t T, int64_t Cin, const float* frag, int64_t M,
+                    const float* bias, int relu, float* y, int64_t ldy, void* workspace,
+                    size_t workspace_bytes, void* stream);
 int heads_pairgrid(const float* y, int64_t ldt, int64_t B, int64_t N, int64_t C, int64_t T,
                    const float* Wh, const float* bh, int64_t H, float* out, void* stream, float* Wp12 = nullptr);
 inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }

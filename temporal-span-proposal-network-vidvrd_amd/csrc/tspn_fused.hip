@@ -43,7 +43,10 @@ FusedLayout layout_of(const tspn_fused_desc* d) {
   L.lin_bytes = tspn::pair_predicate_workspace_bytes((int64_t)NT, (int64_t)D, d->K);
   L.lin = take(L.lin_bytes);
   // pre-transformed input of the F(4,3) kernel of tspn_wino43v.hip (conv_algo 3 with D % 32 == 0)
-  L.vt_bytes = (D % 32 == 0) ? tspn::wino43v_workspace_bytes((int64_t)NT, (int64_t)T, (int64_t)D) : 0;
+  // (sized for whichever of F(4,3) / F(6,3) needs more: 6/4 against 8/6 of x, padded to 64 tiles)
+  L.vt_bytes = (D % 32 == 0) ? std::max(tspn::wino43v_workspace_bytes((int64_t)NT, (int64_t)T, (int64_t)D),
+                                        tspn::wino63_workspace_bytes((int64_t)NT, (int64_t)T, (int64_t)D))
+                             : 0;
   L.vt = take(L.vt_bytes);
   L.hwp = take(C * 12 * sizeof(float));   // head weights packed [C][12] for the scalar-weight pair stage (H == 12)
   L.total = off;
@@ -113,8 +116,10 @@ extern "C" int tspn_forward_fused_f32(const tspn_fused_desc* d, void* stream) {
   // through a transpose to channels-first [NT,D,T] and the general kernel.
   const bool tc = (D % 16 == 0) && ((reinterpret_cast<uintptr_t>(d->feats) & 15) == 0) &&
                   ((reinterpret_cast<uintptr_t>(d->conv_packed) & 15) == 0);
-  TSPN_REQUIRE(d->conv_algo >= 0 && d->conv_algo <= 3, TSPN_EINVAL,
-               "tspn_forward_fused: conv_algo must be 0, 1, 2 or 3");
+  TSPN_REQUIRE(d->conv_algo >= 0 && d->conv_algo <= 4, TSPN_EINVAL,
+               "tspn_forward_fused: conv_algo must be 0 .. 4");
+  TSPN_REQUIRE(d->conv_algo != 4 || (tc && tspn::wino63_supported(D, 2 * C)), TSPN_EUNSUPPORTED,
+               "tspn_forward_fused: conv_algo 4 (Winograd F(6,3)) needs D %% 32 == 0, aligned operands");
   TSPN_REQUIRE(d->conv_algo != 1 || (tc && T % 2 == 0), TSPN_EUNSUPPORTED,
                "tspn_forward_fused: conv_algo 1 (Winograd F(2,3)) needs T even, D %% 16 == 0, aligned operands");
   TSPN_REQUIRE(d->conv_algo != 2 || tc, TSPN_EUNSUPPORTED,
@@ -132,8 +137,12 @@ extern "C" int tspn_forward_fused_f32(const tspn_fused_desc* d, void* stream) {
   // the profiling events bracket the MFMA kernel only
   const bool pre_v = d->conv_algo == 3 && tspn::wino43v_supported(D, 2 * C);
   if (pre_v && (rc = tspn::wino43v_input_transform(d->feats, NT, T, D, ws + L.vt, L.vt_bytes, stream))) return rc;
+  if (d->conv_algo == 4 && (rc = tspn::wino63_input_transform(d->feats, NT, T, D, ws + L.vt, L.vt_bytes, stream)))
+    return rc;
   if (d->ev_conv_begin) (void)hipEventRecord(static_cast<hipEvent_t>(d->ev_conv_begin), s);
-  if (pre_v)
+  if (d->conv_algo == 4)
+    rc = tspn::wino63_contract(ws + L.vt, NT, T, D, d->conv_packed, 2 * C, bias2, 0, y, ldy, stream);
+  else if (pre_v)
     rc = tspn::wino43v_contract(ws + L.vt, NT, T, D, d->conv_packed, 2 * C, bias2, 0, y, ldy, stream);
   else if (d->conv_algo == 3)
     rc = tspn::conv3_tc_wino43r(d->feats, NT, T, D, d->conv_packed, 2 * C, bias2, 0, y, ldy, stream);

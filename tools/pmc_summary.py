@@ -70,7 +70,11 @@ def main():
             allsets = {"sets": {}}
     except (OSError, ValueError):
         allsets = {"sets": {}}
-    allsets["sets"][f"{args.workload}:{args.videos}"] = out
+    key = f"{args.workload}:{args.videos}"
+    for k, d in allsets["sets"].get(key, {}).get("kernels", {}).items():
+        # kernels of an earlier pass that this one did not launch (another --conv): keep, with their source
+        out["kernels"].setdefault(k, dict(d, source=d.get("source", allsets["sets"][key].get("source"))))
+    allsets["sets"][key] = out
     with open(path, "w") as fh:
         json.dump(allsets, fh, indent=1, sort_keys=True)
     print(json.dumps(out["kernels"], indent=1)[:1500])
