@@ -499,6 +499,7 @@ def main():
                          "direct_equivalent_tflops": conv_flop_direct / conv_avg_s / 1e12,
                          "flop_per_launch": conv_flop, "avg_launch_ms": conv_avg_s * 1e3,
                          "min_launch_ms": float(np.min(conv_ms)), "max_launch_ms": float(np.max(conv_ms)),
+                         "launch_ms": [round(float(v), 2) for v in conv_ms],
                          "share_of_step": conv_avg_s / (elapsed / args.steps),
                          "clock_mhz": clock_mhz,
                          "frac_at_held_clock": (achieved / (peak * clock_mhz["mean"] / PEAK_CLOCK_MHZ)

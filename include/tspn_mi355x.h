@@ -421,6 +421,22 @@ int tspn_temporal_encoder_heads_f32(const float* x, int64_t P, int64_t C, int64_
                                     const float* head_w, const float* head_b, int64_t H,
                                     float* h_ws, float* out_heads, void* stream);
 
+/* The same on bf16 operands (semantics of tspn_forward_fused_bf16: bf16 x / weights, exact products, fp32
+ * accumulation, relu(conv + b) rounded to bf16 once, fp32 outputs) -- what `DPNHead.bfloat16()` computes
+ * (lib/modeling/relpn/dpn.py:55-73), pinned by golden g8.
+ *   tspn_transpose_cast_bf16   x [P,C,T] fp32 (DPNHead's input layout) -> bf16 channels-last [P,T,C]
+ *   tspn_heads_dense_bf16      out[p][h][t] = head_b[h] + sum_c Wh[h][c] * bf16(relu(y[p][t][c])); y fp32 [P,T,ldm]
+ *   tspn_temporal_encoder_heads_bf16 = tspn_conv3_tc_bf16 (conv_packed = tspn_pack_conv3_bf16(conv.weight, split=0),
+ *                                conv_bias fp32 holding bf16 values or NULL) into y_ws [P,T,C] fp32, then the heads
+ *                                (head_packed = tspn_pack_heads_bf16).  Needs C % 32 == 0, H <= 16.                 */
+int tspn_transpose_cast_bf16(const float* x, int64_t P, int64_t C, int64_t T, uint16_t* out, void* stream);
+int tspn_heads_dense_bf16(const float* y, int64_t ldm, int64_t P, int64_t C, int64_t T,
+                          const uint16_t* head_packed, const float* head_b, int64_t H, float* out, void* stream);
+int tspn_temporal_encoder_heads_bf16(const uint16_t* x_tc, int64_t P, int64_t C, int64_t T,
+                                     const uint16_t* conv_packed, const float* conv_bias,
+                                     const uint16_t* head_packed, const float* head_b, int64_t H,
+                                     float* y_ws, float* out_heads, void* stream);
+
 /* ---- f4 (first slice): RoI feature head ------------------------------------------------------
  * The reference extracts tracklet RoI features with detectron2's R101-C4 model, configured in
  * lib/detectron/trainer.py:23-33 (no code of its own): ROIAlign 14x14 on the res4 map -> res5

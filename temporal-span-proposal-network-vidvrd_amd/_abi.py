@@ -133,6 +133,9 @@ PROTOTYPES = {
     "tspn_span_predicate_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _sz, _vp]),
     "tspn_cast_bf16": (_int, [_vp, _i64, _vp, _vp]),
     "tspn_pack_conv3_bf16": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
+    "tspn_transpose_cast_bf16": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
+    "tspn_heads_dense_bf16": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp]),
+    "tspn_temporal_encoder_heads_bf16": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "tspn_pack_heads_bf16": (_int, [_vp, _i64, _i64, _vp, _vp]),
     "tspn_conv3_tc_bf16": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _vp]),
     "tspn_heads_pairgrid_bf16": (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp]),

@@ -557,6 +557,80 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void heads_pairgrid_bf16_
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Dense (reference-faithful) bf16 form: DPNHead on a materialised pair tensor.
+// x [P, C, T] fp32 (the layout DPNHead.forward is handed, dpn.py:69) -> bf16 channels-last [P, T, C]
+__global__ __launch_bounds__(256) void transpose_cast_bf16_kernel(const float* __restrict__ x, int C, int T,
+                                                                  __bf16* __restrict__ out) {
+  __shared__ float tile[32][33];
+  const int p = blockIdx.z, c0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const float* xp = x + (int64_t)p * C * T;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, t = t0 + tx;
+    tile[ty + 8 * i][tx] = (c < C && t < T) ? xp[(int64_t)c * T + t] : 0.f;
+  }
+  __syncthreads();
+  __bf16* op = out + (int64_t)p * T * C;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int t = t0 + ty + 8 * i, c = c0 + tx;
+    if (t < T && c < C) op[(int64_t)t * C + c] = (__bf16)tile[tx][ty + 8 * i];
+  }
+}
+
+// out[p][h][t] = bh[h] + sum_c Wh[h][c] * bf16(relu(y[p][t][c])) on v_mfma_f32_16x16x32_bf16; y fp32 channels-last
+// [P, T, ldm] (the conv kernel's output, bias included).  Wave = (pair, 16 frames): lane (f, kq) reads channels
+// 8 kq .. 8 kq + 7 of frame f per k-step of 32 channels -- the 16 lanes of a kq group cover 16 full 128-byte lines
+// between the four groups.  HBM-bound by construction (y is read once), four k-steps in flight per wave.
+__global__ __launch_bounds__(256) void heads_dense_bf16_kernel(
+    const float* __restrict__ y, int64_t ldm, int64_t P, int C, int T, const __bf16* __restrict__ Whp,
+    const float* __restrict__ bh, int H, float* __restrict__ out, int nfb) {
+  const int lane = threadIdx.x & 63;
+  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= P * nfb) return;
+  const int64_t p = item / nfb;
+  const int fb = (int)(item - p * nfb);
+  const int f = lane & 15, kq = lane >> 4;
+  const int t0 = fb * 16;
+  const int t = min(t0 + f, T - 1);
+  const float* src = y + (p * T + t) * ldm + 8 * kq;
+  const bf16x8* wsrc = reinterpret_cast<const bf16x8*>(Whp) + lane;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int nk = C / HP_KC;
+  int k = 0;
+  for (; k + 4 <= nk; k += 4) {
+    f32x4 b0[4], b1[4];
+    bf16x8 w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      b0[j] = *reinterpret_cast<const f32x4*>(src + (k + j) * HP_KC);
+      b1[j] = *reinterpret_cast<const f32x4*>(src + (k + j) * HP_KC + 4);
+      w[j] = wsrc[(k + j) * 64];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const u32x4 pk = {relu_pack(b0[j][0], b0[j][1]), relu_pack(b0[j][2], b0[j][3]), relu_pack(b1[j][0], b1[j][1]),
+                        relu_pack(b1[j][2], b1[j][3])};
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j], __builtin_bit_cast(bf16x8, pk), acc, 0, 0, 0);
+    }
+  }
+  for (; k < nk; ++k) {
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(src + k * HP_KC);
+    const f32x4 b1 = *reinterpret_cast<const f32x4*>(src + k * HP_KC + 4);
+    const u32x4 pk = {relu_pack(b0[0], b0[1]), relu_pack(b0[2], b0[3]), relu_pack(b1[0], b1[1]), relu_pack(b1[2], b1[3])};
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wsrc[k * 64], __builtin_bit_cast(bf16x8, pk), acc, 0, 0, 0);
+  }
+  if (t0 + f < T) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int h = 4 * kq + r;
+      if (h < H) out[(p * H + h) * T + t0 + f] = acc[r] + bh[h];
+    }
+  }
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -675,6 +749,52 @@ extern "C" int tspn_heads_pairgrid_bf16(const float* y, int64_t ldm, int64_t B, 
                        reinterpret_cast<const __bf16*>(head_packed), head_b, (int)H, out, (int)nsb, (int)nsb,
                        (int)nfb);
   return tspn::check_launch("tspn_heads_pairgrid_bf16");
+}
+
+extern "C" int tspn_transpose_cast_bf16(const float* x, int64_t P, int64_t C, int64_t T, uint16_t* out, void* stream) {
+  TSPN_REQUIRE(P >= 0 && C > 0 && T > 0 && C < (1 << 24) && T < (1 << 24) && P < 65536 * 32768LL, TSPN_EINVAL,
+               "tspn_transpose_cast_bf16: bad sizes P=%lld C=%lld T=%lld", (long long)P, (long long)C, (long long)T);
+  if (P == 0) return TSPN_OK;
+  TSPN_REQUIRE(x && out, TSPN_EINVAL, "tspn_transpose_cast_bf16: null pointer");
+  // gridDim.z <= 65535: pairs in slabs
+  for (int64_t p0 = 0; p0 < P; p0 += 65535) {
+    const int64_t np = std::min<int64_t>(65535, P - p0);
+    hipLaunchKernelGGL(transpose_cast_bf16_kernel,
+                       dim3((unsigned)tspn::ceil_div(T, 32), (unsigned)tspn::ceil_div(C, 32), (unsigned)np), dim3(256), 0,
+                       TSPN_STREAM(stream), x + p0 * C * T, (int)C, (int)T, reinterpret_cast<__bf16*>(out) + p0 * T * C);
+  }
+  return tspn::check_launch("tspn_transpose_cast_bf16");
+}
+
+extern "C" int tspn_heads_dense_bf16(const float* y, int64_t ldm, int64_t P, int64_t C, int64_t T,
+                                     const uint16_t* head_packed, const float* head_b, int64_t H, float* out,
+                                     void* stream) {
+  TSPN_REQUIRE(P >= 0 && C > 0 && T > 0 && H > 0 && H <= 16 && ldm >= C, TSPN_EINVAL,
+               "tspn_heads_dense_bf16: bad sizes P=%lld C=%lld T=%lld H=%lld ldm=%lld", (long long)P, (long long)C,
+               (long long)T, (long long)H, (long long)ldm);
+  if (P == 0) return TSPN_OK;
+  TSPN_REQUIRE(y && head_packed && head_b && out, TSPN_EINVAL, "tspn_heads_dense_bf16: null pointer");
+  TSPN_REQUIRE(C % HP_KC == 0 && ldm % 4 == 0 && aligned16(y) && aligned16(head_packed), TSPN_EUNSUPPORTED,
+               "tspn_heads_dense_bf16: needs C %% 32 == 0, ldm %% 4 == 0, 16-byte aligned y / weights");
+  const int64_t nfb = tspn::ceil_div(T, 16);
+  const int64_t blocks = tspn::ceil_div(P * nfb, 4);
+  TSPN_REQUIRE(blocks < (1LL << 31) && C < (1 << 24) && T < (1 << 24), TSPN_EUNSUPPORTED,
+               "tspn_heads_dense_bf16: problem too large");
+  hipLaunchKernelGGL(heads_dense_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, TSPN_STREAM(stream), y, ldm, P,
+                     (int)C, (int)T, reinterpret_cast<const __bf16*>(head_packed), head_b, (int)H, out, (int)nfb);
+  return tspn::check_launch("tspn_heads_dense_bf16");
+}
+
+extern "C" int tspn_temporal_encoder_heads_bf16(const uint16_t* x_tc, int64_t P, int64_t C, int64_t T,
+                                                const uint16_t* conv_packed, const float* conv_bias,
+                                                const uint16_t* head_packed, const float* head_b, int64_t H,
+                                                float* y_ws, float* out_heads, void* stream) {
+  TSPN_REQUIRE(P >= 0 && C > 0 && T > 0 && H > 0, TSPN_EINVAL, "tspn_temporal_encoder_heads_bf16: bad sizes");
+  if (P == 0) return TSPN_OK;
+  TSPN_REQUIRE(x_tc && conv_packed && head_packed && head_b && y_ws && out_heads, TSPN_EINVAL,
+               "tspn_temporal_encoder_heads_bf16: null pointer");
+  if (int rc = tspn_conv3_tc_bf16(x_tc, P, T, C, conv_packed, C, conv_bias, y_ws, C, stream)) return rc;
+  return tspn_heads_dense_bf16(y_ws, C, P, C, T, head_packed, head_b, H, out_heads, stream);
 }
 
 // ---- whole pass ---------------------------------------------------------------------------------

@@ -16,6 +16,7 @@ __all__ = [
     "pair_gather", "pack_conv3", "conv3", "conv3_tc", "pack_conv3_wino", "conv3_tc_wino", "pack_conv3_wino43", "conv3_tc_wino43", "repack_wino43_frag", "conv3_tc_wino43r", "conv3_tc_wino43v", "pack_conv3_wino63", "conv3_tc_wino63", "heads", "heads_pairgrid", "temporal_mean", "pair_rows", "transpose_td",
     "forward_fused", "temporal_encoder_heads", "fused_workspace_bytes", "decode_topk", "decode_spans",
     "cast_bf16", "pack_conv3_bf16", "pack_heads_bf16", "conv3_tc_bf16", "heads_pairgrid_bf16",
+    "transpose_cast_bf16", "temporal_encoder_heads_bf16",
     "temporal_mean_bf16", "forward_fused_bf16", "span_predicate",
     "proposal_pair_filter", "gather_rows",
     "pack_conv2d", "pack_conv2d_frag", "conv2d_nhwc", "roi_align_nhwc", "pack_conv2d_frag_bf16", "conv2d_nhwc_bf16", "max_pool_nhwc", "pack_conv2d_frag_cin4", "conv2d_nhwc_cin4",
@@ -760,6 +761,38 @@ def conv3_tc_bf16(x, packed, bias=None, ldm=None):
     y = torch.empty((B, T, ldm), dtype=torch.float32, device=x.device)
     _abi.check(_abi.lib().tspn_conv3_tc_bf16(_p(x), B, T, Cin, _p(packed), M, _p(bias), _p(y), ldm, _stream()))
     return y
+
+
+def transpose_cast_bf16(x):
+    """x fp32 [P,C,T] (DPNHead's input layout) -> bf16 channels-last [P,T,C] (tspn_transpose_cast_bf16)."""
+    _dev(x, "x")
+    P, C, T = x.shape
+    out = torch.empty((P, T, C), dtype=torch.bfloat16, device=x.device)
+    _abi.check(_abi.lib().tspn_transpose_cast_bf16(_p(x), P, C, T, _p(out), _stream()))
+    return out
+
+
+def temporal_encoder_heads_bf16(x, conv_packed, conv_bias, head_packed, head_b, H, y_ws=None):
+    """DPNHead.forward (dpn.py:69-73) on bf16 operands: x fp32 [P,C,T] (transposed and rounded here) or bf16
+    channels-last [P,T,C]; conv_packed = pack_conv3_bf16(conv.weight) (no split), head_packed =
+    pack_heads_bf16(cat(relness, duration weights)); biases fp32 holding bf16 values -> heads fp32 [P,H,T]."""
+    if x.dtype == torch.float32:
+        x = transpose_cast_bf16(x.contiguous())
+    _dev(x, "x", torch.bfloat16); _dev(conv_packed, "conv_packed", torch.bfloat16)
+    _dev(head_packed, "head_packed", torch.bfloat16); _dev(head_b, "head_b")
+    if conv_bias is not None:
+        _dev(conv_bias, "conv_bias")
+    P, T, C = x.shape
+    if tuple(conv_packed.shape) != (3, C // 8, C, 8) or tuple(head_packed.shape) != (C // 8, 16, 8):
+        raise ValueError(f"temporal_encoder_heads_bf16: packed weights do not match C={C}")
+    if head_b.numel() != H:
+        raise ValueError("temporal_encoder_heads_bf16: head_b must have H entries")
+    if y_ws is None:
+        y_ws = torch.empty((P, T, C), dtype=torch.float32, device=x.device)
+    out = torch.empty((P, H, T), dtype=torch.float32, device=x.device)
+    _abi.check(_abi.lib().tspn_temporal_encoder_heads_bf16(
+        _p(x), P, C, T, _p(conv_packed), _p(conv_bias), _p(head_packed), _p(head_b), H, _p(y_ws), _p(out), _stream()))
+    return out
 
 
 def heads_pairgrid_bf16(y, B, N, head_packed, head_b, H):

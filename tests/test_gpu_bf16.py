@@ -367,3 +367,72 @@ def test_fused_passes_are_graph_capturable(tspn, device):
     torch.cuda.synchronize()
     rh, rl = tspn.ops.forward_fused_bf16(f_b.to(torch.bfloat16), pairs, B, N, p16, w["conv_b"], h16, hb, w["cls_w"], w["cls_b"])
     assert torch.equal(out["h"], rh) and torch.equal(out["l"], rl)
+
+
+@pytest.mark.parametrize("tag", list(cases.G3_SHAPES))
+def test_dense_bf16_encoder_heads_vs_reference_bf16_modules_g8(tspn, device, tag):
+    """tspn_temporal_encoder_heads_bf16 (the reference-faithful dense form on a materialised [P,C,T]) against
+    golden g8 = the reference's own DPNHead cast with .bfloat16() (dpn.py:55-73, torch CPU bf16 kernels) on the G3
+    inputs: rounding the HIP output to bf16 reproduces the reference's output on (nearly) every element and never
+    differs by more than two bf16 ulps; against the oracle's unrounded restatement within fp32 accumulation."""
+    g = cases.load("g8_bf16.npz")
+    c = cases.g3_inputs(tag)
+    sd = {k: t(v) for k, v in c["state_dict"].items()}
+    x = t(c["x"])
+    P, C, T = x.shape
+    d = lambda v: v.to(device).contiguous()   # noqa: E731
+    hw = torch.cat([sd[DPN_PRE + "relness_pred.weight"][:, :, 0], sd[DPN_PRE + "duration_pred.weight"][:, :, 0]])
+    hb = torch.cat([sd[DPN_PRE + "relness_pred.bias"], sd[DPN_PRE + "duration_pred.bias"]])
+    A = sd[DPN_PRE + "relness_pred.bias"].numel()
+    out = tspn.ops.temporal_encoder_heads_bf16(
+        d(x), tspn.ops.pack_conv3_bf16(d(sd[DPN_PRE + "conv.weight"])), d(r16(sd[DPN_PRE + "conv.bias"])),
+        tspn.ops.pack_heads_bf16(d(hw)), d(r16(hb)), 3 * A).cpu()
+    assert out.shape == (P, 3 * A, T)
+    ref = g[f"{tag}_duration"]
+    dur = out[:, A:]
+    same = (oracle.bf16_round(dur).numpy() == ref).mean()
+    assert same > 0.999, same
+    ulp = np.maximum(np.abs(ref), 2.0 ** -126) * 2.0 ** -7
+    assert np.all(np.abs(dur.numpy() - ref) <= 2 * ulp)
+    rel_o, dur_o, _ = oracle.dpn_head_bf16(x, sd[DPN_PRE + "conv.weight"], sd[DPN_PRE + "conv.bias"],
+                                           sd[DPN_PRE + "duration_pred.weight"], sd[DPN_PRE + "duration_pred.bias"],
+                                           sd[DPN_PRE + "relness_pred.weight"], sd[DPN_PRE + "relness_pred.bias"])
+    exp = torch.cat([rel_o, dur_o], dim=1)
+    scale = float(exp.abs().max())
+    # a bf16 activation that sits on a rounding boundary may flip by one ulp (2^-8 relative) between fp32 and
+    # float64 accumulation of the conv: a few elements move by up to |w_head| * ulp
+    assert float((out - exp).abs().max()) <= 2e-3 * scale
+    assert float((out - exp).abs().mean()) <= 2e-6 * scale
+
+
+def test_dense_bf16_pieces_ragged_and_errors(tspn, device):
+    """transpose_cast_bf16 is bit-exact; heads_dense on ragged T (not a multiple of 16) and H < 16 against float64;
+    channels-last bf16 input is accepted as is; bad shapes raise."""
+    P, C, T, H = 5, 96, 37, 12
+    x = tspn.hashrng.uniform(91, "x", (P, C, T), -1, 1)
+    xt = tspn.ops.transpose_cast_bf16(t(x).to(device))
+    assert xt.shape == (P, T, C) and xt.dtype == torch.bfloat16
+    assert torch.equal(xt.cpu().view(torch.int16), t(x).transpose(1, 2).contiguous().to(torch.bfloat16).view(torch.int16))
+    cw = tspn.hashrng.normal(91, "cw", (C, C, 3), std=0.08)
+    cb = r16(tspn.hashrng.normal(91, "cb", (C,), std=0.1))
+    hw = tspn.hashrng.normal(91, "hw", (H, C), std=0.1)
+    hb = r16(tspn.hashrng.normal(91, "hb", (H,), std=0.1))
+    d = lambda v: v.to(device).contiguous()   # noqa: E731
+    packed, hp = tspn.ops.pack_conv3_bf16(d(t(cw))), tspn.ops.pack_heads_bf16(d(t(hw)))
+    out = tspn.ops.temporal_encoder_heads_bf16(d(t(x)), packed, d(cb), hp, d(hb), H).cpu()
+    out2 = tspn.ops.temporal_encoder_heads_bf16(xt, packed, d(cb), hp, d(hb), H).cpu()
+    assert torch.equal(out, out2)
+    h = torch.nn.functional.conv1d(r16(x).double(), r16(cw).double(), cb.double(), padding=1)
+    h = oracle.bf16_round(torch.relu(h).float()).double()
+    exp = torch.einsum("hc,pct->pht", r16(hw).double(), h) + hb.double()[None, :, None]
+    scale = float(exp.abs().max())
+    assert float((out.double() - exp).abs().max()) <= 2e-3 * scale
+    assert float((out.double() - exp).abs().mean()) <= 2e-6 * scale
+    with pytest.raises(ValueError):
+        tspn.ops.temporal_encoder_heads_bf16(d(t(x)), packed, d(cb), hp, d(hb), H - 1)
+    with pytest.raises(RuntimeError):   # C % 32 != 0 is refused by the library
+        x2 = t(tspn.hashrng.uniform(92, "x", (2, 48, 8), -1, 1))
+        tspn.ops.temporal_encoder_heads_bf16(d(x2), tspn.ops.pack_conv3_bf16(d(t(tspn.hashrng.normal(92, "w", (48, 48, 3))))),
+                                             None, tspn.ops.pack_heads_bf16(d(t(tspn.hashrng.normal(92, "h", (H, 48))))),
+                                             d(hb), H)
+    assert tspn.ops.temporal_encoder_heads_bf16(d(t(x[:0])), packed, d(cb), hp, d(hb), H).shape == (0, H, T)
