@@ -60,8 +60,8 @@ TOPK_PAIR, TOPK_SEG, TOPK_PPN = 20, 200, 256   # PREDICT.TOPK_PER_PAIR / TOPK_PE
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--videos", type=int, default=None,
                     help="videos per GPU per step (default: 16 for cfg2, 64 for cfg4, 4 for cfg3)")
     ap.add_argument("--batches", type=int, default=2,
