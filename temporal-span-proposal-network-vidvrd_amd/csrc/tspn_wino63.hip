@@ -60,10 +60,11 @@ constexpr int NVB = 2;                    // ring of super-stage buffers
 constexpr int NPIECE = 16;                // DMA pieces (1 KiB) per wave and super-stage: 64 / 4
 constexpr size_t SMEM_BYTES = sizeof(float) * NVB * VSS;
 #ifndef TSPN_WINO63_GM
-// Weight panels (128 rows) per tile group.  Measured on one box at cfg2:16 (kernel + pre-pass, ms / FETCH_SIZE
-// M KiB): 1: 26.62 / 37.1, 2: 26.43 / 42.6, 3: 27.21 / 50.1, 4: 27.20 / 53.2, 6: 28.48 / 57.5, 8: 29.11 / 62.6
-// (tspn_wino43v.hip on the same box: 29.0-29.3 ms).
-#define TSPN_WINO63_GM 2
+// Weight panels (128 rows) per tile group: the 32 workgroups an XCD runs at a time are GM panels x 32 / GM sextet
+// tiles and stream GM x 8.4 MB of weights + 32 / GM x 4.2 MB of V through its L2 -- least for GM = 4 (67 MB per
+// round, 26.9 GB per launch at cfg2:16).  Measured on one box (kernel + pre-pass ms / FETCH_SIZE M KiB):
+// 1: 24.20 / 28.2, 2: 23.76 / 16.8, 3: 23.94 / 14.8, 4: 23.76 / 13.4, 8: 24.33 / 16.4.
+#define TSPN_WINO63_GM 4
 #endif
 
 #ifndef TSPN_WINO63_VAUX
