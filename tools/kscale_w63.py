@@ -1,5 +1,10 @@
-import os, sys
-sys.path.insert(0, "/root/repo")
+#!/usr/bin/env python3
+"""How much of the F(6,3) conv's run time does not scale with the channel count (output transform + stores, launch,
+first burst): the kernel at Cin = 512 .. 4096 on the cfg2 column shape; 2 t(K) - t(2K) is the K-independent part."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import tspn_mi355x as tspn
 dev = torch.device("cuda", 0)
