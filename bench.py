@@ -28,7 +28,7 @@ DECODED per-video results — top-200 (score, triplet, pair) + top-256 pair prop
 
 Printed JSON (rank 0): see the task contract; extras:
   roofline     dominant kernel = the temporal conv of the tracklet projections (fp32 MFMA; Winograd
-               F(6,3) by default, --conv winograd4 | winograd2 | direct for the other algorithms);
+               F(6,3) by default, --conv direct for the direct taps);
                achieved = executed FLOP per launch / HIP-event time of that launch inside the
                timed steps (events recorded on the launch stream by the C ABI's hook);
                clock_mhz = shader clock sampled from the driver while the timed steps ran (box-to-box
@@ -68,15 +68,12 @@ def parse():
                     help="different input batches resident in HBM, rotated step by step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-runs", type=int, default=5, help="timed runs of the CPU baseline (median reported)")
-    ap.add_argument("--conv", choices=["winograd6", "winograd4", "winograd2", "winograd", "direct"], default="winograd6",
-                    help="temporal-conv algorithm of the tracklet projections (all fp32 MFMA): Winograd F(6,3) "
-                         "(default), F(4,3), F(2,3) (= winograd), direct taps")
+    ap.add_argument("--conv", choices=["winograd6", "direct"], default="winograd6",
+                    help="temporal-conv algorithm of the tracklet projections (both fp32 MFMA): Winograd F(6,3) "
+                         "(default, what RELPN.DPN.CONV_ALGO = auto selects at this shape) or the direct taps")
     ap.add_argument("--workload", choices=["cfg2", "cfg3", "cfg4"], default="cfg2",
                     help="cfg2 = headline (N=32,T=150,D=2048, fp32, 16 videos/GPU/step); cfg4 = its 64-videos-per-GPU "
                          "shard of the 512-video batch; cfg3 = N=64,T=900,D=1024 bf16 operands")
-    ap.add_argument("--canonical-weights", action="store_true",
-                    help="winograd4 only: keep the canonical [6][D][2C] weights (LDS-staged kernel "
-                         "conv3_wino43_cl_kernel) instead of the fragment-major default")
     ap.add_argument("--gather", choices=["decoded", "logits"], default="decoded",
                     help="payload of the N>1 result gather: decoded top-k results (default) or raw logits")
     ap.add_argument("--force-collective", action="store_true",
@@ -173,8 +170,7 @@ def pmc_traffic(workload, videos, conv):
     "<workload>:<videos per launch>"); null if this step size was not measured.  PMC counters cannot be
     read from inside the process."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    kernel = {"winograd4": "conv3_wino43v_kernel", "winograd6": "conv3_wino63_kernel", "winograd4c": "conv3_wino43_cl_kernel",
-              "winograd2": "conv3_wino2_cl_kernel", "bf16": "conv3_bf16_big_kernel"}.get(conv, "conv3_mfma_cl_kernel")
+    kernel = {"winograd6": "conv3_wino63_kernel", "bf16": "conv3_bf16_big_kernel"}.get(conv, "conv3_mfma_cl_kernel")
     try:
         data = json.load(open(path))
         ms = data["sets"][f"{'cfg2' if workload == 'cfg4' else workload}:{videos}"]
@@ -301,13 +297,7 @@ def main():
     if bf16:
         packed = tspn.ops.pack_conv3_bf16(conv_w, split=D)
     else:
-        if args.conv == "winograd":
-            args.conv = "winograd2"
-        packed = {"direct": tspn.ops.pack_conv3, "winograd2": tspn.ops.pack_conv3_wino,
-                  "winograd4": tspn.ops.pack_conv3_wino43, "winograd6": tspn.ops.pack_conv3_wino63}[args.conv](
-                      conv_w, split=D)
-        if args.conv == "winograd4" and not args.canonical_weights:
-            packed = tspn.ops.repack_wino43_frag(packed)   # fragment-major: registers-direct kernel
+        packed = {"direct": tspn.ops.pack_conv3, "winograd6": tspn.ops.pack_conv3_wino63}[args.conv](conv_w, split=D)
     del conv_w
     conv_b = d(wnp["conv_b"])
     head_w = d(np.concatenate([wnp["rel_w"][:, :, 0], wnp["dur_w"][:, :, 0]]))
@@ -438,11 +428,8 @@ def main():
     conv_ms = [a.elapsed_time(b) for a, b in events[args.warmup:]]
     conv_avg_s = float(np.mean(conv_ms)) * 1e-3
     conv_flop_direct = 2.0 * (2 * C) * (3 * D) * (B * N * T)  # M=2C, K=3D, columns=B*N*T
-    # Winograd F(2,3) issues 4 channel-GEMMs on half the columns: 2/3 of the direct MFMA work;
-    # F(4,3) issues 6 on a quarter of the columns (ceil(T/4) quads per tracklet): 1/2
-    # F(6,3) issues 8 on a sixth of the columns (ceil(T/6) sextets per tracklet): 4/9
-    frac = {"direct": 1.0, "winograd2": 2.0 / 3.0, "winograd4": 0.5 * (4 * -(-T // 4)) / T,
-            "winograd6": (4.0 / 9.0) * (6 * -(-T // 6)) / T}[args.conv]
+    # F(6,3) issues 8 channel-GEMMs on a sixth of the columns (ceil(T/6) sextets per tracklet): 4/9 of the direct work
+    frac = {"direct": 1.0, "winograd6": (4.0 / 9.0) * (6 * -(-T // 6)) / T}[args.conv]
     conv_flop = conv_flop_direct * (1.0 if bf16 else frac)
     achieved = conv_flop / conv_avg_s / 1e12
     peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
@@ -476,26 +463,18 @@ def main():
                                   else ""),
                        "dense_equivalent_gflop_per_pair": (2.0 * T * C * (3 * C + 3 * A_ANCH) + 2.0 * C * K_PRED) / 1e9,
                        "conv_algo": "direct" if bf16 else args.conv,
-                       "executed_gflop_per_pair": (conv_flop + 2.0 * P * T * C * 16 + 2.0 * P * C * K_PRED) / P / 1e9},
+                       "executed_gflop_per_pair": (conv_flop + 2.0 * P * T * C * 3 * A_ANCH + 2.0 * P * C * K_PRED) / P / 1e9},
             "roofline": {"bound": "mfma",
                          "kernel": ("conv3_bf16_big_kernel (tracklet projections: k=3 conv as bf16 32x32x16 MFMA "
                                     "implicit GEMM, M=2C, K=3D)" if bf16 else
-                                    ("conv3_wino43_cl_kernel" if args.canonical_weights else "conv3_wino43v_kernel") +
-                                    " (tracklet projections: k=3 conv, Winograd F(4,3), "
-                                    "fp32 32x32x2 MFMA, M=2C, 6 channel-GEMMs of K=D on a quarter of the columns)"
-                                    if args.conv == "winograd4" else
                                     "conv3_wino63_kernel (tracklet projections: k=3 conv, Winograd F(6,3), fp32 32x32x2 "
                                     "MFMA, M=2C, 8 channel-GEMMs of K=D on a sixth of the columns)"
                                     if args.conv == "winograd6" else
-                                    "conv3_wino2_cl_kernel (tracklet projections: k=3 conv, Winograd F(2,3), "
-                                    "fp32 32x32x2 MFMA, M=2C, 4 channel-GEMMs of K=D on half the columns)"
-                                    if args.conv == "winograd2" else
                                     "conv3_mfma_cl_kernel (tracklet projections: k=3 conv as fp32 32x32x2 "
                                     "MFMA implicit GEMM, M=2C, K=3D)"),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak,
-                         **pmc_traffic(args.workload, B, "bf16" if bf16 else (
-                             "winograd4c" if (args.conv == "winograd4" and args.canonical_weights) else args.conv)),
+                         **pmc_traffic(args.workload, B, "bf16" if bf16 else args.conv),
                          "direct_equivalent_tflops": conv_flop_direct / conv_avg_s / 1e12,
                          "flop_per_launch": conv_flop, "avg_launch_ms": conv_avg_s * 1e3,
                          "min_launch_ms": float(np.min(conv_ms)), "max_launch_ms": float(np.max(conv_ms)),

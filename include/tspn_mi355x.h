@@ -35,8 +35,10 @@ extern "C" {
 
 /* Bumped whenever a struct layout or a signature changes (2: tspn_fused_desc gained conv_algo /
  * canonical_pairs in round 1 without a bump; round 2 adds the struct-size exports below, which the
- * host checks against its own view of the descriptors at load time; 3: tspn_fused_desc.ev_logits_ready). */
-#define TSPN_ABI_VERSION 3
+ * host checks against its own view of the descriptors at load time; 3: tspn_fused_desc.ev_logits_ready;
+ * 4 (round 3): the Winograd F(2,3) and the three F(4,3) temporal-conv generations and their pack / repack
+ * entry points are gone, tspn_fused_desc.conv_algo is TSPN_CONV_DIRECT | TSPN_CONV_WINOGRAD63).            */
+#define TSPN_ABI_VERSION 4
 
 enum {
   TSPN_OK = 0,
@@ -47,6 +49,12 @@ enum {
 };
 
 #define TSPN_GEOM_CHANNELS 8
+
+/* tspn_fused_desc.conv_algo: which temporal-conv kernel consumes `conv_packed` (the packing IS the choice) */
+enum {
+  TSPN_CONV_DIRECT = 0,      /* conv_packed = tspn_pack_conv3_f32(conv.weight, C, C, split = D): [3][D][2C]; any shape */
+  TSPN_CONV_WINOGRAD63 = 1   /* conv_packed = tspn_pack_conv3_wino63_frag_f32(conv.weight, C, C, split = D); D % 32 == 0 */
+};
 
 int tspn_version(void);
 /* sizeof(tspn_fused_desc) / sizeof(tspn_fused_bf16_desc) as this library was compiled: a host whose
@@ -176,56 +184,18 @@ int tspn_conv3_tc_f32(const float* x, int64_t B, int64_t T, int64_t Cin,
                       const float* packed, int64_t M, const float* bias, int relu,
                       float* y, void* stream);
 
-/* Winograd F(2,3) form of tspn_conv3_tc_f32 (two output frames from four inputs: 2/3 of the MFMA
- * work, same result up to fp32 rounding, |diff| ~ 1e-6).  `packed4`[4][Cin'][M'] comes from
- * tspn_pack_conv3_wino_f32 (same `split` rule as tspn_pack_conv3_f32; 4*M*Cin floats):
- *   U0 = g0, U1 = (g0+g1+g2)/2, U2 = (g0-g1+g2)/2, U3 = g2   (g_tap = W[:, :, tap], rounded from fp64).
- * Needs T even, Cin % 8 == 0, M % 4 == 0, 16-byte aligned x / packed4 (else TSPN_EUNSUPPORTED).   */
-int tspn_pack_conv3_wino_f32(const float* W, int64_t M, int64_t Cin, int64_t split,
-                             float* packed4, void* stream);
-int tspn_conv3_tc_wino_f32(const float* x, int64_t B, int64_t T, int64_t Cin,
-                           const float* packed4, int64_t M, const float* bias, int relu,
-                           float* y, void* stream);
-
-/* Winograd F(4,3) form of the same conv: 4 output frames from 6 inputs, 6 channel-GEMMs on a quarter of the
- * columns = half the MFMA work of the direct form.  packed6 = tspn_pack_conv3_wino43_f32(W, M, Cin, split,
- * ...) -> [6][Cp][Mp] (G g, from fp64).  Any T (a tracklet's last quad is masked); needs Cin % 8 == 0,
- * M % 4 == 0.  fp32 error within ~2.5x of the direct form's own rounding error (tspn_wino43.hip). */
-int tspn_pack_conv3_wino43_f32(const float* W, int64_t M, int64_t Cin, int64_t split, float* packed6,
-                               void* stream);
-int tspn_conv3_tc_wino43_f32(const float* x, int64_t B, int64_t T, int64_t Cin, const float* packed6,
-                             int64_t M, const float* bias, int relu, float* y, void* stream);
-
-/* Same F(4,3) arithmetic on FRAGMENT-MAJOR weights (tspn_wino43r.hip): the A operands of one (32-row
- * block, 8-channel chunk, position j) are one contiguous 1-KiB line, which the kernel loads straight into
- * MFMA operand registers (no LDS transit for weights, one barrier per chunk).
- *   frag[M/32][Cin/8][6][64 lanes = 32 kh + li][4 e] = packed6[j][8 chunk + 4 kh + e][32 (m/32) + li]
- * tspn_repack_wino43_frag_f32 converts the canonical packed6 (6*Cin*M floats, out of place).  Needs
- * Cin % 8 == 0 and M % 32 == 0 (else TSPN_EUNSUPPORTED: use the canonical kernel).  Results are
- * bit-identical to tspn_conv3_tc_wino43_f32 (same contraction order). */
-int tspn_repack_wino43_frag_f32(const float* packed6, int64_t Cin, int64_t M, float* frag, void* stream);
-int tspn_conv3_tc_wino43r_f32(const float* x, int64_t B, int64_t T, int64_t Cin, const float* frag,
-                              int64_t M, const float* bias, int relu, float* y, void* stream);
-/* The same convolution with the input transform V = B^T d taken OUT of the MFMA kernel (on
- * gfx950 fp32 MFMA and VALU instructions do not overlap on a SIMD, so the 24 VALU per chunk of the in-kernel
- * transform cost 6 % of the launch): a first HBM-bound kernel writes V [Cin/4][6][quads padded to 32][4] into
- * `workspace` (tspn_conv3_tc_wino43v_workspace_bytes), the MFMA kernel stages it by LDS-DMA.  Bit-identical
- * to tspn_conv3_tc_wino43r_f32 / tspn_conv3_tc_wino43_f32.  Needs Cin % 32 == 0, M % 32 == 0, 16-byte
- * aligned x / frag / workspace.  This is what tspn_forward_fused_f32 runs for conv_algo 3 when Cin % 32 == 0. */
-size_t tspn_conv3_tc_wino43v_workspace_bytes(int64_t B, int64_t T, int64_t Cin);
-int tspn_conv3_tc_wino43v_f32(const float* x, int64_t B, int64_t T, int64_t Cin, const float* frag,
-                              int64_t M, const float* bias, int relu, float* y,
-                              void* workspace, size_t workspace_bytes, void* stream);
-
-/* Winograd F(6,3) over time (tspn_wino63.hip): six output frames from eight inputs, 8 channel-GEMMs on a sixth of
- * the columns = 4/9 of the direct MFMA work, 12 % less than F(4,3) (and T = 150 tiles exactly: no quad padding).
- * Same structure as tspn_conv3_tc_wino43v_f32: the input transform V = B^T d (points 0, +-1, +-2, +-1/2, inf) is its
- * own pass into `workspace` (tspn_conv3_tc_wino63_workspace_bytes), the MFMA kernel stages it by LDS-DMA.
+/* Winograd F(6,3) form of tspn_conv3_tc_f32 (tspn_wino63.hip): six output frames from eight inputs, 8 channel-GEMMs
+ * on a sixth of the columns = 4/9 of the direct MFMA work (T = 150 tiles exactly: 25 sextets; any T works, a
+ * tracklet's last sextet is masked).  The input transform V = B^T d (points 0, +-1, +-2, +-1/2, inf) is its
+ * own HBM-bound pass into `workspace` (tspn_conv3_tc_wino63_workspace_bytes), the MFMA kernel stages it by LDS-DMA.
  *   frag = tspn_pack_conv3_wino63_frag_f32(conv.weight [M, Cin, 3], split): U_j = G g computed in double, rounded
  *          once, stored fragment-major [M'/32][Cin'/8][8][64 lanes][4] (split as in tspn_pack_conv3_f32)
- * In the K = 2048-deep contraction of the headline config its fp32 error is that of F(4,3) (the accumulation over
- * the channels dominates; tests/test_gpu_wino63.py).  Needs Cin % 32 == 0, M % 32 == 0, 16-byte aligned operands.
- * tspn_forward_fused_f32 runs it for conv_algo 4.                                                           */
+ * fp32 error against float64, measured at K = 3 x 2048 (tests/test_gpu_wino63.py, profiles/r3/conv_error_realistic.txt):
+ * |err| <= 64 eps sum_k |x_k||w_k| per output element (direct form: <= 16 eps ...); on temporally smooth
+ * features it equals the direct form's error, on temporally independent heavy-tailed ones it is up to ~5x larger
+ * (1.3e-5 of max|y|).  Callers that need the direct form's error pass TSPN_CONV_DIRECT (2.25x the MFMA work).
+ * Needs Cin % 32 == 0, M % 32 == 0, 16-byte aligned operands.  tspn_forward_fused_f32 runs it for
+ * conv_algo TSPN_CONV_WINOGRAD63.                                                                           */
 int tspn_pack_conv3_wino63_frag_f32(const float* W, int64_t M, int64_t Cin, int64_t split, float* frag,
                                     void* stream);
 size_t tspn_conv3_tc_wino63_workspace_bytes(int64_t B, int64_t T, int64_t Cin);
@@ -322,14 +292,9 @@ typedef struct tspn_fused_desc {
   int64_t P;
   int64_t canonical_pairs;     /* != 0: `pairs` is the canonical table of tspn_pair_index_i64 for every
                                   video in order (P == B*N*(N-1)): enables the blocked pair stage */
-  const float* conv_packed;    /* conv_algo 0: tspn_pack_conv3_f32(conv.weight [C,C,3], split=D): [3][D][2C]
-                                  conv_algo 1: tspn_pack_conv3_wino_f32(..., split=D):          [4][D][2C] */
-  int64_t conv_algo;           /* 0 = direct k=3 taps; 1 = Winograd F(2,3) (needs T even, D % 16 == 0);
-                                  2 = Winograd F(4,3): conv_packed = tspn_pack_conv3_wino43_f32(..., split=D): [6][D][2C]
-                                  3 = Winograd F(4,3) on fragment-major weights: conv_packed =
-                                      tspn_repack_wino43_frag_f32(packed6 of algo 2, D, 2C)
-                                  4 = Winograd F(6,3): conv_packed = tspn_pack_conv3_wino63_frag_f32(conv.weight,
-                                      C, C, split = D) (needs D % 32 == 0) */
+  const float* conv_packed;    /* packed conv.weight [C,C,3], see TSPN_CONV_* above */
+  int64_t conv_algo;           /* TSPN_CONV_DIRECT (k=3 taps as an implicit GEMM, any shape) or
+                                  TSPN_CONV_WINOGRAD63 (Winograd F(6,3), 4/9 of the MFMA work, D % 32 == 0) */
   const float* conv_bias;      /* [C] */
   const float* head_w;         /* [3A, C]: rows [0,A) relness_pred, [A,3A) duration_pred */
   const float* head_b;         /* [3A] */

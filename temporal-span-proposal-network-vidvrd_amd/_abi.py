@@ -15,13 +15,14 @@ ROOT = os.path.dirname(HERE)
 LIB_PATH = os.environ.get("TSPN_LIB_PATH") or os.path.join(HERE, "libtspn_mi355x.so")
 HEADER_PATH = os.path.join(ROOT, "include", "tspn_mi355x.h")
 
-ABI_VERSION = 3   # TSPN_ABI_VERSION of include/tspn_mi355x.h
+ABI_VERSION = 4   # TSPN_ABI_VERSION of include/tspn_mi355x.h
 TSPN_OK = 0
 TSPN_EINVAL = -1
 TSPN_EUNSUPPORTED = -2
 TSPN_EWORKSPACE = -3
 TSPN_ELAUNCH = -4
 GEOM_CHANNELS = 8
+CONV_DIRECT, CONV_WINOGRAD63 = 0, 1   # tspn_fused_desc.conv_algo
 
 _c_f32p = ctypes.c_void_p   # device pointers travel as integers
 _c_i64p = ctypes.c_void_p
@@ -85,8 +86,6 @@ PROTOTYPES = {
     "tspn_pack_conv3_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "tspn_conv3_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _int, _vp, _vp]),
     "tspn_conv3_tc_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _int, _vp, _vp]),
-    "tspn_pack_conv3_wino_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
-    "tspn_conv3_tc_wino_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _int, _vp, _vp]),
     "tspn_heads_f32": (_int, [_int, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64,
                               _i64, _vp, _vp]),
     "tspn_heads_pairgrid_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp]),
@@ -102,8 +101,6 @@ PROTOTYPES = {
     "tspn_forward_fused_f32": (_int, [ctypes.POINTER(FusedDesc), _vp]),
     "tspn_temporal_encoder_heads_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64,
                                                _vp, _vp, _vp]),
-    "tspn_pack_conv3_wino43_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
-    "tspn_conv3_tc_wino43_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _int, _vp, _vp]),
     "tspn_pack_conv2d_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "tspn_conv2d_nhwc_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp,
                                     _int, _vp, _vp]),
@@ -122,10 +119,6 @@ PROTOTYPES = {
                                         _int, _vp, _vp]),
     "tspn_roi_align_nhwc_f32_bf16out": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, ctypes.c_float, _int,
                                                _int, _vp, _vp]),
-    "tspn_repack_wino43_frag_f32": (_int, [_vp, _i64, _i64, _vp, _vp]),
-    "tspn_conv3_tc_wino43r_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _int, _vp, _vp]),
-    "tspn_conv3_tc_wino43v_workspace_bytes": (_sz, [_i64, _i64, _i64]),
-    "tspn_conv3_tc_wino43v_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _int, _vp, _vp, _sz, _vp]),
     "tspn_pack_conv3_wino63_frag_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "tspn_conv3_tc_wino63_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "tspn_conv3_tc_wino63_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _int, _vp, _vp, _sz, _vp]),

@@ -57,10 +57,10 @@ _DEFAULTS = {
                 # build extension (not in the reference's defaults.py): RelOIPool restricted to each
                 # pair's top temporal span instead of the whole segment (model.py:68-73 is a stub)
                 "POOL_TOP_SPAN": False,
-                # build extension: algorithm of the k=3 temporal conv on the GPU (all exact fp32 MFMA):
-                # "winograd6" = F(6,3) (4/9 of the direct MFMA work; falls back to F(4,3) unless D % 32 == 0),
-                # "winograd4" = F(4,3), "winograd2" = F(2,3), "direct"
-                "CONV_ALGO": "winograd6"},
+                # build extension: algorithm of the k=3 temporal conv on the GPU (both exact fp32 MFMA):
+                # "auto" = Winograd F(6,3) where the shape allows it (D % 32 == 0; 4/9 of the direct MFMA work,
+                # error bound in DESIGN.md §4), else the direct taps; "direct" = always the direct taps
+                "CONV_ALGO": "auto"},
     },
     "ETC": {"RANDOM_SEED": 0, "MODEL_DUMP_FILE": "baseline_weights_epoch_100.pt"},
 }

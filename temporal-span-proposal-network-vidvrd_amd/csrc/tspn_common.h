@@ -52,38 +52,13 @@ struct LdsLimit {
   }
 };
 
-// Weight panels (128 output rows) per tile group of the Winograd conv kernels' XCD-aware tile map:
-// a group sweeps all frame tiles, so x is re-read from beyond L2 once per group.  Measured minimum of
-// the fabric traffic (profiles/r1/conv3_ablation.md); a build-time probe knob, not a run-time switch.
-#ifndef TSPN_WINO_GM
-#define TSPN_WINO_GM 2
-#endif
-constexpr int kWinoPanelGroup = TSPN_WINO_GM;
-
 // Internal (not exported) forms with explicit row strides, shared between translation units.
 // y[b][m][ldy]: the fused driver pads rows of the tracklet projections to a multiple of 4 frames so
 // that the pair stage can stage them with 16-byte LDS-DMA pieces.
 int conv3_tc_direct(const float* x, int64_t B, int64_t T, int64_t Cin, const float* packed, int64_t M,
                     const float* bias, int relu, float* y, int64_t ldy, void* stream);
-int conv3_tc_wino(const float* x, int64_t B, int64_t T, int64_t Cin, const float* packed4, int64_t M,
-                  const float* bias, int relu, float* y, int64_t ldy, void* stream);
-int conv3_tc_wino43(const float* x, int64_t B, int64_t T, int64_t Cin, const float* packed6, int64_t M,
-                    const float* bias, int relu, float* y, int64_t ldy, void* stream);
-// fragment-major weights (tspn_repack_wino43_frag_f32): registers-direct kernel of tspn_wino43r.hip
-bool wino43_frag_supported(int64_t Cin, int64_t M);
-int conv3_tc_wino43r(const float* x, int64_t B, int64_t T, int64_t Cin, const float* frag, int64_t M,
-                     const float* bias, int relu, float* y, int64_t ldy, void* stream);
-// pre-transformed-input form (tspn_wino43v.hip): Cin % 32 == 0, M % 32 == 0; `workspace` holds V
-bool wino43v_supported(int64_t Cin, int64_t M);
-size_t wino43v_workspace_bytes(int64_t B, int64_t T, int64_t Cin);
-int wino43v_input_transform(const float* x, int64_t B, int64_t T, int64_t Cin, void* workspace,
-                            size_t workspace_bytes, void* stream);
-int wino43v_contract(const void* workspace, int64_t B, int64_t T, int64_t Cin, const float* frag, int64_t M,
-                     const float* bias, int relu, float* y, int64_t ldy, void* stream);
-int conv3_tc_wino43v(const float* x, int64_t B, int64_t T, int64_t Cin, const float* frag, int64_t M,
-                     const float* bias, int relu, float* y, int64_t ldy, void* workspace,
-                     size_t workspace_bytes, void* stream);
-// Winograd F(6,3) (tspn_wino63.hip): same structure, 8 positions per 6 output frames
+// Winograd F(6,3) (tspn_wino63.hip): input transform V = B^T d as its own pass into `workspace`, then the
+// MFMA contraction on fragment-major weights; Cin % 32 == 0, M % 32 == 0
 bool wino63_supported(int64_t Cin, int64_t M);
 size_t wino63_workspace_bytes(int64_t B, int64_t T, int64_t Cin);
 int wino63_input_transform(const float* x, int64_t B, int64_t T, int64_t Cin, void* workspace,

@@ -838,257 +838,6 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_mfma_cl_kernel(
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// Winograd F(2,3) variant of the channels-last kernel: the k=3 temporal conv of two adjacent
-// output frames (t, t+1) from the four inputs d = x[t-1..t+2]
-//     y_t   = M0 + M1 + M2          M_j = U_j . V_j   (contraction over input channels only)
-//     y_t+1 = M1 - M2 - M3          U = (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2)   (packed once, fp64->fp32)
-//                                   V = (d0-d2, d1+d2, d2-d1, d1-d3)           (formed in registers)
-// needs 4 channel-GEMMs on half the columns instead of 3 on all of them: 2/3 of the MFMA work of
-// the direct form, exact in real arithmetic and within a few 1e-6 of it in fp32 (tests).
-// Tile: 128 output channels x 128 frames (64 frame pairs); wave w = rows [32w, 32w+32) x 64 pairs x
-// 4 positions j (8 accumulator blocks, the output transform stays inside the wave's registers).
-// K chunk = 8 input channels: lanes k=0 / k=1 take channel group 0 / 1 (4 channels each = 4 MFMA
-// k-steps), so every x value a lane reads from LDS (b128 = 4 channels of one column) is used.
-// Requires T even (frame pairs never straddle sequences), Cin % 8 == 0, M % 4 == 0.
-constexpr int WN_KC = 8;
-constexpr int WN_SLP = 132;
-
-__global__ void pack_conv3_wino_kernel(const float* __restrict__ W, int64_t M, int64_t Cin,
-                                       int64_t split, float* __restrict__ packed) {
-  const int64_t Mp = split > 0 ? 2 * M : M;
-  const int64_t Cp = split > 0 ? split : Cin;
-  const int64_t total = Cp * Mp;
-  for (int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; o < total;
-       o += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = o % Mp;
-    const int64_t ci = o / Mp;
-    const int64_t m = r < M ? r : r - M;
-    const int64_t c = r < M ? ci : ci + split;
-    const float* g = W + (m * Cin + c) * 3;
-    const double g0 = g[0], g1 = g[1], g2 = g[2];
-    packed[0 * total + o] = (float)g0;
-    packed[1 * total + o] = (float)(0.5 * (g0 + g1 + g2));
-    packed[2 * total + o] = (float)(0.5 * (g0 - g1 + g2));
-    packed[3 * total + o] = (float)g2;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Winograd F(2,3) kernel: the input transform V = B^T d is computed ONCE per workgroup
-// (one (group, pair, half) item per thread, written to an LDS V tile) instead of once per wave —
-// the four waves of a workgroup cover different output channels of the SAME columns (a first
-// version repeated the transform, 48 VALU per wave and chunk = 8 % of its time, four times).
-// The transform of chunk c+1 runs under the MFMAs of chunk c: x tiles are DMA'd two chunks ahead
-// (two x stages), V tiles are double-buffered, one barrier per chunk as before.
-constexpr int W2_A_ST = 4 * WN_KC * BM;       // [4 j][8 ch][128 m]
-constexpr int W2_X_ST = 2 * WN_SLP * 4;       // [2 g][132 slots][4 ch]
-constexpr int W2_V_ST = 2 * 4 * 64 * 4;       // [2 g][4 j][64 pairs][4 ch]
-constexpr size_t W2_SMEM_BYTES = sizeof(float) * 2 * (W2_A_ST + W2_X_ST + W2_V_ST);
-
-__global__ __launch_bounds__(THREADS, 2) void conv3_wino2_cl_kernel(
-    const float* __restrict__ x, const float* __restrict__ Wp, const float* __restrict__ bias,
-    float* __restrict__ y, int Cin, int T, int M, int64_t ncols, int tiles_m, int tiles_n,
-    int relu, int ldy, int GM) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* As = reinterpret_cast<float*>(smem_raw);
-  float* Xs = As + 2 * W2_A_ST;
-  float* Vs = Xs + 2 * W2_X_ST;
-
-  // ---- workgroup -> tile: bijective XCD remap (XCD = bid % 8 gets a contiguous range), then groups of
-  // GM weight panels x all frame tiles with the panel index fastest, so the 64 workgroups resident on
-  // one XCD share panels (4 MB each) and x tiles (1 MB each) in its L2.  GM = 2 (launcher) measured the
-  // least L2-miss traffic (FETCH_SIZE, 8 videos: 25 GB against 36 GB at GM = 8, 67 GB at 16); cutting
-  // the dispatch order into frame superblocks changed neither traffic nor time (MFMA-bound; r1 notes).
-  const int nwg = gridDim.x;
-  const int bid = blockIdx.x;
-  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int group_sz = GM * tiles_n;
-  const int group = wg / group_sz;
-  const int first_m = group * GM;
-  const int gm = min(GM, tiles_m - first_m);
-  const int in_group = wg - group * group_sz;
-  const int tile_m = first_m + in_group % gm;
-  const int tile_n = in_group / gm;
-  const int m0 = tile_m * BM;
-  const int64_t n0 = (int64_t)tile_n * BN;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 31, kh = lane >> 5;
-
-  // ---- DMA sources (as in v1): wave w stages U_w; x pieces p = wave + 4q
-  const float* asrc[4];
-  {
-    const int am = (lane & 31) * 4;
-    const int amc = m0 + am < M ? m0 + am : 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int ch = 2 * i + (lane >> 5);
-      asrc[i] = Wp + ((int64_t)wave * Cin + ch) * M + amc;
-    }
-  }
-  const float* bsrc[2];
-  bool bval[2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int u = 64 * (wave + 4 * q) + lane;
-    const int g = u / WN_SLP, slot = u - g * WN_SLP;
-    bval[q] = u < 2 * WN_SLP && slot < BN + 2;
-    int64_t n = n0 + slot - 1;
-    n = n < 0 ? 0 : (n < ncols ? n : ncols - 1);
-    bsrc[q] = x + n * Cin + 4 * (g < 2 ? g : 0);
-  }
-  const int64_t a_step = (int64_t)WN_KC * M;
-  auto stage_a = [&](int buf, auto d_tag) {
-    constexpr int d = decltype(d_tag)::value;
-    glds16(asrc[d], As + buf * W2_A_ST + (wave * WN_KC + 2 * d) * BM);
-    asrc[d] += a_step;
-  };
-  auto stage_x = [&](int buf, auto q_tag) {
-    constexpr int q = decltype(q_tag)::value;
-    if (bval[q]) glds16(bsrc[q], Xs + buf * W2_X_ST + 64 * (wave + 4 * q) * 4);
-    bsrc[q] += WN_KC;
-  };
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
-  using I2 = std::integral_constant<int, 2>;
-  using I3 = std::integral_constant<int, 3>;
-
-  // ---- transform item of this thread: wave = (half jh, group g), lane = frame pair q
-  const int tq = tid & 63, tg = (tid >> 6) & 1, tjh = tid >> 7;
-  float tmask;  // jh = 0: d0 is outside the sequence at t = 0; jh = 1: d3 at t = T-2
-  {
-    const int t = (int)((n0 + 2 * tq) % T);
-    tmask = tjh == 0 ? (t != 0 ? 1.f : 0.f) : (t != T - 2 ? 1.f : 0.f);
-  }
-  auto transform = [&](int xbuf, int vbuf) {
-    const float* xp = Xs + xbuf * W2_X_ST + (tg * WN_SLP + 2 * tq + tjh) * 4;  // slots 2q+jh .. +2
-    const float4 e0 = *reinterpret_cast<const float4*>(xp);
-    const float4 e1 = *reinterpret_cast<const float4*>(xp + 4);
-    const float4 e2 = *reinterpret_cast<const float4*>(xp + 8);
-    float4 va, vb;
-    if (tjh == 0) {  // (d0, d1, d2): V0 = d0 - d2, V1 = d1 + d2
-      va = make_float4(e0.x * tmask - e2.x, e0.y * tmask - e2.y, e0.z * tmask - e2.z, e0.w * tmask - e2.w);
-      vb = make_float4(e1.x + e2.x, e1.y + e2.y, e1.z + e2.z, e1.w + e2.w);
-    } else {         // (d1, d2, d3): V2 = d2 - d1, V3 = d1 - d3
-      va = make_float4(e1.x - e0.x, e1.y - e0.y, e1.z - e0.z, e1.w - e0.w);
-      vb = make_float4(e0.x - e2.x * tmask, e0.y - e2.y * tmask, e0.z - e2.z * tmask, e0.w - e2.w * tmask);
-    }
-    float* vp = Vs + vbuf * W2_V_ST + ((tg * 4 + 2 * tjh) * 64 + tq) * 4;
-    *reinterpret_cast<float4*>(vp) = va;
-    *reinterpret_cast<float4*>(vp + 64 * 4) = vb;
-  };
-
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[j][qb][e] = 0.f;
-
-  const int nchunks = Cin / WN_KC;
-  stage_a(0, I0{}); stage_a(0, I1{}); stage_a(0, I2{}); stage_a(0, I3{});
-  stage_x(0, I0{}); stage_x(0, I1{});
-  if (nchunks > 1) { stage_x(1, I0{}); stage_x(1, I1{}); }
-  __syncthreads();
-  transform(0, 0);
-  __syncthreads();
-
-  // chunk c: MFMAs on (A_c, V_c); meanwhile DMA A_{c+1}, x_{c+2} and transform x_{c+1} -> V_{c+1}
-  auto chunk_body = [&](int c, auto more1_tag, auto more2_tag) {
-    constexpr bool MORE1 = decltype(more1_tag)::value;  // chunk c+1 exists
-    constexpr bool MORE2 = decltype(more2_tag)::value;  // chunk c+2 exists
-    const int buf = c & 1;
-    const float* Ab = As + buf * W2_A_ST + (4 * kh) * BM + wave * 32 + li;
-    const float* Vb = Vs + buf * W2_V_ST + (kh * 4 * 64 + li) * 4;
-    float4 v[4][2];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb)
-        v[j][qb] = *reinterpret_cast<const float4*>(Vb + (j * 64 + qb * 32) * 4);
-    float a[4][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) a[j][e] = Ab[(j * WN_KC + e) * BM];
-    if (MORE1) transform(buf ^ 1, buf ^ 1);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float* vp = reinterpret_cast<const float*>(&v[j][qb]);
-          acc[j][qb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j][e], vp[e], acc[j][qb], 0, 0, 0);
-        }
-        if (MORE1) {
-          if (e == 0 && qb == 0) stage_a(buf ^ 1, I0{});
-          if (e == 0 && qb == 1) stage_a(buf ^ 1, I1{});
-          if (e == 1 && qb == 0) stage_a(buf ^ 1, I2{});
-          if (e == 1 && qb == 1) stage_a(buf ^ 1, I3{});
-        }
-        if (MORE2) {
-          if (e == 2 && qb == 0) stage_x(buf, I0{});
-          if (e == 2 && qb == 1) stage_x(buf, I1{});
-        }
-      }
-    }
-#if !defined(TSPN_WINO_NOSCHED)
-    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-#define TSPN_G(NVM)                                     \
-  __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);    \
-  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    \
-  __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);    \
-  __builtin_amdgcn_sched_group_barrier(0x020, NVM, 0);
-    TSPN_G(0) TSPN_G(0) TSPN_G(0) TSPN_G(1) TSPN_G(0) TSPN_G(0) TSPN_G(0) TSPN_G(1)
-    TSPN_G(0) TSPN_G(0) TSPN_G(0) TSPN_G(1) TSPN_G(0) TSPN_G(0) TSPN_G(0) TSPN_G(1)
-    TSPN_G(0) TSPN_G(0) TSPN_G(0) TSPN_G(1) TSPN_G(0) TSPN_G(0) TSPN_G(0) TSPN_G(1)
-    TSPN_G(0) TSPN_G(0) TSPN_G(0) TSPN_G(0) TSPN_G(0) TSPN_G(0) TSPN_G(0) TSPN_G(0)
-#undef TSPN_G
-#endif
-    __syncthreads();
-  };
-  int c = 0;
-  for (; c + 2 < nchunks; ++c) chunk_body(c, std::true_type{}, std::true_type{});
-  if (c + 1 < nchunks) {
-    chunk_body(c, std::true_type{}, std::false_type{});
-    ++c;
-  }
-  chunk_body(c, std::false_type{}, std::false_type{});
-
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    const int64_t n = n0 + 2 * (qb * 32 + li);
-    if (n >= ncols) continue;
-    const int64_t b = n / T;
-    const int64_t t = n - b * T;
-    float* ycol = y + (b * M) * (int64_t)ldy + t;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int m = m0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-      if (m < M) {
-        float v0 = acc[0][qb][e] + acc[1][qb][e] + acc[2][qb][e];
-        float v1 = acc[1][qb][e] - acc[2][qb][e] - acc[3][qb][e];
-        if (bias != nullptr) {
-          const float bb = bias[m];
-          v0 += bb;
-          v1 += bb;
-        }
-        if (relu) {
-          v0 = fmaxf(v0, 0.f);
-          v1 = fmaxf(v1, 0.f);
-        }
-        *reinterpret_cast<float2*>(ycol + (int64_t)m * ldy) = make_float2(v0, v1);
-      }
-    }
-  }
-}
-
 }  // namespace
 
 extern "C" int tspn_pack_conv3_f32(const float* W, int64_t M, int64_t Cin, int64_t split,
@@ -1174,58 +923,4 @@ int tspn::conv3_tc_direct(const float* x, int64_t B, int64_t T, int64_t Cin, con
                      CL_SMEM_BYTES, TSPN_STREAM(stream), x, packed, bias, y, (int)Cin, (int)T, (int)M,
                      ncols, (int)tiles_m, (int)tiles_n, relu, (int)ldy);
   return tspn::check_launch("tspn_conv3_tc_f32");
-}
-
-
-extern "C" int tspn_pack_conv3_wino_f32(const float* W, int64_t M, int64_t Cin, int64_t split,
-                                        float* packed, void* stream) {
-  TSPN_REQUIRE(W && packed, TSPN_EINVAL, "tspn_pack_conv3_wino_f32: null pointer");
-  TSPN_REQUIRE(M > 0 && Cin > 0 && split >= 0, TSPN_EINVAL, "tspn_pack_conv3_wino_f32: bad sizes");
-  TSPN_REQUIRE(split == 0 || Cin == 2 * split, TSPN_EINVAL,
-               "tspn_pack_conv3_wino_f32: split=%lld requires Cin == 2*split (Cin=%lld)",
-               (long long)split, (long long)Cin);
-  const int64_t total = M * Cin;
-  const int blocks = (int)std::min<int64_t>(tspn::ceil_div(total, 256), 8192);
-  hipLaunchKernelGGL(pack_conv3_wino_kernel, dim3(blocks), dim3(256), 0, TSPN_STREAM(stream), W, M,
-                     Cin, split, packed);
-  return tspn::check_launch("tspn_pack_conv3_wino_f32");
-}
-
-extern "C" int tspn_conv3_tc_wino_f32(const float* x, int64_t B, int64_t T, int64_t Cin,
-                                      const float* packed4, int64_t M, const float* bias, int relu,
-                                      float* y, void* stream) {
-  return tspn::conv3_tc_wino(x, B, T, Cin, packed4, M, bias, relu, y, T, stream);
-}
-
-int tspn::conv3_tc_wino(const float* x, int64_t B, int64_t T, int64_t Cin, const float* packed4,
-                        int64_t M, const float* bias, int relu, float* y, int64_t ldy, void* stream) {
-  TSPN_REQUIRE(ldy >= T && (ldy % 2 == 0 || T % 2 != 0) && ldy < (1 << 24), TSPN_EINVAL,
-               "tspn_conv3_tc_wino_f32: bad ldy");
-  TSPN_REQUIRE(B >= 0 && Cin > 0 && T > 0 && M > 0, TSPN_EINVAL,
-               "tspn_conv3_tc_wino_f32: bad sizes B=%lld T=%lld Cin=%lld M=%lld", (long long)B,
-               (long long)T, (long long)Cin, (long long)M);
-  if (B == 0) return TSPN_OK;
-  TSPN_REQUIRE(x && packed4 && y, TSPN_EINVAL, "tspn_conv3_tc_wino_f32: null pointer");
-  TSPN_REQUIRE(Cin % WN_KC == 0 && M % 4 == 0 && T % 2 == 0, TSPN_EUNSUPPORTED,
-               "tspn_conv3_tc_wino_f32: needs Cin %% 8 == 0, M %% 4 == 0, T even (Cin=%lld M=%lld T=%lld)",
-               (long long)Cin, (long long)M, (long long)T);
-  TSPN_REQUIRE((reinterpret_cast<uintptr_t>(packed4) & 15) == 0 &&
-                   (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
-                   (reinterpret_cast<uintptr_t>(y) & 7) == 0,
-               TSPN_EUNSUPPORTED, "tspn_conv3_tc_wino_f32: x/packed must be 16-byte, y 8-byte aligned");
-  TSPN_REQUIRE(Cin < (1 << 24) && T < (1 << 24) && M < (1 << 24), TSPN_EUNSUPPORTED,
-               "tspn_conv3_tc_wino_f32: dimension too large");
-  const int64_t ncols = B * T;
-  const int64_t tiles_m = tspn::ceil_div(M, BM);
-  const int64_t tiles_n = tspn::ceil_div(ncols, BN);
-  TSPN_REQUIRE(tiles_m * tiles_n < (1LL << 31), TSPN_EUNSUPPORTED,
-               "tspn_conv3_tc_wino_f32: grid too large");
-  static tspn::LdsLimit lds;
-  if (int rc = lds.ensure(reinterpret_cast<const void*>(conv3_wino2_cl_kernel), W2_SMEM_BYTES,
-                          "tspn_conv3_tc_wino_f32"))
-    return rc;
-  hipLaunchKernelGGL(conv3_wino2_cl_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(THREADS),
-                     W2_SMEM_BYTES, TSPN_STREAM(stream), x, packed4, bias, y, (int)Cin, (int)T, (int)M,
-                     ncols, (int)tiles_m, (int)tiles_n, relu, (int)ldy, tspn::kWinoPanelGroup);
-  return tspn::check_launch("tspn_conv3_tc_wino_f32");
 }

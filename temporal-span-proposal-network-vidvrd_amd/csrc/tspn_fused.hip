@@ -42,11 +42,8 @@ FusedLayout layout_of(const tspn_fused_desc* d) {
   L.pooled = take(256);  // (unused since the predicate head is evaluated per tracklet)
   L.lin_bytes = tspn::pair_predicate_workspace_bytes((int64_t)NT, (int64_t)D, d->K);
   L.lin = take(L.lin_bytes);
-  // pre-transformed input of the F(4,3) kernel of tspn_wino43v.hip (conv_algo 3 with D % 32 == 0)
-  // (sized for whichever of F(4,3) / F(6,3) needs more: 6/4 against 8/6 of x, padded to 64 tiles)
-  L.vt_bytes = (D % 32 == 0) ? std::max(tspn::wino43v_workspace_bytes((int64_t)NT, (int64_t)T, (int64_t)D),
-                                        tspn::wino63_workspace_bytes((int64_t)NT, (int64_t)T, (int64_t)D))
-                             : 0;
+  // Winograd-transformed input V of the F(6,3) kernel (conv_algo TSPN_CONV_WINOGRAD63)
+  L.vt_bytes = (D % 32 == 0) ? tspn::wino63_workspace_bytes((int64_t)NT, (int64_t)T, (int64_t)D) : 0;
   L.vt = take(L.vt_bytes);
   L.hwp = take(C * 12 * sizeof(float));   // head weights packed [C][12] for the scalar-weight pair stage (H == 12)
   L.total = off;
@@ -116,40 +113,25 @@ extern "C" int tspn_forward_fused_f32(const tspn_fused_desc* d, void* stream) {
   // through a transpose to channels-first [NT,D,T] and the general kernel.
   const bool tc = (D % 16 == 0) && ((reinterpret_cast<uintptr_t>(d->feats) & 15) == 0) &&
                   ((reinterpret_cast<uintptr_t>(d->conv_packed) & 15) == 0);
-  TSPN_REQUIRE(d->conv_algo >= 0 && d->conv_algo <= 4, TSPN_EINVAL,
-               "tspn_forward_fused: conv_algo must be 0 .. 4");
-  TSPN_REQUIRE(d->conv_algo != 4 || (tc && tspn::wino63_supported(D, 2 * C)), TSPN_EUNSUPPORTED,
-               "tspn_forward_fused: conv_algo 4 (Winograd F(6,3)) needs D %% 32 == 0, aligned operands");
-  TSPN_REQUIRE(d->conv_algo != 1 || (tc && T % 2 == 0), TSPN_EUNSUPPORTED,
-               "tspn_forward_fused: conv_algo 1 (Winograd F(2,3)) needs T even, D %% 16 == 0, aligned operands");
-  TSPN_REQUIRE(d->conv_algo != 2 || tc, TSPN_EUNSUPPORTED,
-               "tspn_forward_fused: conv_algo 2 (Winograd F(4,3)) needs D %% 16 == 0, aligned operands");
-  TSPN_REQUIRE(d->conv_algo != 3 || (tc && tspn::wino43_frag_supported(D, 2 * C)), TSPN_EUNSUPPORTED,
-               "tspn_forward_fused: conv_algo 3 (Winograd F(4,3), fragment-major weights) needs D %% 16 == 0, "
-               "aligned operands");
+  TSPN_REQUIRE(d->conv_algo == TSPN_CONV_DIRECT || d->conv_algo == TSPN_CONV_WINOGRAD63, TSPN_EINVAL,
+               "tspn_forward_fused: conv_algo must be TSPN_CONV_DIRECT (0) or TSPN_CONV_WINOGRAD63 (1), got %d",
+               d->conv_algo);
+  const bool w63 = d->conv_algo == TSPN_CONV_WINOGRAD63;
+  TSPN_REQUIRE(!w63 || (tc && tspn::wino63_supported(D, 2 * C)), TSPN_EUNSUPPORTED,
+               "tspn_forward_fused: TSPN_CONV_WINOGRAD63 needs D %% 32 == 0 and 16-byte aligned operands "
+               "(pack the weights with tspn_pack_conv3_f32 and pass TSPN_CONV_DIRECT otherwise)");
   // On the fast path the rows of y are padded to ldy = ceil4(T) frames so that the blocked pair stage
   // can stage them with 16-byte LDS-DMA pieces that never leave a row (pad frames are never read out).
   // (needs what the DMA pair-stage kernel needs: even T, C % 16 == 0 — implied by tc)
   const int64_t ldy =
       (tc && d->canonical_pairs && T % 2 == 0) ? (int64_t)tspn::align_up((size_t)T, 4) : T;
   if (!tc && (rc = tspn_transpose_td_f32(d->feats, NT, T, D, xt, stream))) return rc;
-  // conv_algo 3 with D % 32 == 0: the Winograd input transform runs as its own HBM-bound pass (tspn_wino43v.hip);
-  // the profiling events bracket the MFMA kernel only
-  const bool pre_v = d->conv_algo == 3 && tspn::wino43v_supported(D, 2 * C);
-  if (pre_v && (rc = tspn::wino43v_input_transform(d->feats, NT, T, D, ws + L.vt, L.vt_bytes, stream))) return rc;
-  if (d->conv_algo == 4 && (rc = tspn::wino63_input_transform(d->feats, NT, T, D, ws + L.vt, L.vt_bytes, stream)))
-    return rc;
+  // F(6,3): the Winograd input transform runs as its own HBM-bound pass; the profiling events bracket the
+  // MFMA kernel only
+  if (w63 && (rc = tspn::wino63_input_transform(d->feats, NT, T, D, ws + L.vt, L.vt_bytes, stream))) return rc;
   if (d->ev_conv_begin) (void)hipEventRecord(static_cast<hipEvent_t>(d->ev_conv_begin), s);
-  if (d->conv_algo == 4)
+  if (w63)
     rc = tspn::wino63_contract(ws + L.vt, NT, T, D, d->conv_packed, 2 * C, bias2, 0, y, ldy, stream);
-  else if (pre_v)
-    rc = tspn::wino43v_contract(ws + L.vt, NT, T, D, d->conv_packed, 2 * C, bias2, 0, y, ldy, stream);
-  else if (d->conv_algo == 3)
-    rc = tspn::conv3_tc_wino43r(d->feats, NT, T, D, d->conv_packed, 2 * C, bias2, 0, y, ldy, stream);
-  else if (d->conv_algo == 2)
-    rc = tspn::conv3_tc_wino43(d->feats, NT, T, D, d->conv_packed, 2 * C, bias2, 0, y, ldy, stream);
-  else if (d->conv_algo == 1)
-    rc = tspn::conv3_tc_wino(d->feats, NT, T, D, d->conv_packed, 2 * C, bias2, 0, y, ldy, stream);
   else
     rc = tc ? tspn::conv3_tc_direct(d->feats, NT, T, D, d->conv_packed, 2 * C, bias2, 0, y, ldy, stream)
             : tspn_conv3_f32(xt, NT, D, T, d->conv_packed, 2 * C, bias2, 0, y, stream);

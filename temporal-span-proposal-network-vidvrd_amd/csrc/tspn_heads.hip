@@ -410,6 +410,7 @@ __global__ __launch_bounds__(256, 2) void heads_pairgrid3_kernel(
   load_w(0);
 #pragma unroll
   for (int ks = 0; ks < PG_CK / 4; ++ks) wa[ks] = (o_a < H) ? wreg[ks] : 0.f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed before the barrier publishes them
   __syncthreads();
 
   struct UV {
@@ -484,6 +485,7 @@ __global__ __launch_bounds__(256, 2) void heads_pairgrid3_kernel(
 #pragma unroll
       for (int ks = 0; ks < PG_CK / 4; ++ks) wa[ks] = (o_a < H) ? wreg[ks] : 0.f;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed before the barrier publishes them
     __syncthreads();
   };
   for (int c = 0; c + 1 < nchunks; ++c) chunk_body(c, std::true_type{});
@@ -643,6 +645,7 @@ __global__ __launch_bounds__(256, 2) void heads_pairgrid4_kernel(
 
   const int nchunks = C / PG_CK;
   stage_chunk(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed before the barrier publishes them
   __syncthreads();
   const float* urow = S + ((2 * wave + si) * PG_CK) * PG_T + tl;   // + buffer + channel * 32
   const float* vrow = S + (PG_S * PG_CK) * PG_T + tl;              // + buffer + (object * 16 + channel) * 32
@@ -677,6 +680,7 @@ __global__ __launch_bounds__(256, 2) void heads_pairgrid4_kernel(
 #undef TSPN_STEP2
     wbase += PG_CK * H;
     if (c + 1 < nchunks) { TSPN_WLOAD(w0, 0, wbase) }   // weights do not depend on the barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed before the barrier publishes them
     __syncthreads();
     if (c + 1 < nchunks)      // first step of the next chunk: its tile landed before the barrier
       fetch_uv(s0, urow + (buf ^ 1) * PG_STAGE, vrow + (buf ^ 1) * PG_STAGE, 0);

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_nhwc_kernel(
 
 // ------------------------------------------------------------------------------------------------
 // Fast variant for Cout % 32 == 0: FRAGMENT-MAJOR weights loaded straight into MFMA operand registers
-// (the recipe of tspn_wino43r.hip).  Tile 128 output channels x 128 pixels; wave w = rows [32 w, 32 w + 32)
+// (the recipe of the temporal conv, tspn_wino63.hip).  Tile 128 output channels x 128 pixels; wave w = rows [32 w, 32 w + 32)
 // x all 128 pixels (4 accumulator blocks), so a wave's weight slice is private and never needs LDS:
 //     Wf[Cout / 32][tap][Cin / 16][lane = 32 kh + li][8]  =  w[32 mb + li][16 c + 4 g + 2 kh + r][tap],  8 = (g, r)
 // is two global_load_dwordx4 per lane and chunk (one 2-KiB line per wave), refilled for chunk i+1 as soon

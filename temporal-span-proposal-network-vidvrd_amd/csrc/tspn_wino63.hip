@@ -1,13 +1,11 @@
 // Winograd F(6,3) temporal conv (gfx950, fp32): six output frames from eight inputs, 8 channel-GEMMs on a sixth
-// of the columns = 4/9 of the direct MFMA work (F(4,3): 1/2 plus the 152/150 quad padding at T = 150, which
-// F(6,3) tiles exactly: 25 sextets) — 12.3 % fewer MFMAs than tspn_wino43v.hip for the same structure.
+// of the columns = 4/9 of the direct MFMA work; T = 150 tiles exactly (25 sextets), any other T masks the last
+// sextet of a tracklet.
 //
-// Why it is safe: conv3_wino43v_kernel runs within 3 % of what the power-managed clock allows for its MFMA
-// stream (profiles/r2/conv_traffic_sweep.md), so fewer MFMAs is the only lever left.  The usual worry with
-// F(6,3) is fp32 accuracy (output-transform entries up to 32).  In this 1-D, K = 2048-deep contraction the error
-// is set by the fp32 accumulation over the channels, not by the transforms: emulated with sequential fp32
-// accumulation on the config-2 distribution the worst element is 4.9e-6 off float64 for F(6,3), 4.6e-6 for
-// F(4,3), 2.1e-6 for the direct form (tests/test_gpu_wino63.py measures the kernels themselves).
+// Accuracy: exact in real arithmetic.  In fp32, at the K = 3 x 2048 contraction of the headline config, the
+// error against float64 is <= 64 eps sum_k |x_k||w_k| per output (direct kernel: <= 16 eps ...); on temporally
+// smooth features it equals the direct kernel's, on temporally independent heavy-tailed ones it is up to 5x
+// larger (tests/test_gpu_wino63.py, profiles/r3/conv_error_realistic.txt).
 //
 // Points 0, +-1, +-2, +-1/2, inf (Lavin & Gray).  d_i = x[6s + i - 1], i = 0..7 (zero outside the tracklet):
 //   V0 = d0 - d6 + 5.25 (d4 - d2)                       V7 = d7 - d1 + 5.25 (d3 - d5)

@@ -391,25 +391,13 @@ class DPN(nn.Module):
                                lambda ts: (ops.pack_conv3(ts[0]), ts[1]))
 
     def _conv_split(self, dev, winograd=False):
-        """Packed weights of the factorised pair form (subject / object halves stacked along M);
-        `winograd`: False = direct taps, 2 = F(2,3) (T even, D % 16 == 0), 4 = F(4,3) (D % 16 == 0)."""
+        """Packed weights of the factorised pair form (subject / object halves stacked along M): Winograd
+        F(6,3) fragment-major weights (needs D % 32 == 0) or the three direct taps."""
         c = self.dpn_head.conv
         half = self.dpn_head.in_channels // 2
-        if winograd == 6:
+        if winograd:
             return self._cache.get("conv_split_wino63", (c.weight, c.bias), dev,
                                    lambda ts: (ops.pack_conv3_wino63(ts[0], split=half), ts[1]))
-        if winograd == 4:
-            def build43(ts):
-                # fragment-major weights select the registers-direct kernel (tspn_wino43r.hip); shapes it
-                # does not take (2C % 32 != 0) keep the canonical layout and kernel
-                p6 = ops.pack_conv3_wino43(ts[0], split=half)
-                if p6.shape[1] % 8 == 0 and p6.shape[2] % 32 == 0:
-                    p6 = ops.repack_wino43_frag(p6)
-                return p6, ts[1]
-            return self._cache.get("conv_split_wino43", (c.weight, c.bias), dev, build43)
-        if winograd:
-            return self._cache.get("conv_split_wino", (c.weight, c.bias), dev,
-                                   lambda ts: (ops.pack_conv3_wino(ts[0], split=half), ts[1]))
         return self._cache.get("conv_split", (c.weight, c.bias), dev,
                                lambda ts: (ops.pack_conv3(ts[0], split=half), ts[1]))
 
@@ -536,9 +524,9 @@ class BaseModel(_CachedWeightsMixin, nn.Module):
                                             fuse_preprocess=getattr(cfg.PREDICT, "FUSE_PREPROCESS", False))
         self._anchor_sizes_cfg = getattr(cfg.RELPN.DPN, "ANCHOR_SIZES", None)
         self.pool_top_span = bool(getattr(cfg.RELPN.DPN, "POOL_TOP_SPAN", False))
-        self.conv_algo = str(getattr(cfg.RELPN.DPN, "CONV_ALGO", "winograd6"))
-        if self.conv_algo not in ("winograd6", "winograd4", "winograd2", "direct"):
-            raise ValueError(f"RELPN.DPN.CONV_ALGO must be winograd6, winograd4, winograd2 or direct (got {self.conv_algo})")
+        self.conv_algo = str(getattr(cfg.RELPN.DPN, "CONV_ALGO", "auto"))
+        if self.conv_algo not in ("auto", "direct"):
+            raise ValueError(f"RELPN.DPN.CONV_ALGO must be auto or direct (got {self.conv_algo})")
 
     def forward(self, pair_list, target_list=None):
         if self.training:
@@ -677,15 +665,9 @@ class BaseModel(_CachedWeightsMixin, nn.Module):
                     pairs.append(p.to(dev) + k * n)
             counts = [p.shape[0] for p in pairs]
             allp = torch.cat(pairs).contiguous()
-            # temporal conv algorithm: RELPN.DPN.CONV_ALGO = "winograd6" (default; F(6,3), 4/9 of the MFMA
-            # work), "winograd4" (F(4,3), half), "winograd2" (F(2,3), the most accurate), "direct"
-            algo = self.conv_algo
-            if algo == "winograd6" and d % 32:
-                algo = "winograd4"       # F(6,3) needs 32-channel super-stages
-            wino = 6 if algo == "winograd6" else (4 if (algo == "winograd4" and d % 16 == 0) else
-                                                  (2 if (algo in ("winograd4", "winograd2") and t % 2 == 0
-                                                         and d % 16 == 0) else False))
-            packed, cbias = dpn._conv_split(dev, winograd=wino)
+            # temporal conv algorithm: RELPN.DPN.CONV_ALGO = "auto" (Winograd F(6,3) when D % 32 == 0: 4/9 of the
+            # MFMA work; its fp32 error bound is in DESIGN.md §4) or "direct" (the k=3 taps as one implicit GEMM)
+            packed, cbias = dpn._conv_split(dev, winograd=(self.conv_algo == "auto" and d % 32 == 0))
             heads, lg = ops.forward_fused(feats, allp, len(members), n, packed, cbias, hw, hb, cw, cb,
                                           check_pairs=False, canonical_pairs=canonical)
             if self.pool_top_span and allp.shape[0]:

@@ -13,7 +13,7 @@ from . import _abi
 
 __all__ = [
     "predicate_head", "feature_preprocess_", "ppn_pair_matrix_topk", "traj_iou", "pair_index",
-    "pair_gather", "pack_conv3", "conv3", "conv3_tc", "pack_conv3_wino", "conv3_tc_wino", "pack_conv3_wino43", "conv3_tc_wino43", "repack_wino43_frag", "conv3_tc_wino43r", "conv3_tc_wino43v", "pack_conv3_wino63", "conv3_tc_wino63", "heads", "heads_pairgrid", "temporal_mean", "pair_rows", "transpose_td",
+    "pair_gather", "pack_conv3", "conv3", "conv3_tc", "pack_conv3_wino63", "conv3_tc_wino63", "heads", "heads_pairgrid", "temporal_mean", "pair_rows", "transpose_td",
     "forward_fused", "temporal_encoder_heads", "fused_workspace_bytes", "decode_topk", "decode_spans",
     "cast_bf16", "pack_conv3_bf16", "pack_heads_bf16", "conv3_tc_bf16", "heads_pairgrid_bf16",
     "transpose_cast_bf16", "temporal_encoder_heads_bf16",
@@ -320,81 +320,6 @@ def conv3_tc(x, packed, bias=None, relu=False):
     return y
 
 
-def pack_conv3_wino(weight, split=0):
-    """nn.Conv1d weight [M,Cin,3] -> Winograd F(2,3) layout [4][Cin'][M'] (tspn_pack_conv3_wino_f32)."""
-    _dev(weight, "conv weight")
-    if weight.dim() != 3 or weight.shape[2] != 3:
-        raise ValueError("pack_conv3_wino: weight must be [M,Cin,3]")
-    M, Cin, _ = weight.shape
-    shape = (4, split, 2 * M) if split else (4, Cin, M)
-    packed = torch.empty(shape, dtype=torch.float32, device=weight.device)
-    _abi.check(_abi.lib().tspn_pack_conv3_wino_f32(_p(weight), M, Cin, split, _p(packed), _stream()))
-    return packed
-
-
-def conv3_tc_wino(x, packed4, bias=None, relu=False):
-    """Winograd F(2,3) conv3 on channels-last x[B,T,Cin] -> y[B,M,T]; needs T even, Cin % 8 == 0."""
-    _dev(x, "x"); _dev(packed4, "packed4")
-    if bias is not None:
-        _dev(bias, "bias")
-    B, T, Cin = x.shape
-    if packed4.dim() != 3 or packed4.shape[0] != 4 or packed4.shape[1] != Cin:
-        raise ValueError(f"conv3_tc_wino: packed weights {tuple(packed4.shape)} do not match Cin={Cin}")
-    M = packed4.shape[2]
-    y = torch.empty((B, M, T), dtype=torch.float32, device=x.device)
-    _abi.check(_abi.lib().tspn_conv3_tc_wino_f32(_p(x), B, T, Cin, _p(packed4), M, _p(bias),
-                                                 1 if relu else 0, _p(y), _stream()))
-    return y
-
-
-def pack_conv3_wino43(weight, split=0):
-    """nn.Conv1d weight [M,Cin,3] -> Winograd F(4,3) layout [6][Cin'][M'] (tspn_pack_conv3_wino43_f32)."""
-    _dev(weight, "conv weight")
-    if weight.dim() != 3 or weight.shape[2] != 3:
-        raise ValueError("pack_conv3_wino43: weight must be [M,Cin,3]")
-    M, Cin, _ = weight.shape
-    shape = (6, split, 2 * M) if split else (6, Cin, M)
-    packed = torch.empty(shape, dtype=torch.float32, device=weight.device)
-    _abi.check(_abi.lib().tspn_pack_conv3_wino43_f32(_p(weight), M, Cin, split, _p(packed), _stream()))
-    return packed
-
-
-def conv3_tc_wino43(x, packed6, bias=None, relu=False):
-    """Winograd F(4,3) conv3 on channels-last x[B,T,Cin] -> y[B,M,T]; any T, Cin % 8 == 0."""
-    _dev(x, "x"); _dev(packed6, "packed6")
-    if bias is not None:
-        _dev(bias, "bias")
-    B, T, Cin = x.shape
-    if packed6.dim() != 3 or packed6.shape[0] != 6 or packed6.shape[1] != Cin:
-        raise ValueError(f"conv3_tc_wino43: packed weights {tuple(packed6.shape)} do not match Cin={Cin}")
-    M = packed6.shape[2]
-    y = torch.empty((B, M, T), dtype=torch.float32, device=x.device)
-    _abi.check(_abi.lib().tspn_conv3_tc_wino43_f32(_p(x), B, T, Cin, _p(packed6), M, _p(bias),
-                                                   1 if relu else 0, _p(y), _stream()))
-    return y
-
-
-def repack_wino43_frag(packed6):
-    """Canonical F(4,3) weights [6][Cin][M] -> fragment-major [M/32][Cin/8][6][64][4]
-    (tspn_repack_wino43_frag_f32); needs Cin % 8 == 0, M % 32 == 0."""
-    _dev(packed6, "packed6")
-    if packed6.dim() != 3 or packed6.shape[0] != 6:
-        raise ValueError("repack_wino43_frag: packed6 must be [6,Cin,M]")
-    _, Cin, M = packed6.shape
-    if Cin % 8 or M % 32:
-        raise ValueError(f"repack_wino43_frag: needs Cin % 8 == 0 and M % 32 == 0 (Cin={Cin}, M={M})")
-    frag = torch.empty((M // 32, Cin // 8, 6, 64, 4), dtype=torch.float32, device=packed6.device)
-    _abi.check(_abi.lib().tspn_repack_wino43_frag_f32(_p(packed6.contiguous()), Cin, M, _p(frag), _stream()))
-    return frag
-
-
-def wino43_frag_dims(frag):
-    """(Cin, M) of a fragment-major F(4,3) weight tensor."""
-    if frag.dim() != 5 or tuple(frag.shape[2:]) != (6, 64, 4):
-        raise ValueError(f"not a fragment-major F(4,3) weight tensor: {tuple(frag.shape)}")
-    return frag.shape[1] * 8, frag.shape[0] * 32
-
-
 def wino63_frag_dims(frag):
     """(Cin, M) of a fragment-major F(6,3) weight tensor (pack_conv3_wino63)."""
     if frag.dim() != 5 or tuple(frag.shape[2:]) != (8, 64, 4):
@@ -436,44 +361,6 @@ def conv3_tc_wino63(x, frag, bias=None, relu=False, workspace=None):
     y = torch.empty((B, M, T), dtype=torch.float32, device=x.device)
     _abi.check(l.tspn_conv3_tc_wino63_f32(_p(x), B, T, Cin, _p(frag), M, _p(bias), 1 if relu else 0, _p(y),
                                           _p(workspace), workspace.numel() * workspace.element_size(), _stream()))
-    return y
-
-
-def conv3_tc_wino43r(x, frag, bias=None, relu=False):
-    """Winograd F(4,3) conv3 on channels-last x[B,T,Cin] with fragment-major weights -> y[B,M,T]."""
-    _dev(x, "x"); _dev(frag, "frag")
-    if bias is not None:
-        _dev(bias, "bias")
-    B, T, Cin = x.shape
-    cin_w, M = wino43_frag_dims(frag)
-    if cin_w != Cin:
-        raise ValueError(f"conv3_tc_wino43r: weights are for Cin={cin_w}, x has Cin={Cin}")
-    y = torch.empty((B, M, T), dtype=torch.float32, device=x.device)
-    _abi.check(_abi.lib().tspn_conv3_tc_wino43r_f32(_p(x), B, T, Cin, _p(frag), M, _p(bias),
-                                                    1 if relu else 0, _p(y), _stream()))
-    return y
-
-
-def conv3_tc_wino43v(x, frag, bias=None, relu=False, workspace=None):
-    """Winograd F(4,3) conv3 with the input transform as a separate HBM-bound pass (tspn_wino43v.hip):
-    channels-last x[B,T,Cin] with fragment-major weights -> y[B,M,T], bit-identical to conv3_tc_wino43r.
-    Needs Cin % 32 == 0; `workspace` (uint8, >= tspn_conv3_tc_wino43v_workspace_bytes) holds V."""
-    _dev(x, "x"); _dev(frag, "frag")
-    if bias is not None:
-        _dev(bias, "bias")
-    B, T, Cin = x.shape
-    cin_w, M = wino43_frag_dims(frag)
-    if cin_w != Cin:
-        raise ValueError(f"conv3_tc_wino43v: weights are for Cin={cin_w}, x has Cin={Cin}")
-    l = _abi.lib()
-    need = l.tspn_conv3_tc_wino43v_workspace_bytes(B, T, Cin)
-    if workspace is None:
-        workspace = _ws(need, x.device)
-    elif workspace.numel() * workspace.element_size() < need:
-        raise ValueError(f"conv3_tc_wino43v: workspace too small ({workspace.numel()} < {need})")
-    y = torch.empty((B, M, T), dtype=torch.float32, device=x.device)
-    _abi.check(l.tspn_conv3_tc_wino43v_f32(_p(x), B, T, Cin, _p(frag), M, _p(bias), 1 if relu else 0, _p(y),
-                                           _p(workspace), workspace.numel() * workspace.element_size(), _stream()))
     return y
 
 
@@ -627,16 +514,13 @@ def _fused_desc(feats, pairs, B, N, conv_packed, conv_bias, head_w, head_b, cls_
     H = head_w.shape[0]
     if H % 3 or head_w.shape[1] != C or head_b.shape != (H,):
         raise ValueError("forward_fused: head_w must be [3A, 2D]")
-    frag = conv_packed.dim() == 5   # fragment-major weights: F(4,3) (repack_wino43_frag) or F(6,3) (pack_conv3_wino63)
-    f63 = frag and conv_packed.shape[2] == 8
-    if frag and (wino63_frag_dims if f63 else wino43_frag_dims)(conv_packed) != (D, 2 * C):
-        raise ValueError(f"forward_fused: fragment-major conv weights are for (Cin, M) = "
-                         f"{(wino63_frag_dims if f63 else wino43_frag_dims)(conv_packed)}, expected ({D}, {2 * C})")
-    if (not frag and tuple(conv_packed.shape) not in ((3, D, 2 * C), (4, D, 2 * C), (6, D, 2 * C))) \
-            or conv_bias.shape != (C,):
-        raise ValueError(f"forward_fused: conv_packed must be [3, 4 or 6, D={D}, 4D={2 * C}] "
-                         "(pack_conv3 / pack_conv3_wino / pack_conv3_wino43 with split=D) or the "
-                         "fragment-major form of the latter (repack_wino43_frag)")
+    w63 = conv_packed.dim() == 5     # fragment-major Winograd F(6,3) weights (pack_conv3_wino63); else direct taps
+    if w63 and wino63_frag_dims(conv_packed) != (D, 2 * C):
+        raise ValueError(f"forward_fused: Winograd F(6,3) conv weights are for (Cin, M) = "
+                         f"{wino63_frag_dims(conv_packed)}, expected ({D}, {2 * C})")
+    if (not w63 and tuple(conv_packed.shape) != (3, D, 2 * C)) or conv_bias.shape != (C,):
+        raise ValueError(f"forward_fused: conv_packed must be pack_conv3(conv.weight, split=D) = [3, D={D}, 4D={2 * C}] "
+                         "or pack_conv3_wino63(conv.weight, split=D)")
     if cls_w.dim() != 2 or cls_w.shape[1] != C or cls_b.shape != (cls_w.shape[0],):
         raise ValueError("forward_fused: cls_w must be [K, 2D]")
     d = _abi.FusedDesc()
@@ -644,9 +528,7 @@ def _fused_desc(feats, pairs, B, N, conv_packed, conv_bias, head_w, head_b, cls_
     d.A, d.K = H // 3, cls_w.shape[0]
     d.feats, d.pairs, d.P = feats.data_ptr(), pairs.data_ptr(), pairs.shape[0]
     d.conv_packed, d.conv_bias = conv_packed.data_ptr(), conv_bias.data_ptr()
-    # direct: 3 tap matrices; Winograd F(2,3): 4 transformed matrices; F(4,3): 6 (canonical) or fragment-major;
-    # F(6,3): fragment-major with 8 positions
-    d.conv_algo = (4 if f63 else 3) if frag else {3: 0, 4: 1, 6: 2}[conv_packed.shape[0]]
+    d.conv_algo = _abi.CONV_WINOGRAD63 if w63 else _abi.CONV_DIRECT   # the packing is the choice of kernel
     d.head_w, d.head_b = head_w.data_ptr(), head_b.data_ptr()
     d.cls_w, d.cls_b = cls_w.data_ptr(), cls_b.data_ptr()
     return d

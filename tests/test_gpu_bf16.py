@@ -223,7 +223,7 @@ def test_cfg3_full_size_bf16_vs_fp32_path(tspn, device):
     args16 = (feats.to(torch.bfloat16), pairs, 1, N, tspn.ops.pack_conv3_bf16(w["conv_w"], split=D), w["conv_b"],
               tspn.ops.pack_heads_bf16(hw), hb, w["cls_w"], w["cls_b"])
     h16, l16 = tspn.ops.forward_fused_bf16(*args16)
-    h32, l32 = tspn.ops.forward_fused(feats, pairs, 1, N, tspn.ops.pack_conv3_wino(w["conv_w"], split=D),
+    h32, l32 = tspn.ops.forward_fused(feats, pairs, 1, N, tspn.ops.pack_conv3_wino63(w["conv_w"], split=D),
                                       w["conv_b"], hw, hb, w["cls_w"], w["cls_b"], canonical_pairs=True)
     assert h16.shape == (N * (N - 1), 12, T) and l16.shape == (N * (N - 1), 132)
     scale = float(h32.abs().max())
@@ -327,7 +327,7 @@ def test_fused_passes_are_graph_capturable(tspn, device):
     f_a = t(np.concatenate([tspn.synth.make_video(130 + b, N, T, D)["tracklet_feats"] for b in range(B)])).to(device)
     f_b = t(np.concatenate([tspn.synth.make_video(140 + b, N, T, D)["tracklet_feats"] for b in range(B)])).to(device)
     # ---- fp32
-    packed = tspn.ops.pack_conv3_wino(w["conv_w"], split=D)
+    packed = tspn.ops.pack_conv3_wino63(w["conv_w"], split=D)
     ws = torch.empty(tspn.ops.fused_workspace_bytes(B, N, T, D, 4, 132, P), dtype=torch.uint8, device=device)
     oh, ol = torch.empty((P, 12, T), device=device), torch.empty((P, 132), device=device)
     feats = f_a.clone()

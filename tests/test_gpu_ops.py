@@ -240,40 +240,6 @@ def test_conv3_channels_last_vs_fp64(tspn, device, B, Cin, T, M, relu):
     np.testing.assert_allclose(y.cpu().numpy(), y2.cpu().numpy(), rtol=0, atol=1e-5)
 
 
-@pytest.mark.parametrize("B,Cin,T,M", [(1, 8, 2, 4), (3, 16, 30, 128), (5, 24, 34, 132), (7, 64, 150, 64),
-                                       (2, 144, 258, 260), (40, 32, 30, 36)])
-@pytest.mark.parametrize("relu", [False, True])
-def test_conv3_winograd_vs_fp64(tspn, device, B, Cin, T, M, relu):
-    """Winograd F(2,3) kernel == the conv (fp64 reference); error stays within a few 1e-6."""
-    x = tspn.hashrng.uniform(46, "x", (B, T, Cin), -1, 1)
-    w = tspn.hashrng.normal(46, "w", (M, Cin, 3), std=0.1)
-    b = tspn.hashrng.normal(46, "b", (M,), std=0.1)
-    p4 = tspn.ops.pack_conv3_wino(t(w).to(device))
-    g = w.astype(np.float64).transpose(2, 1, 0)  # [3][Cin][M]
-    u = np.stack([g[0], 0.5 * (g[0] + g[1] + g[2]), 0.5 * (g[0] - g[1] + g[2]), g[2]]).astype(np.float32)
-    np.testing.assert_array_equal(p4.cpu().numpy(), u)
-    y = tspn.ops.conv3_tc_wino(t(x).to(device), p4, t(b).to(device), relu=relu)
-    ref = conv_ref(np.ascontiguousarray(x.transpose(0, 2, 1)), w, b, relu)
-    np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=0, atol=3e-5)
-    if Cin % 16 == 0:
-        y2 = tspn.ops.conv3_tc(t(x).to(device), tspn.ops.pack_conv3(t(w).to(device)), t(b).to(device), relu=relu)
-        np.testing.assert_allclose(y.cpu().numpy(), y2.cpu().numpy(), rtol=0, atol=2e-5)
-
-
-def test_conv3_winograd_exact_integers_and_limits(tspn, device):
-    """Exact-integer operands: the F(2,3) transforms (incl. the 1/2 factors) are exact, so the
-    result must equal the direct conv bit for bit; odd T is rejected."""
-    B, C, T = 2, 32, 70
-    x = ((np.arange(B * T * C, dtype=np.float32).reshape(B, T, C) * 7) % 23) - 11.0
-    w = (((np.arange(C * C * 3, dtype=np.float32).reshape(C, C, 3) * 5) % 9) - 4.0) * 2.0
-    y = tspn.ops.conv3_tc_wino(t(x).to(device), tspn.ops.pack_conv3_wino(t(w).to(device)), None).cpu().numpy()
-    ref = conv_ref(np.ascontiguousarray(x.transpose(0, 2, 1)), w, None, False)
-    np.testing.assert_array_equal(y, ref)
-    with pytest.raises(tspn._abi.TspnError) as e:
-        tspn.ops.conv3_tc_wino(torch.zeros(2, 31, 16, device=device), torch.zeros(4, 16, 8, device=device))
-    assert e.value.code == tspn._abi.TSPN_EUNSUPPORTED
-
-
 def test_conv3_channels_last_rejects_ragged(tspn, device):
     with pytest.raises(tspn._abi.TspnError) as e:
         tspn.ops.conv3_tc(torch.zeros(2, 5, 20, device=device), torch.zeros(3, 20, 8, device=device))
@@ -577,147 +543,3 @@ def test_cfg4_batch_independence(tspn, device):
     # determinism: two runs of the same launch are bitwise identical (no atomics anywhere)
     hb2, lb2 = run_fused(tspn, device, feats, pairs, B, N, w, canonical=True)
     assert torch.equal(hb, hb2) and torch.equal(lb, lb2)
-
-
-@pytest.mark.parametrize("B,Cin,T,M", [(1, 8, 1, 4), (2, 8, 5, 8), (3, 16, 30, 128), (5, 24, 33, 132),
-                                       (7, 64, 150, 64), (2, 136, 257, 260), (40, 32, 30, 36), (3, 16, 7, 12)])
-@pytest.mark.parametrize("relu", [False, True])
-def test_conv3_winograd43_vs_fp64(tspn, device, B, Cin, T, M, relu):
-    """Winograd F(4,3) kernel == the conv (fp64 reference) for any T (quads are masked at tracklet ends);
-    its fp32 error stays within a small multiple of the direct kernel's."""
-    x = tspn.hashrng.uniform(47, "x", (B, T, Cin), -1, 1)
-    w = tspn.hashrng.normal(47, "w", (M, Cin, 3), std=0.1)
-    b = tspn.hashrng.normal(47, "b", (M,), std=0.1)
-    p6 = tspn.ops.pack_conv3_wino43(t(w).to(device))
-    g = w.astype(np.float64).transpose(2, 1, 0)  # [3][Cin][M]
-    u = np.stack([g[0] / 4, -(g[0] + g[1] + g[2]) / 6, -(g[0] - g[1] + g[2]) / 6,
-                  g[0] / 24 + g[1] / 12 + g[2] / 6, g[0] / 24 - g[1] / 12 + g[2] / 6, g[2]]).astype(np.float32)
-    np.testing.assert_array_equal(p6.cpu().numpy(), u)
-    y = tspn.ops.conv3_tc_wino43(t(x).to(device), p6, t(b).to(device), relu=relu)
-    ref = conv_ref(np.ascontiguousarray(x.transpose(0, 2, 1)), w, b, relu)
-    np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=0, atol=6e-5)
-    y0 = tspn.ops.conv3_tc_wino43(t(x).to(device), p6, None, relu=relu)
-    np.testing.assert_allclose(y0.cpu().numpy(), conv_ref(np.ascontiguousarray(x.transpose(0, 2, 1)), w, None, relu),
-                               rtol=0, atol=6e-5)
-
-
-def test_conv3_algorithms_error_at_headline_depth(tspn, device):
-    """fp32 error of the three temporal-conv kernels against float64 at the contraction depth of the
-    headline config (K = 3 x 2048 channels, inputs in [0,1), weights N(0, 0.01^2)): F(2,3) <= direct;
-    F(4,3) within a small multiple of the direct kernel's own rounding error and far inside the path's
-    1e-4 bound (the number DESIGN.md quotes for the default algorithm)."""
-    B, T, Cin, M = 3, 150, 2048, 128
-    x = tspn.hashrng.uniform(48, "x", (B, T, Cin))
-    w = tspn.hashrng.normal(48, "w", (M, Cin, 3), std=0.01)
-    ref = conv_ref(np.ascontiguousarray(x.transpose(0, 2, 1)), w, None, False).astype(np.float64)
-    ref = torch.nn.functional.conv1d(t(x).double().transpose(1, 2), t(w).double(), None, padding=1).numpy()
-    xd, wd = t(x).to(device), t(w).to(device)
-    err = {}
-    err["direct"] = np.abs(tspn.ops.conv3_tc(xd, tspn.ops.pack_conv3(wd)).cpu().numpy() - ref).max()
-    err["F(2,3)"] = np.abs(tspn.ops.conv3_tc_wino(xd, tspn.ops.pack_conv3_wino(wd)).cpu().numpy() - ref).max()
-    err["F(4,3)"] = np.abs(tspn.ops.conv3_tc_wino43(xd, tspn.ops.pack_conv3_wino43(wd)).cpu().numpy() - ref).max()
-    scale = np.abs(ref).max()
-    print("conv3 max abs error vs float64 (|y| max %.3f):" % scale, {k: "%.2e" % v for k, v in err.items()})
-    assert err["F(2,3)"] <= 1.5 * err["direct"]
-    assert err["F(4,3)"] <= 4.0 * err["direct"] and err["F(4,3)"] <= 3e-5
-
-
-@pytest.mark.parametrize("B,Cin,T,M", [(1, 8, 1, 32), (2, 8, 5, 32), (3, 16, 30, 128), (5, 24, 33, 160),
-                                       (7, 64, 150, 64), (2, 136, 257, 288), (40, 32, 30, 96), (3, 16, 7, 32),
-                                       (33, 48, 13, 128), (1, 8, 4, 32)])
-@pytest.mark.parametrize("relu", [False, True])
-def test_conv3_winograd43_fragment_major_kernel(tspn, device, B, Cin, T, M, relu):
-    """Registers-direct F(4,3) kernel (fragment-major weights, tspn_wino43r.hip): the repacked layout is
-    the documented permutation of the canonical one, the result is BIT-IDENTICAL to the canonical kernel
-    (same contraction order) for 1, 2, 3 and many K chunks, ragged T, partial weight / quad tiles, and
-    within the F(4,3) tolerance of the fp64 conv."""
-    x = tspn.hashrng.uniform(49, "x", (B, T, Cin), -1, 1)
-    w = tspn.hashrng.normal(49, "w", (M, Cin, 3), std=0.1)
-    b = tspn.hashrng.normal(49, "b", (M,), std=0.1)
-    p6 = tspn.ops.pack_conv3_wino43(t(w).to(device))
-    fr = tspn.ops.repack_wino43_frag(p6)
-    assert tuple(fr.shape) == (M // 32, Cin // 8, 6, 64, 4) and tspn.ops.wino43_frag_dims(fr) == (Cin, M)
-    # frag[mb][c][j][32 kh + li][e] = packed6[j][8 c + 4 kh + e][32 mb + li]
-    want = p6.cpu().numpy().reshape(6, Cin // 8, 2, 4, M // 32, 32).transpose(4, 1, 0, 2, 5, 3)
-    np.testing.assert_array_equal(fr.cpu().numpy().reshape(M // 32, Cin // 8, 6, 2, 32, 4), want)
-    for bias in (t(b).to(device), None):
-        y0 = tspn.ops.conv3_tc_wino43(t(x).to(device), p6, bias, relu=relu)
-        y1 = tspn.ops.conv3_tc_wino43r(t(x).to(device), fr, bias, relu=relu)
-        assert torch.equal(y0, y1)
-    ref = conv_ref(np.ascontiguousarray(x.transpose(0, 2, 1)), w, b, relu)
-    y = tspn.ops.conv3_tc_wino43r(t(x).to(device), fr, t(b).to(device), relu=relu)
-    np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=0, atol=6e-5)
-
-
-def test_conv3_winograd43_fragment_major_errors(tspn, device):
-    """Shapes the fragment-major kernel does not take are refused (loudly), not silently mis-tiled."""
-    p6 = torch.zeros((6, 8, 36), device=device)
-    with pytest.raises(ValueError):
-        tspn.ops.repack_wino43_frag(p6)                              # M % 32 != 0
-    with pytest.raises(ValueError):
-        tspn.ops.repack_wino43_frag(torch.zeros((6, 12, 32), device=device))   # Cin % 8 != 0
-    rc = tspn._abi.lib().tspn_repack_wino43_frag_f32(p6.data_ptr(), 8, 36, p6.data_ptr(), None)
-    assert rc != 0 and "tspn_repack_wino43_frag_f32" in tspn._abi.lib().tspn_last_error().decode()
-    fr = tspn.ops.repack_wino43_frag(torch.zeros((6, 16, 64), device=device))
-    with pytest.raises(ValueError):
-        tspn.ops.conv3_tc_wino43r(torch.zeros((2, 9, 8), device=device), fr)   # Cin mismatch
-    y = tspn.ops.conv3_tc_wino43r(torch.zeros((0, 9, 16), device=device), fr)   # empty batch
-    assert y.shape == (0, 64, 9)
-
-
-@pytest.mark.parametrize("B,N,T,D", [(2, 5, 30, 16), (1, 9, 33, 32), (3, 4, 150, 48)])
-def test_fused_fragment_major_equals_canonical(tspn, device, B, N, T, D):
-    """tspn_forward_fused_f32 with conv_algo 3 (fragment-major F(4,3) weights) == conv_algo 2, bit for bit."""
-    _, w = make_w(tspn, 50, D)
-    feats = torch.cat([t(tspn.synth.make_video(60 + b, N, T, D)["tracklet_feats"]) for b in range(B)])
-    pairs = torch.cat([oracle.pair_index(N) + b * N for b in range(B)])
-    d = lambda v: v.to(device).contiguous()
-    p6 = tspn.ops.pack_conv3_wino43(d(w["conv_w"]), split=D)
-    hw = d(torch.cat([w["rel_w"][:, :, 0], w["dur_w"][:, :, 0]]))
-    hb = d(torch.cat([w["rel_b"], w["dur_b"]]))
-    outs = []
-    for packed in (p6, tspn.ops.repack_wino43_frag(p6)):
-        outs.append(tspn.ops.forward_fused(d(feats), d(pairs), B, N, packed, d(w["conv_b"]), hw, hb,
-                                           d(w["cls_w"]), d(w["cls_b"]), canonical_pairs=True))
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-    with pytest.raises(ValueError):   # weights for another D
-        tspn.ops.forward_fused(d(feats), d(pairs), B, N, tspn.ops.repack_wino43_frag(
-            torch.zeros((6, 2 * D, 8 * D), device=device)), d(w["conv_b"]), hw, hb, d(w["cls_w"]), d(w["cls_b"]))
-
-
-@pytest.mark.parametrize("B,Cin,T,M", [(1, 32, 1, 32), (2, 32, 5, 32), (3, 64, 30, 128), (5, 96, 33, 160),
-                                       (7, 64, 150, 64), (2, 160, 257, 288), (40, 32, 30, 96), (3, 32, 7, 32),
-                                       (33, 128, 13, 128), (1, 32, 4, 32), (9, 256, 150, 256)])
-@pytest.mark.parametrize("relu", [False, True])
-def test_conv3_winograd43_pretransformed_input_kernel(tspn, device, B, Cin, T, M, relu):
-    """F(4,3) with the input transform as a separate pass (tspn_wino43v.hip: V by LDS-DMA, ring of three
-    32-channel super-stages, one barrier per super-stage): BIT-IDENTICAL to the canonical and to the
-    fragment-major kernels for 1, 2, 3 and many super-stages, ragged T (quads masked at tracklet ends, tiles
-    that straddle tracklets), partial weight / quad tiles; within the F(4,3) tolerance of the fp64 conv."""
-    x = tspn.hashrng.uniform(51, "x", (B, T, Cin), -1, 1)
-    w = tspn.hashrng.normal(51, "w", (M, Cin, 3), std=0.1)
-    b = tspn.hashrng.normal(51, "b", (M,), std=0.1)
-    p6 = tspn.ops.pack_conv3_wino43(t(w).to(device))
-    fr = tspn.ops.repack_wino43_frag(p6)
-    for bias in (t(b).to(device), None):
-        y0 = tspn.ops.conv3_tc_wino43(t(x).to(device), p6, bias, relu=relu)
-        y1 = tspn.ops.conv3_tc_wino43r(t(x).to(device), fr, bias, relu=relu)
-        y2 = tspn.ops.conv3_tc_wino43v(t(x).to(device), fr, bias, relu=relu)
-        assert torch.equal(y0, y1) and torch.equal(y0, y2)
-    ref = conv_ref(np.ascontiguousarray(x.transpose(0, 2, 1)), w, b, relu)
-    y = tspn.ops.conv3_tc_wino43v(t(x).to(device), fr, t(b).to(device), relu=relu)
-    np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=0, atol=6e-5)
-
-
-def test_conv3_winograd43_pretransformed_errors(tspn, device):
-    fr = tspn.ops.repack_wino43_frag(torch.zeros((6, 24, 64), device=device))
-    with pytest.raises(tspn._abi.TspnError) as e:    # Cin % 32 != 0: this kernel refuses, the r kernel takes it
-        tspn.ops.conv3_tc_wino43v(torch.zeros((2, 9, 24), device=device), fr)
-    assert e.value.code == tspn._abi.TSPN_EUNSUPPORTED
-    fr = tspn.ops.repack_wino43_frag(torch.zeros((6, 32, 64), device=device))
-    with pytest.raises(ValueError):                  # workspace too small
-        tspn.ops.conv3_tc_wino43v(torch.zeros((2, 9, 32), device=device), fr,
-                                  workspace=torch.zeros(16, dtype=torch.uint8, device=device))
-    y = tspn.ops.conv3_tc_wino43v(torch.zeros((0, 9, 32), device=device), fr)   # empty batch
-    assert y.shape == (0, 64, 9)
-    assert tspn._abi.lib().tspn_conv3_tc_wino43v_workspace_bytes(16 * 32, 150, 2048) == 2048 // 4 * 6 * 19456 * 16

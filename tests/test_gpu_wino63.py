@@ -1,7 +1,8 @@
 """Winograd F(6,3) temporal conv (tspn_wino63.hip) through the C ABI: against the float64 conv for ragged shapes
 (sextets masked at tracklet ends, tiles that straddle tracklets, 1 .. many super-stages, partial weight / sextet
-tiles), its packed weights against the closed-form U = G g, its fp32 error next to the other algorithms at the
-contraction depth of the headline config, and the fused path / BaseModel on it against the dense oracle."""
+tiles), its packed weights against the closed-form U = G g, its fp32 error next to the direct kernel at the
+contraction depth of the headline config -- on the benchmark's distribution and on heavy-tailed / trained-scale
+magnitudes, with a relative bound -- and the fused path / BaseModel on it against the dense oracle."""
 import numpy as np
 import pytest
 import torch
@@ -69,25 +70,71 @@ def test_conv3_winograd63_split_packing_and_errors(tspn, device):
     assert tspn._abi.lib().tspn_conv3_tc_wino63_workspace_bytes(16 * 32, 150, 2048) == 2048 // 4 * 8 * 12800 * 16
 
 
-def test_conv3_winograd63_error_at_headline_depth(tspn, device):
-    """fp32 error against float64 at K = 3 x 2048 channels, inputs in [0,1), weights N(0, 0.01^2): F(6,3) stays in
-    the class of F(4,3) (the accumulation over the channels dominates, not the transforms) and an order of
-    magnitude inside the path's 1e-4 bound."""
-    B, T, Cin, M = 3, 150, 2048, 128
-    x = tspn.hashrng.uniform(48, "x", (B, T, Cin))
-    w = tspn.hashrng.normal(48, "w", (M, Cin, 3), std=0.01)
+def heavy_tailed(tspn, seed, shape, scale=4.0, outlier=50.0, frac=1e-3, zeros=0.4):
+    """Post-ReLU-like features: |N(0,1)| * scale, a fraction `frac` of 50x outliers, 40 % exact zeros."""
+    x = np.abs(tspn.hashrng.normal(seed, "x", shape, std=1.0)) * scale
+    x = np.where(tspn.hashrng.uniform(seed, "o", shape) < frac, x * outlier, x)
+    return np.where(tspn.hashrng.uniform(seed, "z", shape) < zeros, 0.0, x).astype(np.float32)
+
+
+def conv_errors(tspn, device, x, w):
+    """max over the outputs of |err| / (eps * sum_k |x_k||w_k|) and of |err| / max|y| against float64, for the direct
+    kernel and for F(6,3)."""
     ref = conv_ref(x, w, None, False)
+    mag = conv_ref(np.abs(x), np.abs(w), None, False)
     xd, wd = t(x).to(device), t(w).to(device)
-    err = {"direct": np.abs(tspn.ops.conv3_tc(xd, tspn.ops.pack_conv3(wd)).cpu().numpy() - ref).max(),
-           "F(4,3)": np.abs(tspn.ops.conv3_tc_wino43(xd, tspn.ops.pack_conv3_wino43(wd)).cpu().numpy() - ref).max(),
-           "F(6,3)": np.abs(tspn.ops.conv3_tc_wino63(xd, tspn.ops.pack_conv3_wino63(wd)).cpu().numpy() - ref).max()}
-    print("conv3 max abs error vs float64 (|y| max %.3f):" % np.abs(ref).max(), {k: "%.2e" % v for k, v in err.items()})
-    assert err["F(6,3)"] <= 2.0 * err["F(4,3)"] and err["F(6,3)"] <= 3e-5
+    out = {}
+    for name, y in (("direct", tspn.ops.conv3_tc(xd, tspn.ops.pack_conv3(wd))),
+                    ("F(6,3)", tspn.ops.conv3_tc_wino63(xd, tspn.ops.pack_conv3_wino63(wd)))):
+        e = np.abs(y.cpu().numpy() - ref)
+        out[name] = (float((e / (2.0 ** -24 * mag + 1e-300)).max()), float(e.max() / np.abs(ref).max()), float(e.max()))
+    return out, float(np.abs(ref).max())
+
+
+def test_conv3_winograd63_error_at_headline_depth(tspn, device):
+    """fp32 error against float64 at K = 3 x 2048 channels on the benchmark's distribution (inputs in [0,1), weights
+    N(0, 0.01^2)): the accumulation over the channels dominates, F(6,3) stays within 2x of the direct kernel and an
+    order of magnitude inside the path's 1e-4 bound."""
+    B, T, Cin, M = 3, 150, 2048, 128
+    err, ymax = conv_errors(tspn, device, tspn.hashrng.uniform(48, "x", (B, T, Cin)),
+                            tspn.hashrng.normal(48, "w", (M, Cin, 3), std=0.01))
+    print("conv3 error vs float64 (|y| max %.3f): (e / eps sum|x||w|, e / max|y|, e)" % ymax, err)
+    assert err["F(6,3)"][2] <= 2.0 * err["direct"][2] and err["F(6,3)"][2] <= 3e-5
+
+
+@pytest.mark.parametrize("case", ["independent_heavy_tail", "outlier_weight_rows", "temporally_smooth"])
+def test_conv3_winograd63_relative_error_on_realistic_magnitudes(tspn, device, case):
+    """full-depth (K = 3 x 2048) error on post-ReLU-like heavy-tailed features (|N(0,1)| * 4, 0.1 %
+    of 50x outliers, 40 % zeros, |x| up to ~500) and weights of trained scale (std 1/sqrt(3 D); or std 0.05 with 2 %
+    of the rows scaled 20x).  The bound is RELATIVE -- no algorithm, the direct form included, holds an absolute
+    1e-4 once |y| reaches 30 (fp32 has 6e-8 relative precision):
+        |err| <= 64 eps sum_k |x_k||w_k|  and  |err| <= 2e-5 max|y|   for F(6,3)   (measured: 51, 1.3e-5)
+        |err| <= 16 eps sum_k |x_k||w_k|                               for direct   (measured: 12)
+    On temporally independent features F(6,3) is up to ~5x the direct kernel's error (the transforms' entries up to
+    32 / 5.25 amplify); on temporally smooth features -- what consecutive frames of a tracklet are -- it is NOT worse
+    than the direct kernel.  RELPN.DPN.CONV_ALGO = "direct" buys the direct bound at 2.25x the MFMA work."""
+    B, T, Cin, M = 3, 150, 2048, 128
+    if case == "independent_heavy_tail":
+        x = heavy_tailed(tspn, 71, (B, T, Cin))
+        w = tspn.hashrng.normal(71, "w", (M, Cin, 3), std=1.0 / np.sqrt(3 * Cin))
+    elif case == "outlier_weight_rows":
+        x = heavy_tailed(tspn, 72, (B, T, Cin))
+        w = (tspn.hashrng.normal(72, "w", (M, Cin, 3), std=0.05)
+             * np.where(tspn.hashrng.uniform(72, "r", (M, 1, 1)) < 0.02, 20.0, 1.0)).astype(np.float32)
+    else:
+        x = (heavy_tailed(tspn, 73, (B, 1, Cin)) + 0.05 * tspn.hashrng.normal(73, "n", (B, T, Cin), std=1.0)).astype(np.float32)
+        w = tspn.hashrng.normal(73, "w", (M, Cin, 3), std=1.0 / np.sqrt(3 * Cin))
+    err, ymax = conv_errors(tspn, device, x, w)
+    print(f"{case}: max|y| {ymax:.3g}, max|x| {np.abs(x).max():.3g}; (e / eps sum|x||w|, e / max|y|, e):", err)
+    assert err["direct"][0] <= 16.0
+    assert err["F(6,3)"][0] <= 64.0 and err["F(6,3)"][1] <= 2e-5
+    if case == "temporally_smooth":
+        assert err["F(6,3)"][2] <= 1.5 * err["direct"][2]
 
 
 @pytest.mark.parametrize("B,N,T,D", [(2, 5, 30, 32), (1, 9, 33, 32), (3, 4, 150, 64)])
 def test_fused_winograd63_vs_dense_oracle(tspn, device, B, N, T, D):
-    """tspn_forward_fused_f32 with conv_algo 4 against the dense oracle (1e-5) and against conv_algo 3 (F(4,3))."""
+    """tspn_forward_fused_f32 with TSPN_CONV_WINOGRAD63 against the dense oracle (1e-5) and against TSPN_CONV_DIRECT."""
     sd = tspn.synth.make_weights(50, c=2 * D, bias_std=0.05)
     w = {"conv_w": t(sd[DPN_PRE + "conv.weight"]), "conv_b": t(sd[DPN_PRE + "conv.bias"]),
          "dur_w": t(sd[DPN_PRE + "duration_pred.weight"]), "dur_b": t(sd[DPN_PRE + "duration_pred.bias"]),
@@ -101,7 +148,7 @@ def test_fused_winograd63_vs_dense_oracle(tspn, device, B, N, T, D):
     hb = d(torch.cat([w["rel_b"], w["dur_b"]]))
     outs = []
     for packed in (tspn.ops.pack_conv3_wino63(d(w["conv_w"]), split=D),
-                   tspn.ops.repack_wino43_frag(tspn.ops.pack_conv3_wino43(d(w["conv_w"]), split=D))):
+                   tspn.ops.pack_conv3(d(w["conv_w"]), split=D)):
         outs.append(tspn.ops.forward_fused(d(feats), d(pairs), B, N, packed, d(w["conv_b"]), hw, hb,
                                            d(w["cls_w"]), d(w["cls_b"]), canonical_pairs=True))
     np.testing.assert_allclose(outs[0][0].cpu().numpy(), outs[1][0].cpu().numpy(), rtol=0, atol=1e-5)
@@ -113,11 +160,13 @@ def test_fused_winograd63_vs_dense_oracle(tspn, device, B, N, T, D):
         np.testing.assert_allclose(outs[0][0][sl, 4:].cpu().numpy(), ref["duration"].numpy(), rtol=0, atol=1e-5)
 
 
-def test_basemodel_winograd6_config(tspn, device):
-    """RELPN.DPN.CONV_ALGO = "winograd6" selects the F(6,3) weights (and falls back to F(4,3) when D % 32 != 0)."""
-    for D, want in ((32, (8, 64, 4)), (16, (6, 64, 4))):
+def test_basemodel_conv_algo_config(tspn, device):
+    """RELPN.DPN.CONV_ALGO = "auto" selects the F(6,3) weights when D % 32 == 0 and the direct taps otherwise;
+    "direct" always selects the direct taps."""
+    for D, algo, want in ((32, "auto", (2 * 64 // 32, 32 // 8, 8, 64, 4)), (16, "auto", (3, 16, 64)),
+                          (32, "direct", (3, 32, 128))):
         cfg = cases.baseline_cfg(**{"RELPN.USE_PPN": False, "RELPN.USE_DPN": True, "RELPN.DPN.IN_CHANNELS": 2 * D,
-                                    "PREDICT.FEATURE_DIM": 2 * D, "RELPN.DPN.CONV_ALGO": "winograd6"})
+                                    "PREDICT.FEATURE_DIM": 2 * D, "RELPN.DPN.CONV_ALGO": algo})
         model = tspn.BaseModel(cfg)
         sd = tspn.synth.make_weights(3, c=2 * D, bias_std=0.05)
         own = model.state_dict()
@@ -128,7 +177,7 @@ def test_basemodel_winograd6_config(tspn, device):
         _, dp, logits = model([pl], None)
         caches = model.relpn.duration_proposal_network._cache._store
         packed = [val[1][0] for key, val in caches.items() if key.startswith("conv_split")]
-        assert len(packed) == 1 and tuple(packed[0].shape[2:]) == want
+        assert len(packed) == 1 and tuple(packed[0].shape) == want
         w = {"conv_w": t(sd[DPN_PRE + "conv.weight"]), "conv_b": t(sd[DPN_PRE + "conv.bias"]),
              "dur_w": t(sd[DPN_PRE + "duration_pred.weight"]), "dur_b": t(sd[DPN_PRE + "duration_pred.bias"]),
              "rel_w": t(sd[DPN_PRE + "relness_pred.weight"]), "rel_b": t(sd[DPN_PRE + "relness_pred.bias"]),

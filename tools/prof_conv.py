@@ -18,23 +18,15 @@ ap.add_argument("--m", type=int, default=8192)
 ap.add_argument("--t", type=int, default=150)
 ap.add_argument("--n", type=int, default=32)
 ap.add_argument("--tc", action="store_true", help="channels-last x (tracklet layout) kernel")
-ap.add_argument("--wino", action="store_true", help="Winograd F(2,3) channels-last kernel")
-ap.add_argument("--wino43", action="store_true", help="Winograd F(4,3) channels-last kernel")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev).manual_seed(0)
 x = torch.rand((args.videos * args.n, args.cin, args.t), device=dev, generator=g)
 conv = tspn.ops.conv3
-if args.tc or args.wino or args.wino43:
+if args.tc:
     x = x.transpose(1, 2).contiguous()
     conv = tspn.ops.conv3_tc
 w = (torch.rand((3, args.cin, args.m), device=dev, generator=g) - 0.5) * 0.02
-if args.wino:
-    w = (torch.rand((4, args.cin, args.m), device=dev, generator=g) - 0.5) * 0.02
-    conv = tspn.ops.conv3_tc_wino
-if args.wino43:
-    w = (torch.rand((6, args.cin, args.m), device=dev, generator=g) - 0.5) * 0.02
-    conv = tspn.ops.conv3_tc_wino43
 for _ in range(2):
     y = conv(x, w)
 torch.cuda.synchronize()
@@ -46,6 +38,6 @@ for a, b in evs:
 torch.cuda.synchronize()
 ms = sorted(a.elapsed_time(b) for a, b in evs)
 flop = 2.0 * args.m * 3 * args.cin * x.shape[0] * args.t
-shape = f"B={x.shape[0]} Cin={args.cin} T={args.t} M={args.m}" + (" [winograd F(4,3)]" if args.wino43 else " [winograd]" if args.wino else " [channels-last]" if args.tc else "")
+shape = f"B={x.shape[0]} Cin={args.cin} T={args.t} M={args.m}" + (" [channels-last]" if args.tc else "")
 print(f"conv3 {shape}: median {ms[len(ms)//2]:.3f} ms "
       f"min {ms[0]:.3f} ms -> {flop / ms[len(ms)//2] / 1e9:.1f} direct-equivalent TFLOP/s (median)")

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time the F(6,3) conv (transform + contract) against the F(4,3) kernel at the cfg2 projection shape on one box.
+"""Time the F(6,3) conv (transform + contract) against the direct kernel at the cfg2 projection shape on one box.
     python tools/time_w63.py [videos] [rounds]      (TSPN_LIB_PATH selects a variant build)"""
 import os
 import sys
@@ -15,13 +15,12 @@ dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev).manual_seed(0)
 x = torch.rand((videos * 32, 150, 2048), device=dev, generator=g)
 w = (torch.rand((8192, 2048, 3), device=dev, generator=g) - 0.5) * 0.02
-f43 = tspn.ops.repack_wino43_frag(tspn.ops.pack_conv3_wino43(w))
+pd = tspn.ops.pack_conv3(w)
 f63 = tspn.ops.pack_conv3_wino63(w)
 del w
 lib = tspn._abi.lib()
-ws = torch.empty(max(lib.tspn_conv3_tc_wino43v_workspace_bytes(videos * 32, 150, 2048),
-                     lib.tspn_conv3_tc_wino63_workspace_bytes(videos * 32, 150, 2048)), dtype=torch.uint8, device=dev)
-arms = {"wino43v": lambda: tspn.ops.conv3_tc_wino43v(x, f43, workspace=ws),
+ws = torch.empty(lib.tspn_conv3_tc_wino63_workspace_bytes(videos * 32, 150, 2048), dtype=torch.uint8, device=dev)
+arms = {"direct": lambda: tspn.ops.conv3_tc(x, pd),
         "wino63": lambda: tspn.ops.conv3_tc_wino63(x, f63, workspace=ws)}
 times = {k: [] for k in arms}
 for fn in arms.values():
