@@ -515,7 +515,8 @@ __global__ __launch_bounds__(THREADS, (KCD == 8 ? 4 : 2)) void conv3_mfma_dma_ke
   float h_reg = *hptr;
   hptr += b_step;
   if (tid < 2 * KCD) Bs[hrow * BNP + hslot] = hvalid ? h_reg : 0.f;
-  __syncthreads();  // (hipcc drains the LDS-DMA with vmcnt(0) here)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed before the barrier publishes them
+  __syncthreads();
 
   constexpr int KSTEPS = KCD / 2;
   // The chunk body is instantiated twice: with staging of the next chunk (all chunks but the
@@ -591,6 +592,7 @@ __global__ __launch_bounds__(THREADS, (KCD == 8 ? 4 : 2)) void conv3_mfma_dma_ke
     }
     if (MORE && tid < 2 * KCD) Bs[(buf ^ 1) * B_ST + hrow * BNP + hslot] = hvalid ? h_reg : 0.f;
 #if !defined(TSPN_ABLATE_NOBARRIER)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed before the barrier publishes them
     __syncthreads();
 #endif
   };
@@ -755,7 +757,8 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_mfma_cl_kernel(
   stage_one(0, std::integral_constant<int, 6>{});
   stage_one(0, std::integral_constant<int, 7>{});
   stage_one(0, std::integral_constant<int, 8>{});
-  __syncthreads();  // (hipcc drains the LDS-DMA with vmcnt(0) here)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed before the barrier publishes them
+  __syncthreads();
 
   auto chunk_body = [&](int buf, auto more_tag) {
     constexpr bool MORE = decltype(more_tag)::value;
@@ -809,6 +812,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_mfma_cl_kernel(
       __builtin_amdgcn_sched_barrier(0);
       cur = nxt;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed before the barrier publishes them
     __syncthreads();
   };
   for (int c = 0; c + 1 < nchunks; ++c) chunk_body(c & 1, std::true_type{});

@@ -152,7 +152,8 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_nhwc_kernel(
   };
 
   stage(0, 0);
-  __syncthreads();   // (hipcc drains the LDS-DMA with vmcnt(0) here)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed before the barrier publishes them
+  __syncthreads();
   // chunk i: 2 KC MFMAs per wave on buffer i & 1, the DMA pieces of chunk i+1 and the fragment reads of
   // the next channel group issued between them (1 MFMA : 1 LDS read, a DMA piece behind every other MFMA of
   // the first groups)
@@ -189,6 +190,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_nhwc_kernel(
 #endif
       cur = nxt;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed before the barrier publishes them
     __syncthreads();
   };
   for (int i = 0; i + 1 < nchunks; ++i) chunk_body(i, std::true_type{});
@@ -371,6 +373,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_nhwc_frag_kernel(
 
   // ---- prologue: x_0 landed; the weights of chunk 0 are the two youngest VMEM operations
   stage_x(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed before the barrier publishes them
   __syncthreads();
   load_wfrag<0>(a01, woff, wbase);
   load_wfrag<16>(a23, woff, wbase);

@@ -32,7 +32,7 @@ import torch
 from . import ops
 from .pair_list import PairList, TargetList
 
-__all__ = ["proposal_pair_list", "select_proposal_pairs", "segment_signature", "feature_path",
+__all__ = ["proposal_pair_list", "proposal_pair_lists", "select_proposal_pairs", "segment_signature", "feature_path",
            "write_traj_cls_json", "read_traj_cls_json", "tracklets_to_traj_cls", "write_relation_h5",
            "read_relation_h5"]
 
@@ -66,9 +66,15 @@ def proposal_pair_list(pairs, feats, iou, trackid, cls_logits, pred_labels=None,
                          f"feats {tuple(f_all.shape)})")
     tid = _to_dev(trackid, device, torch.int64).reshape(-1)
     idx, num_tracks = ops.proposal_pair_filter(p_all, tid)
-    kept_feats = ops.gather_rows(f_all, idx)
+    return _assemble(p_all, f_all, idx, num_tracks, iou, trackid, cls_logits, pred_labels, preprocess, device)
+
+
+def _assemble(p_all, f_all, idx, num_tracks, iou, trackid, cls_logits, pred_labels, preprocess, device):
+    """Gathers + normalisation + field wiring of one segment, given its kept row numbers `idx` (produced and
+    range-checked by the filter kernel, hence check_idx=False: no host sync in here)."""
+    kept_feats = ops.gather_rows(f_all, idx, check_idx=False)
     # int64 [P,2] rows are 16 bytes: moved by the same byte-mover as four fp32 columns
-    kept_pairs = ops.gather_rows(p_all.view(torch.float32), idx).view(torch.int64)
+    kept_pairs = ops.gather_rows(p_all.view(torch.float32), idx, check_idx=False).view(torch.int64)
     if preprocess and kept_feats.shape[0]:
         first, block, nblocks = 70, 1000, 8          # vrdataset.py:227-236
         if kept_feats.shape[1] < first + block * nblocks:
@@ -85,8 +91,38 @@ def proposal_pair_list(pairs, feats, iou, trackid, cls_logits, pred_labels=None,
         lab = _to_dev(pred_labels, device, torch.float32)
         if lab.dim() != 2 or lab.shape[0] != p_all.shape[0]:
             raise ValueError("pred_labels must be [P,K] with one row per pair")
-        tlist = TargetList(ops.gather_rows(lab, idx))
+        tlist = TargetList(ops.gather_rows(lab, idx, check_idx=False))
     return plist, tlist
+
+
+def proposal_pair_lists(segments, preprocess=True, device=None):
+    """A batch of segments at once: `segments` = sequence of dicts with the keys of `proposal_pair_list`
+    (pairs, feats, iou, trackid, cls_logits[, pred_labels]).  The pair filter of ALL segments is ONE launch
+    (`pair_off` / `track_off` form of tspn_proposal_pair_filter_i64) and the loader pays ONE host sync per
+    batch (the kept-row counts) instead of several per segment.  Returns [(PairList, TargetList | None)]."""
+    device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    if not len(segments):
+        return []
+    p_all = [_to_dev(s["pairs"], device, torch.int64).reshape(-1, 2) for s in segments]
+    f_all = [_to_dev(s["feats"], device, torch.float32) for s in segments]
+    tids = [_to_dev(s["trackid"], device, torch.int64).reshape(-1) for s in segments]
+    for p, f in zip(p_all, f_all):
+        if f.dim() != 2 or f.shape[0] != p.shape[0]:
+            raise ValueError(f"feats must be [P,F] with one row per pair (pairs {tuple(p.shape)}, feats {tuple(f.shape)})")
+    pair_off = np.concatenate([[0], np.cumsum([p.shape[0] for p in p_all])]).astype(np.int64)
+    track_off = np.concatenate([[0], np.cumsum([t.shape[0] for t in tids])]).astype(np.int64)
+    idx, count, ntr = ops.proposal_pair_filter(torch.cat(p_all), torch.cat(tids),
+                                               torch.from_numpy(pair_off).to(device), torch.from_numpy(track_off).to(device))
+    counts = torch.stack([count, ntr]).cpu().numpy()          # the one sync of the batch
+    if (counts[0] < 0).any():
+        raise IndexError(f"proposal_pair_lists: segment {int(np.argmax(counts[0] < 0))}: a pair names a track index "
+                         "outside trackid")
+    out = []
+    for k, s in enumerate(segments):
+        lo = int(pair_off[k])
+        out.append(_assemble(p_all[k], f_all[k], idx[lo:lo + int(counts[0, k])], int(counts[1, k]), s["iou"], s["trackid"],
+                             s["cls_logits"], s.get("pred_labels"), preprocess, device))
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------

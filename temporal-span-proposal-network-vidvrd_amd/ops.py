@@ -170,12 +170,14 @@ def proposal_pair_filter(pairs, trackid, pair_off=None, track_off=None):
     return idx[:c], int(ntr[0])
 
 
-def gather_rows(src, idx):
-    """out[r] = src[idx[r]] for a 2-D fp32 matrix (feats[proposal_idx], lib/dataset/vrdataset.py:66-67)."""
+def gather_rows(src, idx, check_idx=True):
+    """out[r] = src[idx[r]] for a 2-D fp32 matrix (feats[proposal_idx], lib/dataset/vrdataset.py:66-67).
+    `check_idx=False` skips the range check (two host syncs) for indices a kernel of this library produced
+    (proposal_pair_filter emits range-checked local row numbers)."""
     _dev(src, "src"); _dev(idx, "idx", torch.int64)
     if src.dim() != 2 or idx.dim() != 1:
         raise ValueError("gather_rows: src must be [R,F] and idx [R']")
-    if idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= src.shape[0]):
+    if check_idx and idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= src.shape[0]):
         raise IndexError("gather_rows: row index out of range")
     out = torch.empty((idx.numel(), src.shape[1]), dtype=torch.float32, device=src.device)
     if src.shape[1]:

@@ -123,3 +123,26 @@ def test_dataset_to_predictions_like_the_reference(tspn, device, fuse):
         np.testing.assert_array_equal(out[0].cpu().numpy(), g[f"seg{i}_scores"])
         np.testing.assert_array_equal(out[1].cpu().numpy(), g[f"seg{i}_triplets"])
         np.testing.assert_array_equal(out[2].cpu().numpy(), g[f"seg{i}_pair_tids"])
+
+
+def test_batched_proposal_pair_lists_equal_per_segment_form(tspn, device):
+    """dataset.proposal_pair_lists (one filter launch + one host sync per batch) == proposal_pair_list per
+    segment, bit for bit, on the h5-shaped segments of golden g10 (incl. the 1-tracklet segment); a pair that
+    names a track outside its segment raises like the per-segment form."""
+    segs = cases.g10_segments()
+    batch = [{"pairs": s["pairs"], "feats": s["raw"], "iou": s["iou"], "trackid": s["trackid"], "cls_logits": s["cls"]}
+             for s in segs["segments"]]
+    got = tspn.dataset.proposal_pair_lists(batch, preprocess=True, device=device)
+    _, one = _g10_loader(tspn, device, preprocess=True)
+    assert len(got) == len(one)
+    for (pl, tl), (ref, _, _) in zip(got, one):
+        assert tl is None
+        assert torch.equal(pl.features, ref[0].features)
+        assert torch.equal(pl.get_field("tracklet_pairs"), ref[0].get_field("tracklet_pairs"))
+        assert int(pl.get_field("num_tracklets")) == int(ref[0].get_field("num_tracklets"))
+    bad = dict(batch[0])
+    bad["pairs"] = batch[0]["pairs"].copy()
+    bad["pairs"][3, 1] = 10 ** 6
+    with pytest.raises(IndexError):
+        tspn.dataset.proposal_pair_lists([batch[1], bad], device=device)
+    assert tspn.dataset.proposal_pair_lists([], device=device) == []

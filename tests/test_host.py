@@ -265,3 +265,25 @@ def test_on_disk_formats_of_the_reference(tspn, tmp_path):
         ds.write_relation_h5(h5, [-1, 0], [[0, 1], [1, 0]], np.ones((2, 8)), np.eye(2))
         pairs, feats, iou, tid = ds.read_relation_h5(h5)
         assert pairs.tolist() == [[0, 1], [1, 0]] and feats.dtype == np.float32 and tid.tolist() == [-1, 0]
+
+
+def test_build_records_kernel_resources_and_no_spills():
+    """The build parses hipcc's per-kernel resource remarks into kernel_resources.json next to the library and
+    refuses to link when a kernel whose inline asm splits a load from its wait (weights straight into MFMA operand
+    registers, s_load'ed head weights) spills or uses scratch: a spill between the two would copy
+    registers that are not valid yet."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_tspn_build_t", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "temporal-span-proposal-network-vidvrd_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    res = b.kernel_resources()
+    assert len(res) > 40
+    guarded = [n for n in res if any(k in n for k in b.NO_SPILL_KERNELS)]
+    for want in ("conv3_wino63_kernel", "heads_pairgrid4_kernel", "conv2d_nhwc_bf16_kernel"):
+        assert any(want in n for n in guarded), f"{want} not in the resource table"
+    assert b.check_no_spill(res) == []
+    w63 = next(v for n, v in res.items() if "conv3_wino63_kernel" in n)
+    assert w63["vgprs"] + w63["agprs"] <= 512 and w63["scratch_bytes"] == 0
+    # the guard itself
+    fake = {"conv3_wino63_kernel(float*)": {"vgpr_spill": 3, "sgpr_spill": 0, "scratch_bytes": 12}}
+    assert len(b.check_no_spill(fake)) == 1
