@@ -14,6 +14,11 @@ Workloads (`--workload`):
   cfg4   the per-GPU shard of configs[3]: 512 cfg2-shaped videos over 8 GPUs = 64 videos per GPU per step
   cfg3   configs[2]: N=64, T=900, D=1024, bf16 operands, 4 videos per step
 
+The step runs THROUGH THE DROP-IN SURFACE by default: B device-resident `PairList.from_tracklets` per step ->
+`BaseModel.forward(pair_list)` (reference lib/modeling/model.py:53-65, called as predict.py:57 calls it) ->
+`BaseModel.decode` (predict.py:59-117).  `--ops-level` times the same kernels through `ops.forward_fused` with
+caller-held workspace and outputs instead (the two agree within 1 %, profiles/r3/bench_via_model_vs_ops.md).
+
 A "step" = one pass of the hot path over one batch of synthetic videos per GPU (inputs resident in HBM, a
 rotation of `--batches` different batches): tracklet tensors -> [pair builder + temporal encoder +
 relationness/span heads + RelOIPool + predicate head] (tspn_forward_fused_f32) + pair geometry [P,8,T] from the
@@ -82,6 +87,9 @@ def parse():
                     help="pair geometry, PPN, decode and the result gather on a second HIP stream behind the logits-ready "
                          "event, under the encoder of the same step (measured on one GPU: 32.70 vs 32.65 ms per step, the "
                          "encoder leaves no idle units to fill, so the default keeps one stream)")
+    ap.add_argument("--ops-level", action="store_true",
+                    help="time ops.forward_fused with pre-allocated workspace / outputs instead of BaseModel.forward + "
+                         "BaseModel.decode on PairLists (the default)")
     ap.add_argument("--launch-check", action="store_true",
                     help="rehearse only the rank launch + rendezvous on the CPU (gloo), no GPU work")
     return ap.parse_args()
@@ -292,9 +300,12 @@ def main():
            "rel_w": sd[DPN_PRE + "relness_pred.weight"], "rel_b": sd[DPN_PRE + "relness_pred.bias"],
            "cls_w": sd["classifier.rel_predictor.weight"], "cls_b": sd["classifier.rel_predictor.bias"]}
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    via_model = not args.ops_level
     conv_w = d(wnp["conv_w"])
     r16 = lambda x: tspn.ops.cast_bf16(x.contiguous()).float()  # noqa: E731
-    if bf16:
+    if via_model:
+        packed = None          # BaseModel packs (and caches) its own device copies
+    elif bf16:
         packed = tspn.ops.pack_conv3_bf16(conv_w, split=D)
     else:
         packed = {"direct": tspn.ops.pack_conv3, "winograd6": tspn.ops.pack_conv3_wino63}[args.conv](conv_w, split=D)
@@ -334,16 +345,16 @@ def main():
     local_pairs = tspn.ops.pair_index(N, dev).unsqueeze(0).expand(B, -1, -1).contiguous()
     P = pairs.shape[0]
 
-    ws = None if bf16 else torch.empty(tspn.ops.fused_workspace_bytes(B, N, T, D, A_ANCH, K_PRED, P),
-                                       dtype=torch.uint8, device=dev)
-    out_heads = torch.empty((P, 3 * A_ANCH, T), dtype=torch.float32, device=dev)
+    ws = None if (bf16 or via_model) else torch.empty(tspn.ops.fused_workspace_bytes(B, N, T, D, A_ANCH, K_PRED, P),
+                                                      dtype=torch.uint8, device=dev)
+    out_heads = None if via_model else torch.empty((P, 3 * A_ANCH, T), dtype=torch.float32, device=dev)
     # two logits buffers: the second stream may still be decoding step i - 1 while step i writes its logits
-    out_logits2 = [torch.empty((P, K_PRED), dtype=torch.float32, device=dev) for _ in range(2)]
+    out_logits2 = None if via_model else [torch.empty((P, K_PRED), dtype=torch.float32, device=dev) for _ in range(2)]
     state = {}
     total_steps = args.warmup + args.steps
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
               for _ in range(total_steps)]
-    overlap = args.overlap and not bf16
+    overlap = args.overlap and not bf16 and not via_model
     side = torch.cuda.Stream(device=dev) if overlap else None
     ev_logits = [torch.cuda.Event() for _ in range(total_steps)]
     ev_side = [torch.cuda.Event() for _ in range(total_steps)]
@@ -397,6 +408,35 @@ def main():
             side.wait_event(ev_logits[i])
             tail(i, lg, cls, boxes)
             ev_side[i].record(side)
+
+    if via_model:
+        # the drop-in surface: BaseModel(cfg) with the same synthetic weights, PairLists in, forward + decode
+        cfg = tspn.load_cfg(None, **{"RELPN.USE_PPN": True, "RELPN.USE_DPN": True, "RELPN.DPN.IN_CHANNELS": C,
+                                     "PREDICT.FEATURE_DIM": C, "RELPN.DPN.NUM_ANCHORS_PER_LOCATION": A_ANCH,
+                                     "PREDICT.PREDICATE_NUM": K_PRED, "RELPN.PPN.NUM_PAIR_PROPOSALS": TOPK_PPN,
+                                     "RELPN.DPN.PAIR_GEOMETRY": True,
+                                     "RELPN.DPN.CONV_ALGO": "direct" if args.conv == "direct" else "auto"})
+        model = tspn.BaseModel(cfg)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        model = model.to(dev).eval()
+
+        def step(i):  # noqa: F811
+            feats, cls, boxes = feats_all[i % nb], cls_all[i % nb], boxes_all[i % nb]
+            plists = [tspn.PairList.from_tracklets(feats[b * N:(b + 1) * N], boxes[b * N:(b + 1) * N], cls[b])
+                      for b in range(B)]
+            model.profile_conv_events(events[i])
+            pair_props, dur_props, rel_logits = model(plists, None)
+            dec = model.decode(plists, rel_logits, topk_per_pair=TOPK_PAIR, topk_per_seg=TOPK_SEG)
+            sc, trip, tid = (torch.stack([d[k] for d in dec]) for k in range(3))
+            idx = torch.stack(pair_props)
+            state["geom"] = dur_props[0].geom
+            if use_dist:  # the one collective of the path: final result gather over RCCL
+                if args.gather == "decoded":
+                    state["gathered"] = tspn.dist.gather_decoded(sc, trip, tid, world * B, pair_proposals=idx, force=True)
+                else:
+                    tspn.dist.gather_results(torch.stack(rel_logits), world * B, force=True)
+                    tspn.dist.gather_results(idx, world * B, force=True)
+            state["last"] = (sc, trip, tid, idx)
 
     for i in range(args.warmup):
         step(i)
@@ -456,6 +496,8 @@ def main():
             "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
             "config": {"workload": cfg_name,
                        "videos_per_gpu_per_step": B, "pairs_per_video": P_vid, "resident_input_batches": nb,
+                       "surface": ("BaseModel.forward(pair_list) + BaseModel.decode on device-resident PairLists"
+                                   if via_model else "ops.forward_fused (pre-allocated workspace and outputs)"),
                        "path": ("fused/factorised (tspn_forward_fused_bf16)" if bf16 else
                                 "fused/factorised (tspn_forward_fused_f32)")
                                + " + pair geometry + PPN top-k + top-k triplet decode" + gather_txt

@@ -57,6 +57,9 @@ _DEFAULTS = {
                 # build extension (not in the reference's defaults.py): RelOIPool restricted to each
                 # pair's top temporal span instead of the whole segment (model.py:68-73 is a stub)
                 "POOL_TOP_SPAN": False,
+                # build extension: forward also returns the relative box geometry [P,8,T] of every pair
+                # (TemporalProposals.geom, the bbox half of the pair builder); nothing downstream reads it
+                "PAIR_GEOMETRY": False,
                 # build extension: algorithm of the k=3 temporal conv on the GPU (both exact fp32 MFMA):
                 # "auto" = Winograd F(6,3) where the shape allows it (D % 32 == 0; 4/9 of the direct MFMA work,
                 # error bound in DESIGN.md §4), else the direct taps; "direct" = always the direct taps

@@ -80,6 +80,40 @@ def _f32(t, device):
     return t.to(device=device, dtype=torch.float32).contiguous()
 
 
+def _consecutive_view(tensors):
+    """Zero-copy batch of equal-shape tensors that already lie back to back in ONE allocation (the slices
+    `big[b*N:(b+1)*N]` of a batched tensor a loader handed out per segment): the [len * rows, ...] view of that
+    allocation, or None when the tensors are not laid out that way."""
+    t0 = tensors[0]
+    if not isinstance(t0, torch.Tensor) or t0.dim() == 0 or not t0.is_contiguous():
+        return None
+    step = t0.numel() * t0.element_size()
+    base = t0.untyped_storage().data_ptr()
+    for k, t in enumerate(tensors):
+        if (not isinstance(t, torch.Tensor) or t.shape != t0.shape or t.dtype != t0.dtype or t.device != t0.device
+                or not t.is_contiguous() or t.data_ptr() != t0.data_ptr() + k * step
+                or t.untyped_storage().data_ptr() != base):
+            return None
+    if t0.storage_offset() * t0.element_size() + len(tensors) * step > t0.untyped_storage().nbytes():
+        return None
+    return torch.as_strided(t0, (len(tensors) * t0.shape[0],) + tuple(t0.shape[1:]), t0.stride())
+
+
+def _batch_rows(tensors, device, dtype=torch.float32):
+    """cat(tensors) on `device` as `dtype` — without the copy when they are consecutive slices of one tensor."""
+    t0 = tensors[0]
+    if isinstance(t0, torch.Tensor) and t0.device == device and t0.dtype == dtype:
+        v = _consecutive_view(tensors)
+        if v is not None:
+            return v
+    conv = []
+    for t in tensors:
+        if isinstance(t, np.ndarray):
+            t = torch.from_numpy(t)
+        conv.append(t.to(device=device, dtype=dtype).contiguous())
+    return conv[0] if len(conv) == 1 else torch.cat(conv)
+
+
 def _segment_pairs(plist, n, device):
     """int64 [P,2] pair table of a tracklet segment: its 'tracklet_pairs' field or all ordered pairs."""
     if plist.has_field("tracklet_pairs") and plist.get_field("tracklet_pairs") is not None:
@@ -302,7 +336,7 @@ class PPN(nn.Module):
         for i, c in enumerate(cls_logits):
             groups.setdefault(tuple(c.shape), []).append(i)
         for shape, members in groups.items():
-            batch = torch.stack([_f32(cls_logits[i], dev) for i in members])
+            batch = _batch_rows([cls_logits[i] for i in members], dev).view((len(members),) + tuple(shape))
             mat, idx = ops.ppn_pair_matrix_topk(batch, w, self.num_pair_proposals)
             for k, i in enumerate(members):
                 mats[i] = mat[k].to(cls_logits[i].device)
@@ -524,6 +558,13 @@ class BaseModel(_CachedWeightsMixin, nn.Module):
                                             fuse_preprocess=getattr(cfg.PREDICT, "FUSE_PREPROCESS", False))
         self._anchor_sizes_cfg = getattr(cfg.RELPN.DPN, "ANCHOR_SIZES", None)
         self.pool_top_span = bool(getattr(cfg.RELPN.DPN, "POOL_TOP_SPAN", False))
+        # build extension: also return the bbox half of the pair builder (relative geometry [P,8,T]) from the
+        # eval forward.  Nothing downstream of forward consumes it, so it is off unless asked for
+        # (`model.pair_geometry(pair_list)` computes it on demand).
+        self.pair_geometry_in_forward = bool(getattr(cfg.RELPN.DPN, "PAIR_GEOMETRY", False))
+        self._workspaces = {}        # (device index, stream) -> uint8 workspace of the fused pass, grown on demand
+        self._pair_tables = {}       # (device, B, N) -> (batched canonical pair table [B*P,2], per-video table [B,P,2])
+        self._conv_events = None     # optional (begin, end) torch.cuda.Event pair around the dominant kernel
         self.conv_algo = str(getattr(cfg.RELPN.DPN, "CONV_ALGO", "auto"))
         if self.conv_algo not in ("auto", "direct"):
             raise ValueError(f"RELPN.DPN.CONV_ALGO must be auto or direct (got {self.conv_algo})")
@@ -565,6 +606,36 @@ class BaseModel(_CachedWeightsMixin, nn.Module):
         """[P, 2D] = cat(mean_t f[s], mean_t f[o]): the segment-pooled pair feature of a tracklet sample."""
         f = _f32(plist.get_field("tracklet_feats"), dev)
         return ops.pair_rows(ops.temporal_mean(f, layout_tc=True), _segment_pairs(plist, f.shape[0], dev))
+
+    def profile_conv_events(self, events):
+        """(begin, end) torch.cuda.Event pair (enable_timing=True, recorded once) re-recorded around the dominant
+        kernel of the next fused forwards — the hook bench.py's roofline figure uses; None switches it off."""
+        self._conv_events = events
+
+    def _workspace(self, dev, nbytes):
+        """Scratch of the fused pass, kept on the module and reused by every forward on the same (device, stream):
+        launches on one stream are ordered, so the buffer is free again when the next pass starts."""
+        key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+        ws = self._workspaces.get(key)
+        if ws is None or ws.numel() < nbytes:
+            self._workspaces.pop(key, None)
+            ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
+            self._workspaces[key] = ws
+        return ws
+
+    def _canonical_pairs(self, dev, b, n):
+        """(global pair table [B*N(N-1), 2] with video b's ids offset by b*N, per-video table [B, N(N-1), 2]) of B
+        equal-N videos, built once per (device, B, N)."""
+        key = (str(dev), b, n)
+        hit = self._pair_tables.get(key)
+        if hit is None:
+            if len(self._pair_tables) >= 16:
+                self._pair_tables.clear()
+            local = ops.pair_index(n, dev)
+            allp = (local.unsqueeze(0) + (torch.arange(b, device=dev, dtype=torch.int64) * n).view(b, 1, 1))
+            hit = (allp.reshape(-1, 2).contiguous(), local.unsqueeze(0).expand(b, -1, -1).contiguous())
+            self._pair_tables[key] = hit
+        return hit
 
     def _forward_test(self, pair_list):
         with torch.no_grad():
@@ -626,61 +697,65 @@ class BaseModel(_CachedWeightsMixin, nn.Module):
             groups.setdefault(key, []).append(i)
         for (shape, _, bf16), members in groups.items():
             n, t, d = shape
+            nm = len(members)
+            per = n * (n - 1)
+            src = [pair_list[i].get_field("tracklet_feats") for i in members]
             if bf16:
                 # bf16 tracklet features select the bf16-operand kernels (BASELINE config 3)
                 if any(custom_pairs(pair_list[i]) is not None for i in members):
                     raise NotImplementedError("the bf16 path scores the canonical pair table only")
                 if d % 16:
                     raise ValueError(f"the bf16 path needs D % 16 == 0 (D={d})")
-                feats = torch.cat([pair_list[i].get_field("tracklet_feats").to(dev).contiguous()
-                                   for i in members])
-                allp = torch.cat([ops.pair_index(n, dev, base=k * n) for k in range(len(members))])
+                feats = _batch_rows(src, dev, torch.bfloat16)
+                allp, _ = self._canonical_pairs(dev, nm, n)
                 packed, cbias, hpk, hb16 = dpn._bf16_weights(dev)
                 cw16, cb16 = self.classifier._cache.get(
                     "cls_bf16", (cls.weight, cls.bias), dev,
                     lambda ts: tuple(ops.cast_bf16(x.contiguous()).float() for x in ts))
-                heads, lg = ops.forward_fused_bf16(feats, allp, len(members), n, packed, cbias, hpk, hb16,
-                                                   cw16, cb16)
-                per = n * (n - 1)
-                geom = self._pair_geometry_batch(pair_list, members, allp, dev)
-                for k, i in enumerate(members):
-                    src_dev = pair_list[i].get_field("tracklet_feats").device
-                    durations[i] = dpn._wrap(heads[k * per:(k + 1) * per].to(src_dev),
-                                             None if geom is None else geom[k * per:(k + 1) * per].to(src_dev))
-                    logits[i] = lg[k * per:(k + 1) * per].to(src_dev)
-                continue
-            feats = torch.cat([_f32(pair_list[i].get_field("tracklet_feats"), dev) for i in members])
-            pairs = []
-            canonical = True
-            for k, i in enumerate(members):
-                p = custom_pairs(pair_list[i])
-                canonical = canonical and p is None
-                if p is None:
-                    pairs.append(ops.pair_index(n, dev, base=k * n))
+                need = ops.fused_bf16_workspace_bytes(nm, n, t, d, hb16.numel() // 3, cw16.shape[0], allp.shape[0])
+                heads, lg = ops.forward_fused_bf16(feats, allp, nm, n, packed, cbias, hpk, hb16, cw16, cb16,
+                                                   workspace=self._workspace(dev, need), conv_events=self._conv_events)
+                counts = [per] * nm
+            else:
+                feats = _batch_rows(src, dev)
+                customs = [custom_pairs(pair_list[i]) for i in members]
+                canonical = all(p is None for p in customs)
+                if canonical:
+                    allp, _ = self._canonical_pairs(dev, nm, n)
+                    counts = [per] * nm
                 else:
-                    if p.dim() != 2 or p.shape[1] != 2:
-                        raise ValueError("tracklet_pairs must be [P,2]")
-                    if p.numel() and (int(p.min()) < 0 or int(p.max()) >= n):
-                        raise IndexError("tracklet_pairs index out of range")
-                    pairs.append(p.to(dev) + k * n)
-            counts = [p.shape[0] for p in pairs]
-            allp = torch.cat(pairs).contiguous()
-            # temporal conv algorithm: RELPN.DPN.CONV_ALGO = "auto" (Winograd F(6,3) when D % 32 == 0: 4/9 of the
-            # MFMA work; its fp32 error bound is in DESIGN.md §4) or "direct" (the k=3 taps as one implicit GEMM)
-            packed, cbias = dpn._conv_split(dev, winograd=(self.conv_algo == "auto" and d % 32 == 0))
-            heads, lg = ops.forward_fused(feats, allp, len(members), n, packed, cbias, hw, hb, cw, cb,
-                                          check_pairs=False, canonical_pairs=canonical)
-            if self.pool_top_span and allp.shape[0]:
-                # RelOIPool over each pair's best span (decode + NMS, top-1) instead of the whole segment
-                top = ops.decode_spans(heads, self.anchor_sizes(t), top_k=1)["span"][:, 0].contiguous()
-                lg = ops.span_predicate(feats, allp, top, cw, cb)
-            geom = self._pair_geometry_batch(pair_list, members, allp, dev)
+                    pairs = []
+                    for k, p in enumerate(customs):
+                        if p is None:
+                            pairs.append(ops.pair_index(n, dev, base=k * n))
+                            continue
+                        if p.dim() != 2 or p.shape[1] != 2:
+                            raise ValueError("tracklet_pairs must be [P,2]")
+                        if p.numel() and (int(p.min()) < 0 or int(p.max()) >= n):
+                            raise IndexError("tracklet_pairs index out of range")
+                        pairs.append(p.to(dev) + k * n)
+                    counts = [p.shape[0] for p in pairs]
+                    allp = torch.cat(pairs).contiguous()
+                # temporal conv algorithm: RELPN.DPN.CONV_ALGO = "auto" (Winograd F(6,3) when D % 32 == 0: 4/9 of the
+                # MFMA work; its fp32 error bound is in DESIGN.md §4) or "direct" (the k=3 taps as one implicit GEMM)
+                packed, cbias = dpn._conv_split(dev, winograd=(self.conv_algo == "auto" and d % 32 == 0))
+                need = ops.fused_workspace_bytes(nm, n, t, d, hb.numel() // 3, cw.shape[0], allp.shape[0])
+                heads, lg = ops.forward_fused(feats, allp, nm, n, packed, cbias, hw, hb, cw, cb,
+                                              workspace=self._workspace(dev, need), check_pairs=False,
+                                              canonical_pairs=canonical, conv_events=self._conv_events)
+                if self.pool_top_span and allp.shape[0]:
+                    # RelOIPool over each pair's best span (decode + NMS, top-1) instead of the whole segment
+                    top = ops.decode_spans(heads, self.anchor_sizes(t), top_k=1)["span"][:, 0].contiguous()
+                    lg = ops.span_predicate(feats, allp, top, cw, cb)
+            geom = self._pair_geometry_batch(pair_list, members, allp, dev) if self.pair_geometry_in_forward else None
+            # per-segment results are VIEWS of the batched outputs (copies only when a segment's inputs live on
+            # another device, e.g. the host tensors predict.py hands over)
             off = 0
             for k, i in enumerate(members):
-                src_dev = pair_list[i].get_field("tracklet_feats").device
-                h = heads[off:off + counts[k]].to(src_dev)
-                durations[i] = dpn._wrap(h, None if geom is None else geom[off:off + counts[k]].to(src_dev))
-                logits[i] = lg[off:off + counts[k]].to(src_dev)
+                src_dev = src[k].device
+                sl = slice(off, off + counts[k])
+                durations[i] = dpn._wrap(heads[sl].to(src_dev), None if geom is None else geom[sl].to(src_dev))
+                logits[i] = lg[sl].to(src_dev)
                 off += counts[k]
         return pair_proposals, durations, logits
 
@@ -692,7 +767,7 @@ class BaseModel(_CachedWeightsMixin, nn.Module):
         if not all(pair_list[i].has_field("tracklet_boxes") and pair_list[i].get_field("tracklet_boxes") is not None
                    for i in members) or allp.shape[0] == 0:
             return None
-        boxes = torch.cat([_f32(pair_list[i].get_field("tracklet_boxes"), dev) for i in members])
+        boxes = _batch_rows([pair_list[i].get_field("tracklet_boxes") for i in members], dev)
         _, geom = ops.pair_gather(None, boxes, allp, want_feat=False, check_pairs=False)   # allp was validated above
         return geom
 
@@ -718,33 +793,47 @@ class BaseModel(_CachedWeightsMixin, nn.Module):
                           torch.empty((0, 2), dtype=torch.int64, device=dev))
                 continue
             groups.setdefault((n, tuple(lg.shape), quirk, tuple(plist.features.shape) if quirk else None), []).append(i)
-        for (n, _, quirk, _), members in groups.items():
+        for (n, lshape, quirk, _), members in groups.items():
             dev = _compute_device(*[rel_logits[i] for i in members])
-            lg = torch.stack([_f32(rel_logits[i], dev) for i in members])
-            pairs = []
-            for i in members:
-                plist = pair_list[i]
-                if plist.has_field("tracklet_pairs") and plist.get_field("tracklet_pairs") is not None:
-                    p = plist.get_field("tracklet_pairs")
-                    p = p.detach().long() if isinstance(p, torch.Tensor) else torch.as_tensor(np.asarray(p)).long()
-                    if tuple(p.shape) != (rel_logits[i].shape[0], 2):
-                        raise ValueError(f"decode: segment {i}: 'tracklet_pairs' must be [P,2] with one row per "
-                                         f"rel_logits row (P={rel_logits[i].shape[0]}), got {tuple(p.shape)}")
-                    pairs.append(p.to(dev))
-                else:
+            nm = len(members)
+            lg = _batch_rows([rel_logits[i] for i in members], dev).view(nm, lshape[0], lshape[1])
+            custom = [pair_list[i].has_field("tracklet_pairs") and pair_list[i].get_field("tracklet_pairs") is not None
+                      for i in members]
+            if not any(custom):
+                for i in members:
                     if n * (n - 1) != rel_logits[i].shape[0]:
                         raise ValueError(f"decode: segment {i}: rel_logits has {rel_logits[i].shape[0]} rows but "
                                          f"{n} tracklets give {n * (n - 1)} pairs and no 'tracklet_pairs' field is set")
-                    pairs.append(ops.pair_index(n, dev))
-            pairs = torch.stack(pairs).contiguous()
-            if quirk:
-                cls = torch.stack([_f32(pair_list[i].features, dev) for i in members])
-                res = ops.decode_topk(lg, pairs, cls, row_mul=n - 1, num_obj=num_obj,
-                                      topk_per_pair=topk_per_pair, topk_per_seg=topk_per_seg)
+                pairs = self._canonical_pairs(dev, nm, n)[1]
+                trusted = True
             else:
-                cls = torch.stack([_f32(pair_list[i].get_field("track_cls_logits"), dev) for i in members])
+                pairs = []
+                for i in members:
+                    plist = pair_list[i]
+                    if plist.has_field("tracklet_pairs") and plist.get_field("tracklet_pairs") is not None:
+                        p = plist.get_field("tracklet_pairs")
+                        p = p.detach().long() if isinstance(p, torch.Tensor) else torch.as_tensor(np.asarray(p)).long()
+                        if tuple(p.shape) != (rel_logits[i].shape[0], 2):
+                            raise ValueError(f"decode: segment {i}: 'tracklet_pairs' must be [P,2] with one row per "
+                                             f"rel_logits row (P={rel_logits[i].shape[0]}), got {tuple(p.shape)}")
+                        pairs.append(p.to(dev))
+                    else:
+                        if n * (n - 1) != rel_logits[i].shape[0]:
+                            raise ValueError(f"decode: segment {i}: rel_logits has {rel_logits[i].shape[0]} rows but "
+                                             f"{n} tracklets give {n * (n - 1)} pairs and no 'tracklet_pairs' field is set")
+                        pairs.append(ops.pair_index(n, dev))
+                pairs = torch.stack(pairs).contiguous()
+                trusted = False
+            if quirk:
+                fshape = tuple(pair_list[members[0]].features.shape)
+                cls = _batch_rows([pair_list[i].features for i in members], dev).view((nm,) + fshape)
+                res = ops.decode_topk(lg, pairs, cls, row_mul=n - 1, num_obj=num_obj,
+                                      topk_per_pair=topk_per_pair, topk_per_seg=topk_per_seg, check_pairs=not trusted)
+            else:
+                cshape = tuple(pair_list[members[0]].get_field("track_cls_logits").shape)
+                cls = _batch_rows([pair_list[i].get_field("track_cls_logits") for i in members], dev).view((nm,) + cshape)
                 res = ops.decode_topk(lg, pairs, cls, row_mul=1, num_obj=num_obj,
-                                      topk_per_pair=topk_per_pair, topk_per_seg=topk_per_seg)
+                                      topk_per_pair=topk_per_pair, topk_per_seg=topk_per_seg, check_pairs=not trusted)
             for k, i in enumerate(members):
                 tgt = rel_logits[i].device
                 out[i] = tuple(r[k].to(tgt) for r in res)

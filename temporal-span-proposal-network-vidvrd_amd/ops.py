@@ -14,7 +14,7 @@ from . import _abi
 __all__ = [
     "predicate_head", "feature_preprocess_", "ppn_pair_matrix_topk", "traj_iou", "pair_index",
     "pair_gather", "pack_conv3", "conv3", "conv3_tc", "pack_conv3_wino63", "conv3_tc_wino63", "heads", "heads_pairgrid", "temporal_mean", "pair_rows", "transpose_td",
-    "forward_fused", "temporal_encoder_heads", "fused_workspace_bytes", "decode_topk", "decode_spans",
+    "forward_fused", "temporal_encoder_heads", "fused_workspace_bytes", "fused_bf16_workspace_bytes", "decode_topk", "decode_spans",
     "cast_bf16", "pack_conv3_bf16", "pack_heads_bf16", "conv3_tc_bf16", "heads_pairgrid_bf16",
     "transpose_cast_bf16", "temporal_encoder_heads_bf16",
     "temporal_mean_bf16", "forward_fused_bf16", "span_predicate",
@@ -700,6 +700,12 @@ def temporal_mean_bf16(x):
     out = torch.empty((R, D), dtype=torch.float32, device=x.device)
     _abi.check(_abi.lib().tspn_temporal_mean_bf16(_p(x), R, T, D, _p(out), _stream()))
     return out
+
+
+def fused_bf16_workspace_bytes(B, N, T, D, A, K, P):
+    d = _abi.FusedBf16Desc()
+    d.B, d.N, d.T, d.D, d.A, d.K, d.P = B, N, T, D, A, K, P
+    return _abi.lib().tspn_forward_fused_bf16_workspace_bytes(ctypes.byref(d))
 
 
 def forward_fused_bf16(feats, pairs, B, N, conv_packed, conv_bias, head_packed, head_b, cls_w, cls_b,

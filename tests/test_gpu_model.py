@@ -130,7 +130,15 @@ def test_temporal_forward_tracklets_fused(tspn, device):
     geo = model.pair_geometry(plists)
     ref_g = oracle.pair_geometry(t(vids[1]["tracklet_boxes"]), oracle.pair_index(4))
     np.testing.assert_allclose(geo[1].numpy(), ref_g.numpy(), rtol=2e-6, atol=2e-6)
-    # the bbox half of the pair builder is part of forward's output: one launch per group of segments
+    # the bbox half of the pair builder is an opt-in output of forward (RELPN.DPN.PAIR_GEOMETRY; nothing downstream
+    # consumes it): off by default, one launch per group of segments when on
+    assert all(d.geom is None for d in dp)
+    gmodel = tspn.BaseModel(cases.baseline_cfg(**{"RELPN.USE_PPN": True, "RELPN.USE_DPN": True, "RELPN.DPN.IN_CHANNELS": 2 * D,
+                                                  "PREDICT.FEATURE_DIM": 2 * D, "RELPN.DPN.PAIR_GEOMETRY": True}))
+    load(gmodel, sd)
+    gmodel.eval()
+    _, dp, logits_g = gmodel(plists, None)
+    assert all(torch.equal(a, b) for a, b in zip(logits, logits_g))
     for i, v in enumerate(vids):
         n = shapes[i][0]
         assert dp[i].geom.shape == (n * (n - 1), 8, shapes[i][1]) and dp[i].geom.device.type == "cpu"
@@ -138,7 +146,7 @@ def test_temporal_forward_tracklets_fused(tspn, device):
                                    rtol=2e-6, atol=2e-6)
         assert torch.equal(dp[i].geom, geo[i])
     no_boxes = tspn.PairList.from_tracklets(t(vids[0]["tracklet_feats"]), None, t(vids[0]["track_cls_logits"]))
-    assert model([no_boxes], None)[1][0].geom is None
+    assert gmodel([no_boxes], None)[1][0].geom is None
 
 
 def test_temporal_forward_materialised_features_dense(tspn, device):
@@ -505,3 +513,47 @@ def test_temporal_branch_training_errors(tspn, device):
     cpu_model = tspn.BaseModel(temporal_cfg(D, use_ppn=False)).train()
     with pytest.raises(RuntimeError):
         cpu_model([plist], [tl.to(device)])                   # parameters not on the HIP device
+
+
+def test_forward_on_slices_of_one_batched_tensor_is_zero_copy_and_equal(tspn, device):
+    """A loader that hands out `big[b*N:(b+1)*N]` slices of one device-resident [B*N,T,D] tensor (what
+    bench.py --via-model does): the fused forward batches them back WITHOUT a copy (model._consecutive_view) and
+    returns per-segment VIEWS of one batched output; results equal the forward on independent copies bit for
+    bit, a second call reuses the module's workspace and pair table, and decode on the views equals decode on
+    copies."""
+    from tspn_mi355x import model as M
+    D, N, T, B = 32, 5, 30, 3
+    sd = tspn.synth.make_weights(4, c=2 * D, bias_std=0.05)
+    model = tspn.BaseModel(temporal_cfg(D))
+    load(model, sd)
+    model.eval()
+    vids = [tspn.synth.make_video(300 + b, N, T, D) for b in range(B)]
+    big = torch.cat([t(v["tracklet_feats"]) for v in vids]).to(device)
+    boxes = torch.cat([t(v["tracklet_boxes"]) for v in vids]).to(device)
+    cls = torch.stack([8.0 * t(v["track_cls_logits"]) for v in vids]).to(device)
+    sl = [big[b * N:(b + 1) * N] for b in range(B)]
+    view = M._consecutive_view(sl)
+    assert view is not None and view.data_ptr() == big.data_ptr() and view.shape == big.shape
+    assert M._consecutive_view([sl[0], sl[2]]) is None and M._consecutive_view([sl[1].clone(), sl[2]]) is None
+    assert M._consecutive_view([big[1:N + 1], big[N + 1:2 * N + 1]]).data_ptr() == big[1:].data_ptr()
+    plists = [tspn.PairList.from_tracklets(sl[b], boxes[b * N:(b + 1) * N], cls[b]) for b in range(B)]
+    pp, dp, lg = model(plists, None)
+    P = N * (N - 1)
+    assert all(lg[b].data_ptr() == lg[0].data_ptr() + b * P * 132 * 4 for b in range(B))      # views of one output
+    assert all(dp[b].heads.data_ptr() == dp[0].heads.data_ptr() + b * P * 12 * T * 4 for b in range(B))
+    copies = [tspn.PairList.from_tracklets(sl[b].clone(), boxes[b * N:(b + 1) * N].clone(), cls[b].clone()) for b in range(B)]
+    pp2, dp2, lg2 = model(copies, None)
+    for b in range(B):
+        assert torch.equal(lg[b], lg2[b]) and torch.equal(dp[b].heads, dp2[b].heads) and torch.equal(pp[b], pp2[b])
+    assert len(model._workspaces) == 1 and len(model._pair_tables) == 1
+    ws_ptr = next(iter(model._workspaces.values())).data_ptr()
+    model(plists, None)
+    assert next(iter(model._workspaces.values())).data_ptr() == ws_ptr
+    d1 = model.decode(plists, lg)
+    d2 = model.decode(copies, [x.clone() for x in lg2])
+    for a, b in zip(d1, d2):
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
+    w = oracle_weights(sd)
+    ref = oracle.forward_dense(t(vids[1]["tracklet_feats"]), t(vids[1]["tracklet_boxes"]), oracle.pair_index(N), w)
+    np.testing.assert_allclose(lg[1].cpu().numpy(), ref["rel_logits"].numpy(), rtol=0, atol=1e-5)
+    np.testing.assert_allclose(dp[1].duration.cpu().numpy(), ref["duration"].numpy(), rtol=0, atol=1e-5)
