@@ -13,6 +13,9 @@ Workloads (`--workload`):
   cfg2 (default, the headline) 16 videos per GPU per step of BASELINE.json configs[1]
   cfg4   the per-GPU shard of configs[3]: 512 cfg2-shaped videos over 8 GPUs = 64 videos per GPU per step
   cfg3   configs[2]: N=64, T=900, D=1024, bf16 operands, 4 videos per step
+  cfg5   configs[4]: frames -> triplets at VidOR scale, one video (900 frames of 720p, 64 tracklets) per GPU per
+         step: ResNet-101-C4 backbone (bf16 MFMA convs) -> res4 maps -> RoIAlign + res5 + mean = tracklet_feats
+         [64,900,2048] -> BaseModel.forward (bf16 scorer) -> BaseModel.decode
 
 The step runs THROUGH THE DROP-IN SURFACE by default: B device-resident `PairList.from_tracklets` per step ->
 `BaseModel.forward(pair_list)` (reference lib/modeling/model.py:53-65, called as predict.py:57 calls it) ->
@@ -22,24 +25,29 @@ caller-held workspace and outputs instead (the two agree within 1 %, profiles/r3
 A "step" = one pass of the hot path over one batch of synthetic videos per GPU (inputs resident in HBM, a
 rotation of `--batches` different batches): tracklet tensors -> [pair builder + temporal encoder +
 relationness/span heads + RelOIPool + predicate head] (tspn_forward_fused_f32) + pair geometry [P,8,T] from the
-boxes (tspn_pair_gather_f32) + PPN pair-matrix/top-k + top-k triplet decode (tspn_decode_topk_f32, the reference's predict.py:66-106).  The predicate logits are ready
-before the encoder starts (they depend on the tracklet means only; tspn_fused_desc.ev_logits_ready), so with
-`--overlap` geometry, PPN, decode and the result gather run on a second HIP stream under the encoder of the same
-step — on one GPU that buys nothing (the encoder fills the chip), so it is off by default.
-Videos shard across ranks
-(weak scaling, no collective in the forward); with N>1 each step ends with ONE RCCL all-gather of the
-DECODED per-video results — top-200 (score, triplet, pair) + top-256 pair proposals, 10.8 KB per video
-(`--gather logits` gathers the 524 KB of predicate logits per video instead, as round 1 did).
+boxes (tspn_pair_gather_f32) + PPN pair-matrix/top-k + top-k triplet decode (tspn_decode_topk_f32, the
+reference's predict.py:66-106).  Videos shard across ranks (weak scaling, no collective in the forward); with
+N>1 each step ends with ONE RCCL all-gather of the DECODED per-video results — top-200 (score, triplet, pair) +
+top-256 pair proposals, 10.8 KB per video (`--gather logits` gathers the 524 KB of predicate logits per video
+instead, as round 1 did).
 
 Printed JSON (rank 0): see the task contract; extras:
   roofline     dominant kernel = the temporal conv of the tracklet projections (fp32 MFMA; Winograd
-               F(6,3) by default, --conv direct for the direct taps);
-               achieved = executed FLOP per launch / HIP-event time of that launch inside the
-               timed steps (events recorded on the launch stream by the C ABI's hook);
-               clock_mhz = shader clock sampled from the driver while the timed steps ran (box-to-box
-               variance of `frac` is mostly the clock the chip holds under this kernel).
-  cpu_baseline the oracle's reference-faithful dense forward on a FIXED sample of pairs (all 31 objects
-               of 8 subjects = 248 pairs), median of 5 runs after a warm-up, on the cores this process may use.
+               F(6,3) by default, --conv direct for the direct taps); achieved = executed FLOP per launch /
+               HIP-event time of that launch inside the timed steps (events recorded on the launch stream by
+               the C ABI's hook); clock_mhz = shader clock sampled from the driver while the timed steps ran
+               (box-to-box variance of `frac` is mostly the clock the chip holds under this kernel).
+               cfg5: the backbone's convolutions as a whole (executed conv FLOP of one video / HIP-event time of
+               the backbone inside the timed steps) against the dense bf16 MFMA peak.
+  cpu_baseline the oracle on a FIXED bounded sample of the same workload on the cores this process may use
+               (cfg2/cfg4: dense fp32 forward of 248 pairs, median of 5; cfg3: bf16 restatement of 96 pairs, one
+               run; cfg5: backbone of 8 frames + RoI head of their 64 boxes each + scorer of 8 pairs, one run each,
+               scaled to a video).
+
+`--stub-gpu` (CPU rehearsal, used by tests/test_dist_gloo.py): the rank body of this file — rendezvous, warm-up,
+barrier-bracketed timed loop, the decoded-result all-gather of every step, max-over-ranks time, the
+`gathered[rank*B:(rank+1)*B] == local` check, the JSON line — with the GPU step replaced by recorded decoded
+rows and `gloo` in place of RCCL.  Its JSON says `"stub": true`; it measures nothing.
 """
 import argparse
 import json
@@ -53,46 +61,60 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 N_TRK, T_FRAMES, D_ROI, A_ANCH, K_PRED = 32, 150, 2048, 4, 132
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 (no sparsity), v_mfma_f32_32x32x16_bf16
-PEAK_CLOCK_MHZ = 2400.0  # the clock the 157.3 TFLOP/s figure is quoted at
+PEAK_CLOCK_MHZ = 2400.0  # the clock the peak figures are quoted at
 # --workload cfg3: BASELINE.json configs[2] (VidOR long-clip shape, bf16 operands); not the headline
 CFG3 = (64, 900, 1024)
+# --workload cfg5: BASELINE.json configs[4] (frames -> triplets at VidOR scale): tracklets, frames, frame size
+CFG5 = (64, 900, 720, 1280)
 DPN_PRE = "relpn.duration_proposal_network.dpn_head."
 PPN_PRE = "relpn.pair_proposal_network.ppn_head."
-CPU_SUBJECTS = 8   # cpu_baseline sample: all 31 objects of this many subjects
+CPU_SUBJECTS = 8   # cpu_baseline sample (cfg2): all 31 objects of this many subjects
 TOPK_PAIR, TOPK_SEG, TOPK_PPN = 20, 200, 256   # PREDICT.TOPK_PER_PAIR / TOPK_PER_SEG, PPN.NUM_PAIR_PROPOSALS
+DEFAULT_STEPS = {"cfg2": (50, 5), "cfg4": (12, 2), "cfg3": (50, 5), "cfg5": (3, 1)}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 50; cfg4 12; cfg5 3)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default: 5; cfg4 2; cfg5 1)")
     ap.add_argument("--videos", type=int, default=None,
-                    help="videos per GPU per step (default: 16 for cfg2, 64 for cfg4, 4 for cfg3)")
+                    help="videos per GPU per step (default: 16 for cfg2, 64 for cfg4, 4 for cfg3, 1 for cfg5)")
     ap.add_argument("--batches", type=int, default=2,
                     help="different input batches resident in HBM, rotated step by step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-runs", type=int, default=5, help="timed runs of the CPU baseline (median reported)")
+    ap.add_argument("--cpu-runs", type=int, default=5, help="timed runs of the cfg2 CPU baseline (median reported)")
     ap.add_argument("--conv", choices=["winograd6", "direct"], default="winograd6",
                     help="temporal-conv algorithm of the tracklet projections (both fp32 MFMA): Winograd F(6,3) "
                          "(default, what RELPN.DPN.CONV_ALGO = auto selects at this shape) or the direct taps")
-    ap.add_argument("--workload", choices=["cfg2", "cfg3", "cfg4"], default="cfg2",
+    ap.add_argument("--workload", choices=["cfg2", "cfg3", "cfg4", "cfg5"], default="cfg2",
                     help="cfg2 = headline (N=32,T=150,D=2048, fp32, 16 videos/GPU/step); cfg4 = its 64-videos-per-GPU "
-                         "shard of the 512-video batch; cfg3 = N=64,T=900,D=1024 bf16 operands")
+                         "shard of the 512-video batch; cfg3 = N=64,T=900,D=1024 bf16 operands; cfg5 = frames -> "
+                         "triplets (ResNet-101-C4 + RoI head + scorer) at VidOR scale, one video per step")
     ap.add_argument("--gather", choices=["decoded", "logits"], default="decoded",
                     help="payload of the N>1 result gather: decoded top-k results (default) or raw logits")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the RCCL result gather even with one rank (exercises the N>1 code path)")
     ap.add_argument("--overlap", action="store_true",
-                    help="pair geometry, PPN, decode and the result gather on a second HIP stream behind the logits-ready "
-                         "event, under the encoder of the same step (measured on one GPU: 32.70 vs 32.65 ms per step, the "
-                         "encoder leaves no idle units to fill, so the default keeps one stream)")
+                    help="--ops-level only: pair geometry, PPN, decode and the result gather on a second HIP stream "
+                         "behind the logits-ready event, under the encoder of the same step (measured on one GPU: "
+                         "32.70 vs 32.65 ms per step, so the default keeps one stream)")
     ap.add_argument("--ops-level", action="store_true",
                     help="time ops.forward_fused with pre-allocated workspace / outputs instead of BaseModel.forward + "
                          "BaseModel.decode on PairLists (the default)")
+    ap.add_argument("--frames", type=int, default=None, help="cfg5: frames per video (default 900)")
+    ap.add_argument("--tracklets", type=int, default=None, help="cfg5: tracklets per video (default 64)")
+    ap.add_argument("--fused-bottleneck", choices=["auto", "off"], default="auto",
+                    help="cfg5: `off` runs every backbone convolution as its own launch (the round-2 path)")
     ap.add_argument("--launch-check", action="store_true",
                     help="rehearse only the rank launch + rendezvous on the CPU (gloo), no GPU work")
-    return ap.parse_args()
+    ap.add_argument("--stub-gpu", action="store_true",
+                    help="CPU rehearsal of the whole rank body (gloo, recorded decoded rows instead of the GPU step)")
+    args = ap.parse_args(argv)
+    steps, warm = DEFAULT_STEPS[args.workload]
+    args.steps = steps if args.steps is None else args.steps
+    args.warmup = warm if args.warmup is None else args.warmup
+    return args
 
 
 def free_port():
@@ -138,6 +160,13 @@ def cpu_model():
     return "unknown"
 
 
+def oracle_weights(sd):
+    return {"conv_w": sd[DPN_PRE + "conv.weight"], "conv_b": sd[DPN_PRE + "conv.bias"],
+            "dur_w": sd[DPN_PRE + "duration_pred.weight"], "dur_b": sd[DPN_PRE + "duration_pred.bias"],
+            "rel_w": sd[DPN_PRE + "relness_pred.weight"], "rel_b": sd[DPN_PRE + "relness_pred.bias"],
+            "cls_w": sd["classifier.rel_predictor.weight"], "cls_b": sd["classifier.rel_predictor.bias"]}
+
+
 def cpu_baseline(weights, runs):
     """Reference-faithful dense forward (oracle.forward_dense: materialise [P,4096,150] -> DPNHead -> heads;
     RelOIPool; predicate head) on a FIXED sample of one cfg2 video: all 31 objects of subjects 0..7
@@ -170,6 +199,75 @@ def cpu_baseline(weights, runs):
             "sample": f"all {N_TRK - 1} objects of {CPU_SUBJECTS} subjects = {p} of 992 pairs of one cfg2 video, dense reference "
                       f"formulation (oracle.forward_dense), median of {len(times)} runs after 1 warm-up "
                       f"({med:.2f} s per run), torch {torch.__version__} CPU, {cores} threads"}
+
+
+def cpu_baseline_cfg3(weights, n, t, d, pairs_in_sample=96):
+    """The oracle's bf16 restatement (oracle.forward_bf16: bf16 operands, the reference's DPNHead / RelationPredictor
+    under .bfloat16() pin its rounding points, golden g8) on the first `pairs_in_sample` pairs of one video of the
+    shape, ONE run (22.7 GFLOP per cfg3 pair in the dense formulation)."""
+    import torch
+
+    import oracle
+    import tspn_mi355x as tspn
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    v = tspn.synth.make_video(1, n, t, d)
+    feats = torch.from_numpy(v["tracklet_feats"])
+    w = {k: torch.from_numpy(x) for k, x in weights.items()}
+    pairs = oracle.pair_index(n)[:pairs_in_sample]
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        oracle.forward_bf16(feats, pairs, w)
+    dt = time.perf_counter() - t0
+    return {"value": pairs_in_sample / dt, "unit": "tracklet-pairs/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
+            "runs": 1, "seconds": dt,
+            "sample": f"the first {pairs_in_sample} of {n * (n - 1)} pairs of one video (N={n}, T={t}, D={d}), bf16-operand "
+                      f"dense restatement (oracle.forward_bf16), one run of {dt:.2f} s, torch {torch.__version__} CPU, "
+                      f"{cores} threads"}
+
+
+def cpu_baseline_cfg5(bb_sd, r5_sd, score_w, n, t, h, w_img, frames=8, pairs_in_sample=8):
+    """frames -> triplets on the CPU, bounded: `frames` 720p frames through the oracle's ResNet-101-C4 (fp32 torch
+    convs), the RoI head of those frames' `n` boxes each (restated ROIAlign + res5), and the bf16 scorer restatement
+    on `pairs_in_sample` pairs at T frames; scaled to a video: t/frames * (backbone + RoI head) + n(n-1)/pairs * scorer."""
+    import numpy as np
+    import torch
+
+    import oracle
+    from oracle import roi_head_oracle as ro
+    import tspn_mi355x as tspn
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    img = torch.from_numpy(tspn.hashrng.uniform(9, "img", (frames, h, w_img, 3), -0.5, 0.5))
+    bb = {k: torch.from_numpy(v) for k, v in bb_sd.items()}
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        fm = ro.resnet_c4(img, bb, tspn.ResNetC4.BLOCKS[101], dtype=torch.float32)
+    t_bb = time.perf_counter() - t0
+    xy = tspn.hashrng.uniform(9, "xy", (n, frames, 2)) * np.array([900.0, 400.0], np.float32)
+    wh = 40 + tspn.hashrng.uniform(9, "wh", (n, frames, 2)) * 260
+    boxes = torch.from_numpy(np.concatenate([xy, xy + wh], axis=2).astype(np.float32))
+    r5 = {k: torch.from_numpy(v) for k, v in r5_sd.items()}
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        ro.res5_roi_head(fm, boxes, r5)
+    t_roi = time.perf_counter() - t0
+    d = 2048
+    feats = torch.from_numpy(tspn.hashrng.uniform(9, "f", (4, t, d)))
+    wts = {k: torch.from_numpy(x) for k, x in score_w.items()}
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        oracle.forward_bf16(feats, oracle.pair_index(4)[:pairs_in_sample], wts)
+    t_pairs = time.perf_counter() - t0
+    p_vid = n * (n - 1)
+    video_s = t / frames * (t_bb + t_roi) + p_vid / pairs_in_sample * t_pairs
+    return {"value": p_vid / video_s, "unit": "tracklet-pairs/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
+            "runs": 1, "videos_per_s": 1.0 / video_s,
+            "seconds": {"backbone": t_bb, "roi_head": t_roi, "scorer": t_pairs},
+            "sample": f"{frames} frames of {h}x{w_img} through the oracle's ResNet-101-C4 ({t_bb:.2f} s), the RoI head of their "
+                      f"{n} boxes each ({t_roi:.2f} s), the bf16 scorer restatement on {pairs_in_sample} pairs at T={t}, D={d} "
+                      f"({t_pairs:.2f} s); scaled to one video = {t}/{frames} x (backbone + RoI head) + {p_vid}/{pairs_in_sample} x "
+                      f"scorer = {video_s:.0f} s; one run each, torch {torch.__version__} CPU, {cores} threads"}
 
 
 def pmc_traffic(workload, videos, conv):
@@ -249,6 +347,422 @@ def launch_check(args):
         dist.destroy_process_group()
 
 
+# ------------------------------------------------------------------------------------------------ workloads
+class Gatherer:
+    """The one collective of the path: all-gather of per-video results at the end of a step (RCCL; gloo in the
+    CPU rehearsal).  Keeps the last local and gathered rows for the post-run check."""
+
+    def __init__(self, tspn, args, world, use_dist):
+        self.tspn, self.args, self.world, self.use_dist = tspn, args, world, use_dist
+        self.last, self.gathered = None, None
+
+    def __call__(self, sc, trip, tid, idx, logits=None):
+        b = sc.shape[0]
+        if self.use_dist:
+            if self.args.gather == "decoded" or logits is None:
+                self.gathered = self.tspn.dist.gather_decoded(sc, trip, tid, self.world * b, pair_proposals=idx, force=True)
+            else:
+                self.tspn.dist.gather_results(logits, self.world * b, force=True)
+                self.tspn.dist.gather_results(idx, self.world * b, force=True)
+        self.last = (sc, trip, tid, idx)
+
+    def check(self, rank):
+        """Every rank holds every video's decoded rows, in global order; its own block equals what it computed."""
+        import torch
+        if not self.use_dist or self.gathered is None:
+            return
+        g, b = self.gathered, self.last[0].shape[0]
+        assert g["scores"].shape == (self.world * b, self.last[0].shape[1]), g["scores"].shape
+        assert g["pair_proposals"].shape == (self.world * b, self.last[3].shape[1]), g["pair_proposals"].shape
+        assert torch.equal(g["scores"][rank * b:(rank + 1) * b], self.last[0]), "gathered scores differ from the local block"
+        assert torch.equal(g["triplets"][rank * b:(rank + 1) * b], self.last[1]), "gathered triplets differ"
+        assert torch.equal(g["pair_proposals"][rank * b:(rank + 1) * b], self.last[3]), "gathered pair proposals differ"
+
+
+class StubWorkload:
+    """--stub-gpu: recorded decoded rows (deterministic per global video index) in place of the GPU step."""
+
+    def __init__(self, args, tspn, torch, np, dev, world, rank, gather):
+        self.args, self.world, self.rank, self.gather = args, world, rank, gather
+        self.B = args.videos if args.videos is not None else 4
+        self.units_per_step = self.B * N_TRK * (N_TRK - 1)
+        rows = []
+        for b in range(self.B):
+            g = rank * self.B + b     # global video index
+            sc = np.sort(tspn.hashrng.uniform(1000 + g, "sc", (TOPK_SEG,)))[::-1].copy()
+            trip = np.stack([tspn.hashrng.integers(1000 + g, "s", (TOPK_SEG,), 0, 35),
+                             tspn.hashrng.integers(1000 + g, "p", (TOPK_SEG,), 0, K_PRED),
+                             tspn.hashrng.integers(1000 + g, "o", (TOPK_SEG,), 0, 35)], axis=1).astype(np.int64)
+            tid = tspn.hashrng.integers(1000 + g, "t", (TOPK_SEG, 2), 0, N_TRK).astype(np.int64)
+            idx = tspn.hashrng.integers(1000 + g, "i", (TOPK_PPN,), 0, N_TRK * N_TRK).astype(np.int64)
+            rows.append((sc, trip, tid, idx))
+        self.rows = tuple(torch.from_numpy(np.stack([r[k] for r in rows])) for k in range(4))
+
+    def step(self, i):
+        self.gather(*self.rows)
+
+    def sync(self):
+        pass
+
+    def report(self, elapsed, clock_mhz):
+        return {"metric": f"tracklet-pairs/sec scored (N={N_TRK}, T={T_FRAMES}, D={D_ROI})", "dtype": "none", "stub": True,
+                "config": {"workload": "STUB: recorded decoded rows instead of the GPU step (CPU rehearsal of the rank "
+                                       "body over gloo; measures nothing)", "videos_per_gpu_per_step": self.B},
+                "roofline": None}
+
+    def cpu_baseline(self):
+        return None
+
+
+class ScoringWorkload:
+    """cfg2 / cfg4 / cfg3: tracklet tensors -> scores, through BaseModel or at ops level."""
+
+    def __init__(self, args, tspn, torch, np, dev, world, rank, gather):
+        self.args, self.tspn, self.torch, self.np, self.dev, self.world, self.rank, self.gather = \
+            args, tspn, torch, np, dev, world, rank, gather
+        bf16 = self.bf16 = args.workload == "cfg3"
+        N, T, D = self.N, self.T, self.D = CFG3 if bf16 else (N_TRK, T_FRAMES, D_ROI)
+        C = self.C = 2 * D
+        B = self.B = args.videos if args.videos is not None else {"cfg2": 16, "cfg4": 64, "cfg3": 4}[args.workload]
+        self.P_vid = N * (N - 1)
+        self.P = B * self.P_vid
+        self.units_per_step = self.P
+        self.via_model = not args.ops_level
+        total_steps = args.warmup + args.steps
+
+        # ---- weights (seed 0) and inputs (seed 1 + global video index), random-init / synthetic
+        sd = self.sd = tspn.synth.make_weights(0, c=C, a=A_ANCH, k=K_PRED)
+        self.wnp = oracle_weights(sd)
+        d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+        # `--batches` resident input batches; the first holds hash-RNG videos (seed 1 + global video index, the
+        # inputs the parity tests use), the others are drawn on the device from the same U[0,1) distribution
+        nb = self.nb = max(1, args.batches)
+        gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+        hashed = min(B, 16)
+        vids = [tspn.synth.make_video(1 + rank * B + b, N, T, D) for b in range(hashed)]
+        self.feats_all, self.cls_all, self.boxes_all = [], [], []
+        for k in range(nb):
+            f = torch.rand((B * N, T, D), device=dev, generator=gen)
+            c = torch.rand((B, N, 35), device=dev, generator=gen)
+            # integer-valued boxes (l, t, r, b) as in SURVEY.md §8d: x, y in [0, 900), w, h in [10, 300)
+            xy = torch.floor(torch.rand((B * N, T, 2), device=dev, generator=gen) * 900.0)
+            wh = torch.floor(10.0 + torch.rand((B * N, T, 2), device=dev, generator=gen) * 290.0)
+            bx = torch.cat([xy, xy + wh], dim=2).contiguous()
+            if k == 0:
+                f[: hashed * N] = d(np.concatenate([v["tracklet_feats"] for v in vids]))
+                c[:hashed] = d(np.stack([v["track_cls_logits"] for v in vids]))
+                bx[: hashed * N] = d(np.concatenate([v["tracklet_boxes"] for v in vids]))
+            self.feats_all.append(tspn.ops.cast_bf16(f) if bf16 else f)
+            self.cls_all.append(c)
+            self.boxes_all.append(bx)
+        del vids
+        self.events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                       for _ in range(total_steps)]
+        self.overlap = args.overlap and not bf16 and not self.via_model
+        self.side = torch.cuda.Stream(device=dev) if self.overlap else None
+        self.ev_logits = [torch.cuda.Event() for _ in range(total_steps)]
+        self.ev_side = [torch.cuda.Event() for _ in range(total_steps)]
+        for i, (a, b) in enumerate(self.events):  # create the HIP event handles
+            a.record(); b.record(); self.ev_logits[i].record(); self.ev_side[i].record()
+        self.geom = None
+        if self.via_model:
+            self._init_model()
+        else:
+            self._init_ops(d)
+        torch.cuda.synchronize()
+
+    # -- the drop-in surface: BaseModel(cfg) with the synthetic weights, PairLists in, forward + decode
+    def _init_model(self):
+        tspn, torch = self.tspn, self.torch
+        cfg = tspn.load_cfg(None, **{"RELPN.USE_PPN": True, "RELPN.USE_DPN": True, "RELPN.DPN.IN_CHANNELS": self.C,
+                                     "PREDICT.FEATURE_DIM": self.C, "RELPN.DPN.NUM_ANCHORS_PER_LOCATION": A_ANCH,
+                                     "PREDICT.PREDICATE_NUM": K_PRED, "RELPN.PPN.NUM_PAIR_PROPOSALS": TOPK_PPN,
+                                     "RELPN.DPN.PAIR_GEOMETRY": True,
+                                     "RELPN.DPN.CONV_ALGO": "direct" if self.args.conv == "direct" else "auto"})
+        model = tspn.BaseModel(cfg)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in self.sd.items()})
+        self.model = model.to(self.dev).eval()
+
+    def _step_model(self, i):
+        tspn, torch, N, B = self.tspn, self.torch, self.N, self.B
+        feats, cls, boxes = self.feats_all[i % self.nb], self.cls_all[i % self.nb], self.boxes_all[i % self.nb]
+        plists = [tspn.PairList.from_tracklets(feats[b * N:(b + 1) * N], boxes[b * N:(b + 1) * N], cls[b])
+                  for b in range(B)]
+        self.model.profile_conv_events(self.events[i])
+        pair_props, dur_props, rel_logits = self.model(plists, None)
+        dec = self.model.decode(plists, rel_logits, topk_per_pair=TOPK_PAIR, topk_per_seg=TOPK_SEG)
+        sc, trip, tid = (torch.stack([d[k] for d in dec]) for k in range(3))
+        self.geom = dur_props[0].geom
+        self.gather(sc, trip, tid, torch.stack(pair_props),
+                    logits=torch.stack(rel_logits) if self.args.gather == "logits" else None)
+
+    # -- ops level: caller-held packed weights, workspace and outputs
+    def _init_ops(self, d):
+        tspn, torch, np, dev = self.tspn, self.torch, self.np, self.dev
+        args, wnp, B, N, T, D, P = self.args, self.wnp, self.B, self.N, self.T, self.D, self.P
+        r16 = lambda x: tspn.ops.cast_bf16(x.contiguous()).float()  # noqa: E731
+        conv_w = d(wnp["conv_w"])
+        if self.bf16:
+            self.packed = tspn.ops.pack_conv3_bf16(conv_w, split=D)
+        else:
+            self.packed = {"direct": tspn.ops.pack_conv3, "winograd6": tspn.ops.pack_conv3_wino63}[args.conv](conv_w, split=D)
+        del conv_w
+        self.conv_b = d(wnp["conv_b"])
+        self.head_w = d(np.concatenate([wnp["rel_w"][:, :, 0], wnp["dur_w"][:, :, 0]]))
+        self.head_b = d(np.concatenate([wnp["rel_b"], wnp["dur_b"]]))
+        self.cls_w, self.cls_b = d(wnp["cls_w"]), d(wnp["cls_b"])
+        if self.bf16:
+            self.conv_b, self.head_b, self.cls_w, self.cls_b = r16(self.conv_b), r16(self.head_b), r16(self.cls_w), r16(self.cls_b)
+            self.head_pk = tspn.ops.pack_heads_bf16(self.head_w)
+            self.ws = torch.empty(tspn.ops.fused_bf16_workspace_bytes(B, N, T, D, A_ANCH, K_PRED, P), dtype=torch.uint8, device=dev)
+        else:
+            self.ws = torch.empty(tspn.ops.fused_workspace_bytes(B, N, T, D, A_ANCH, K_PRED, P), dtype=torch.uint8, device=dev)
+        self.ppn_w = {k[len(PPN_PRE):]: d(v) for k, v in self.sd.items() if k.startswith(PPN_PRE)}
+        self.pairs = torch.cat([tspn.ops.pair_index(N, dev, base=b * N) for b in range(B)]).contiguous()
+        self.local_pairs = tspn.ops.pair_index(N, dev).unsqueeze(0).expand(B, -1, -1).contiguous()
+        self.out_heads = torch.empty((P, 3 * A_ANCH, T), dtype=torch.float32, device=dev)
+        # two logits buffers: the second stream may still be decoding step i - 1 while step i writes its logits
+        self.out_logits2 = [torch.empty((P, K_PRED), dtype=torch.float32, device=dev) for _ in range(2)]
+
+    def _tail(self, lg, cls, boxes):
+        """What only needs the logits (and the boxes): pair geometry, PPN, top-k decode, result gather."""
+        tspn = self.tspn
+        # the bbox half of the N^2 pair builder: relative geometry [P, 8, T] of every pair (one lane per
+        # (pair, frame), motion channels by wavefront shuffle)
+        _, self.geom = tspn.ops.pair_gather(None, boxes, self.pairs, want_feat=False, check_pairs=False)
+        _, idx = tspn.ops.ppn_pair_matrix_topk(cls, self.ppn_w, TOPK_PPN)
+        # top-k triplet decode (predict.py:66-106): per pair top-20 of 132, per video top-200
+        lg3 = lg.view(self.B, self.P_vid, K_PRED)
+        sc, trip, tid = tspn.ops.decode_topk(lg3, self.local_pairs, cls, row_mul=1, topk_per_pair=TOPK_PAIR,
+                                             topk_per_seg=TOPK_SEG, check_pairs=False)
+        self.gather(sc, trip, tid, idx, logits=lg3 if self.args.gather == "logits" else None)
+
+    def _step_ops(self, i):
+        tspn, torch = self.tspn, self.torch
+        feats, cls, boxes = self.feats_all[i % self.nb], self.cls_all[i % self.nb], self.boxes_all[i % self.nb]
+        if self.bf16:
+            _, lg = tspn.ops.forward_fused_bf16(feats, self.pairs, self.B, self.N, self.packed, self.conv_b, self.head_pk,
+                                                self.head_b, self.cls_w, self.cls_b, workspace=self.ws,
+                                                conv_events=self.events[i])
+            return self._tail(lg, cls, boxes)
+        lg = self.out_logits2[i % 2]
+        main = torch.cuda.current_stream()
+        if self.overlap and i >= 2:
+            main.wait_event(self.ev_side[i - 2])      # the second stream has finished reading this logits buffer
+        # the logits are computed first inside the call (they depend on the tracklet means only) and the
+        # event fires there: the second stream decodes and gathers under this step's encoder
+        tspn.ops.forward_fused(feats, self.pairs, self.B, self.N, self.packed, self.conv_b, self.head_w, self.head_b,
+                               self.cls_w, self.cls_b, workspace=self.ws, out_heads=self.out_heads, out_logits=lg,
+                               check_pairs=False, conv_events=self.events[i], canonical_pairs=True,
+                               logits_event=self.ev_logits[i] if self.overlap else None)
+        if not self.overlap:
+            return self._tail(lg, cls, boxes)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self.ev_logits[i])
+            self._tail(lg, cls, boxes)
+            self.ev_side[i].record(self.side)
+
+    def step(self, i):
+        return self._step_model(i) if self.via_model else self._step_ops(i)
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def report(self, elapsed, clock_mhz):
+        np, args, bf16 = self.np, self.args, self.bf16
+        N, T, D, C, B, P = self.N, self.T, self.D, self.C, self.B, self.P
+        # dominant kernel: the temporal conv of the tracklet projections, HIP events inside the timed steps
+        conv_ms = [a.elapsed_time(b) for a, b in self.events[args.warmup:]]
+        conv_avg_s = float(np.mean(conv_ms)) * 1e-3
+        conv_flop_direct = 2.0 * (2 * C) * (3 * D) * (B * N * T)  # M=2C, K=3D, columns=B*N*T
+        # F(6,3) issues 8 channel-GEMMs on a sixth of the columns (ceil(T/6) sextets per tracklet): 4/9 of the direct work
+        frac = {"direct": 1.0, "winograd6": (4.0 / 9.0) * (6 * -(-T // 6)) / T}[args.conv]
+        conv_flop = conv_flop_direct * (1.0 if bf16 else frac)
+        achieved = conv_flop / conv_avg_s / 1e12
+        peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
+        cfg_name = {"cfg2": "BASELINE cfg2: synthetic VidVRD shape N=32 T=150 D=2048 (C=4096, A=4, K=132), fp32, "
+                            "random-init weights",
+                    "cfg4": "BASELINE cfg4 shard: 64 of the 512 synthetic VidVRD-shaped videos per GPU per step "
+                            "(N=32 T=150 D=2048, C=4096, A=4, K=132), fp32, random-init weights",
+                    "cfg3": "BASELINE cfg3: VidOR long-clip shape N=64 T=900 D=1024 (C=2048, A=4, K=132), "
+                            "bf16 operands / fp32 accumulation, random-init weights"}[args.workload]
+        gather_txt = ""
+        if self.gather.use_dist:
+            gather_txt = (" + RCCL all-gather of the decoded results (10.8 KB per video)" if args.gather == "decoded"
+                          else " + RCCL all-gather of logits/top-k")
+        return {
+            "metric": f"tracklet-pairs/sec scored (N={N}, T={T}, D={D})",
+            "dtype": "bf16" if bf16 else "f32",
+            "config": {"workload": cfg_name,
+                       "videos_per_gpu_per_step": B, "pairs_per_video": self.P_vid, "resident_input_batches": self.nb,
+                       "surface": ("BaseModel.forward(pair_list) + BaseModel.decode on device-resident PairLists"
+                                   if self.via_model else "ops.forward_fused (pre-allocated workspace and outputs)"),
+                       "path": ("fused/factorised (tspn_forward_fused_bf16)" if bf16 else
+                                "fused/factorised (tspn_forward_fused_f32)")
+                               + " + pair geometry + PPN top-k + top-k triplet decode" + gather_txt
+                               + (" (geometry, PPN, decode and gather on a second stream under the encoder)" if self.overlap
+                                  else ""),
+                       "dense_equivalent_gflop_per_pair": (2.0 * T * C * (3 * C + 3 * A_ANCH) + 2.0 * C * K_PRED) / 1e9,
+                       "conv_algo": "direct" if bf16 else args.conv,
+                       "executed_gflop_per_pair": (conv_flop + 2.0 * P * T * C * 3 * A_ANCH + 2.0 * P * C * K_PRED) / P / 1e9},
+            "roofline": {"bound": "mfma",
+                         "kernel": ("conv3_bf16_big_kernel (tracklet projections: k=3 conv as bf16 32x32x16 MFMA "
+                                    "implicit GEMM, M=2C, K=3D)" if bf16 else
+                                    "conv3_wino63_kernel (tracklet projections: k=3 conv, Winograd F(6,3), fp32 32x32x2 "
+                                    "MFMA, M=2C, 8 channel-GEMMs of K=D on a sixth of the columns)"
+                                    if args.conv == "winograd6" else
+                                    "conv3_mfma_cl_kernel (tracklet projections: k=3 conv as fp32 32x32x2 "
+                                    "MFMA implicit GEMM, M=2C, K=3D)"),
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak,
+                         **pmc_traffic(args.workload, B, "bf16" if bf16 else args.conv),
+                         "direct_equivalent_tflops": conv_flop_direct / conv_avg_s / 1e12,
+                         "flop_per_launch": conv_flop, "avg_launch_ms": conv_avg_s * 1e3,
+                         "min_launch_ms": float(np.min(conv_ms)), "max_launch_ms": float(np.max(conv_ms)),
+                         "launch_ms": [round(float(v), 2) for v in conv_ms],
+                         "share_of_step": conv_avg_s / (elapsed / args.steps),
+                         "clock_mhz": clock_mhz,
+                         "frac_at_held_clock": (achieved / (peak * clock_mhz["mean"] / PEAK_CLOCK_MHZ)
+                                                if clock_mhz else None)},
+        }
+
+    def cpu_baseline(self):
+        if self.bf16:
+            return cpu_baseline_cfg3(self.wnp, self.N, self.T, self.D)
+        return cpu_baseline(self.wnp, self.args.cpu_runs)
+
+
+def backbone_conv_flops(tspn, h, w, depth=101):
+    """2 * MACs of every convolution of the C4 backbone for one frame (real channel counts: the stem's zero
+    channel and the halo recomputation of fused bottlenecks are executed but not counted)."""
+    def out(n, k, s, p):
+        return (n + 2 * p - k) // s + 1
+    h, w = out(h, 7, 2, 3), out(w, 7, 2, 3)
+    fl = 2.0 * h * w * 64 * 3 * 49
+    h, w = out(h, 3, 2, 1), out(w, 3, 2, 1)
+    cin, cout = 64, 256
+    for i, nb in enumerate(tspn.ResNetC4.BLOCKS[depth]):
+        for b in range(nb):
+            s = 2 if (b == 0 and i > 0) else 1
+            mid = cout // 4
+            h2, w2 = out(h, 1, s, 0), out(w, 1, s, 0)
+            fl += 2.0 * h2 * w2 * (mid * cin + 9 * mid * mid + cout * mid + (cout * cin if cin != cout else 0))
+            h, w, cin = h2, w2, cout
+        cout *= 2
+    return fl
+
+
+class Cfg5Workload:
+    """BASELINE configs[4]: frames -> triplets at VidOR scale.  One video per GPU per step: T frames of 720p resident in
+    HBM (fp32, mean-subtracted) -> ResNetC4 (R-101, bf16) -> res4 maps -> Res5RoIHead over N x T boxes ->
+    tracklet_feats bf16 [N,T,2048] -> BaseModel.forward (bf16 scorer, PPN) -> BaseModel.decode."""
+
+    def __init__(self, args, tspn, torch, np, dev, world, rank, gather):
+        self.args, self.tspn, self.torch, self.np, self.dev, self.world, self.rank, self.gather = \
+            args, tspn, torch, np, dev, world, rank, gather
+        N, T, H, W = CFG5
+        N = self.N = args.tracklets or N
+        T = self.T = args.frames or T
+        self.H, self.W = H, W
+        self.B = args.videos if args.videos is not None else 1
+        if self.B != 1:
+            raise SystemExit("bench.py --workload cfg5 scores one video per GPU per step (--videos 1)")
+        D = self.D = 2048
+        self.P_vid = N * (N - 1)
+        self.units_per_step = self.P_vid
+        t = lambda sd: {k: torch.from_numpy(v) for k, v in sd.items()}  # noqa: E731
+        self.bb_sd = tspn.synth.make_backbone_weights(0)
+        self.r5_sd = tspn.synth.make_res5_weights(0)
+        self.sd = tspn.synth.make_weights(0, c=2 * D, a=A_ANCH, k=K_PRED)
+        self.net = tspn.ResNetC4(depth=101, frame_chunk=16)
+        self.net.load_state_dict(t(self.bb_sd))
+        self.net = self.net.to(dev)
+        if hasattr(self.net, "fuse_bottlenecks"):
+            self.net.fuse_bottlenecks = args.fused_bottleneck == "auto"
+        self.head = tspn.Res5RoIHead()
+        self.head.load_state_dict(t(self.r5_sd))
+        self.head = self.head.to(dev)
+        cfg = tspn.load_cfg(None, **{"RELPN.USE_PPN": True, "RELPN.USE_DPN": True, "RELPN.DPN.IN_CHANNELS": 2 * D,
+                                     "PREDICT.FEATURE_DIM": 2 * D, "RELPN.DPN.NUM_ANCHORS_PER_LOCATION": A_ANCH,
+                                     "PREDICT.PREDICATE_NUM": K_PRED, "RELPN.PPN.NUM_PAIR_PROPOSALS": TOPK_PPN})
+        self.model = tspn.BaseModel(cfg)
+        self.model.load_state_dict(t(self.sd))
+        self.model = self.model.to(dev).eval()
+        nb = self.nb = max(1, min(args.batches, 2))
+        gen = torch.Generator(device=dev).manual_seed(4321 + rank)
+        self.imgs, self.boxes, self.cls = [], [], []
+        for _ in range(nb):
+            self.imgs.append(torch.rand((T, H, W, 3), device=dev, generator=gen) - 0.5)
+            xy = torch.rand((N, T, 2), device=dev, generator=gen) * torch.tensor([900.0, 400.0], device=dev)
+            wh = 40 + torch.rand((N, T, 2), device=dev, generator=gen) * 260
+            self.boxes.append(torch.cat([xy, xy + wh], dim=2).contiguous())
+            self.cls.append(torch.rand((N, 35), device=dev, generator=gen))
+        total = args.warmup + args.steps
+        self.events = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(4)) for _ in range(total)]
+        for ev in self.events:
+            for e in ev:
+                e.record()
+        torch.cuda.synchronize()
+
+    def step(self, i):
+        tspn, torch = self.tspn, self.torch
+        img, boxes, cls = self.imgs[i % self.nb], self.boxes[i % self.nb], self.cls[i % self.nb]
+        e0, e1, e2, e3 = self.events[i]
+        e0.record()
+        maps = self.net(img, bf16=True)                 # [T, H/16, W/16, 1024] bf16
+        e1.record()
+        feats = self.head(maps, boxes)                  # [N, T, 2048] bf16
+        e2.record()
+        plist = tspn.PairList.from_tracklets(feats, boxes, cls)
+        pair_props, _, rel_logits = self.model([plist], None)
+        dec = self.model.decode([plist], rel_logits, topk_per_pair=TOPK_PAIR, topk_per_seg=TOPK_SEG)
+        e3.record()
+        sc, trip, tid = (torch.stack([d[k] for d in dec]) for k in range(3))
+        self.gather(sc, trip, tid, torch.stack(pair_props))
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def report(self, elapsed, clock_mhz):
+        np, args, tspn = self.np, self.args, self.tspn
+        ev = self.events[args.warmup:]
+        bb_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+        roi_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+        sc_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))
+        flop = backbone_conv_flops(tspn, self.H, self.W) * self.T
+        achieved = flop / (bb_ms * 1e-3) / 1e12
+        return {
+            "metric": f"tracklet-pairs/sec scored (N={self.N}, T={self.T}, D={self.D})",
+            "dtype": "bf16",
+            "config": {"workload": f"BASELINE cfg5: frames -> triplets at VidOR scale: {self.T} frames of {self.H}x{self.W} "
+                                   f"and {self.N} tracklets per video, ResNet-101-C4 backbone + Res5 RoI head (bf16 MFMA convs, "
+                                   "fp32 stem) -> tracklet_feats [N,T,2048] bf16 -> BaseModel.forward (bf16 scorer) + "
+                                   "BaseModel.decode; random-init weights, one video per GPU per step",
+                       "videos_per_gpu_per_step": 1, "pairs_per_video": self.P_vid, "resident_input_batches": self.nb,
+                       "videos_per_s": self.world * args.steps / elapsed,
+                       "frames_per_s": self.world * args.steps * self.T / elapsed,
+                       "rois_per_s": self.world * args.steps * self.T * self.N / elapsed,
+                       "stage_ms": {"backbone": bb_ms, "roi_head": roi_ms, "scoring_and_decode": sc_ms},
+                       "backbone_ms_per_frame": bb_ms / self.T,
+                       "fused_bottlenecks": bool(getattr(self.net, "fuse_bottlenecks", False))},
+            "roofline": {"bound": "mfma",
+                         "kernel": "ResNet-101-C4 backbone, all convolutions of one video (bf16 32x32x16 MFMA implicit GEMMs: "
+                                   "bottleneck_bf16_kernel / conv2d_nhwc_bf16_kernel; fp32 stem)",
+                         "achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_BF16_MFMA_TFLOPS, "traffic": None,
+                         "flop_per_launch": flop, "avg_launch_ms": bb_ms,
+                         "flop_note": "algorithmic conv FLOP of the backbone per video (251 GFLOP per 720p frame; halo "
+                                      "recomputation and channel padding executed but not counted) / HIP-event time of the "
+                                      "backbone call inside the timed steps",
+                         "share_of_step": bb_ms * 1e-3 / (elapsed / args.steps),
+                         "clock_mhz": clock_mhz},
+        }
+
+    def cpu_baseline(self):
+        return cpu_baseline_cfg5(self.bb_sd, self.r5_sd, oracle_weights(self.sd), self.N, self.T, self.H, self.W)
+
+
+# ------------------------------------------------------------------------------------------------ rank body
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -277,257 +791,76 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); every rank is one "
                          "GPU, so the two must agree")
     use_dist = world > 1 or args.force_collective
-    if not torch.cuda.is_available():
-        raise RuntimeError("bench.py needs a HIP device (no CPU fallback)")
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+    stub = args.stub_gpu
+    if stub:
+        dev = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise RuntimeError("bench.py needs a HIP device (no CPU fallback)")
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        if torch.cuda.device_count() < local_world:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} starts {local_world} rank(s) on this node, one GPU each, but only "
+                             f"{torch.cuda.device_count()} HIP device(s) are visible (check HIP_VISIBLE_DEVICES / "
+                             "ROCR_VISIBLE_DEVICES)")
+        dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev)
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if stub:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         assert dist.get_world_size() == args.gpus
-    bf16 = args.workload == "cfg3"
-    N, T, D = CFG3 if bf16 else (N_TRK, T_FRAMES, D_ROI)
-    C = 2 * D
-    B = args.videos if args.videos is not None else {"cfg2": 16, "cfg4": 64, "cfg3": 4}[args.workload]
-    P_vid = N * (N - 1)
 
-    # ---- weights (seed 0) and inputs (seed 1 + global video index), random-init / synthetic
-    sd = tspn.synth.make_weights(0, c=C, a=A_ANCH, k=K_PRED)
-    wnp = {"conv_w": sd[DPN_PRE + "conv.weight"], "conv_b": sd[DPN_PRE + "conv.bias"],
-           "dur_w": sd[DPN_PRE + "duration_pred.weight"], "dur_b": sd[DPN_PRE + "duration_pred.bias"],
-           "rel_w": sd[DPN_PRE + "relness_pred.weight"], "rel_b": sd[DPN_PRE + "relness_pred.bias"],
-           "cls_w": sd["classifier.rel_predictor.weight"], "cls_b": sd["classifier.rel_predictor.bias"]}
-    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
-    via_model = not args.ops_level
-    conv_w = d(wnp["conv_w"])
-    r16 = lambda x: tspn.ops.cast_bf16(x.contiguous()).float()  # noqa: E731
-    if via_model:
-        packed = None          # BaseModel packs (and caches) its own device copies
-    elif bf16:
-        packed = tspn.ops.pack_conv3_bf16(conv_w, split=D)
-    else:
-        packed = {"direct": tspn.ops.pack_conv3, "winograd6": tspn.ops.pack_conv3_wino63}[args.conv](conv_w, split=D)
-    del conv_w
-    conv_b = d(wnp["conv_b"])
-    head_w = d(np.concatenate([wnp["rel_w"][:, :, 0], wnp["dur_w"][:, :, 0]]))
-    head_b = d(np.concatenate([wnp["rel_b"], wnp["dur_b"]]))
-    cls_w, cls_b = d(wnp["cls_w"]), d(wnp["cls_b"])
-    if bf16:
-        conv_b, head_b, cls_w, cls_b = r16(conv_b), r16(head_b), r16(cls_w), r16(cls_b)
-        head_pk = tspn.ops.pack_heads_bf16(head_w)
-    ppn_w = {k[len(PPN_PRE):]: d(v) for k, v in sd.items() if k.startswith(PPN_PRE)}
-
-    # `--batches` resident input batches; the first holds hash-RNG videos (seed 1 + global video index, the
-    # inputs the parity tests use), the others are drawn on the device from the same U[0,1) distribution
-    nb = max(1, args.batches)
-    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    hashed = min(B, 16)
-    vids = [tspn.synth.make_video(1 + rank * B + b, N, T, D) for b in range(hashed)]
-    feats_all, cls_all, boxes_all = [], [], []
-    for k in range(nb):
-        f = torch.rand((B * N, T, D), device=dev, generator=gen)
-        c = torch.rand((B, N, 35), device=dev, generator=gen)
-        # integer-valued boxes (l, t, r, b) as in SURVEY.md §8d: x, y in [0, 900), w, h in [10, 300)
-        xy = torch.floor(torch.rand((B * N, T, 2), device=dev, generator=gen) * 900.0)
-        wh = torch.floor(10.0 + torch.rand((B * N, T, 2), device=dev, generator=gen) * 290.0)
-        bx = torch.cat([xy, xy + wh], dim=2).contiguous()
-        if k == 0:
-            f[: hashed * N] = d(np.concatenate([v["tracklet_feats"] for v in vids]))
-            c[:hashed] = d(np.stack([v["track_cls_logits"] for v in vids]))
-            bx[: hashed * N] = d(np.concatenate([v["tracklet_boxes"] for v in vids]))
-        feats_all.append(tspn.ops.cast_bf16(f) if bf16 else f)
-        cls_all.append(c)
-        boxes_all.append(bx)
-    del vids
-    pairs = torch.cat([tspn.ops.pair_index(N, dev, base=b * N) for b in range(B)]).contiguous()
-    local_pairs = tspn.ops.pair_index(N, dev).unsqueeze(0).expand(B, -1, -1).contiguous()
-    P = pairs.shape[0]
-
-    ws = None if (bf16 or via_model) else torch.empty(tspn.ops.fused_workspace_bytes(B, N, T, D, A_ANCH, K_PRED, P),
-                                                      dtype=torch.uint8, device=dev)
-    out_heads = None if via_model else torch.empty((P, 3 * A_ANCH, T), dtype=torch.float32, device=dev)
-    # two logits buffers: the second stream may still be decoding step i - 1 while step i writes its logits
-    out_logits2 = None if via_model else [torch.empty((P, K_PRED), dtype=torch.float32, device=dev) for _ in range(2)]
-    state = {}
+    gather = Gatherer(tspn, args, world, use_dist)
+    wl_cls = StubWorkload if stub else (Cfg5Workload if args.workload == "cfg5" else ScoringWorkload)
+    wl = wl_cls(args, tspn, torch, np, dev, world, rank, gather)
     total_steps = args.warmup + args.steps
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-              for _ in range(total_steps)]
-    overlap = args.overlap and not bf16 and not via_model
-    side = torch.cuda.Stream(device=dev) if overlap else None
-    ev_logits = [torch.cuda.Event() for _ in range(total_steps)]
-    ev_side = [torch.cuda.Event() for _ in range(total_steps)]
-    for i, (a, b) in enumerate(events):  # create the HIP event handles
-        a.record(); b.record(); ev_logits[i].record(); ev_side[i].record()
-    torch.cuda.synchronize()
-
-    def tail(i, lg, cls, boxes):
-        """What only needs the logits (and the boxes): pair geometry, PPN, top-k decode, result gather."""
-        # the bbox half of the N^2 pair builder: relative geometry [P, 8, T] of every pair (one lane per
-        # (pair, frame), motion channels by wavefront shuffle)
-        _, state["geom"] = tspn.ops.pair_gather(None, boxes, pairs, want_feat=False, check_pairs=False)
-        _, idx = tspn.ops.ppn_pair_matrix_topk(cls, ppn_w, TOPK_PPN)
-        # top-k triplet decode (predict.py:66-106): per pair top-20 of 132, per video top-200
-        sc, trip, tid = tspn.ops.decode_topk(lg.view(B, P_vid, K_PRED), local_pairs, cls, row_mul=1,
-                                             topk_per_pair=TOPK_PAIR, topk_per_seg=TOPK_SEG, check_pairs=False)
-        if use_dist:  # the one collective of the path: final result gather over RCCL
-            if args.gather == "decoded":
-                state["gathered"] = tspn.dist.gather_decoded(sc, trip, tid, world * B, pair_proposals=idx, force=True)
-            else:
-                tspn.dist.gather_results(lg.view(B, P_vid, K_PRED), world * B, force=True)
-                tspn.dist.gather_results(idx, world * B, force=True)
-        state["last"] = (sc, trip, tid, idx)
-
-    def step(i):
-        feats, cls, boxes = feats_all[i % nb], cls_all[i % nb], boxes_all[i % nb]
-        if bf16:
-            if "ws" not in state:   # allocate the workspace once (first warm-up step), then reuse it
-                d16 = tspn._abi.FusedBf16Desc()
-                d16.B, d16.N, d16.T, d16.D, d16.A, d16.K, d16.P = B, N, T, D, A_ANCH, K_PRED, P
-                state["ws"] = torch.empty(tspn._abi.lib().tspn_forward_fused_bf16_workspace_bytes(d16),
-                                          dtype=torch.uint8, device=dev)
-            _, lg = tspn.ops.forward_fused_bf16(feats, pairs, B, N, packed, conv_b, head_pk, head_b, cls_w,
-                                                cls_b, workspace=state["ws"], conv_events=events[i])
-            tail(i, lg, cls, boxes)
-            return
-        lg = out_logits2[i % 2]
-        main = torch.cuda.current_stream()
-        if overlap and i >= 2:
-            main.wait_event(ev_side[i - 2])      # the second stream has finished reading this logits buffer
-        # the logits are computed first inside the call (they depend on the tracklet means only) and the
-        # event fires there: the second stream decodes and gathers under this step's encoder
-        tspn.ops.forward_fused(feats, pairs, B, N, packed, conv_b, head_w, head_b, cls_w, cls_b,
-                               workspace=ws, out_heads=out_heads, out_logits=lg, check_pairs=False,
-                               conv_events=events[i], canonical_pairs=True,
-                               logits_event=ev_logits[i] if overlap else None)
-        if not overlap:
-            tail(i, lg, cls, boxes)
-            return
-        with torch.cuda.stream(side):
-            side.wait_event(ev_logits[i])
-            tail(i, lg, cls, boxes)
-            ev_side[i].record(side)
-
-    if via_model:
-        # the drop-in surface: BaseModel(cfg) with the same synthetic weights, PairLists in, forward + decode
-        cfg = tspn.load_cfg(None, **{"RELPN.USE_PPN": True, "RELPN.USE_DPN": True, "RELPN.DPN.IN_CHANNELS": C,
-                                     "PREDICT.FEATURE_DIM": C, "RELPN.DPN.NUM_ANCHORS_PER_LOCATION": A_ANCH,
-                                     "PREDICT.PREDICATE_NUM": K_PRED, "RELPN.PPN.NUM_PAIR_PROPOSALS": TOPK_PPN,
-                                     "RELPN.DPN.PAIR_GEOMETRY": True,
-                                     "RELPN.DPN.CONV_ALGO": "direct" if args.conv == "direct" else "auto"})
-        model = tspn.BaseModel(cfg)
-        model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
-        model = model.to(dev).eval()
-
-        def step(i):  # noqa: F811
-            feats, cls, boxes = feats_all[i % nb], cls_all[i % nb], boxes_all[i % nb]
-            plists = [tspn.PairList.from_tracklets(feats[b * N:(b + 1) * N], boxes[b * N:(b + 1) * N], cls[b])
-                      for b in range(B)]
-            model.profile_conv_events(events[i])
-            pair_props, dur_props, rel_logits = model(plists, None)
-            dec = model.decode(plists, rel_logits, topk_per_pair=TOPK_PAIR, topk_per_seg=TOPK_SEG)
-            sc, trip, tid = (torch.stack([d[k] for d in dec]) for k in range(3))
-            idx = torch.stack(pair_props)
-            state["geom"] = dur_props[0].geom
-            if use_dist:  # the one collective of the path: final result gather over RCCL
-                if args.gather == "decoded":
-                    state["gathered"] = tspn.dist.gather_decoded(sc, trip, tid, world * B, pair_proposals=idx, force=True)
-                else:
-                    tspn.dist.gather_results(torch.stack(rel_logits), world * B, force=True)
-                    tspn.dist.gather_results(idx, world * B, force=True)
-            state["last"] = (sc, trip, tid, idx)
 
     for i in range(args.warmup):
-        step(i)
+        wl.step(i)
     if use_dist:
         dist.barrier()
-    torch.cuda.synchronize()
-    props = torch.cuda.get_device_properties(dev)
-    clock = ClockSampler("%04x:%02x:%02x.0" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0),
-                                               getattr(props, "pci_device_id", 0)))
-    clock.start()
+    wl.sync()
+    clock = None
+    if not stub:
+        props = torch.cuda.get_device_properties(dev)
+        clock = ClockSampler("%04x:%02x:%02x.0" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0),
+                                                   getattr(props, "pci_device_id", 0)))
+        clock.start()
     t0 = time.perf_counter()
     for i in range(args.warmup, total_steps):
-        step(i)
+        wl.step(i)
     if use_dist:
         dist.barrier()
-    torch.cuda.synchronize()
+    wl.sync()
     elapsed = time.perf_counter() - t0
-    clock_mhz = clock.stop()
+    clock_mhz = clock.stop() if clock is not None else None
     if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)   # the slowest rank sets the job's time
         elapsed = float(tmax.item())
-        if args.gather == "decoded":   # every rank holds every video's decoded rows, in global order
-            g = state["gathered"]
-            assert g["scores"].shape == (world * B, TOPK_SEG) and g["pair_proposals"].shape == (world * B, TOPK_PPN)
-            assert torch.equal(g["scores"][rank * B:(rank + 1) * B], state["last"][0])
-
-    # dominant kernel: the temporal conv of the tracklet projections, HIP events inside the timed steps
-    conv_ms = [a.elapsed_time(b) for a, b in events[args.warmup:]]
-    conv_avg_s = float(np.mean(conv_ms)) * 1e-3
-    conv_flop_direct = 2.0 * (2 * C) * (3 * D) * (B * N * T)  # M=2C, K=3D, columns=B*N*T
-    # F(6,3) issues 8 channel-GEMMs on a sixth of the columns (ceil(T/6) sextets per tracklet): 4/9 of the direct work
-    frac = {"direct": 1.0, "winograd6": (4.0 / 9.0) * (6 * -(-T // 6)) / T}[args.conv]
-    conv_flop = conv_flop_direct * (1.0 if bf16 else frac)
-    achieved = conv_flop / conv_avg_s / 1e12
-    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
+        gather.check(rank)
 
     if rank == 0:
-        pairs_total = world * P * args.steps
-        cfg_name = {"cfg2": "BASELINE cfg2: synthetic VidVRD shape N=32 T=150 D=2048 (C=4096, A=4, K=132), fp32, "
-                            "random-init weights",
-                    "cfg4": "BASELINE cfg4 shard: 64 of the 512 synthetic VidVRD-shaped videos per GPU per step "
-                            "(N=32 T=150 D=2048, C=4096, A=4, K=132), fp32, random-init weights",
-                    "cfg3": "BASELINE cfg3: VidOR long-clip shape N=64 T=900 D=1024 (C=2048, A=4, K=132), "
-                            "bf16 operands / fp32 accumulation, random-init weights"}[args.workload]
-        gather_txt = ""
-        if use_dist:
-            gather_txt = (" + RCCL all-gather of the decoded results (10.8 KB per video)" if args.gather == "decoded"
-                          else " + RCCL all-gather of logits/top-k")
+        rep = wl.report(elapsed, clock_mhz)
         out = {
-            "metric": f"tracklet-pairs/sec scored (N={N}, T={T}, D={D})",
-            "value": pairs_total / elapsed,
+            "metric": rep["metric"],
+            "value": world * wl.units_per_step * args.steps / elapsed,
             "unit": "tracklet-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
-            "config": {"workload": cfg_name,
-                       "videos_per_gpu_per_step": B, "pairs_per_video": P_vid, "resident_input_batches": nb,
-                       "surface": ("BaseModel.forward(pair_list) + BaseModel.decode on device-resident PairLists"
-                                   if via_model else "ops.forward_fused (pre-allocated workspace and outputs)"),
-                       "path": ("fused/factorised (tspn_forward_fused_bf16)" if bf16 else
-                                "fused/factorised (tspn_forward_fused_f32)")
-                               + " + pair geometry + PPN top-k + top-k triplet decode" + gather_txt
-                               + (" (geometry, PPN, decode and gather on a second stream under the encoder)" if overlap
-                                  else ""),
-                       "dense_equivalent_gflop_per_pair": (2.0 * T * C * (3 * C + 3 * A_ANCH) + 2.0 * C * K_PRED) / 1e9,
-                       "conv_algo": "direct" if bf16 else args.conv,
-                       "executed_gflop_per_pair": (conv_flop + 2.0 * P * T * C * 3 * A_ANCH + 2.0 * P * C * K_PRED) / P / 1e9},
-            "roofline": {"bound": "mfma",
-                         "kernel": ("conv3_bf16_big_kernel (tracklet projections: k=3 conv as bf16 32x32x16 MFMA "
-                                    "implicit GEMM, M=2C, K=3D)" if bf16 else
-                                    "conv3_wino63_kernel (tracklet projections: k=3 conv, Winograd F(6,3), fp32 32x32x2 "
-                                    "MFMA, M=2C, 8 channel-GEMMs of K=D on a sixth of the columns)"
-                                    if args.conv == "winograd6" else
-                                    "conv3_mfma_cl_kernel (tracklet projections: k=3 conv as fp32 32x32x2 "
-                                    "MFMA implicit GEMM, M=2C, K=3D)"),
-                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak,
-                         **pmc_traffic(args.workload, B, "bf16" if bf16 else args.conv),
-                         "direct_equivalent_tflops": conv_flop_direct / conv_avg_s / 1e12,
-                         "flop_per_launch": conv_flop, "avg_launch_ms": conv_avg_s * 1e3,
-                         "min_launch_ms": float(np.min(conv_ms)), "max_launch_ms": float(np.max(conv_ms)),
-                         "launch_ms": [round(float(v), 2) for v in conv_ms],
-                         "share_of_step": conv_avg_s / (elapsed / args.steps),
-                         "clock_mhz": clock_mhz,
-                         "frac_at_held_clock": (achieved / (peak * clock_mhz["mean"] / PEAK_CLOCK_MHZ)
-                                                if clock_mhz else None)},
+            "dtype": rep["dtype"], "data": "synthetic",
+            "config": rep["config"],
+            "roofline": rep["roofline"],
         }
-        if world == 1 and not args.no_cpu_baseline and not bf16:
-            out["cpu_baseline"] = cpu_baseline(wnp, args.cpu_runs)
+        if rep.get("stub"):
+            out["stub"] = True
+        if world == 1 and not args.no_cpu_baseline and not stub:
+            out["cpu_baseline"] = wl.cpu_baseline()
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)

@@ -60,3 +60,55 @@ def make_weights(seed, c, a=4, k=132, feat_dim=None, ppn=(35, 64, 35), bias_std=
             sd[f"{ppre}{emb}.{idx}.weight"] = hashrng.uniform(seed, f"{emb}.{idx}.weight", (fo, fi), -bound, bound)
             sd[f"{ppre}{emb}.{idx}.bias"] = hashrng.uniform(seed, f"{emb}.{idx}.bias", (fo,), -bound, bound)
     return sd
+
+
+def _conv_bn(sd, seed, prefix, tag, cout, cin, k, gamma=(0.5, 1.5)):
+    """One detectron2 `Conv2d(bias=False, norm=FrozenBN)`: He-normal weight, FrozenBN statistics away from the
+    identity so that the folding is exercised."""
+    std = float(np.sqrt(2.0 / (cin * k * k)))
+    sd[prefix + "weight"] = hashrng.normal(seed, tag + ".w", (cout, cin, k, k), std=std)
+    sd[prefix + "norm.weight"] = hashrng.uniform(seed, tag + ".g", (cout,), gamma[0], gamma[1])
+    sd[prefix + "norm.bias"] = hashrng.uniform(seed, tag + ".b", (cout,), -0.2, 0.2)
+    sd[prefix + "norm.running_mean"] = hashrng.uniform(seed, tag + ".m", (cout,), -0.2, 0.2)
+    sd[prefix + "norm.running_var"] = hashrng.uniform(seed, tag + ".v", (cout,), 0.5, 1.5)
+
+
+def _stage(sd, seed, name, nblocks, cin, cout, gamma3):
+    for b in range(nblocks):
+        pre, mid = f"{name}.{b}.", cout // 4
+        _conv_bn(sd, seed, pre + "conv1.", pre + "conv1", mid, cin, 1)
+        _conv_bn(sd, seed, pre + "conv2.", pre + "conv2", mid, mid, 3)
+        _conv_bn(sd, seed, pre + "conv3.", pre + "conv3", cout, mid, 1, gamma3)
+        if cin != cout:
+            _conv_bn(sd, seed, pre + "shortcut.", pre + "shortcut", cout, cin, 1)
+        cin = cout
+    return cin
+
+
+def make_backbone_weights(seed, blocks=(3, 4, 23), stem_out=64, res2_out=256):
+    """Random-init C4 backbone (detectron2 key names: stem.conv1.*, res2..res4.<b>.{conv1,conv2,conv3,shortcut}.*)
+    for `ResNetC4.load_state_dict`; the last batch norm of every block is damped (gamma in [0.1, 0.4]) so that
+    activations stay O(1) over the 33 blocks of R-101.  BASELINE cfg5 (detectron/trainer.py:23-33: R101-C4)."""
+    sd = {}
+    _conv_bn(sd, seed, "stem.conv1.", "stem", stem_out, 3, 7)
+    sd["stem.conv1.weight"] = hashrng.normal(seed, "stem.w", (stem_out, 3, 7, 7), std=float(np.sqrt(2.0 / (3 * 49))))
+    cin, cout = stem_out, res2_out
+    for i, nb in enumerate(blocks):
+        cin = _stage(sd, seed, f"res{i + 2}", nb, cin, cout, (0.1, 0.4))
+        cout *= 2
+    return sd
+
+
+def make_res5_weights(seed, in_channels=1024, bottleneck_channels=512, out_channels=2048, num_blocks=3):
+    """Random-init res5 of the ROI head (`Res5RoIHead.load_state_dict`): three bottleneck blocks, the first with
+    a projection shortcut."""
+    sd, cin = {}, in_channels
+    for b in range(num_blocks):
+        pre = f"res5.{b}."
+        _conv_bn(sd, seed, pre + "conv1.", pre + "conv1", bottleneck_channels, cin, 1)
+        _conv_bn(sd, seed, pre + "conv2.", pre + "conv2", bottleneck_channels, bottleneck_channels, 3)
+        _conv_bn(sd, seed, pre + "conv3.", pre + "conv3", out_channels, bottleneck_channels, 1)
+        if cin != out_channels:
+            _conv_bn(sd, seed, pre + "shortcut.", pre + "shortcut", out_channels, cin, 1)
+        cin = out_channels
+    return sd

@@ -133,3 +133,48 @@ def test_bench_self_launches_its_ranks():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--no-cpu-baseline"],
                        capture_output=True, text=True, timeout=300, env=env2)
     assert r.returncode != 0 and "--gpus 4" in (r.stderr + r.stdout)
+
+
+def test_bench_rank_body_world2_with_stubbed_gpu_step():
+    """the REAL rank body of bench.py on two gloo ranks — self-launch of torch.distributed.run,
+    rendezvous, warm-up, barrier-bracketed timed loop with the decoded-result all-gather in every step, the
+    max-over-ranks time (all_reduce MAX), the `gathered[rank*B:(rank+1)*B] == local` check on every rank, ONE JSON
+    line from rank 0 — with only the GPU step replaced by recorded decoded rows (`--stub-gpu`).  Whole-job value =
+    world x units per step x steps / max time."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stub-gpu", "--steps", "4",
+                        "--warmup", "1", "--videos", "3"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["stub"] is True and out["n_gpus"] == 2 and out["steps"] == 4 and out["warmup"] == 1
+    assert out["scaling"] == "weak" and out["unit"] == "tracklet-pairs/s" and out["roofline"] is None
+    assert "cpu_baseline" not in out
+    pairs = 2 * 3 * 32 * 31 * 4      # world x videos x N(N-1) x steps
+    assert abs(out["value"] * out["ms_per_step"] * 1e-3 * 4 - pairs) < 1e-6 * pairs
+    # one rank through the same body (no collective unless forced), and the forced collective on one rank
+    for extra in ([], ["--force-collective"]):
+        r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--stub-gpu", "--steps", "2", "--warmup", "1"]
+                            + extra, capture_output=True, text=True, timeout=300, env=env)
+        assert r1.returncode == 0, r1.stderr[-3000:]
+        assert json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][0])["n_gpus"] == 1
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """`--gpus N` on a node that shows fewer HIP devices must stop with a clear message before any launch."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "bench.py")).read()
+    assert "HIP device(s) are visible" in src and "torch.cuda.device_count() < local_world" in src
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    # here (no GPU at all) the non-stub body stops earlier, with the no-CPU-fallback message
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and "needs a HIP device" in r.stderr
