@@ -471,6 +471,20 @@ int tspn_roi_align_nhwc_f32_bf16out(const float* feat, int64_t NF, int64_t H, in
 int tspn_max_pool_nhwc_f32(const float* x, int64_t NB, int64_t H, int64_t W, int64_t C, int64_t k,
                            int64_t stride, int64_t pad, void* out, int out_bf16, void* stream);
 
+/* ---- f4: bf16-operand stem of the C4 backbone (tspn_stem_bf16.hip) ----------------------------------------
+ * detectron2 BasicStem conv (modeling/backbone/resnet.py: 7x7, stride 2, padding 3, RGB in, FrozenBN folded by the
+ * caller into w / bias) + ReLU with bf16 operands: image and weights rounded to bf16, exact products, fp32
+ * accumulation, relu(acc + bias) rounded to bf16 once.  x fp32 [NB,H,W,3] -> out bf16 [NB,OH,OW,Cout],
+ * OH = (H - 1) / 2 + 1.  Cout = 32 or 64.  `frag` = tspn_pack_stem_bf16(w fp32 [Cout,3,7,7]) (Cout * 256 bf16);
+ * `workspace` (tspn_stem_bf16_workspace_bytes) holds the 2x2 space-to-depth image the conv kernel streams.
+ * tspn_max_pool_nhwc_bf16: max_pool2d(k, stride, pad) on a bf16 channels-last map (C % 8 == 0). */
+size_t tspn_stem_bf16_workspace_bytes(int64_t NB, int64_t H, int64_t W);
+int tspn_pack_stem_bf16(const float* w, int64_t Cout, uint16_t* frag, void* stream);
+int tspn_stem_conv_bf16(const float* x, int64_t NB, int64_t H, int64_t W, const uint16_t* frag, int64_t Cout,
+                        const float* bias, void* workspace, size_t workspace_bytes, uint16_t* out, void* stream);
+int tspn_max_pool_nhwc_bf16(const uint16_t* x, int64_t NB, int64_t H, int64_t W, int64_t C, int64_t k,
+                            int64_t stride, int64_t pad, uint16_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,7 +20,7 @@ import torch
 import torch.nn.functional as F
 
 __all__ = ["roi_align_nhwc", "frozen_bn", "bottleneck_block", "res5_roi_head", "make_res5_weights",
-           "conv2d_bf16", "res5_roi_head_bf16", "resnet_c4", "resnet_c4_bf16", "make_backbone_weights"]
+           "conv2d_bf16", "res5_roi_head_bf16", "resnet_c4", "resnet_c4_bf16", "stem_bf16", "make_backbone_weights"]
 
 BN_EPS = 1e-5
 
@@ -258,12 +258,19 @@ def _bottleneck_bf16(x, p, pre, s):
     return conv2d_bf16(out, w3, b3, residual=sc, relu=True)
 
 
-def resnet_c4_bf16(images_nhwc, p, blocks):
-    """The backbone as the GPU runs it with bf16=True: stem conv + FrozenBN + ReLU + max pool in fp32 (float64
-    here), the pooled map rounded once to bf16, res2-res4 as conv2d_bf16 chains."""
+def stem_bf16(images_nhwc, p):
+    """detectron2 BasicStem on bf16 operands: relu(conv7x7/2/pad3 + folded FrozenBN) rounded to bf16 once, then
+    max_pool2d(3, 2, 1).  images [T,H,W,3] -> NCHW float64 holding bf16 values."""
     w, b = _fold(p, "stem.conv1.")
-    x = F.relu(F.conv2d(images_nhwc.permute(0, 3, 1, 2).double(), w.double(), b.double(), stride=2, padding=3))
-    x = _r16(F.max_pool2d(x, kernel_size=3, stride=2, padding=1))
+    x = conv2d_bf16(images_nhwc.permute(0, 3, 1, 2), w, b, stride=2, padding=3, relu=True)
+    return F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+
+
+def resnet_c4_bf16(images_nhwc, p, blocks):
+    """The backbone as the GPU runs it with bf16=True: EVERY conv a conv2d_bf16 (bf16 operands -- the image and
+    the folded stem weight included since round 3 --, exact products, one rounding of act(sum + bias)); the max
+    pool acts on the rounded stem map (max commutes with the monotone rounding, so this equals pool-then-round)."""
+    x = stem_bf16(images_nhwc, p)
     for i, nb in enumerate(blocks):
         for bidx in range(nb):
             x = _bottleneck_bf16(x, p, f"res{i + 2}.{bidx}.", 2 if (bidx == 0 and i > 0) else 1)

@@ -19,7 +19,7 @@ __all__ = [
     "transpose_cast_bf16", "temporal_encoder_heads_bf16",
     "temporal_mean_bf16", "forward_fused_bf16", "span_predicate",
     "proposal_pair_filter", "gather_rows",
-    "pack_conv2d", "pack_conv2d_frag", "conv2d_nhwc", "roi_align_nhwc", "pack_conv2d_frag_bf16", "conv2d_nhwc_bf16", "max_pool_nhwc", "pack_conv2d_frag_cin4", "conv2d_nhwc_cin4",
+    "pack_conv2d", "pack_conv2d_frag", "conv2d_nhwc", "roi_align_nhwc", "pack_conv2d_frag_bf16", "conv2d_nhwc_bf16", "max_pool_nhwc", "pack_conv2d_frag_cin4", "conv2d_nhwc_cin4", "max_pool_nhwc_bf16", "pack_stem_bf16", "stem_conv_bf16",
 ]
 
 
@@ -909,6 +909,52 @@ def max_pool_nhwc(x, kernel_size=3, stride=2, padding=1, out_bf16=False):
     out = torch.empty((NB, OH, OW, C), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
     _abi.check(_abi.lib().tspn_max_pool_nhwc_f32(_p(x), NB, H, W, C, kernel_size, stride, padding, _p(out),
                                                  1 if out_bf16 else 0, _stream()))
+    return out
+
+
+def max_pool_nhwc_bf16(x, kernel_size=3, stride=2, padding=1):
+    """max_pool2d on a channels-last bf16 map [NB,H,W,C] -> bf16 [NB,OH,OW,C] (tspn_max_pool_nhwc_bf16; C % 8 == 0)."""
+    _dev(x, "x", torch.bfloat16)
+    NB, H, W, C = x.shape
+    OH, OW = (H + 2 * padding - kernel_size) // stride + 1, (W + 2 * padding - kernel_size) // stride + 1
+    if OH <= 0 or OW <= 0:
+        raise ValueError("max_pool_nhwc_bf16: empty output")
+    out = torch.empty((NB, OH, OW, C), dtype=torch.bfloat16, device=x.device)
+    _abi.check(_abi.lib().tspn_max_pool_nhwc_bf16(_p(x), NB, H, W, C, kernel_size, stride, padding, _p(out), _stream()))
+    return out
+
+
+def pack_stem_bf16(weight):
+    """Stem weight [Cout in (32, 64), 3, 7, 7] fp32 (batch norm folded) -> bf16 fragment-major [Cout/32, 16, 64, 8]
+    (tspn_pack_stem_bf16: the 7x7/2 conv as a 4x4/1 conv on the 2x2 space-to-depth image)."""
+    _dev(weight, "stem weight")
+    if weight.dim() != 4 or tuple(weight.shape[1:]) != (3, 7, 7) or weight.shape[0] not in (32, 64):
+        raise ValueError(f"pack_stem_bf16: weight must be [32 | 64, 3, 7, 7], got {tuple(weight.shape)}")
+    frag = torch.empty((weight.shape[0] // 32, 16, 64, 8), dtype=torch.bfloat16, device=weight.device)
+    _abi.check(_abi.lib().tspn_pack_stem_bf16(_p(weight), weight.shape[0], _p(frag), _stream()))
+    return frag
+
+
+def stem_conv_bf16(x, frag, bias, workspace=None):
+    """relu(conv7x7/2/pad3(x) + bias) with bf16 operands: x fp32 [NB,H,W,3] -> bf16 [NB,OH,OW,Cout]
+    (tspn_stem_conv_bf16; `workspace` >= tspn_stem_bf16_workspace_bytes holds the space-to-depth image)."""
+    _dev(x, "x"); _dev(frag, "frag", torch.bfloat16); _dev(bias, "bias")
+    if x.dim() != 4 or x.shape[3] != 3 or frag.dim() != 4 or tuple(frag.shape[1:]) != (16, 64, 8):
+        raise ValueError("stem_conv_bf16: x must be [NB,H,W,3] and frag = pack_stem_bf16(weight)")
+    NB, H, W, _ = x.shape
+    Cout = frag.shape[0] * 32
+    if bias.shape != (Cout,):
+        raise ValueError("stem_conv_bf16: bias shape mismatch")
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    l = _abi.lib()
+    need = l.tspn_stem_bf16_workspace_bytes(NB, H, W)
+    if workspace is None:
+        workspace = _ws(need, x.device)
+    elif workspace.numel() * workspace.element_size() < need:
+        raise ValueError("stem_conv_bf16: workspace too small")
+    out = torch.empty((NB, OH, OW, Cout), dtype=torch.bfloat16, device=x.device)
+    _abi.check(l.tspn_stem_conv_bf16(_p(x), NB, H, W, _p(frag), Cout, _p(bias), _p(workspace),
+                                     workspace.numel() * workspace.element_size(), _p(out), _stream()))
     return out
 
 

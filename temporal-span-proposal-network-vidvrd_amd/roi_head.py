@@ -166,8 +166,8 @@ class Res5RoIHead(_CachedWeightsMixin, nn.Module):
 
 class BasicStem(nn.Module):
     """detectron2 BasicStem (modeling/backbone/resnet.py): 7x7 stride-2 conv + FrozenBN + ReLU, then
-    max_pool2d(3, 2, 1).  The RGB input runs on 16 zero-padded channels (fp32 kernel); the pool emits bf16 when
-    the rest of the backbone runs in bf16."""
+    max_pool2d(3, 2, 1).  fp32 backbone: the RGB input runs on zero-padded channels through the fp32 kernels.
+    bf16 backbone (`out_bf16`): bf16-operand stem kernel + bf16 pool (csrc/tspn_stem_bf16.hip)."""
 
     def __init__(self, in_channels=3, out_channels=64):
         super().__init__()
@@ -184,8 +184,27 @@ class BasicStem(nn.Module):
         n = c.norm
         return c._cache.get("folded_cin4", (c.weight, n.weight, n.bias, n.running_mean, n.running_var), dev, build)
 
+    def _folded_bf16(self, dev):
+        c = self.conv1
+
+        def build(ts):
+            w, g, b, m, v = ts
+            scale = g * torch.rsqrt(v + BN_EPS)
+            return ops.pack_stem_bf16((w * scale.reshape(-1, 1, 1, 1)).contiguous()), (b - m * scale).contiguous()
+        n = c.norm
+        return c._cache.get("folded_stem_bf16", (c.weight, n.weight, n.bias, n.running_mean, n.running_var), dev, build)
+
     def forward(self, x, out_bf16=False):
         c = self.conv1
+        if out_bf16:
+            # bf16 backbone: the stem is a bf16-operand conv like every other layer (image and folded weights rounded
+            # to bf16, fp32 accumulation, one rounding of relu(acc + bias)); 7x7/2 as a 4x4/1 conv on the 2x2
+            # space-to-depth image (csrc/tspn_stem_bf16.hip), then the 3x3/2 max pool on the bf16 map
+            if self.in_channels != 3 or c.kernel_size != 7 or c.stride != 2 or c.padding != 3 or c.weight.shape[0] not in (32, 64):
+                raise ValueError("the bf16 backbone needs detectron2's BasicStem: 7x7 / stride 2 / padding 3 on 3 channels, "
+                                 f"32 or 64 output channels (got {tuple(c.weight.shape)}, stride {c.stride}, padding {c.padding})")
+            frag, bias = self._folded_bf16(x.device)
+            return ops.max_pool_nhwc_bf16(ops.stem_conv_bf16(x.contiguous(), frag, bias), 3, 2, 1)
         if self.in_channels <= 4 and c.weight.shape[0] % 32 == 0:
             # stem form: RGB + zero channel, one K chunk = four taps (13 chunks for 7x7 instead of 49)
             frag, bias = self._folded_cin4(x.device)
@@ -204,7 +223,8 @@ class ResNetC4(_CachedWeightsMixin, nn.Module):
 
     forward(images): channels-last frames [T,H,W,3] float (already mean-subtracted, BGR for the MSRA weights the
     reference's config uses) -> res4 maps [T,H/16,W/16,1024] channels-last on the HIP device, fp32 or — with
-    `bf16=True` — bf16 (stem in fp32, res2-res4 on the bf16 MFMA kernels): the input of Res5RoIHead."""
+    `bf16=True` — bf16 (every convolution, the stem included, on bf16 operands with fp32 accumulation and one
+    rounding per layer): the input of Res5RoIHead."""
 
     BLOCKS = {50: (3, 4, 6), 101: (3, 4, 23)}
 

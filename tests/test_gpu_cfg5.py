@@ -101,16 +101,16 @@ def test_cfg5_shapes_and_finiteness(cfg5):
 
 
 def test_cfg5_stem_on_720p_frames(tspn, cfg5):
-    """7x7/2 stem + FrozenBN + ReLU + 3x3/2 max pool in fp32, the pooled map rounded once to bf16 == the input of
-    res2.0, on the top-left 128 x 160 pixel crop of two frames (zero padding on the true image border)."""
+    """bf16-operand stem (7x7/2 conv as a 4x4 conv on the space-to-depth image, + FrozenBN + ReLU, one rounding) and
+    the 3x3/2 max pool == the input of res2.0, on the top-left 128 x 160 pixel crop of two frames (zero padding on
+    the true image border) and on the bottom-right corner crop."""
     p = {k: t(v) for k, v in cfg5["bb_sd"].items()}
-    x = t(cfg5["img"][[0, 3], :128, :160]).permute(0, 3, 1, 2).double()
-    w, b = ro._fold(p, "stem.conv1.")
-    y = torch.nn.functional.max_pool2d(torch.relu(torch.nn.functional.conv2d(x, w.double(), b.double(), stride=2, padding=3)),
-                                       3, 2, 1)
-    ref = y[:, :, :28, :36].float().to(torch.bfloat16)           # rows / columns the crop's cut does not touch
+    ref = ro.stem_bf16(t(cfg5["img"][[0, 3], :128, :160]), p)[:, :, :28, :36]   # rows / columns the crop's cut does not touch
     got = nchw(cfg5["taps"]["res2.0"][0][[0, 3]].cpu())[:, :, :28, :36]
-    close_bf16(got, ref, "stem + pool", max_ulps=2.0, frac=0.995)
+    close_bf16(got, ref, "stem + pool, top-left", max_ulps=2.0, frac=0.995)
+    ref = ro.stem_bf16(t(cfg5["img"][[1], -128:, -160:]), p)[:, :, -28:, -36:]
+    got = nchw(cfg5["taps"]["res2.0"][0][[1]].cpu())[:, :, -28:, -36:]
+    close_bf16(got, ref, "stem + pool, bottom-right", max_ulps=2.0, frac=0.995)
 
 
 @pytest.mark.parametrize("name,stride", [("res2.0", 1), ("res2.2", 1), ("res3.0", 2), ("res3.3", 1), ("res4.0", 2),

@@ -305,3 +305,39 @@ def test_conv2d_stem_form_vs_torch(tspn, device, NB, H, W, Cin, Cout, k, stride,
     y = tspn.ops.conv2d_nhwc_cin4(x4, frag, (k, k), stride, pad, bias=t(b).to(device), relu=True)
     assert tuple(y.shape) == tuple(ref.shape)
     np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("NB,H,W,Cout", [(2, 30, 41, 64), (1, 7, 7, 32), (3, 64, 300, 64), (1, 33, 515, 32), (2, 16, 258, 64)])
+def test_stem_bf16_vs_oracle(tspn, device, NB, H, W, Cout):
+    """bf16-operand stem conv (space-to-depth + persistent 4x4 conv kernel, tspn_stem_bf16.hip) == conv2d_bf16 of
+    the restatement (bf16 image and weights, exact products, one rounding), odd sizes, several 128-pixel tiles per
+    row with a ragged last one, 32 and 64 output channels; then the bf16 max pool, bit-exact."""
+    x = tspn.hashrng.uniform(88, "x", (NB, H, W, 3), -2, 2)
+    w = tspn.hashrng.normal(88, "w", (Cout, 3, 7, 7), std=0.1)
+    b = tspn.hashrng.normal(88, "b", (Cout,), std=0.1)
+    ref = ro.conv2d_bf16(t(x).permute(0, 3, 1, 2), t(w), t(b), stride=2, padding=3, relu=True).permute(0, 2, 3, 1)
+    frag = tspn.ops.pack_stem_bf16(t(w).to(device))
+    y = tspn.ops.stem_conv_bf16(t(x).to(device), frag, t(b).to(device))
+    assert y.dtype == torch.bfloat16 and tuple(y.shape) == tuple(ref.shape)
+    err = (y.cpu().double() - ref).abs()
+    scale = float(ref.abs().max())
+    assert float(err.max()) <= 2.0 ** -8 * scale and float((err > 0).double().mean()) < 0.01   # rare one-ulp flips
+    pooled = tspn.ops.max_pool_nhwc_bf16(y, 3, 2, 1)
+    want = torch.nn.functional.max_pool2d(y.cpu().float().permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
+    assert torch.equal(pooled.cpu().float(), want)
+    assert torch.equal(tspn.ops.stem_conv_bf16(t(x).to(device), frag, t(b).to(device)), y)      # deterministic
+
+
+def test_stem_bf16_errors(tspn, device):
+    with pytest.raises(ValueError):
+        tspn.ops.pack_stem_bf16(torch.zeros((48, 3, 7, 7), device=device))
+    with pytest.raises(ValueError):
+        tspn.ops.pack_stem_bf16(torch.zeros((64, 3, 3, 3), device=device))
+    frag = tspn.ops.pack_stem_bf16(torch.zeros((64, 3, 7, 7), device=device))
+    y = tspn.ops.stem_conv_bf16(torch.zeros((0, 8, 8, 3), device=device), frag, torch.zeros(64, device=device))
+    assert y.shape == (0, 4, 4, 64)
+    with pytest.raises(ValueError):
+        tspn.ops.stem_conv_bf16(torch.zeros((1, 8, 8, 4), device=device), frag, torch.zeros(64, device=device))
+    net = tspn.ResNetC4(stem_out=16, res2_out=64, blocks=(1, 1, 1)).to(device)
+    with pytest.raises(ValueError):          # the bf16 backbone needs a 32- or 64-channel detectron2 stem
+        net(torch.zeros((1, 32, 32, 3), device=device), bf16=True)
