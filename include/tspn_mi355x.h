@@ -471,6 +471,17 @@ int tspn_roi_align_nhwc_f32_bf16out(const float* feat, int64_t NF, int64_t H, in
 int tspn_max_pool_nhwc_f32(const float* x, int64_t NB, int64_t H, int64_t W, int64_t C, int64_t k,
                            int64_t stride, int64_t pad, void* out, int out_bf16, void* stream);
 
+/* ---- f4: fused tail of a bottleneck block on bf16 operands (tspn_bottleneck_bf16.hip) -----------------------
+ * detectron2 BottleneckBlock.forward after conv1 (modeling/backbone/resnet.py), FrozenBN folded by the caller:
+ *     out = relu( W3 . relu(W2 (*) h1 + b2) + b3 + residual )      conv2 = 3x3 / pad 1 / stride 1, conv3 = 1x1
+ * h1 bf16 [NB,H,W,CM] (conv1's output), residual / out bf16 [NB,H,W,4 CM] (the block input or its projection
+ * shortcut); CM = 64, 128 or 256.  frag2 = tspn_pack_conv2d_frag_bf16(W2 [CM,CM,3,3]), frag3 =
+ * tspn_pack_conv2d_frag_bf16(W3 [4 CM,CM,1,1]); biases fp32.  Same rounding points and contraction order as
+ * tspn_conv2d_nhwc_bf16 applied twice (h2 rounded to bf16 once): bit-identical results, one launch, h2 never in HBM. */
+int tspn_bottleneck_tail_bf16(const uint16_t* h1, int64_t NB, int64_t H, int64_t W, int64_t CM,
+                              const uint16_t* frag2, const float* bias2, const uint16_t* frag3,
+                              const float* bias3, const uint16_t* residual, uint16_t* out, void* stream);
+
 /* ---- f4: bf16-operand stem of the C4 backbone (tspn_stem_bf16.hip) ----------------------------------------
  * detectron2 BasicStem conv (modeling/backbone/resnet.py: 7x7, stride 2, padding 3, RGB in, FrozenBN folded by the
  * caller into w / bias) + ReLU with bf16 operands: image and weights rounded to bf16, exact products, fp32

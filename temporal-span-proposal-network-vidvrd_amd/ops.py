@@ -19,7 +19,7 @@ __all__ = [
     "transpose_cast_bf16", "temporal_encoder_heads_bf16",
     "temporal_mean_bf16", "forward_fused_bf16", "span_predicate",
     "proposal_pair_filter", "gather_rows",
-    "pack_conv2d", "pack_conv2d_frag", "conv2d_nhwc", "roi_align_nhwc", "pack_conv2d_frag_bf16", "conv2d_nhwc_bf16", "max_pool_nhwc", "pack_conv2d_frag_cin4", "conv2d_nhwc_cin4", "max_pool_nhwc_bf16", "pack_stem_bf16", "stem_conv_bf16",
+    "pack_conv2d", "pack_conv2d_frag", "conv2d_nhwc", "roi_align_nhwc", "pack_conv2d_frag_bf16", "conv2d_nhwc_bf16", "max_pool_nhwc", "pack_conv2d_frag_cin4", "conv2d_nhwc_cin4", "max_pool_nhwc_bf16", "pack_stem_bf16", "stem_conv_bf16", "bottleneck_tail_bf16",
 ]
 
 
@@ -909,6 +909,25 @@ def max_pool_nhwc(x, kernel_size=3, stride=2, padding=1, out_bf16=False):
     out = torch.empty((NB, OH, OW, C), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
     _abi.check(_abi.lib().tspn_max_pool_nhwc_f32(_p(x), NB, H, W, C, kernel_size, stride, padding, _p(out),
                                                  1 if out_bf16 else 0, _stream()))
+    return out
+
+
+def bottleneck_tail_bf16(h1, frag2, bias2, frag3, bias3, residual):
+    """relu(conv1x1(relu(conv3x3(h1) + b2)) + b3 + residual) in one launch (tspn_bottleneck_tail_bf16): h1 bf16
+    [NB,H,W,CM], CM in (64, 128, 256); frag2 / frag3 = pack_conv2d_frag_bf16 of the folded conv2 / conv3 weights;
+    residual bf16 [NB,H,W,4 CM] -> bf16 [NB,H,W,4 CM]."""
+    _dev(h1, "h1", torch.bfloat16); _dev(frag2, "frag2", torch.bfloat16); _dev(frag3, "frag3", torch.bfloat16)
+    _dev(bias2, "bias2"); _dev(bias3, "bias3"); _dev(residual, "residual", torch.bfloat16)
+    NB, H, W, CM = h1.shape
+    if CM not in (64, 128, 256):
+        raise ValueError(f"bottleneck_tail_bf16: bottleneck channels must be 64, 128 or 256 (got {CM})")
+    if tuple(frag2.shape) != (CM // 32, 9, CM // 64, 4, 64, 8) or tuple(frag3.shape) != (CM // 8, 1, CM // 64, 4, 64, 8):
+        raise ValueError("bottleneck_tail_bf16: frag2 / frag3 must be pack_conv2d_frag_bf16 of [CM,CM,3,3] / [4CM,CM,1,1]")
+    if bias2.shape != (CM,) or bias3.shape != (4 * CM,) or tuple(residual.shape) != (NB, H, W, 4 * CM):
+        raise ValueError("bottleneck_tail_bf16: bias / residual shape mismatch")
+    out = torch.empty((NB, H, W, 4 * CM), dtype=torch.bfloat16, device=h1.device)
+    _abi.check(_abi.lib().tspn_bottleneck_tail_bf16(_p(h1), NB, H, W, CM, _p(frag2), _p(bias2), _p(frag3), _p(bias3),
+                                                    _p(residual), _p(out), _stream()))
     return out
 
 

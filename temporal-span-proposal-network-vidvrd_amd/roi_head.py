@@ -93,16 +93,30 @@ class BottleneckBlock(nn.Module):
         self.conv2 = ConvFrozenBN(bottleneck_channels, bottleneck_channels, 3, 1, 1)
         self.conv3 = ConvFrozenBN(bottleneck_channels, out_channels, 1)
         self.stride = stride
+        # bf16 maps: run conv2 + conv3 + residual + ReLU as ONE launch (csrc/tspn_bottleneck_bf16.hip; h2 stays in
+        # LDS, results bit-identical to the two separate launches).  Needs 64 / 128 / 256 bottleneck channels and
+        # the 4x expansion of the standard block; switched off by ResNetC4 / Res5RoIHead `fuse_bottlenecks = False`.
+        self.fuse_tail = True
+
+    def _can_fuse(self, x):
+        c2, c3 = self.conv2, self.conv3
+        cm = c2.weight.shape[0]
+        return (self.fuse_tail and x.dtype == torch.bfloat16 and cm in (64, 128, 256) and c2.weight.shape[1] == cm
+                and c3.weight.shape[0] == 4 * cm and c2.kernel_size == 3 and c2.stride == 1 and c2.padding == 1)
 
     def forward(self, x):
         out = self.conv1(x, relu=True)
-        out = self.conv2(out, relu=True)
         if self.shortcut is not None:
             sc = self.shortcut(x)
         elif self.stride == 1:
             sc = x
         else:
             raise ValueError("identity shortcut needs stride 1")
+        if self._can_fuse(x):
+            f2, b2 = self.conv2.folded_bf16(x.device)
+            f3, b3 = self.conv3.folded_bf16(x.device)
+            return ops.bottleneck_tail_bf16(out, f2, b2, f3, b3, sc.contiguous())
+        out = self.conv2(out, relu=True)
         return self.conv3(out, residual=sc, relu=True)
 
 
@@ -126,6 +140,7 @@ class Res5RoIHead(_CachedWeightsMixin, nn.Module):
             blocks.append(BottleneckBlock(cin, out_channels, bottleneck_channels, first_stride if b == 0 else 1))
             cin = out_channels
         self.res5 = nn.Sequential(*blocks)
+        self.fuse_bottlenecks = True
         self.in_channels, self.out_channels = in_channels, out_channels
         self.pooler_resolution, self.spatial_scale, self.sampling_ratio = pooler_resolution, spatial_scale, sampling_ratio
         self.roi_chunk = int(roi_chunk)
@@ -137,6 +152,8 @@ class Res5RoIHead(_CachedWeightsMixin, nn.Module):
 
     def forward(self, feature_maps, tracklet_boxes):
         with torch.no_grad():
+            for blk in self.res5:
+                blk.fuse_tail = bool(self.fuse_bottlenecks)
             dev = _compute_device(feature_maps, tracklet_boxes, self.res5[0].conv1.weight)
             bf16 = isinstance(feature_maps, torch.Tensor) and feature_maps.dtype == torch.bfloat16
             # RoIAlign interpolates in fp32 and reads a bf16 map as it is (bf16 values are exact in fp32)
@@ -242,12 +259,16 @@ class ResNetC4(_CachedWeightsMixin, nn.Module):
             cout *= 2
         self.out_channels = cin
         self.frame_chunk = int(frame_chunk)
+        self.fuse_bottlenecks = True     # bf16 maps: conv2 + conv3 + residual of every block in one launch
 
     def forward(self, images, bf16=False):
         with torch.no_grad():
             dev = _compute_device(images, self.stem.conv1.weight)
             if images.dim() != 4 or images.shape[3] != 3:
                 raise ValueError(f"images must be channels-last [T,H,W,3], got {tuple(images.shape)}")
+            for m in self.modules():
+                if isinstance(m, BottleneckBlock):
+                    m.fuse_tail = bool(self.fuse_bottlenecks)
             out = []
             for lo in range(0, images.shape[0], self.frame_chunk):
                 x = self.stem(_f32(images[lo:lo + self.frame_chunk], dev), out_bf16=bf16)

@@ -341,3 +341,54 @@ def test_stem_bf16_errors(tspn, device):
     net = tspn.ResNetC4(stem_out=16, res2_out=64, blocks=(1, 1, 1)).to(device)
     with pytest.raises(ValueError):          # the bf16 backbone needs a 32- or 64-channel detectron2 stem
         net(torch.zeros((1, 32, 32, 3), device=device), bf16=True)
+
+
+@pytest.mark.parametrize("CM,NB,H,W", [(64, 2, 9, 13), (128, 1, 16, 16), (256, 3, 7, 11), (64, 1, 1, 1), (256, 1, 45, 80),
+                                      (128, 2, 30, 17)])
+def test_bottleneck_tail_fused_bit_identical_to_two_convs(tspn, device, CM, NB, H, W):
+    """tspn_bottleneck_tail_bf16 (3x3 conv + 1x1 expand + residual + ReLU in one launch, h2 in LDS, half-wave-swapped
+    16-byte epilogue) == tspn_conv2d_nhwc_bf16 applied twice, BIT FOR BIT (same contraction order, same rounding
+    points), and == the float64 restatement within bf16 rounding: pixel counts that are not a multiple of the 128-pixel
+    tile, images smaller than the 3x3 halo, all three channel widths (wave tilings 1x4 / 2x2 / 4x1)."""
+    h1 = tspn.hashrng.uniform(90, "h1", (NB, H, W, CM), 0, 1)
+    res = tspn.hashrng.uniform(90, "res", (NB, H, W, 4 * CM), -1, 1)
+    w2 = tspn.hashrng.normal(90, "w2", (CM, CM, 3, 3), std=float(np.sqrt(2.0 / (9 * CM))))
+    w3 = tspn.hashrng.normal(90, "w3", (4 * CM, CM, 1, 1), std=float(np.sqrt(2.0 / CM)))
+    b2 = tspn.hashrng.normal(90, "b2", (CM,), std=0.1)
+    b3 = tspn.hashrng.normal(90, "b3", (4 * CM,), std=0.1)
+    d = lambda a, dt=None: (t(a).to(device) if dt is None else t(a).to(device).to(dt))   # noqa: E731
+    f2, f3 = tspn.ops.pack_conv2d_frag_bf16(d(w2)), tspn.ops.pack_conv2d_frag_bf16(d(w3))
+    h1d, resd = d(h1, torch.bfloat16), d(res, torch.bfloat16)
+    h2 = tspn.ops.conv2d_nhwc_bf16(h1d, f2, (3, 3), 1, 1, bias=d(b2), relu=True)
+    want = tspn.ops.conv2d_nhwc_bf16(h2, f3, (1, 1), 1, 0, bias=d(b3), residual=resd, relu=True)
+    got = tspn.ops.bottleneck_tail_bf16(h1d, f2, d(b2), f3, d(b3), resd)
+    assert got.dtype == torch.bfloat16 and tuple(got.shape) == (NB, H, W, 4 * CM)
+    assert torch.equal(got, want), f"max diff {float((got.float() - want.float()).abs().max())}"
+    r2 = ro.conv2d_bf16(h1d.cpu().float().permute(0, 3, 1, 2), t(w2), t(b2), padding=1, relu=True)
+    ref = ro.conv2d_bf16(r2, t(w3), t(b3), residual=resd.cpu().float().permute(0, 3, 1, 2), relu=True).permute(0, 2, 3, 1)
+    err = (got.cpu().double() - ref).abs()
+    scale = float(ref.abs().max())
+    assert float(err.max()) <= 4 * 2.0 ** -8 * scale and float((err <= 2.0 ** -8 * ref.abs() + 1e-6).double().mean()) > 0.97
+
+
+def test_backbone_and_roi_head_fused_equal_unfused(tspn, device):
+    """ResNetC4 / Res5RoIHead with fuse_bottlenecks on and off: the same bf16 maps and features, bit for bit (every
+    block incl. the stride-2 ones with a projection shortcut goes through the fused tail)."""
+    blocks = (2, 2, 2)
+    net, _ = _backbone_and_weights(tspn, device, 64, 256, blocks)
+    img = t(tspn.hashrng.uniform(91, "img", (3, 64, 96, 3), -1, 1)).to(device)
+    net.fuse_bottlenecks = True
+    a = net(img, bf16=True)
+    net.fuse_bottlenecks = False
+    b = net(img, bf16=True)
+    assert a.dtype == torch.bfloat16 and torch.equal(a, b)
+    head = tspn.Res5RoIHead(1024, 128, 512).to(device)
+    boxes = torch.tensor([[[4.0, 4, 60, 50], [10, 8, 90, 60], [0, 0, 95, 63]], [[0, 0, 95, 63], [30, 20, 50, 40], [1, 2, 3, 4]]],
+                         device=device)
+    head.fuse_bottlenecks = True
+    fa = head(a, boxes)
+    head.fuse_bottlenecks = False
+    fb = head(a, boxes)
+    assert torch.equal(fa, fb)
+    with pytest.raises(ValueError):
+        tspn.ops.bottleneck_tail_bf16(torch.zeros((1, 4, 4, 32), dtype=torch.bfloat16, device=device), a, a.float(), a, a.float(), a)
