@@ -7,13 +7,16 @@
 //   phase 2  the 3x3 conv exactly as conv2d_nhwc_bf16_kernel does it (implicit GEMM, M = CM output channels, N = 128
 //            pixels per workgroup, K = 9 taps x CM in chunks of 64 channels of one tap; x through LDS by DMA with a
 //            zero page for padding taps, fragment-major weights straight into MFMA operand registers, counted
-//            vmcnt, one bare s_barrier per chunk) -- the WHOLE channel range of the tile stays in one workgroup:
+//            vmcnt, one bare s_barrier per chunk) but with the x stages as a ring filled 2-3 chunks ahead -- the
+//            WHOLE channel range of the tile stays in one workgroup:
 //            wave (wm, wn) owns rows [64 wm, 64 wm + 64) x pixel blocks [NI wn, NI wn + NI), with
 //            (WM, WN) = (4, 1) / (2, 2) / (1, 4) for CM = 256 / 128 / 64;
 //   h2       relu(acc + b2) is rounded to bf16 ONCE (the same rounding point as the unfused chain) and written
 //            into the now idle stage memory in the B-operand layout [CM / 8 groups][132 slots][8 bf16];
-//   phase 3  the 1x1 expand as four passes of a [CM rows x 128 pixels] GEMM with K = CM: B fragments from the h2
-//            image in LDS (conflict-free 16-byte reads), W3 fragments from L2 through a 4-deep register ring;
+//   phase 3  the 1x1 expand (M = 4 CM rows, K = CM) as eight sub-passes per wave on two alternating accumulator
+//            sets: B fragments from the h2 image in LDS (conflict-free 16-byte reads), W3 fragments from L2 as one
+//            continuous stream through a 4-deep register ring; the epilogue of sub-pass i is fed into the MFMA
+//            gaps of sub-pass i + 1, one group per two k-steps, residual rows requested three groups ahead;
 //   epilogue v_permlane32_swap pairs turn the MFMA layout (4 consecutive channels per lane and half-wave) into 8
 //            consecutive channels per lane, so the residual read, ReLU, the single rounding and the store are
 //            16 bytes per lane with no LDS transpose (CDNA4 guide, T21).
@@ -61,7 +64,7 @@ __device__ __forceinline__ void swap32(float& a, float& b) {
 }
 
 template <int CM>
-__global__ __launch_bounds__(THREADS, 2) void bottleneck_bf16_kernel(
+__global__ __launch_bounds__(THREADS, (CM == 256 ? 2 : 3)) void bottleneck_bf16_kernel(
     const __bf16* __restrict__ h1, const __bf16* __restrict__ Wf2, const float* __restrict__ bias2,
     const __bf16* __restrict__ Wf3, const float* __restrict__ bias3, const __bf16* __restrict__ residual,
     __bf16* __restrict__ out, int H, int W, int64_t npix) {
@@ -70,7 +73,12 @@ __global__ __launch_bounds__(THREADS, 2) void bottleneck_bf16_kernel(
   constexpr int CCH = CM / KC;                            // 64-channel chunks per tap = chunks of phase 3
   constexpr int NCHUNKS = 9 * CCH;
   constexpr int C4 = 4 * CM;
-  extern __shared__ __attribute__((aligned(16))) char Bs[];   // max(2 stages, h2 image) = max(2, CCH) * B_ST
+  // x stages: a ring of NST, filled NST - 1 chunks ahead (the DMA latency under load is 2-4 chunk times: with one
+  // chunk of lookahead the MFMA pipe idled more than half of phase 2); NST = 4 costs nothing at CM = 256, where the
+  // h2 image needs the same 67.6 KB
+  constexpr int NST = CM == 256 ? 4 : 3;
+  constexpr int DIST = NST - 1;
+  extern __shared__ __attribute__((aligned(16))) char Bs[];   // max(NST stages, h2 image) = max(NST, CCH) * B_ST
 
   const int nwg = gridDim.x;
   const int bid = blockIdx.x;
@@ -152,7 +160,9 @@ __global__ __launch_bounds__(THREADS, 2) void bottleneck_bf16_kernel(
     for (int mi = 0; mi < MI; ++mi) wbase[mi] += 4096;
   };
 
-  stage_x(0, 0);
+  static_assert(NCHUNKS > DIST, "ring prologue");
+#pragma unroll
+  for (int i = 0; i < DIST; ++i) stage_x(i, i);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   load_step(K0{}); load_step(K1{}); load_step(K2{}); load_step(K3{});
@@ -161,15 +171,16 @@ __global__ __launch_bounds__(THREADS, 2) void bottleneck_bf16_kernel(
 
   // lane's fragment base inside a stage: slot = pixel block offset + li, channel-group half kh
   const int bofs = ((kh * SLP) + wn * NI * 32 + li) * 16;
-  // chunk i.  VMEM issue order: [x_{i+1}: 4 pieces] a0' | a1' | a2' | a3' (MI loads each); counts = YOUNGER operations
-  auto chunk_body = [&](int i, auto more_tag) {
-    constexpr bool MORE = decltype(more_tag)::value;
-    constexpr int NX = MORE ? 4 : 0, R = MORE ? MI : 0, L = MI;
-    const int buf = i & 1;
+  // chunk i.  VMEM issue order: [x_{i+DIST}: 4 pieces] a0' | a1' | a2' | a3' (MI loads each, the weights of chunk
+  // i + 1); counts = YOUNGER operations at each wait.  x_{i+1} was requested DIST - 1 >= 1 chunks ago, BEFORE the
+  // weights of this chunk: in-order VMEM return makes the wait for a3 of this chunk the wait for x_{i+1} as well.
+  auto chunk_body = [&](int i, int buf, auto stage_tag, auto more_tag) {
+    constexpr bool STAGE = decltype(stage_tag)::value, MORE = decltype(more_tag)::value;
+    constexpr int NX = STAGE ? 4 : 0, R = MORE ? MI : 0, L = MI;
     const char* Bb = Bs + buf * B_ST + bofs;
     bf16x8 b0[NI], b1[NI];
     wait_w<3 * L>(a[0][0], a[0][1]);
-    if (MORE) stage_x(buf ^ 1, i + 1);
+    if (STAGE) stage_x(buf >= 1 ? buf - 1 : NST - 1, i + DIST);      // the stage chunk i - 1 has just left
     __builtin_amdgcn_sched_barrier(0);
     read_b(Bb, 0, b0);
     read_b(Bb, 2, b1);
@@ -190,13 +201,25 @@ __global__ __launch_bounds__(THREADS, 2) void bottleneck_bf16_kernel(
     mfma_step(acc, a[3], b1);
     if (MORE) { load_step(K3{}); bump(); }
     __builtin_amdgcn_sched_barrier(0);
-    if (MORE) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * MI) : "memory");
+    // every LDS read of this chunk has returned; x_{i+1} landed with a3 (see above); the last chunk drains everything
+    if (MORE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
-  for (int i = 0; i + 1 < NCHUNKS; ++i) chunk_body(i, std::true_type{});
-  chunk_body(NCHUNKS - 1, std::false_type{});      // ends with a barrier: nobody reads the stages any more
+  {
+    int buf = 0;
+    int i = 0;
+    for (; i + DIST < NCHUNKS; ++i) {
+      chunk_body(i, buf, std::true_type{}, std::true_type{});
+      buf = buf + 1 == NST ? 0 : buf + 1;
+    }
+    for (; i + 1 < NCHUNKS; ++i) {
+      chunk_body(i, buf, std::false_type{}, std::true_type{});
+      buf = buf + 1 == NST ? 0 : buf + 1;
+    }
+    chunk_body(i, buf, std::false_type{}, std::false_type{});   // ends with a barrier: nobody reads the stages any more
+  }
 
   // ---------------------------------------------------------------- h2 = relu(acc + b2) -> bf16 -> LDS (B-operand image)
 #pragma unroll
@@ -216,94 +239,162 @@ __global__ __launch_bounds__(THREADS, 2) void bottleneck_bf16_kernel(
       }
     }
   __syncthreads();
-
-  // ---------------------------------------------------------------- phase 3: 1x1 expand, four passes of CM rows, K = CM
-  constexpr int KSTEPS = CM / 16;
-  constexpr int RING = KSTEPS < 4 ? KSTEPS : 4;
-  const char* Hb = Bs + bofs;
-#pragma unroll 1
-  for (int pass = 0; pass < 4; ++pass) {
-    const int rb0 = (wm * 4 + pass) * MI;                       // first 32-row block of this wave and pass
-    const char* w3[MI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-      w3[mi] = reinterpret_cast<const char*>(Wf3) + (int64_t)(rb0 + mi) * (CCH * 4096) + woff;
-    f32x4 ar[RING][MI];
-#pragma unroll
-    for (int k = 0; k < RING; ++k)
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) ar[k][mi] = *reinterpret_cast<const f32x4*>(w3[mi] + k * 1024);
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
-#pragma unroll
-    for (int k = 0; k < KSTEPS; ++k) {
-      bf16x8 b[NI];
-      read_b(Hb, 2 * k, b);
-      mfma_step(acc, ar[k % RING], b);
-      if (k + RING < KSTEPS) {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) ar[k % RING][mi] = *reinterpret_cast<const f32x4*>(w3[mi] + (k + RING) * 1024);
-      }
-      __builtin_amdgcn_sched_barrier(0);     // keep the ring a ring: no hoisting of later refills (register pressure)
-    }
-    // epilogue: 8 consecutive channels per lane after the half-wave swaps; + b3 + residual, ReLU, one rounding
-#if defined(TSPN_BT_DIRECT_EPILOGUE)
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int ch0 = 32 * (rb0 + mi) + 8 * q + 4 * kh;
-        const float4 bv = *reinterpret_cast<const float4*>(bias3 + ch0);
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          const int64_t n = n0 + (wn * NI + ni) * 32 + li;
-          if (n < npix) {
-            const bf16x4 rv = *reinterpret_cast<const bf16x4*>(residual + n * C4 + ch0);
-            bf16x4 o;
-            o[0] = (__bf16)fmaxf(acc[mi][ni][4 * q] + bv.x + (float)rv[0], 0.f);
-            o[1] = (__bf16)fmaxf(acc[mi][ni][4 * q + 1] + bv.y + (float)rv[1], 0.f);
-            o[2] = (__bf16)fmaxf(acc[mi][ni][4 * q + 2] + bv.z + (float)rv[2], 0.f);
-            o[3] = (__bf16)fmaxf(acc[mi][ni][4 * q + 3] + bv.w + (float)rv[3], 0.f);
-            *reinterpret_cast<bf16x4*>(out + n * C4 + ch0) = o;
-          }
-        }
-      }
-#else
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        // bias in the MFMA layout (own channels 16 s + 4 kh + e and + 8), BEFORE the swaps: the permlane then reads
-        // a VALU result (hazard padded by hipcc), never an MFMA result directly
-        const int chm = 32 * (rb0 + mi) + 16 * s + 4 * kh;
-        const float4 bv0 = *reinterpret_cast<const float4*>(bias3 + chm);
-        const float4 bv1 = *reinterpret_cast<const float4*>(bias3 + chm + 8);
-        const int ch0 = 32 * (rb0 + mi) + 16 * s + 8 * kh;      // first of this lane's 8 channels AFTER the swaps
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          float lo[4] = {acc[mi][ni][8 * s] + bv0.x, acc[mi][ni][8 * s + 1] + bv0.y, acc[mi][ni][8 * s + 2] + bv0.z,
-                         acc[mi][ni][8 * s + 3] + bv0.w};
-          float hi[4] = {acc[mi][ni][8 * s + 4] + bv1.x, acc[mi][ni][8 * s + 5] + bv1.y, acc[mi][ni][8 * s + 6] + bv1.z,
-                         acc[mi][ni][8 * s + 7] + bv1.w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) swap32(lo[e], hi[e]);
-          const int64_t n = n0 + (wn * NI + ni) * 32 + li;
-          if (n < npix) {
-            const bf16x8 rv = *reinterpret_cast<const bf16x8*>(residual + n * C4 + ch0);
-            const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            bf16x8 o;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (__bf16)fmaxf(v[j] + (float)rv[j], 0.f);
-            *reinterpret_cast<bf16x8*>(out + n * C4 + ch0) = o;
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);   // at most NI residual loads in flight per group
-      }
+#if defined(TSPN_BT_ABL_NOP3)       // probe build: phase 2 + h2 only
+  if (npix >= 0) return;
 #endif
+
+  // ---------------------------------------------------------------- phase 3: 1x1 expand, K = CM, software-pipelined
+  // Eight sub-passes per wave, each a [32 MS rows x 32 NS pixels] accumulator set (half of what the wave owns in a pass
+  // of CM rows); two sets alternate: while the MFMAs of sub-pass i + 1 run, the epilogue of sub-pass i -- bias,
+  // half-wave swaps, residual, ReLU, rounding, 16-byte stores -- is fed into the gaps one group per two k-steps,
+  // its residual loads issued three groups ahead.  The W3 fragments are one continuous stream through a 4-deep
+  // register ring that runs across sub-pass boundaries.
+  constexpr int KSTEPS = CM / 16;
+  constexpr int MS = CM >= 128 ? 2 : 1;            // row blocks per sub-pass
+  constexpr int NS = CM == 256 ? 2 : 1;            // pixel blocks per sub-pass
+  constexpr int NSUB = 8;
+  constexpr int G = MS * 2 * NS;                   // epilogue groups per sub-pass (8 channels x 32 pixels per lane-row)
+  constexpr int RING = 4;
+  static_assert(KSTEPS == 2 * G && KSTEPS >= RING, "phase-3 schedule: one epilogue group per two k-steps");
+  const char* Hb = Bs + (kh * SLP + li) * 16;
+  // sub-pass sp = 2 pass + part: rows (wm 4 + pass) MI + mi0 .., pixel blocks wn NI + ni0 ..
+  auto sub_rb = [&](int sp) { return (wm * 4 + (sp >> 1)) * MI + (NS < NI ? 0 : (sp & 1) * MS); };
+  auto sub_nb = [&](int sp) { return wn * NI + (NS < NI ? (sp & 1) * NS : 0); };
+  const char* const w3base = reinterpret_cast<const char*>(Wf3) + woff;
+  auto a_ptr = [&](int sp, int k, int ms) {         // fragment of k-step k, row block ms of sub-pass sp
+    return w3base + (int64_t)(sub_rb(sp) + ms) * (CCH * 4096) + k * 1024;
+  };
+  f32x4 ar[RING][MS];
+#pragma unroll
+  for (int k = 0; k < RING; ++k)
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms) ar[k][ms] = *reinterpret_cast<const f32x4*>(a_ptr(0, k, ms));
+  f32x16 accA[MS][NS], accB[MS][NS];
+
+  // one k-step of sub-pass sp into `c`; refills the ring slot with the fragment RING k-steps ahead in the stream
+  auto kstep = [&](f32x16 (&c)[MS][NS], int sp, auto k_tag) {
+    constexpr int k = decltype(k_tag)::value;
+    const int nb = sub_nb(sp);
+    bf16x8 b[NS];
+#pragma unroll
+    for (int nj = 0; nj < NS; ++nj)
+      b[nj] = *reinterpret_cast<const bf16x8*>(Hb + ((2 * k) * SLP + (nb + nj) * 32) * 16);
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms) {
+      const bf16x8 av = __builtin_bit_cast(bf16x8, ar[k % RING][ms]);
+#pragma unroll
+      for (int nj = 0; nj < NS; ++nj) c[ms][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b[nj], c[ms][nj], 0, 0, 0);
+    }
+    constexpr int kn = k + RING;                     // position in the stream of the fragment that takes this slot
+    if (kn < KSTEPS || sp + 1 < NSUB) {
+#pragma unroll
+      for (int ms = 0; ms < MS; ++ms)
+        ar[k % RING][ms] = *reinterpret_cast<const f32x4*>(kn < KSTEPS ? a_ptr(sp, kn, ms) : a_ptr(sp + 1, kn - KSTEPS, ms));
+    }
+  };
+  // epilogue group g of sub-pass sp held in `c`: (ms, s, nj) = 8 consecutive channels x 32 pixels after the swaps
+  bf16x8 rres[3];                                    // residual rows in flight (three groups ahead)
+  auto res_ptr = [&](int sp, int g) {
+    const int ms = g / (2 * NS), s2 = (g / NS) & 1, nj = g % NS;
+    const int64_t n = n0 + (sub_nb(sp) + nj) * 32 + li;
+    const int ch0 = 32 * (sub_rb(sp) + ms) + 16 * s2 + 8 * kh;
+    return (n < npix ? n : 0) * C4 + ch0;            // clamped: the value is dropped for pixels beyond the end
+  };
+  auto res_issue = [&](int sp, auto g_tag) {
+    constexpr int g = decltype(g_tag)::value;
+#if defined(TSPN_BT_ABL_NORES)      // probe build: no residual traffic
+    (void)sp;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) rres[g % 3][j] = (__bf16)0.f;
+#else
+    rres[g % 3] = *reinterpret_cast<const bf16x8*>(residual + res_ptr(sp, g));
+#endif
+  };
+  auto group_finish = [&](f32x16 (&c)[MS][NS], int sp, auto g_tag) {
+    constexpr int g = decltype(g_tag)::value;
+    constexpr int ms = g / (2 * NS), s2 = (g / NS) & 1, nj = g % NS;
+    const int chm = 32 * (sub_rb(sp) + ms) + 16 * s2 + 4 * kh;   // bias in the MFMA layout, before the swaps
+    const float4 bv0 = *reinterpret_cast<const float4*>(bias3 + chm);
+    const float4 bv1 = *reinterpret_cast<const float4*>(bias3 + chm + 8);
+    float lo[4] = {c[ms][nj][8 * s2] + bv0.x, c[ms][nj][8 * s2 + 1] + bv0.y, c[ms][nj][8 * s2 + 2] + bv0.z,
+                   c[ms][nj][8 * s2 + 3] + bv0.w};
+    float hi[4] = {c[ms][nj][8 * s2 + 4] + bv1.x, c[ms][nj][8 * s2 + 5] + bv1.y, c[ms][nj][8 * s2 + 6] + bv1.z,
+                   c[ms][nj][8 * s2 + 7] + bv1.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) swap32(lo[e], hi[e]);
+    const int64_t n = n0 + (sub_nb(sp) + nj) * 32 + li;
+    const bf16x8 rv = rres[g % 3];
+    const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (__bf16)fmaxf(v[j] + (float)rv[j], 0.f);
+#if defined(TSPN_BT_ABL_NOSTORE)    // probe build: results are computed but (almost) never stored
+    if (n < npix && o[0] == (__bf16)12345.f) *reinterpret_cast<bf16x8*>(out + n * C4 + 32 * (sub_rb(sp) + ms) + 16 * s2 + 8 * kh) = o;
+#else
+    if (n < npix) *reinterpret_cast<bf16x8*>(out + n * C4 + 32 * (sub_rb(sp) + ms) + 16 * s2 + 8 * kh) = o;
+#endif
+  };
+  auto zero = [&](f32x16 (&c)[MS][NS]) {
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+      for (int nj = 0; nj < NS; ++nj)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) c[ms][nj][e] = 0.f;
+  };
+  // sub-pass sp into `cur` while the epilogue of sub-pass sp - 1 (in `prev`) drains: group g is finished after k-step
+  // 2 g + 1, its residual row was requested three groups earlier
+  auto subpass = [&](f32x16 (&cur)[MS][NS], f32x16 (&prev)[MS][NS], int sp, auto drain_tag) {
+    constexpr bool DRAIN = decltype(drain_tag)::value;
+    zero(cur);
+    if constexpr (DRAIN) {
+      res_issue(sp - 1, std::integral_constant<int, 0>{});
+      if constexpr (G > 1) res_issue(sp - 1, std::integral_constant<int, 1>{});
+      if constexpr (G > 2) res_issue(sp - 1, std::integral_constant<int, 2>{});
+    }
+    auto two = [&](auto g_tag) {
+      constexpr int g = decltype(g_tag)::value;
+      kstep(cur, sp, std::integral_constant<int, 2 * g>{});
+      __builtin_amdgcn_sched_barrier(0);
+      kstep(cur, sp, std::integral_constant<int, 2 * g + 1>{});
+      if constexpr (DRAIN) {
+        group_finish(prev, sp - 1, g_tag);
+        if constexpr (g + 3 < G) res_issue(sp - 1, std::integral_constant<int, g + 3>{});
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    two(std::integral_constant<int, 0>{});
+    if constexpr (G > 1) two(std::integral_constant<int, 1>{});
+    if constexpr (G > 2) { two(std::integral_constant<int, 2>{}); two(std::integral_constant<int, 3>{}); }
+    if constexpr (G > 4) {
+      two(std::integral_constant<int, 4>{}); two(std::integral_constant<int, 5>{});
+      two(std::integral_constant<int, 6>{}); two(std::integral_constant<int, 7>{});
+    }
+  };
+  subpass(accA, accB, 0, std::false_type{});
+#pragma unroll 1
+  for (int sp = 1; sp < NSUB; sp += 2) {
+    subpass(accB, accA, sp, std::true_type{});
+    if (sp + 1 < NSUB) subpass(accA, accB, sp + 1, std::true_type{});
+  }
+  // the last sub-pass (odd, in accB) drains on its own
+  {
+    constexpr int sp = NSUB - 1;
+    res_issue(sp, std::integral_constant<int, 0>{});
+    if constexpr (G > 1) res_issue(sp, std::integral_constant<int, 1>{});
+    if constexpr (G > 2) res_issue(sp, std::integral_constant<int, 2>{});
+    auto fin = [&](auto g_tag) {
+      constexpr int g = decltype(g_tag)::value;
+      group_finish(accB, sp, g_tag);
+      if constexpr (g + 3 < G) res_issue(sp, std::integral_constant<int, g + 3>{});
+    };
+    fin(std::integral_constant<int, 0>{});
+    if constexpr (G > 1) fin(std::integral_constant<int, 1>{});
+    if constexpr (G > 2) { fin(std::integral_constant<int, 2>{}); fin(std::integral_constant<int, 3>{}); }
+    if constexpr (G > 4) {
+      fin(std::integral_constant<int, 4>{}); fin(std::integral_constant<int, 5>{});
+      fin(std::integral_constant<int, 6>{}); fin(std::integral_constant<int, 7>{});
+    }
   }
 }
 
@@ -313,7 +404,8 @@ int launch(const uint16_t* h1, int64_t NB, int64_t H, int64_t W, const uint16_t*
   const int64_t npix = NB * H * W;
   const int64_t tiles = tspn::ceil_div(npix, BN);
   TSPN_REQUIRE(tiles < (1LL << 31), TSPN_EUNSUPPORTED, "tspn_bottleneck_tail_bf16: grid too large");
-  constexpr size_t smem = (size_t)(CM / KC > 2 ? CM / KC : 2) * B_ST;
+  constexpr int nst = CM == 256 ? 4 : 3;
+  constexpr size_t smem = (size_t)(CM / KC > nst ? CM / KC : nst) * B_ST;
   static tspn::LdsLimit lds;
   if (int rc = lds.ensure(reinterpret_cast<const void*>(bottleneck_bf16_kernel<CM>), smem, "tspn_bottleneck_tail_bf16"))
     return rc;
