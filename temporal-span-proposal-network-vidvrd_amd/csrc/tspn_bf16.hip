@@ -381,6 +381,9 @@ __global__ __launch_bounds__(G_THREADS, 1) void conv3_bf16_big_kernel(
 // fetches complete 128-byte lines AND the B fragment of lane (f = l&15, kg = l>>4) -- channels
 // 8kg .. 8kg+7 of frame f -- is two conflict-free ds_read_b128.  The VALU work (1.5 packed
 // instructions per activation) hides under the operand stream, which is what bounds the kernel.
+#ifndef TSPN_HPB_SW
+#define TSPN_HPB_SW 2        // subjects per wave of the <8, 16> form (probe knob: 4 = 4 subjects x 8 objects per wave)
+#endif
 constexpr int HP_FB = 16;
 constexpr int HP_KC = 32;
 constexpr int HP_ROW = HP_FB * HP_KC * 4;  // 2048 B
@@ -398,12 +401,14 @@ __device__ __forceinline__ unsigned relu_pack(float a, float b) {
 // stage, 1 workgroup/CU -- half the bytes streamed from L2 per activation, which is what bounds the
 // kernel (ablation at the config-3 shape, 8 x 8: 4.5 ms, without the DMA stream 2.2, without the
 // VALU work still 4.5).
-template <int NW, int OB>
+template <int NW, int OB, int SW>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void heads_pairgrid_bf16_kernel(
     const float* __restrict__ y, int64_t ldm, int B, int N, int C, int T,
     const __bf16* __restrict__ Whp, const float* __restrict__ bh, int H, float* __restrict__ out,
     int nsb, int nob, int nfb) {
   constexpr int SBLK = 2 * NW;
+  constexpr int WS = SBLK / SW, WO = NW / WS, OW = OB / WO;   // waves along subjects / objects, objects per wave
+  static_assert(WS * WO == NW && OW * WO == OB, "wave tiling");
   constexpr int ROWS = SBLK + OB;
   constexpr int ST = ROWS * HP_ROW + 1024;  // + the k-step's slice of the head weights (one piece)
   static_assert(ROWS == 4 * NW, "each wave stages 4 rows");
@@ -425,6 +430,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void heads_pairgrid_bf16_
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int f = lane & 15, kg = lane >> 4;
   const int t0 = fb * HP_FB;
+  const int ws = wave % WS, wo = wave / WS;      // this wave's subjects SW ws .., objects OW wo ..
 
   // DMA sources: wave w stages rows 4w .. 4w+3 (2 pieces each); row r < SBLK: subject SBLK sb + r
   // (U half, channels [0,C)), else object OB ob + r - SBLK (V half, channels [C,2C))
@@ -466,11 +472,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void heads_pairgrid_bf16_
     }
   };
 
-  f32x4 acc[2][OB];
+  f32x4 acc[SW][OW];
 #pragma unroll
-  for (int s = 0; s < 2; ++s)
+  for (int s = 0; s < SW; ++s)
 #pragma unroll
-    for (int o = 0; o < OB; ++o) acc[s][o] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int o = 0; o < OW; ++o) acc[s][o] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = C / HP_KC;
   // fragment of lane (f, kg): quads 2 kg (here) and 2 kg + 1 (256 bytes further)
@@ -485,43 +491,52 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void heads_pairgrid_bf16_
     __builtin_amdgcn_sched_barrier(0);
     const bf16x8 wfrag = *reinterpret_cast<const bf16x8*>(smem + buf * ST + ROWS * HP_ROW + lane * 16);
     const char* base = smem + buf * ST + frag_off;
-    f32x4 u[2][2];
+    f32x4 u[SW][2];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      u[s][0] = *reinterpret_cast<const f32x4*>(base + (2 * wave + s) * HP_ROW);
-      u[s][1] = *reinterpret_cast<const f32x4*>(base + (2 * wave + s) * HP_ROW + 256);
+    for (int s = 0; s < SW; ++s) {
+      u[s][0] = *reinterpret_cast<const f32x4*>(base + (SW * ws + s) * HP_ROW);
+      u[s][1] = *reinterpret_cast<const f32x4*>(base + (SW * ws + s) * HP_ROW + 256);
     }
     // V fragments are read two objects ahead of their use (LDS latency off the critical path).  The
     // reads and their counted waits are written out: left to itself the compiler issues every
     // fragment read right before its first use and waits for it at once (32 exposed LDS round trips
     // per k-step).  LDS returns in order, so "lgkmcnt(n)" = all but the newest n reads have landed.
-    const unsigned vaddr = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(base);
+    const unsigned vaddr = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(base + (SBLK + OW * wo) * HP_ROW);
     f32x4 vq[3][2];
 #define TSPN_VREAD(slot, o)                                                                             \
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(vq[slot][0]) : "v"(vaddr), "n"((SBLK + (o)) * HP_ROW)); \
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(vq[slot][1]) : "v"(vaddr), "n"((SBLK + (o)) * HP_ROW + 256));
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(vq[slot][0]) : "v"(vaddr), "n"((o) * HP_ROW)); \
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(vq[slot][1]) : "v"(vaddr), "n"((o) * HP_ROW + 256));
     TSPN_VREAD(0, 0)
     TSPN_VREAD(1, 1)
 #pragma unroll
-    for (int o = 0; o < OB; ++o) {
-      if (o + 2 < OB) {
+    for (int o = 0; o < OW; ++o) {
+      if (o + 2 < OW) {
         TSPN_VREAD((o + 2) % 3, o + 2)
         asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(vq[o % 3][0]), "+v"(vq[o % 3][1]));
-      } else if (o + 1 < OB) {
+      } else if (o + 1 < OW) {
         asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(vq[o % 3][0]), "+v"(vq[o % 3][1]));
       } else {
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vq[o % 3][0]), "+v"(vq[o % 3][1]));
       }
       const f32x4 v0 = vq[o % 3][0], v1 = vq[o % 3][1];
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
+      for (int s = 0; s < SW; ++s) {
 #if defined(TSPN_HPB_ABL_NOVALU)
         u32x4 pk = {__builtin_bit_cast(unsigned, u[s][0][0]) ^ __builtin_bit_cast(unsigned, v0[0]),
                     __builtin_bit_cast(unsigned, u[s][0][1]) ^ __builtin_bit_cast(unsigned, v0[2]),
                     __builtin_bit_cast(unsigned, u[s][1][0]) ^ __builtin_bit_cast(unsigned, v1[1]),
                     __builtin_bit_cast(unsigned, u[s][1][1]) ^ __builtin_bit_cast(unsigned, v1[3])};
 #else
+#if defined(TSPN_HPB_SCALAR_ADD)   // probe: eight v_add_f32 instead of four v_pk_add_f32
+        f32x4 a0, a1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          asm("v_add_f32 %0, %1, %2" : "=v"(a0[e]) : "v"(u[s][0][e]), "v"(v0[e]));
+          asm("v_add_f32 %0, %1, %2" : "=v"(a1[e]) : "v"(u[s][1][e]), "v"(v1[e]));
+        }
+#else
         const f32x4 a0 = u[s][0] + v0, a1 = u[s][1] + v1;
+#endif
         u32x4 pk = {relu_pack(a0[0], a0[1]), relu_pack(a0[2], a0[3]), relu_pack(a1[0], a1[1]),
                     relu_pack(a1[2], a1[3])};
 #endif
@@ -541,11 +556,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void heads_pairgrid_bf16_
 #pragma unroll
   for (int r = 0; r < 4; ++r) bias[r] = (4 * hg + r < H) ? bh[4 * hg + r] : 0.f;
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int sg = sb * SBLK + 2 * wave + s;
+  for (int s = 0; s < SW; ++s) {
+    const int sg = sb * SBLK + SW * ws + s;
 #pragma unroll
-    for (int o = 0; o < OB; ++o) {
-      const int og = ob * OB + o;
+    for (int o = 0; o < OW; ++o) {
+      const int og = ob * OB + OW * wo + o;
       if (sg >= N || og >= N || sg == og || t >= T) continue;
       const int64_t p = (int64_t)b * N * (N - 1) + (int64_t)sg * (N - 1) + (og < sg ? og : og - 1);
 #pragma unroll
@@ -733,18 +748,18 @@ extern "C" int tspn_heads_pairgrid_bf16(const float* y, int64_t ldm, int64_t B, 
                "tspn_heads_pairgrid_bf16: problem too large");
   const size_t smem = 2 * ((size_t)(2 * sblk) * HP_ROW + 1024);
   static tspn::LdsLimit lds[2];
-  if (int rc = big ? lds[1].ensure(reinterpret_cast<const void*>(heads_pairgrid_bf16_kernel<8, 16>), smem,
+  if (int rc = big ? lds[1].ensure(reinterpret_cast<const void*>(heads_pairgrid_bf16_kernel<8, 16, TSPN_HPB_SW>), smem,
                                    "tspn_heads_pairgrid_bf16")
-                   : lds[0].ensure(reinterpret_cast<const void*>(heads_pairgrid_bf16_kernel<4, 8>), smem,
+                   : lds[0].ensure(reinterpret_cast<const void*>(heads_pairgrid_bf16_kernel<4, 8, 2>), smem,
                                    "tspn_heads_pairgrid_bf16"))
     return rc;
   if (big)
-    hipLaunchKernelGGL((heads_pairgrid_bf16_kernel<8, 16>), dim3((unsigned)grid), dim3(512), smem,
+    hipLaunchKernelGGL((heads_pairgrid_bf16_kernel<8, 16, TSPN_HPB_SW>), dim3((unsigned)grid), dim3(512), smem,
                        TSPN_STREAM(stream), y, ldm, (int)B, (int)N, (int)C, (int)T,
                        reinterpret_cast<const __bf16*>(head_packed), head_b, (int)H, out, (int)nsb, (int)nsb,
                        (int)nfb);
   else
-    hipLaunchKernelGGL((heads_pairgrid_bf16_kernel<4, 8>), dim3((unsigned)grid), dim3(256), smem,
+    hipLaunchKernelGGL((heads_pairgrid_bf16_kernel<4, 8, 2>), dim3((unsigned)grid), dim3(256), smem,
                        TSPN_STREAM(stream), y, ldm, (int)B, (int)N, (int)C, (int)T,
                        reinterpret_cast<const __bf16*>(head_packed), head_b, (int)H, out, (int)nsb, (int)nsb,
                        (int)nfb);
