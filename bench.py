@@ -736,7 +736,7 @@ class Cfg5Workload:
             "dtype": "bf16",
             "config": {"workload": f"BASELINE cfg5: frames -> triplets at VidOR scale: {self.T} frames of {self.H}x{self.W} "
                                    f"and {self.N} tracklets per video, ResNet-101-C4 backbone + Res5 RoI head (bf16 MFMA convs, "
-                                   "fp32 stem) -> tracklet_feats [N,T,2048] bf16 -> BaseModel.forward (bf16 scorer) + "
+                                   "the stem included) -> tracklet_feats [N,T,2048] bf16 -> BaseModel.forward (bf16 scorer) + "
                                    "BaseModel.decode; random-init weights, one video per GPU per step",
                        "videos_per_gpu_per_step": 1, "pairs_per_video": self.P_vid, "resident_input_batches": self.nb,
                        "videos_per_s": self.world * args.steps / elapsed,
@@ -747,7 +747,7 @@ class Cfg5Workload:
                        "fused_bottlenecks": bool(getattr(self.net, "fuse_bottlenecks", False))},
             "roofline": {"bound": "mfma",
                          "kernel": "ResNet-101-C4 backbone, all convolutions of one video (bf16 32x32x16 MFMA implicit GEMMs: "
-                                   "bottleneck_bf16_kernel / conv2d_nhwc_bf16_kernel; fp32 stem)",
+                                   "bottleneck_bf16_kernel / conv2d_nhwc_bf16_kernel / stem_conv_bf16_kernel)",
                          "achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_MFMA_TFLOPS, "traffic": None,
                          "flop_per_launch": flop, "avg_launch_ms": bb_ms,
