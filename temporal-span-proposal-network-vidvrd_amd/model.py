@@ -619,6 +619,8 @@ class BaseModel(_CachedWeightsMixin, nn.Module):
         ws = self._workspaces.get(key)
         if ws is None or ws.numel() < nbytes:
             self._workspaces.pop(key, None)
+            while len(self._workspaces) >= 4:        # streams come and go: never hold more than four (5 GB each at cfg2)
+                self._workspaces.pop(next(iter(self._workspaces)))
             ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
             self._workspaces[key] = ws
         return ws
