@@ -451,19 +451,21 @@ int tspn_conv2d_nhwc_bf16(const uint16_t* x, int64_t NB, int64_t H, int64_t W, i
                           uint16_t* out, void* stream);
 /* tspn_roi_align_nhwc_f32: detectron2 ROIAlign on a channels-last map feat[NF,H,W,C]:
  *   rois[R,5] = (map index, x1, y1, x2, y2) in image coordinates, `spatial_scale` image -> map,
- *   out[R,P,P,C]; sampling_ratio 0 = adaptive grid ceil(roi size / P) (detectron2's POOLER_SAMPLING_RATIO 0);
- *   aligned != 0 = the half-pixel-corrected form (ROIAlignV2).  Needs C % 4 == 0. */
+ *   out[R,OP,OP,C]; sampling_ratio 0 = adaptive grid ceil(roi size / P) (detectron2's POOLER_SAMPLING_RATIO 0);
+ *   aligned != 0 = the half-pixel-corrected form (ROIAlignV2).  `bin_stride` >= 1: only the bins (bs i, bs j) of the
+ *   P x P grid are produced, OP = ceil(P / bs) -- with bs = 2 exactly the bins the stride-2 1x1 convolutions of res5's
+ *   first block read (stride_in_1x1), a quarter of the work and of the output.  Needs C % 4 == 0. */
 int tspn_roi_align_nhwc_f32(const float* feat, int64_t NF, int64_t H, int64_t W, int64_t C,
                             const float* rois, int64_t R, int64_t P, float spatial_scale,
-                            int sampling_ratio, int aligned, float* out, void* stream);
+                            int sampling_ratio, int aligned, int bin_stride, float* out, void* stream);
 /* bf16 map in (values exact in fp32, interpolation in fp32), bf16 out */
 int tspn_roi_align_nhwc_bf16(const uint16_t* feat, int64_t NF, int64_t H, int64_t W, int64_t C,
                              const float* rois, int64_t R, int64_t P, float spatial_scale,
-                             int sampling_ratio, int aligned, uint16_t* out, void* stream);
+                             int sampling_ratio, int aligned, int bin_stride, uint16_t* out, void* stream);
 /* same interpolation in fp32, result rounded once to bf16 (input of tspn_conv2d_nhwc_bf16) */
 int tspn_roi_align_nhwc_f32_bf16out(const float* feat, int64_t NF, int64_t H, int64_t W, int64_t C,
                                     const float* rois, int64_t R, int64_t P, float spatial_scale,
-                                    int sampling_ratio, int aligned, uint16_t* out, void* stream);
+                                    int sampling_ratio, int aligned, int bin_stride, uint16_t* out, void* stream);
 
 /* max_pool2d(k, stride, pad) on a channels-last fp32 map x[NB,H,W,C] -> out[NB,OH,OW,C], fp32 (out_bf16 == 0)
  * or bf16 (rounded once); padding positions do not take part.  detectron2 BasicStem uses 3 / 2 / 1.

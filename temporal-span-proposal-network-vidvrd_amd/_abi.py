@@ -110,7 +110,7 @@ PROTOTYPES = {
     "tspn_pack_conv2d_frag_bf16": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "tspn_conv2d_nhwc_bf16": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp,
                                      _int, _vp, _vp]),
-    "tspn_roi_align_nhwc_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, ctypes.c_float, _int,
+    "tspn_roi_align_nhwc_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, ctypes.c_float, _int, _int,
                                        _int, _vp, _vp]),
     "tspn_pack_conv2d_frag_cin4_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "tspn_conv2d_nhwc_cin4_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _int, _vp, _vp]),
@@ -120,9 +120,9 @@ PROTOTYPES = {
     "tspn_pack_stem_bf16": (_int, [_vp, _i64, _vp, _vp]),
     "tspn_stem_conv_bf16": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _sz, _vp, _vp]),
     "tspn_max_pool_nhwc_bf16": (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp]),
-    "tspn_roi_align_nhwc_bf16": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, ctypes.c_float, _int,
+    "tspn_roi_align_nhwc_bf16": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, ctypes.c_float, _int, _int,
                                         _int, _vp, _vp]),
-    "tspn_roi_align_nhwc_f32_bf16out": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, ctypes.c_float, _int,
+    "tspn_roi_align_nhwc_f32_bf16out": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, ctypes.c_float, _int, _int,
                                                _int, _vp, _vp]),
     "tspn_pack_conv3_wino63_frag_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "tspn_conv3_tc_wino63_workspace_bytes": (_sz, [_i64, _i64, _i64]),

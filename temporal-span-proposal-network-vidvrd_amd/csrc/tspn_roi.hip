@@ -472,10 +472,12 @@ __device__ __forceinline__ float4 load4(const void* base, int64_t idx) {
 template <bool BF16IN, bool BF16OUT>
 __global__ __launch_bounds__(256) void roi_align_nhwc_kernel(
     const void* __restrict__ feat, int NF, int H, int W, int C, const float* __restrict__ rois, int64_t R,
-    int P, float scale, int sampling_ratio, int aligned, void* __restrict__ out_v) {
-  const int64_t item = blockIdx.x;                 // (roi, ph)
-  const int64_t r = item / P;
-  const int ph = (int)(item - r * P);
+    int P, float scale, int sampling_ratio, int aligned, int bs, int OP, void* __restrict__ out_v) {
+  // bins (ph, pw) = (bs * oph, bs * opw) only: OP = ceil(P / bs) rows and columns of the P x P grid are produced
+  const int64_t item = blockIdx.x;                 // (roi, oph)
+  const int64_t r = item / OP;
+  const int oph = (int)(item - r * OP);
+  const int ph = oph * bs;
   const float* roi = rois + r * 5;
   int bi = (int)roi[0];
   bi = bi < 0 ? 0 : (bi >= NF ? NF - 1 : bi);
@@ -489,8 +491,9 @@ __global__ __launch_bounds__(256) void roi_align_nhwc_kernel(
   const float count = (float)max(gh * gw, 1);
   const int64_t fb = (int64_t)bi * H * W * C;
   const int c4 = C >> 2;
-  for (int idx = threadIdx.x; idx < P * c4; idx += blockDim.x) {
-    const int pw = idx / c4, cg = idx - pw * c4;
+  for (int idx = threadIdx.x; idx < OP * c4; idx += blockDim.x) {
+    const int opw = idx / c4, cg = idx - opw * c4;
+    const int pw = opw * bs;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int iy = 0; iy < gh; ++iy) {
       const float y = sh + (float)ph * bin_h + ((float)iy + .5f) * bin_h / (float)gh;
@@ -512,7 +515,7 @@ __global__ __launch_bounds__(256) void roi_align_nhwc_kernel(
       }
     }
     acc.x /= count; acc.y /= count; acc.z /= count; acc.w /= count;
-    const int64_t o = ((r * P + ph) * P + pw) * (int64_t)C + 4 * cg;
+    const int64_t o = ((r * OP + oph) * OP + opw) * (int64_t)C + 4 * cg;
     if constexpr (BF16OUT) {     // the fp32 result rounded once to bf16 (operand of the bf16 conv kernels)
       const bf16x4 ob = {(__bf16)acc.x, (__bf16)acc.y, (__bf16)acc.z, (__bf16)acc.w};
       *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(out_v) + o) = ob;
@@ -685,9 +688,9 @@ extern "C" int tspn_conv2d_nhwc_cin4_f32(const float* x, int64_t NB, int64_t H, 
 
 static int roi_align_launch(const void* feat, bool bf16_in, int64_t NF, int64_t H, int64_t W, int64_t C,
                             const float* rois, int64_t R, int64_t P, float spatial_scale, int sampling_ratio,
-                            int aligned, void* out, bool bf16_out, void* stream) {
-  TSPN_REQUIRE(NF > 0 && H > 0 && W > 0 && C > 0 && R >= 0 && P > 0 && sampling_ratio >= 0, TSPN_EINVAL,
-               "tspn_roi_align_nhwc_f32: bad sizes");
+                            int aligned, int bin_stride, void* out, bool bf16_out, void* stream) {
+  TSPN_REQUIRE(NF > 0 && H > 0 && W > 0 && C > 0 && R >= 0 && P > 0 && sampling_ratio >= 0 && bin_stride >= 1,
+               TSPN_EINVAL, "tspn_roi_align_nhwc_f32: bad sizes");
   if (R == 0) return TSPN_OK;
   TSPN_REQUIRE(feat && rois && out, TSPN_EINVAL, "tspn_roi_align_nhwc_f32: null pointer");
   TSPN_REQUIRE(C % 4 == 0 && (reinterpret_cast<uintptr_t>(feat) & 15) == 0 &&
@@ -695,10 +698,12 @@ static int roi_align_launch(const void* feat, bool bf16_in, int64_t NF, int64_t 
                TSPN_EUNSUPPORTED, "tspn_roi_align_nhwc_f32: needs C %% 4 == 0 and 16-byte aligned tensors");
   TSPN_REQUIRE(R * P < (1LL << 31) && H < (1 << 20) && W < (1 << 20), TSPN_EUNSUPPORTED,
                "tspn_roi_align_nhwc_f32: problem too large");
+  const int64_t OP = tspn::ceil_div(P, bin_stride);
   auto launch = [&](auto kern) {
-    hipLaunchKernelGGL(kern, dim3((unsigned)(R * P)), dim3(256), 0, TSPN_STREAM(stream), feat, (int)NF, (int)H,
-                       (int)W, (int)C, rois, R, (int)P, spatial_scale, sampling_ratio, aligned, out);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(R * OP)), dim3(256), 0, TSPN_STREAM(stream), feat, (int)NF, (int)H,
+                       (int)W, (int)C, rois, R, (int)P, spatial_scale, sampling_ratio, aligned, (int)bin_stride, (int)OP, out);
   };
+
   if (bf16_in) launch(roi_align_nhwc_kernel<true, true>);
   else if (bf16_out) launch(roi_align_nhwc_kernel<false, true>);
   else launch(roi_align_nhwc_kernel<false, false>);
@@ -707,22 +712,22 @@ static int roi_align_launch(const void* feat, bool bf16_in, int64_t NF, int64_t 
 
 extern "C" int tspn_roi_align_nhwc_f32(const float* feat, int64_t NF, int64_t H, int64_t W, int64_t C,
                                        const float* rois, int64_t R, int64_t P, float spatial_scale,
-                                       int sampling_ratio, int aligned, float* out, void* stream) {
-  return roi_align_launch(feat, false, NF, H, W, C, rois, R, P, spatial_scale, sampling_ratio, aligned, out, false,
+                                       int sampling_ratio, int aligned, int bin_stride, float* out, void* stream) {
+  return roi_align_launch(feat, false, NF, H, W, C, rois, R, P, spatial_scale, sampling_ratio, aligned, bin_stride, out, false,
                           stream);
 }
 
 extern "C" int tspn_roi_align_nhwc_f32_bf16out(const float* feat, int64_t NF, int64_t H, int64_t W, int64_t C,
                                                const float* rois, int64_t R, int64_t P, float spatial_scale,
-                                               int sampling_ratio, int aligned, uint16_t* out, void* stream) {
-  return roi_align_launch(feat, false, NF, H, W, C, rois, R, P, spatial_scale, sampling_ratio, aligned, out, true,
+                                               int sampling_ratio, int aligned, int bin_stride, uint16_t* out, void* stream) {
+  return roi_align_launch(feat, false, NF, H, W, C, rois, R, P, spatial_scale, sampling_ratio, aligned, bin_stride, out, true,
                           stream);
 }
 
 extern "C" int tspn_roi_align_nhwc_bf16(const uint16_t* feat, int64_t NF, int64_t H, int64_t W, int64_t C,
                                         const float* rois, int64_t R, int64_t P, float spatial_scale,
-                                        int sampling_ratio, int aligned, uint16_t* out, void* stream) {
-  return roi_align_launch(feat, true, NF, H, W, C, rois, R, P, spatial_scale, sampling_ratio, aligned, out, true,
+                                        int sampling_ratio, int aligned, int bin_stride, uint16_t* out, void* stream) {
+  return roi_align_launch(feat, true, NF, H, W, C, rois, R, P, spatial_scale, sampling_ratio, aligned, bin_stride, out, true,
                           stream);
 }
 

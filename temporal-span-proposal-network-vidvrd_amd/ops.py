@@ -839,22 +839,27 @@ def conv2d_nhwc(x, packed, kernel_size, stride=1, padding=0, bias=None, residual
     return out
 
 
-def roi_align_nhwc(feat, rois, output_size, spatial_scale, sampling_ratio=0, aligned=True, out_bf16=False):
+def roi_align_nhwc(feat, rois, output_size, spatial_scale, sampling_ratio=0, aligned=True, out_bf16=False,
+                   bin_stride=1):
     """detectron2 ROIAlign on a channels-last map: feat [NF,H,W,C], rois [R,5] = (map index, x1, y1, x2, y2)
     -> [R,P,P,C]; `out_bf16`: the fp32 result rounded once to bf16.  A bf16 map is read as it is
-    (interpolation in fp32) and always gives bf16."""
+    (interpolation in fp32) and always gives bf16.  `bin_stride` = bs: only the bins (bs i, bs j) -> [R,OP,OP,C],
+    OP = ceil(P / bs)."""
     bf16_in = isinstance(feat, torch.Tensor) and feat.dtype == torch.bfloat16
     _dev(feat, "feat", torch.bfloat16 if bf16_in else torch.float32); _dev(rois, "rois")
     out_bf16 = out_bf16 or bf16_in
     NF, H, W, C = feat.shape
     if rois.dim() != 2 or rois.shape[1] != 5:
         raise ValueError("roi_align_nhwc: rois must be [R,5]")
-    R, P = rois.shape[0], int(output_size)
-    out = torch.empty((R, P, P, C), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=feat.device)
+    R, P, bs = rois.shape[0], int(output_size), int(bin_stride)
+    if bs < 1:
+        raise ValueError("roi_align_nhwc: bin_stride must be >= 1")
+    OP = (P + bs - 1) // bs
+    out = torch.empty((R, OP, OP, C), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=feat.device)
     fn = _abi.lib().tspn_roi_align_nhwc_bf16 if bf16_in else (
         _abi.lib().tspn_roi_align_nhwc_f32_bf16out if out_bf16 else _abi.lib().tspn_roi_align_nhwc_f32)
     _abi.check(fn(_p(feat), NF, H, W, C, _p(rois), R, P, float(spatial_scale),
-                  int(sampling_ratio), 1 if aligned else 0, _p(out), _stream()))
+                  int(sampling_ratio), 1 if aligned else 0, bs, _p(out), _stream()))
     return out
 
 

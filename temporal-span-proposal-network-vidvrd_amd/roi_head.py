@@ -71,15 +71,17 @@ class ConvFrozenBN(nn.Module):
         return self._cache.get("folded_bf16", (self.weight, n.weight, n.bias, n.running_mean, n.running_var),
                                dev, build)
 
-    def forward(self, x, residual=None, relu=False):
+    def forward(self, x, residual=None, relu=False, stride=None):
         """x channels-last [NB,H,W,Cin] on the HIP device -> act(bn(conv(x)) + residual); bf16 x selects
-        the bf16-operand kernel (bf16 out)."""
+        the bf16-operand kernel (bf16 out).  `stride` overrides the module's (a caller that hands over an
+        already subsampled map runs a strided 1x1 conv with stride 1)."""
         k = (self.kernel_size, self.kernel_size)
+        stride = self.stride if stride is None else stride
         if x.dtype == torch.bfloat16:
             frag, bias = self.folded_bf16(x.device)
-            return ops.conv2d_nhwc_bf16(x, frag, k, self.stride, self.padding, bias=bias, residual=residual, relu=relu)
+            return ops.conv2d_nhwc_bf16(x, frag, k, stride, self.padding, bias=bias, residual=residual, relu=relu)
         packed, bias = self.folded(x.device)
-        return ops.conv2d_nhwc(x, packed, k, self.stride, self.padding, bias=bias, residual=residual, relu=relu)
+        return ops.conv2d_nhwc(x, packed, k, stride, self.padding, bias=bias, residual=residual, relu=relu)
 
 
 class BottleneckBlock(nn.Module):
@@ -104,10 +106,13 @@ class BottleneckBlock(nn.Module):
         return (self.fuse_tail and x.dtype == torch.bfloat16 and cm in (64, 128, 256) and c2.weight.shape[1] == cm
                 and c3.weight.shape[0] == 4 * cm and c2.kernel_size == 3 and c2.stride == 1 and c2.padding == 1)
 
-    def forward(self, x):
-        out = self.conv1(x, relu=True)
+    def forward(self, x, presampled=False):
+        """`presampled`: x already holds only the pixels the strided 1x1 convs (conv1, shortcut) read -- every
+        `stride`-th row and column -- so they run with stride 1 (Res5RoIHead lets ROIAlign produce just those bins)."""
+        st = 1 if presampled else None
+        out = self.conv1(x, relu=True, stride=st)
         if self.shortcut is not None:
-            sc = self.shortcut(x)
+            sc = self.shortcut(x, stride=st)
         elif self.stride == 1:
             sc = x
         else:
@@ -141,6 +146,7 @@ class Res5RoIHead(_CachedWeightsMixin, nn.Module):
             cin = out_channels
         self.res5 = nn.Sequential(*blocks)
         self.fuse_bottlenecks = True
+        self.subsample_roi_align = True     # ROIAlign only the bins res5's strided first block reads (same results)
         self.in_channels, self.out_channels = in_channels, out_channels
         self.pooler_resolution, self.spatial_scale, self.sampling_ratio = pooler_resolution, spatial_scale, sampling_ratio
         self.roi_chunk = int(roi_chunk)
@@ -168,9 +174,17 @@ class Res5RoIHead(_CachedWeightsMixin, nn.Module):
             rois = torch.cat([idx[:, None], boxes.reshape(n * t, 4)], dim=1).contiguous()
             feats = torch.empty((n * t, self.out_channels), dtype=torch.float32, device=dev)
             for lo in range(0, n * t, self.roi_chunk):
+                # res5's first block reads its input only through 1x1 convs of stride s (stride_in_1x1: conv1 and the
+                # projection shortcut): ROIAlign produces just the bins (s i, s j) -- a quarter of the work and of
+                # the 14 x 14 x 1024 output for s = 2 -- and the two convs run with stride 1; same values, bit for bit
+                b0 = self.res5[0]
+                bs = b0.stride if (self.subsample_roi_align and b0.shortcut is not None and b0.conv1.kernel_size == 1
+                                   and b0.shortcut.kernel_size == 1 and b0.conv1.padding == 0) else 1
                 x = ops.roi_align_nhwc(fm, rois[lo:lo + self.roi_chunk].contiguous(), self.pooler_resolution,
-                                       self.spatial_scale, self.sampling_ratio, aligned=True, out_bf16=bf16)
-                x = self.res5(x)
+                                       self.spatial_scale, self.sampling_ratio, aligned=True, out_bf16=bf16, bin_stride=bs)
+                x = b0(x, presampled=bs > 1)
+                for blk in list(self.res5)[1:]:
+                    x = blk(x)
                 r, h, w, c = x.shape
                 if bf16:
                     feats[lo:lo + r] = ops.temporal_mean_bf16(x.view(r, h * w, c))   # bf16-rounded means

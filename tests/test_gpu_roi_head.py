@@ -392,3 +392,28 @@ def test_backbone_and_roi_head_fused_equal_unfused(tspn, device):
     assert torch.equal(fa, fb)
     with pytest.raises(ValueError):
         tspn.ops.bottleneck_tail_bf16(torch.zeros((1, 4, 4, 32), dtype=torch.bfloat16, device=device), a, a.float(), a, a.float(), a)
+
+
+def test_roi_align_bin_stride_and_presampled_first_block(tspn, device):
+    """ROIAlign with bin_stride = s == every s-th bin of the full grid, bit for bit (fp32 and bf16, odd P); and the RoI
+    head that lets ROIAlign produce only the bins res5's strided 1x1 convs read equals the head on the full 14 x 14 grid."""
+    feat = tspn.hashrng.uniform(92, "f", (2, 9, 12, 64), -1, 1)
+    rois = np.array([[0, 10, 20, 100, 120], [1, 0, 0, 191, 143], [1, -30, -10, 60, 50], [0, 150, 100, 260, 200]], dtype=np.float32)
+    for P, bs in ((14, 2), (5, 2), (7, 3), (4, 1)):
+        full = tspn.ops.roi_align_nhwc(t(feat).to(device), t(rois).to(device), P, 1.0 / 16)
+        sub = tspn.ops.roi_align_nhwc(t(feat).to(device), t(rois).to(device), P, 1.0 / 16, bin_stride=bs)
+        assert torch.equal(sub, full[:, ::bs, ::bs].contiguous())
+        f16 = t(feat).to(torch.bfloat16).to(device)
+        assert torch.equal(tspn.ops.roi_align_nhwc(f16, t(rois).to(device), P, 1.0 / 16, bin_stride=bs),
+                           tspn.ops.roi_align_nhwc(f16, t(rois).to(device), P, 1.0 / 16)[:, ::bs, ::bs].contiguous())
+    with pytest.raises(ValueError):
+        tspn.ops.roi_align_nhwc(t(feat).to(device), t(rois).to(device), 7, 1.0 / 16, bin_stride=0)
+    head, _ = _head_and_weights(tspn, device, 128, 64, 256, roi_chunk=7)
+    fm = t(tspn.hashrng.uniform(93, "fm", (4, 10, 12, 128), 0, 1))
+    boxes = t((tspn.synth.make_video(94, 3, 4, 16)["tracklet_boxes"] * np.float32(0.15)).astype(np.float32)).to(device)
+    for maps in (fm.to(device), fm.to(torch.bfloat16).to(device)):
+        head.subsample_roi_align = True
+        a = head(maps, boxes)
+        head.subsample_roi_align = False
+        b = head(maps, boxes)
+        assert torch.equal(a, b)
