@@ -106,6 +106,8 @@ def parse(argv=None):
     ap.add_argument("--tracklets", type=int, default=None, help="cfg5: tracklets per video (default 64)")
     ap.add_argument("--fused-bottleneck", choices=["auto", "off"], default="auto",
                     help="cfg5: `off` runs every backbone convolution as its own launch (the round-2 path)")
+    ap.add_argument("--serial-tail", action="store_true",
+                    help="A/B: RELPN.OVERLAP_TAIL = False (PPN and decode on the caller's stream, after the encoder)")
     ap.add_argument("--launch-check", action="store_true",
                     help="rehearse only the rank launch + rendezvous on the CPU (gloo), no GPU work")
     ap.add_argument("--stub-gpu", action="store_true",
@@ -477,7 +479,7 @@ class ScoringWorkload:
         cfg = tspn.load_cfg(None, **{"RELPN.USE_PPN": True, "RELPN.USE_DPN": True, "RELPN.DPN.IN_CHANNELS": self.C,
                                      "PREDICT.FEATURE_DIM": self.C, "RELPN.DPN.NUM_ANCHORS_PER_LOCATION": A_ANCH,
                                      "PREDICT.PREDICATE_NUM": K_PRED, "RELPN.PPN.NUM_PAIR_PROPOSALS": TOPK_PPN,
-                                     "RELPN.DPN.PAIR_GEOMETRY": True,
+                                     "RELPN.DPN.PAIR_GEOMETRY": True, "RELPN.OVERLAP_TAIL": not self.args.serial_tail,
                                      "RELPN.DPN.CONV_ALGO": "direct" if self.args.conv == "direct" else "auto"})
         model = tspn.BaseModel(cfg)
         model.load_state_dict({k: torch.from_numpy(v) for k, v in self.sd.items()})

@@ -373,6 +373,8 @@ typedef struct tspn_fused_bf16_desc {
   size_t workspace_bytes;
   void* ev_conv_begin;           /* optional hipEvent_t around the conv kernel, as in tspn_fused_desc */
   void* ev_conv_end;
+  void* ev_logits_ready;         /* optional, as in tspn_fused_desc: recorded as soon as out_logits is complete (the logits
+                                    are computed first) */
 } tspn_fused_bf16_desc;
 
 size_t tspn_forward_fused_bf16_workspace_bytes(const tspn_fused_bf16_desc* d);

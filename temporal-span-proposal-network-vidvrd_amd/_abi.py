@@ -58,7 +58,7 @@ class FusedBf16Desc(ctypes.Structure):
         ("cls_w", _vp), ("cls_b", _vp),
         ("out_heads", _vp), ("out_logits", _vp),
         ("workspace", _vp), ("workspace_bytes", _sz),
-        ("ev_conv_begin", _vp), ("ev_conv_end", _vp),
+        ("ev_conv_begin", _vp), ("ev_conv_end", _vp), ("ev_logits_ready", _vp),
     ]
 
 

@@ -50,6 +50,9 @@ _DEFAULTS = {
         "OBJECT_DIM": 1024,
         "USE_PPN": True,
         "USE_DPN": True,
+        # build extension: PPN and the top-k triplet decode run on a second HIP stream under the encoder of the same
+        # forward (they depend on the class / predicate logits only) and join the caller's stream before returning
+        "OVERLAP_TAIL": True,
         "PPN": {"NUM_PAIR_PROPOSALS": 256, "IN_CHANNELS": 35, "HIDDEN_CHANNELS": 64,
                 "OUT_CHANNELS": 35, "BATCH_SIZE_PER_SEGMENT": 256, "POSITIVE_FRACTION": 0.5},
         "DPN": {"NUM_DURATION_PROPOSALS": 64, "DPN_ONLY": False, "IN_CHANNELS": 1024,

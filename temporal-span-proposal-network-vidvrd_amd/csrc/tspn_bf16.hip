@@ -871,14 +871,17 @@ extern "C" int tspn_forward_fused_bf16(const tspn_fused_bf16_desc* d, void* stre
       hipMemcpyAsync(bias2, d->conv_bias, C * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
     return tspn::fail(TSPN_ELAUNCH, "tspn_forward_fused_bf16: bias staging failed");
   int rc;
+  // the predicate logits depend on the tracklet means only: computed FIRST (as in tspn_forward_fused_f32) so that a
+  // caller can decode / gather them on another stream behind ev_logits_ready while the encoder runs
+  if ((rc = tspn_temporal_mean_bf16(d->feats, NT, d->T, d->D, fbar, stream))) return rc;
+  if ((rc = tspn::pair_predicate(fbar, NT, d->D, d->pairs, P, d->cls_w, d->cls_b, d->K, d->out_logits, ws + L.lin,
+                                 L.lin_bytes, stream)))
+    return rc;
+  if (d->ev_logits_ready) (void)hipEventRecord(static_cast<hipEvent_t>(d->ev_logits_ready), s);
   if (d->ev_conv_begin) (void)hipEventRecord(static_cast<hipEvent_t>(d->ev_conv_begin), s);
   rc = tspn_conv3_tc_bf16(d->feats, NT, d->T, d->D, d->conv_packed, 2 * C, bias2, y, 2 * C, stream);
   if (d->ev_conv_end) (void)hipEventRecord(static_cast<hipEvent_t>(d->ev_conv_end), s);
   if (rc) return rc;
-  if ((rc = tspn_heads_pairgrid_bf16(y, 2 * C, d->B, d->N, C, d->T, d->head_packed, d->head_b, 3 * d->A,
-                                     d->out_heads, stream)))
-    return rc;
-  if ((rc = tspn_temporal_mean_bf16(d->feats, NT, d->T, d->D, fbar, stream))) return rc;
-  return tspn::pair_predicate(fbar, NT, d->D, d->pairs, P, d->cls_w, d->cls_b, d->K, d->out_logits,
-                              ws + L.lin, L.lin_bytes, stream);
+  return tspn_heads_pairgrid_bf16(y, 2 * C, d->B, d->N, C, d->T, d->head_packed, d->head_b, 3 * d->A, d->out_heads,
+                                  stream);
 }

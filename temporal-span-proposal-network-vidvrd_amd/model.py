@@ -565,6 +565,13 @@ class BaseModel(_CachedWeightsMixin, nn.Module):
         self._workspaces = {}        # (device index, stream) -> uint8 workspace of the fused pass, grown on demand
         self._pair_tables = {}       # (device, B, N) -> (batched canonical pair table [B*P,2], per-video table [B,P,2])
         self._conv_events = None     # optional (begin, end) torch.cuda.Event pair around the dominant kernel
+        # build extension: the small latency-bound kernels of a step (PPN; the top-k triplet decode of `decode`) run on
+        # a second HIP stream under the encoder of the same forward: PPN needs the class logits only, decode only the
+        # predicate logits, which the fused pass computes FIRST and signals with an event.  Both join the caller's
+        # stream before their results are handed out, so the caller sees ordinary stream semantics.
+        self.overlap_tail = bool(getattr(cfg.RELPN, "OVERLAP_TAIL", True))
+        self._side = {}              # device index -> (side stream, logits-ready event)
+        self._logits_token = None    # (device index, the last fused pass's batched logits tensor, caller stream)
         self.conv_algo = str(getattr(cfg.RELPN.DPN, "CONV_ALGO", "auto"))
         if self.conv_algo not in ("auto", "direct"):
             raise ValueError(f"RELPN.DPN.CONV_ALGO must be auto or direct (got {self.conv_algo})")
@@ -639,6 +646,17 @@ class BaseModel(_CachedWeightsMixin, nn.Module):
             self._pair_tables[key] = hit
         return hit
 
+    def _side_stream(self, dev):
+        hit = self._side.get(dev.index)
+        if hit is None:
+            ev = torch.cuda.Event()
+            with torch.cuda.device(dev):
+                side = torch.cuda.Stream(device=dev)
+                ev.record()                        # creates the HIP event handle the ABI hook re-records
+            hit = (side, ev)
+            self._side[dev.index] = hit
+        return hit
+
     def _forward_test(self, pair_list):
         with torch.no_grad():
             if self.use_dpn and len(pair_list) and all(self._is_tracklet_sample(p) for p in pair_list):
@@ -675,9 +693,20 @@ class BaseModel(_CachedWeightsMixin, nn.Module):
         hw, hb = dpn._head_weights(dev)
         cw, cb = self.classifier._cache.get("cls", (cls.weight, cls.bias), dev, lambda ts: ts)
 
+        main = torch.cuda.current_stream(dev)
+        overlap = self.overlap_tail and all(p.get_field("tracklet_feats").is_cuda for p in pair_list)
+        side, ev_logits = self._side_stream(dev) if overlap else (None, None)
         pair_proposals = None
         if self.use_ppn:
-            pair_proposals, _ = self.relpn.pair_proposal_network(pair_list)
+            if overlap and all(p.get_field("track_cls_logits").is_cuda for p in pair_list):
+                side.wait_stream(main)             # the class logits may have been produced on the caller's stream
+                with torch.cuda.stream(side):
+                    pair_proposals, _ = self.relpn.pair_proposal_network(pair_list)
+                    for t in pair_proposals:
+                        t.record_stream(main)      # allocated under the side stream, consumed on the caller's
+            else:
+                pair_proposals, _ = self.relpn.pair_proposal_network(pair_list)
+        self._logits_token = None
 
         n_seg = len(pair_list)
         durations, logits = [None] * n_seg, [None] * n_seg
@@ -716,7 +745,8 @@ class BaseModel(_CachedWeightsMixin, nn.Module):
                     lambda ts: tuple(ops.cast_bf16(x.contiguous()).float() for x in ts))
                 need = ops.fused_bf16_workspace_bytes(nm, n, t, d, hb16.numel() // 3, cw16.shape[0], allp.shape[0])
                 heads, lg = ops.forward_fused_bf16(feats, allp, nm, n, packed, cbias, hpk, hb16, cw16, cb16,
-                                                   workspace=self._workspace(dev, need), conv_events=self._conv_events)
+                                                   workspace=self._workspace(dev, need), conv_events=self._conv_events,
+                                                   logits_event=ev_logits if (overlap and len(groups) == 1) else None)
                 counts = [per] * nm
             else:
                 feats = _batch_rows(src, dev)
@@ -744,11 +774,16 @@ class BaseModel(_CachedWeightsMixin, nn.Module):
                 need = ops.fused_workspace_bytes(nm, n, t, d, hb.numel() // 3, cw.shape[0], allp.shape[0])
                 heads, lg = ops.forward_fused(feats, allp, nm, n, packed, cbias, hw, hb, cw, cb,
                                               workspace=self._workspace(dev, need), check_pairs=False,
-                                              canonical_pairs=canonical, conv_events=self._conv_events)
+                                              canonical_pairs=canonical, conv_events=self._conv_events,
+                                              logits_event=ev_logits if (overlap and len(groups) == 1) else None)
                 if self.pool_top_span and allp.shape[0]:
                     # RelOIPool over each pair's best span (decode + NMS, top-1) instead of the whole segment
                     top = ops.decode_spans(heads, self.anchor_sizes(t), top_k=1)["span"][:, 0].contiguous()
                     lg = ops.span_predicate(feats, allp, top, cw, cb)
+            if overlap and len(groups) == 1 and not (self.pool_top_span and not bf16):
+                # `decode` may start behind the logits-ready event of THIS pass (same logits tensor, same caller stream)
+                # (the token keeps `lg` alive: its address cannot be handed to another tensor while the token stands)
+                self._logits_token = (dev.index, lg, main.cuda_stream)
             geom = self._pair_geometry_batch(pair_list, members, allp, dev) if self.pair_geometry_in_forward else None
             # per-segment results are VIEWS of the batched outputs (copies only when a segment's inputs live on
             # another device, e.g. the host tensors predict.py hands over)
@@ -759,6 +794,8 @@ class BaseModel(_CachedWeightsMixin, nn.Module):
                 durations[i] = dpn._wrap(heads[sl].to(src_dev), None if geom is None else geom[sl].to(src_dev))
                 logits[i] = lg[sl].to(src_dev)
                 off += counts[k]
+        if side is not None and self.use_ppn:
+            main.wait_stream(side)                 # PPN's results are complete for whatever the caller does next
         return pair_proposals, durations, logits
 
     @staticmethod
@@ -799,8 +836,18 @@ class BaseModel(_CachedWeightsMixin, nn.Module):
             dev = _compute_device(*[rel_logits[i] for i in members])
             nm = len(members)
             lg = _batch_rows([rel_logits[i] for i in members], dev).view(nm, lshape[0], lshape[1])
+            # these are the logits of the last fused forward, still on the stream that produced them: decode on the
+            # side stream behind their ready-event, i.e. UNDER that forward's encoder, and join afterwards
+            main = torch.cuda.current_stream(dev)
             custom = [pair_list[i].has_field("tracklet_pairs") and pair_list[i].get_field("tracklet_pairs") is not None
                       for i in members]
+            side, tok = None, self._logits_token
+            if (self.overlap_tail and tok is not None and tok[0] == dev.index and tok[2] == main.cuda_stream
+                    and tok[1].data_ptr() == lg.data_ptr() and tok[1].numel() == lg.numel() and not quirk
+                    and not any(custom) and all(pair_list[i].get_field("track_cls_logits").is_cuda for i in members)):
+                side, ev_logits = self._side_stream(dev)
+                side.wait_event(ev_logits)
+                self._logits_token = None          # one decode per forward rides the event
             if not any(custom):
                 for i in members:
                     if n * (n - 1) != rel_logits[i].shape[0]:
@@ -834,8 +881,16 @@ class BaseModel(_CachedWeightsMixin, nn.Module):
             else:
                 cshape = tuple(pair_list[members[0]].get_field("track_cls_logits").shape)
                 cls = _batch_rows([pair_list[i].get_field("track_cls_logits") for i in members], dev).view((nm,) + cshape)
-                res = ops.decode_topk(lg, pairs, cls, row_mul=1, num_obj=num_obj,
-                                      topk_per_pair=topk_per_pair, topk_per_seg=topk_per_seg, check_pairs=not trusted)
+                if side is not None:
+                    with torch.cuda.stream(side):
+                        res = ops.decode_topk(lg, pairs, cls, row_mul=1, num_obj=num_obj, topk_per_pair=topk_per_pair,
+                                              topk_per_seg=topk_per_seg, check_pairs=not trusted)
+                        for r in res:
+                            r.record_stream(main)      # allocated under the side stream, consumed on the caller's
+                    main.wait_stream(side)             # the caller's stream sees complete results from here on
+                else:
+                    res = ops.decode_topk(lg, pairs, cls, row_mul=1, num_obj=num_obj, topk_per_pair=topk_per_pair,
+                                          topk_per_seg=topk_per_seg, check_pairs=not trusted)
             for k, i in enumerate(members):
                 tgt = rel_logits[i].device
                 out[i] = tuple(r[k].to(tgt) for r in res)

@@ -709,7 +709,7 @@ def fused_bf16_workspace_bytes(B, N, T, D, A, K, P):
 
 
 def forward_fused_bf16(feats, pairs, B, N, conv_packed, conv_bias, head_packed, head_b, cls_w, cls_b,
-                       workspace=None, conv_events=None):
+                       workspace=None, conv_events=None, logits_event=None):
     """Whole scoring pass, bf16 operands (tspn_forward_fused_bf16), canonical pair table only.
 
     feats bf16 [B*N,T,D]; conv_packed = pack_conv3_bf16(conv.weight, split=D); head_packed =
@@ -751,6 +751,8 @@ def forward_fused_bf16(feats, pairs, B, N, conv_packed, conv_bias, head_packed, 
     d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     if conv_events is not None:
         d.ev_conv_begin, d.ev_conv_end = conv_events[0].cuda_event, conv_events[1].cuda_event
+    if logits_event is not None:
+        d.ev_logits_ready = logits_event.cuda_event
     _abi.check(l.tspn_forward_fused_bf16(ctypes.byref(d), _stream()))
     return out_heads, out_logits
 

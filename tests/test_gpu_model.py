@@ -557,3 +557,50 @@ def test_forward_on_slices_of_one_batched_tensor_is_zero_copy_and_equal(tspn, de
     ref = oracle.forward_dense(t(vids[1]["tracklet_feats"]), t(vids[1]["tracklet_boxes"]), oracle.pair_index(N), w)
     np.testing.assert_allclose(lg[1].cpu().numpy(), ref["rel_logits"].numpy(), rtol=0, atol=1e-5)
     np.testing.assert_allclose(dp[1].duration.cpu().numpy(), ref["duration"].numpy(), rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_overlapped_tail_equals_serial(tspn, device, bf16):
+    """RELPN.OVERLAP_TAIL (default on): PPN and the top-k decode run on a second HIP stream under the encoder of the
+    same forward, behind the logits-ready event, and join the caller's stream -- results equal the single-stream
+    model bit for bit, over repeated steps on rotating inputs, also when the caller works on a non-default stream,
+    when decode is called twice, and when it is handed logits that did not come from the last forward."""
+    D, N, T, B = 32, 6, 30, 3
+    sd = tspn.synth.make_weights(6, c=2 * D, bias_std=0.05)
+    models = []
+    for ov in (True, False):
+        cfg = cases.baseline_cfg(**{"RELPN.USE_PPN": True, "RELPN.USE_DPN": True, "RELPN.DPN.IN_CHANNELS": 2 * D,
+                                    "PREDICT.FEATURE_DIM": 2 * D, "RELPN.OVERLAP_TAIL": ov})
+        m = tspn.BaseModel(cfg)
+        load(m, sd)
+        m.eval()
+        assert m.overlap_tail is ov
+        models.append(m)
+    st = torch.cuda.Stream(device=device)
+    for step in range(4):
+        vids = [tspn.synth.make_video(400 + 10 * step + b, N, T, D) for b in range(B)]
+        big = torch.cat([t(v["tracklet_feats"]) for v in vids]).to(device)
+        if bf16:
+            big = big.to(torch.bfloat16)
+        cls = torch.stack([8.0 * t(v["track_cls_logits"]) for v in vids]).to(device)
+        boxes = torch.cat([t(v["tracklet_boxes"]) for v in vids]).to(device)
+        plists = [tspn.PairList.from_tracklets(big[b * N:(b + 1) * N], boxes[b * N:(b + 1) * N], cls[b]) for b in range(B)]
+        torch.cuda.synchronize()
+        outs = []
+        for m in models:
+            ctx = torch.cuda.stream(st) if step % 2 else torch.cuda.stream(torch.cuda.current_stream(device))
+            with ctx:
+                pp, dp, lg = m(plists, None)
+                dec = m.decode(plists, lg)
+                dec2 = m.decode(plists, lg)                       # the event was consumed: plain path, same answer
+                other = m.decode(plists, [x.clone() for x in lg])  # not the forward's tensor: plain path
+            torch.cuda.synchronize()
+            outs.append((pp, dp, lg, dec))
+            for a, b in zip(dec, dec2):
+                assert all(torch.equal(x, y) for x, y in zip(a, b))
+            for a, b in zip(dec, other):
+                assert all(torch.equal(x, y) for x, y in zip(a, b))
+        (pp0, dp0, lg0, d0), (pp1, dp1, lg1, d1) = outs
+        for b in range(B):
+            assert torch.equal(pp0[b], pp1[b]) and torch.equal(lg0[b], lg1[b]) and torch.equal(dp0[b].heads, dp1[b].heads)
+            assert all(torch.equal(x, y) for x, y in zip(d0[b], d1[b]))
