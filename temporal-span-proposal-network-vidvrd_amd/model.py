@@ -696,10 +696,11 @@ class BaseModel(_CachedWeightsMixin, nn.Module):
         main = torch.cuda.current_stream(dev)
         overlap = self.overlap_tail and all(p.get_field("tracklet_feats").is_cuda for p in pair_list)
         side, ev_logits = self._side_stream(dev) if overlap else (None, None)
+        if side is not None:
+            side.wait_stream(main)                 # class logits / boxes may have been produced on the caller's stream
         pair_proposals = None
         if self.use_ppn:
             if overlap and all(p.get_field("track_cls_logits").is_cuda for p in pair_list):
-                side.wait_stream(main)             # the class logits may have been produced on the caller's stream
                 with torch.cuda.stream(side):
                     pair_proposals, _ = self.relpn.pair_proposal_network(pair_list)
                     for t in pair_proposals:
@@ -707,6 +708,7 @@ class BaseModel(_CachedWeightsMixin, nn.Module):
             else:
                 pair_proposals, _ = self.relpn.pair_proposal_network(pair_list)
         self._logits_token = None
+        join_side = False
 
         n_seg = len(pair_list)
         durations, logits = [None] * n_seg, [None] * n_seg
@@ -784,7 +786,19 @@ class BaseModel(_CachedWeightsMixin, nn.Module):
                 # `decode` may start behind the logits-ready event of THIS pass (same logits tensor, same caller stream)
                 # (the token keeps `lg` alive: its address cannot be handed to another tensor while the token stands)
                 self._logits_token = (dev.index, lg, main.cuda_stream)
-            geom = self._pair_geometry_batch(pair_list, members, allp, dev) if self.pair_geometry_in_forward else None
+            geom = None
+            if self.pair_geometry_in_forward:
+                boxes_on_dev = all(pair_list[i].has_field("tracklet_boxes") and isinstance(pair_list[i].get_field("tracklet_boxes"), torch.Tensor)
+                                   and pair_list[i].get_field("tracklet_boxes").is_cuda for i in members)
+                if side is not None and boxes_on_dev:
+                    # the bbox half of the pair builder needs the boxes only: second stream, under the encoder
+                    with torch.cuda.stream(side):
+                        geom = self._pair_geometry_batch(pair_list, members, allp, dev)
+                        if geom is not None:
+                            geom.record_stream(main)
+                    join_side = True
+                else:
+                    geom = self._pair_geometry_batch(pair_list, members, allp, dev)
             # per-segment results are VIEWS of the batched outputs (copies only when a segment's inputs live on
             # another device, e.g. the host tensors predict.py hands over)
             off = 0
@@ -794,8 +808,8 @@ class BaseModel(_CachedWeightsMixin, nn.Module):
                 durations[i] = dpn._wrap(heads[sl].to(src_dev), None if geom is None else geom[sl].to(src_dev))
                 logits[i] = lg[sl].to(src_dev)
                 off += counts[k]
-        if side is not None and self.use_ppn:
-            main.wait_stream(side)                 # PPN's results are complete for whatever the caller does next
+        if side is not None and (self.use_ppn or join_side):
+            main.wait_stream(side)                 # PPN / geometry are complete for whatever the caller does next
         return pair_proposals, durations, logits
 
     @staticmethod

@@ -604,3 +604,27 @@ def test_overlapped_tail_equals_serial(tspn, device, bf16):
         for b in range(B):
             assert torch.equal(pp0[b], pp1[b]) and torch.equal(lg0[b], lg1[b]) and torch.equal(dp0[b].heads, dp1[b].heads)
             assert all(torch.equal(x, y) for x, y in zip(d0[b], d1[b]))
+
+
+def test_overlapped_geometry_equals_serial(tspn, device):
+    """RELPN.DPN.PAIR_GEOMETRY with and without RELPN.OVERLAP_TAIL (geometry on the second stream), with and without PPN."""
+    D, N, T, B = 32, 5, 30, 2
+    sd = tspn.synth.make_weights(7, c=2 * D, bias_std=0.05)
+    vids = [tspn.synth.make_video(500 + b, N, T, D) for b in range(B)]
+    plists = [tspn.PairList.from_tracklets(t(v["tracklet_feats"]).to(device), t(v["tracklet_boxes"]).to(device),
+                                           t(v["track_cls_logits"]).to(device)) for v in vids]
+    for ppn in (True, False):
+        res = []
+        for ov in (True, False):
+            m = tspn.BaseModel(cases.baseline_cfg(**{"RELPN.USE_PPN": ppn, "RELPN.USE_DPN": True, "RELPN.DPN.IN_CHANNELS": 2 * D,
+                                                     "PREDICT.FEATURE_DIM": 2 * D, "RELPN.OVERLAP_TAIL": ov,
+                                                     "RELPN.DPN.PAIR_GEOMETRY": True}))
+            load(m, sd)
+            m.eval()
+            _, dp, lg = m(plists, None)
+            torch.cuda.synchronize()
+            res.append((dp, lg))
+        for b in range(B):
+            assert torch.equal(res[0][0][b].geom, res[1][0][b].geom) and torch.equal(res[0][1][b], res[1][1][b])
+            ref = oracle.pair_geometry(t(vids[b]["tracklet_boxes"]), oracle.pair_index(N))
+            np.testing.assert_allclose(res[0][0][b].geom.cpu().numpy(), ref.numpy(), rtol=2e-6, atol=2e-6)
