@@ -24,10 +24,10 @@ records = []
 orig = rh.ConvFrozenBN.forward
 
 
-def timed(self, x, residual=None, relu=False):
+def timed(self, x, residual=None, relu=False, stride=None):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
-    y = orig(self, x, residual=residual, relu=relu)
+    y = orig(self, x, residual=residual, relu=relu, stride=stride)
     b.record()
     records.append((tuple(x.shape), tuple(self.weight.shape), self.stride, residual is not None, a, b, y.numel(), x.dtype))
     return y
