@@ -10,8 +10,9 @@ configures it; 35 classes) — it owns no code for the step.  This module mirror
 `roi_heads.` prefix.  Every tensor operation runs in the hand-written HIP library (ops.roi_align_nhwc,
 ops.conv2d_nhwc: fp32 MFMA implicit GEMM, channels-last); there is no CPU path.
 
-Not built: the C4 backbone itself (stem, res2-res4 on full frames) — the caller hands over
-res4 maps, channels-last.
+`ResNetC4` (below) is the C4 backbone that produces the res4 maps from frames; both modules run fp32 or bf16
+(bf16 maps select the bf16 MFMA kernels: dedicated stem kernel, one fused launch per bottleneck tail) and alternate
+their chunks (frames / RoIs) between two HIP streams.
 """
 import torch
 import torch.nn as nn
@@ -147,6 +148,8 @@ class Res5RoIHead(_CachedWeightsMixin, nn.Module):
         self.res5 = nn.Sequential(*blocks)
         self.fuse_bottlenecks = True
         self.subsample_roi_align = True     # ROIAlign only the bins res5's strided first block reads (same results)
+        self.streams = 1                    # > 1: RoI chunks alternate between HIP streams (measured at cfg5: 105 -> 108 ms, so off)
+        self._side_streams = {}
         self.in_channels, self.out_channels = in_channels, out_channels
         self.pooler_resolution, self.spatial_scale, self.sampling_ratio = pooler_resolution, spatial_scale, sampling_ratio
         self.roi_chunk = int(roi_chunk)
@@ -173,13 +176,24 @@ class Res5RoIHead(_CachedWeightsMixin, nn.Module):
             idx = torch.arange(t, dtype=torch.float32, device=dev).repeat(n)
             rois = torch.cat([idx[:, None], boxes.reshape(n * t, 4)], dim=1).contiguous()
             feats = torch.empty((n * t, self.out_channels), dtype=torch.float32, device=dev)
-            for lo in range(0, n * t, self.roi_chunk):
-                # res5's first block reads its input only through 1x1 convs of stride s (stride_in_1x1: conv1 and the
-                # projection shortcut): ROIAlign produces just the bins (s i, s j) -- a quarter of the work and of
-                # the 14 x 14 x 1024 output for s = 2 -- and the two convs run with stride 1; same values, bit for bit
-                b0 = self.res5[0]
-                bs = b0.stride if (self.subsample_roi_align and b0.shortcut is not None and b0.conv1.kernel_size == 1
-                                   and b0.shortcut.kernel_size == 1 and b0.conv1.padding == 0) else 1
+            # RoI chunks alternate between `streams` HIP streams (as the backbone's frame chunks do): the memory-heavy
+            # parts of one chunk run under the MFMA-heavy parts of the other
+            nchunks = -(-(n * t) // self.roi_chunk)
+            ns = min(int(self.streams), nchunks) if fm.is_cuda else 1
+            main = torch.cuda.current_stream(dev)
+            side = None
+            if ns > 1:
+                side = self._side_streams.setdefault((dev.index, ns), [torch.cuda.Stream(device=dev) for _ in range(ns)])
+                for st in side:
+                    st.wait_stream(main)
+            # res5's first block reads its input only through 1x1 convs of stride s (stride_in_1x1: conv1 and the
+            # projection shortcut): ROIAlign produces just the bins (s i, s j) -- a quarter of the work and of the
+            # 14 x 14 x 1024 output for s = 2 -- and the two convs run with stride 1; same values, bit for bit
+            b0 = self.res5[0]
+            bs = b0.stride if (self.subsample_roi_align and b0.shortcut is not None and b0.conv1.kernel_size == 1
+                               and b0.shortcut.kernel_size == 1 and b0.conv1.padding == 0) else 1
+
+            def one_chunk(lo):
                 x = ops.roi_align_nhwc(fm, rois[lo:lo + self.roi_chunk].contiguous(), self.pooler_resolution,
                                        self.spatial_scale, self.sampling_ratio, aligned=True, out_bf16=bf16, bin_stride=bs)
                 x = b0(x, presampled=bs > 1)
@@ -190,6 +204,16 @@ class Res5RoIHead(_CachedWeightsMixin, nn.Module):
                     feats[lo:lo + r] = ops.temporal_mean_bf16(x.view(r, h * w, c))   # bf16-rounded means
                 else:
                     feats[lo:lo + r] = ops.temporal_mean(x.view(r, h * w, c), layout_tc=True)
+
+            for k, lo in enumerate(range(0, n * t, self.roi_chunk)):
+                if side is None:
+                    one_chunk(lo)
+                else:
+                    with torch.cuda.stream(side[k % ns]):
+                        one_chunk(lo)
+            if side is not None:
+                for st in side:
+                    main.wait_stream(st)
             src = tracklet_boxes.device if isinstance(tracklet_boxes, torch.Tensor) else torch.device("cpu")
             feats = feats.view(n, t, self.out_channels)
             return (ops.cast_bf16(feats) if bf16 else feats).to(src)
@@ -274,6 +298,11 @@ class ResNetC4(_CachedWeightsMixin, nn.Module):
         self.out_channels = cin
         self.frame_chunk = int(frame_chunk)
         self.fuse_bottlenecks = True     # bf16 maps: conv2 + conv3 + residual of every block in one launch
+        # frame chunks alternate between this many HIP streams: a launch's workgroups run in lockstep (all in their MFMA
+        # phase, then all in their memory phase), two chunks in flight put the memory phase of one under the MFMA phase
+        # of the other (tools/probe_tail_stagger.py: -10 % on the res4 tails; backbone -5 %)
+        self.streams = 2
+        self._side_streams = {}
 
     def forward(self, images, bf16=False):
         with torch.no_grad():
@@ -284,8 +313,23 @@ class ResNetC4(_CachedWeightsMixin, nn.Module):
                 if isinstance(m, BottleneckBlock):
                     m.fuse_tail = bool(self.fuse_bottlenecks)
             out = []
-            for lo in range(0, images.shape[0], self.frame_chunk):
-                x = self.stem(_f32(images[lo:lo + self.frame_chunk], dev), out_bf16=bf16)
-                x = self.res4(self.res3(self.res2(x)))
-                out.append(x)
-            return torch.cat(out)
+            nchunks = -(-images.shape[0] // self.frame_chunk)
+            ns = min(int(self.streams), nchunks) if images.is_cuda else 1
+            if ns <= 1:
+                for lo in range(0, images.shape[0], self.frame_chunk):
+                    x = self.stem(_f32(images[lo:lo + self.frame_chunk], dev), out_bf16=bf16)
+                    out.append(self.res4(self.res3(self.res2(x))))
+                return torch.cat(out)
+            main = torch.cuda.current_stream(dev)
+            side = self._side_streams.setdefault((dev.index, ns), [torch.cuda.Stream(device=dev) for _ in range(ns)])
+            imgs = _f32(images, dev)
+            for st in side:
+                st.wait_stream(main)
+            for k, lo in enumerate(range(0, images.shape[0], self.frame_chunk)):
+                with torch.cuda.stream(side[k % ns]):
+                    x = self.stem(imgs[lo:lo + self.frame_chunk], out_bf16=bf16)
+                    out.append(self.res4(self.res3(self.res2(x))))
+            for st in side:
+                main.wait_stream(st)
+            res = torch.cat(out)               # on the caller's stream, after both side streams
+            return res

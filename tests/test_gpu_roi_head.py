@@ -417,3 +417,32 @@ def test_roi_align_bin_stride_and_presampled_first_block(tspn, device):
         head.subsample_roi_align = False
         b = head(maps, boxes)
         assert torch.equal(a, b)
+
+
+def test_backbone_and_roi_head_on_two_streams_equal_one(tspn, device):
+    """ResNetC4.streams / Res5RoIHead.streams: chunks alternating between HIP streams give the same maps and features
+    as one stream, bit for bit, also when the caller itself works on a non-default stream."""
+    net, _ = _backbone_and_weights(tspn, device, 64, 256, (1, 1, 2))
+    net.frame_chunk = 2
+    img = t(tspn.hashrng.uniform(96, "img", (7, 64, 96, 3), -1, 1)).to(device)
+    head = tspn.Res5RoIHead(1024, 128, 512, roi_chunk=5).to(device)
+    boxes = t(tspn.hashrng.uniform(96, "bx", (3, 7, 2), 0, 30)).to(device)
+    boxes = torch.cat([boxes, boxes + 25], dim=2).contiguous()
+    outs = []
+    for ns, ctx in ((1, None), (2, None), (3, torch.cuda.Stream(device=device))):
+        net.streams, head.streams = ns, ns
+        if ctx is None:
+            m = net(img, bf16=True)
+            f = head(m, boxes)
+        else:
+            ctx.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(ctx):
+                m = net(img, bf16=True)
+                f = head(m, boxes)
+        torch.cuda.synchronize()
+        outs.append((m, f))
+    for m, f in outs[1:]:
+        assert torch.equal(m, outs[0][0]) and torch.equal(f, outs[0][1])
+    m32 = net(img, bf16=False)                       # fp32 path through the stream-alternating loop as well
+    net.streams = 1
+    assert torch.equal(m32, net(img, bf16=False))
