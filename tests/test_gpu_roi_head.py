@@ -446,3 +446,33 @@ def test_backbone_and_roi_head_on_two_streams_equal_one(tspn, device):
     m32 = net(img, bf16=False)                       # fp32 path through the stream-alternating loop as well
     net.streams = 1
     assert torch.equal(m32, net(img, bf16=False))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_bottleneck_tail_and_stem_random_shapes(tspn, device, seed):
+    """Shape fuzz of the two round-3 backbone kernels (hash-RNG shapes): the fused tail against the two conv launches
+    it replaces (bit-identical) on odd maps -- single rows / columns, tiles that straddle images --, the stem against
+    the bf16 restatement on odd image sizes."""
+    r = lambda tag, lo, hi: int(tspn.hashrng.integers(700 + seed, tag, (1,), lo, hi)[0])   # noqa: E731
+    CM = (64, 128, 256)[r("cm", 0, 3)]
+    NB, H, W = r("nb", 1, 5), r("h", 1, 24), r("w", 1, 40)
+    h1 = t(tspn.hashrng.uniform(700 + seed, "h1", (NB, H, W, CM), 0, 1)).to(device).to(torch.bfloat16)
+    res = t(tspn.hashrng.uniform(700 + seed, "res", (NB, H, W, 4 * CM), -1, 1)).to(device).to(torch.bfloat16)
+    w2 = t(tspn.hashrng.normal(700 + seed, "w2", (CM, CM, 3, 3), std=float(np.sqrt(2.0 / (9 * CM))))).to(device)
+    w3 = t(tspn.hashrng.normal(700 + seed, "w3", (4 * CM, CM, 1, 1), std=float(np.sqrt(2.0 / CM)))).to(device)
+    b2 = t(tspn.hashrng.normal(700 + seed, "b2", (CM,), std=0.1)).to(device)
+    b3 = t(tspn.hashrng.normal(700 + seed, "b3", (4 * CM,), std=0.1)).to(device)
+    f2, f3 = tspn.ops.pack_conv2d_frag_bf16(w2), tspn.ops.pack_conv2d_frag_bf16(w3)
+    h2 = tspn.ops.conv2d_nhwc_bf16(h1, f2, (3, 3), 1, 1, bias=b2, relu=True)
+    want = tspn.ops.conv2d_nhwc_bf16(h2, f3, (1, 1), 1, 0, bias=b3, residual=res, relu=True)
+    got = tspn.ops.bottleneck_tail_bf16(h1, f2, b2, f3, b3, res)
+    assert torch.equal(got, want), (CM, NB, H, W)
+    IH, IW, Cout = r("ih", 1, 70), r("iw", 1, 300), (32, 64)[r("co", 0, 2)]
+    x = tspn.hashrng.uniform(700 + seed, "x", (NB, IH, IW, 3), -2, 2)
+    w = tspn.hashrng.normal(700 + seed, "w", (Cout, 3, 7, 7), std=0.1)
+    b = tspn.hashrng.normal(700 + seed, "b", (Cout,), std=0.1)
+    ref = ro.conv2d_bf16(t(x).permute(0, 3, 1, 2), t(w), t(b), stride=2, padding=3, relu=True).permute(0, 2, 3, 1)
+    y = tspn.ops.stem_conv_bf16(t(x).to(device), tspn.ops.pack_stem_bf16(t(w).to(device)), t(b).to(device))
+    assert tuple(y.shape) == tuple(ref.shape), (IH, IW, Cout)
+    err = (y.cpu().double() - ref).abs()
+    assert float(err.max()) <= 2.0 ** -8 * max(float(ref.abs().max()), 1e-3), (IH, IW, Cout, float(err.max()))
