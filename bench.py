@@ -288,6 +288,20 @@ def pmc_traffic(workload, videos, conv):
         return {"traffic": None}
 
 
+def backbone_traffic(frames, h, w):
+    """Fabric bytes of the backbone per video from the committed PMC passes of tools/bench_backbone.py
+    (tools/pmc_backbone.py: bytes per 720p frame summed over all backbone launches) x the frames of the video."""
+    if (h, w) != (720, 1280):
+        return {"traffic": None}
+    try:
+        ms = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["sets"]["cfg5:1"]
+        return {"traffic": ms["backbone_bytes_per_frame"] * frames,
+                "traffic_unit": "bytes per video's backbone call (sum over its launches of 2*FETCH_SIZE + WRITE_SIZE, "
+                                "measured per 720p frame x frames)", "traffic_source": ms["source"]}
+    except (OSError, KeyError, ValueError, TypeError):
+        return {"traffic": None}
+
+
 class ClockSampler:
     """Shader clock (MHz) of the device while the timed steps run, read from the amdgpu hwmon node
     (`freq1_input`, Hz) by a background thread every few ms.  None when the node is not readable."""
@@ -751,7 +765,7 @@ class Cfg5Workload:
                          "kernel": "ResNet-101-C4 backbone, all convolutions of one video (bf16 32x32x16 MFMA implicit GEMMs: "
                                    "bottleneck_bf16_kernel / conv2d_nhwc_bf16_kernel / stem_conv_bf16_kernel)",
                          "achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_BF16_MFMA_TFLOPS, **backbone_traffic(self.T, self.H, self.W),
                          "flop_per_launch": flop, "avg_launch_ms": bb_ms,
                          "flop_note": "algorithmic conv FLOP of the backbone per video (251 GFLOP per 720p frame; halo "
                                       "recomputation and channel padding executed but not counted) / HIP-event time of the "
