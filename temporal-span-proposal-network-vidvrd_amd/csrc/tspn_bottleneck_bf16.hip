@@ -292,13 +292,27 @@ __global__ __launch_bounds__(THREADS, (CM == 256 ? 2 : 3)) void bottleneck_bf16_
         ar[k % RING][ms] = *reinterpret_cast<const f32x4*>(kn < KSTEPS ? a_ptr(sp, kn, ms) : a_ptr(sp + 1, kn - KSTEPS, ms));
     }
   };
-  // epilogue group g of sub-pass sp held in `c`: (ms, s, nj) = 8 consecutive channels x 32 pixels after the swaps
+  // epilogue group g of sub-pass sp held in `c`: (ms, nj, s2) = 8 consecutive channels x 32 pixels after the swaps.
+  // s2 runs fastest: the two 32-byte pieces of a pixel's 64-byte sector are stored one group apart, not NS groups --
+  // L2 hands half-written sectors to the fabric as whole 64-byte writes quickly (WRITE_SIZE of a res4 launch of 8
+  // frames: 101 MB with nj fastest, 74 MB like this, 59 MB of output; tools/probe_store_order.sh)
   bf16x8 rres[3];                                    // residual rows in flight (three groups ahead)
-  auto res_ptr = [&](int sp, int g) {
-    const int ms = g / (2 * NS), s2 = (g / NS) & 1, nj = g % NS;
-    const int64_t n = n0 + (sub_nb(sp) + nj) * 32 + li;
-    const int ch0 = 32 * (sub_rb(sp) + ms) + 16 * s2 + 8 * kh;
-    return (n < npix ? n : 0) * C4 + ch0;            // clamped: the value is dropped for pixels beyond the end
+  // addresses of the residual / output rows = a wave-uniform base (scalar registers: tile, pixel block, channel
+  // block) + a 32-bit lane offset (pixel li of the block, channels 8 kh ..): no 64-bit per-lane arithmetic in the loop.
+  // Pixels beyond the end read pixel 0 of their block (block 0 of the tensor when the whole block is beyond the end)
+  // and are not stored.
+  unsigned okmask = 0;                               // bit b: pixel li of pixel block b of this tile exists
+#pragma unroll
+  for (int b = 0; b < 4; ++b) okmask |= (n0 + b * 32 + li < npix ? 1u : 0u) << b;
+  const unsigned voff_in = (unsigned)(li * C4 + 8 * kh) * 2, voff_out = (unsigned)(8 * kh) * 2;
+  auto row_base = [&](int sp, int g) {               // uniform element offset of group g's rows
+    const int ms = g / (2 * NS), s2 = g & 1, nj = (g >> 1) % NS;
+    const int64_t pb = n0 + (sub_nb(sp) + nj) * 32;
+    return (pb < npix ? pb : 0) * C4 + 32 * (sub_rb(sp) + ms) + 16 * s2;
+  };
+  auto lane_off = [&](int sp, int g) {
+    const int nj = (g >> 1) % NS;
+    return ((okmask >> (sub_nb(sp) + nj)) & 1u) ? voff_in : voff_out;
   };
   auto res_issue = [&](int sp, auto g_tag) {
     constexpr int g = decltype(g_tag)::value;
@@ -307,12 +321,12 @@ __global__ __launch_bounds__(THREADS, (CM == 256 ? 2 : 3)) void bottleneck_bf16_
 #pragma unroll
     for (int j = 0; j < 8; ++j) rres[g % 3][j] = (__bf16)0.f;
 #else
-    rres[g % 3] = *reinterpret_cast<const bf16x8*>(residual + res_ptr(sp, g));
+    rres[g % 3] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(residual + row_base(sp, g)) + lane_off(sp, g));
 #endif
   };
   auto group_finish = [&](f32x16 (&c)[MS][NS], int sp, auto g_tag) {
     constexpr int g = decltype(g_tag)::value;
-    constexpr int ms = g / (2 * NS), s2 = (g / NS) & 1, nj = g % NS;
+    constexpr int ms = g / (2 * NS), s2 = g & 1, nj = (g >> 1) % NS;
     const int chm = 32 * (sub_rb(sp) + ms) + 16 * s2 + 4 * kh;   // bias in the MFMA layout, before the swaps
     const float4 bv0 = *reinterpret_cast<const float4*>(bias3 + chm);
     const float4 bv1 = *reinterpret_cast<const float4*>(bias3 + chm + 8);
@@ -322,16 +336,16 @@ __global__ __launch_bounds__(THREADS, (CM == 256 ? 2 : 3)) void bottleneck_bf16_
                    c[ms][nj][8 * s2 + 7] + bv1.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) swap32(lo[e], hi[e]);
-    const int64_t n = n0 + (sub_nb(sp) + nj) * 32 + li;
+    const bool okp = (okmask >> (sub_nb(sp) + nj)) & 1u;
     const bf16x8 rv = rres[g % 3];
     const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     bf16x8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = (__bf16)fmaxf(v[j] + (float)rv[j], 0.f);
 #if defined(TSPN_BT_ABL_NOSTORE)    // probe build: results are computed but (almost) never stored
-    if (n < npix && o[0] == (__bf16)12345.f) *reinterpret_cast<bf16x8*>(out + n * C4 + 32 * (sub_rb(sp) + ms) + 16 * s2 + 8 * kh) = o;
+    if (okp && o[0] == (__bf16)12345.f) *reinterpret_cast<bf16x8*>(reinterpret_cast<char*>(out + row_base(sp, g)) + voff_in) = o;
 #else
-    if (n < npix) *reinterpret_cast<bf16x8*>(out + n * C4 + 32 * (sub_rb(sp) + ms) + 16 * s2 + 8 * kh) = o;
+    if (okp) *reinterpret_cast<bf16x8*>(reinterpret_cast<char*>(out + row_base(sp, g)) + voff_in) = o;
 #endif
   };
   auto zero = [&](f32x16 (&c)[MS][NS]) {
