@@ -16,10 +16,13 @@
 //   phase 3  the 1x1 expand (M = 4 CM rows, K = CM) as eight sub-passes per wave on two alternating accumulator
 //            sets: B fragments from the h2 image in LDS (conflict-free 16-byte reads), W3 fragments from L2 as one
 //            continuous stream through a 4-deep register ring; the epilogue of sub-pass i is fed into the MFMA
-//            gaps of sub-pass i + 1, one group per two k-steps, residual rows requested three groups ahead;
-//   epilogue v_permlane32_swap pairs turn the MFMA layout (4 consecutive channels per lane and half-wave) into 8
-//            consecutive channels per lane, so the residual read, ReLU, the single rounding and the store are
-//            16 bytes per lane with no LDS transpose (CDNA4 guide, T21).
+//            gaps of sub-pass i + 1, half a group per two k-steps, residual rows requested two groups ahead;
+//   epilogue the lanes fetch the W3 fragments with their ROWS PERMUTED inside each 32-row block, so that the MFMA
+//            layout (registers 4 q + j = rows 8 q + 4 half + j) becomes 16 consecutive channels per lane: residual
+//            read, ReLU, the single rounding and the store are 32 contiguous bytes per lane with no LDS transpose
+//            and no cross-lane movement, and the two 32-row blocks of a 128-byte line are finished back to back --
+//            a launch writes exactly its output (WRITE_SIZE 59.9 MB for 59.0 MB at res4; 101 MB before, when L2
+//            handed part-written lines to the fabric).
 // Same contraction order and the same rounding points as conv2d_nhwc_bf16 applied twice: bit-identical results
 // (tests/test_gpu_roi_head.py).  Two workgroups per CU (67.6 KB of LDS at CM = 256): while one is in its
 // memory-heavy epilogue the other runs MFMAs.
@@ -55,14 +58,6 @@ template <int VM>
 __device__ __forceinline__ void wait_w(f32x4& r0, f32x4& r1) {
   asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r0), "+v"(r1) : "n"(VM));
 }
-__device__ __forceinline__ void swap32(float& a, float& b) {
-  // v_permlane32_swap_b32 vdst, src: lanes 32-63 of `a` <-> lanes 0-31 of `b`.  Inline asm, not
-  // __builtin_amdgcn_permlane32_swap: hipcc 7.2 dropped the builtin's SECOND result here (it reused the first for both
-  // halves: channels 4-7 / 12-15 of every 16 came out wrong; tools/probes/permlane32_swap_probe.hip shows the
-  // instruction itself is fine).  The two v_nop are the VALU-write -> permlane-read wait states (CDNA4 guide, T21).
-  asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-}
-
 template <int CM>
 __global__ __launch_bounds__(THREADS, (CM == 256 ? 2 : 3)) void bottleneck_bf16_kernel(
     const __bf16* __restrict__ h1, const __bf16* __restrict__ Wf2, const float* __restrict__ bias2,
@@ -246,8 +241,8 @@ __global__ __launch_bounds__(THREADS, (CM == 256 ? 2 : 3)) void bottleneck_bf16_
   // ---------------------------------------------------------------- phase 3: 1x1 expand, K = CM, software-pipelined
   // Eight sub-passes per wave, each a [32 MS rows x 32 NS pixels] accumulator set (half of what the wave owns in a pass
   // of CM rows); two sets alternate: while the MFMAs of sub-pass i + 1 run, the epilogue of sub-pass i -- bias,
-  // half-wave swaps, residual, ReLU, rounding, 16-byte stores -- is fed into the gaps one group per two k-steps,
-  // its residual loads issued three groups ahead.  The W3 fragments are one continuous stream through a 4-deep
+  // residual, ReLU, rounding, 16-byte stores -- is fed into the gaps half a group per two k-steps,
+  // its residual rows requested two groups ahead.  The W3 fragments are one continuous stream through a 4-deep
   // register ring that runs across sub-pass boundaries.
   constexpr int KSTEPS = CM / 16;
   constexpr int MS = CM >= 128 ? 2 : 1;            // row blocks per sub-pass
@@ -260,7 +255,13 @@ __global__ __launch_bounds__(THREADS, (CM == 256 ? 2 : 3)) void bottleneck_bf16_
   // sub-pass sp = 2 pass + part: rows (wm 4 + pass) MI + mi0 .., pixel blocks wn NI + ni0 ..
   auto sub_rb = [&](int sp) { return (wm * 4 + (sp >> 1)) * MI + (NS < NI ? 0 : (sp & 1) * MS); };
   auto sub_nb = [&](int sp) { return wn * NI + (NS < NI ? (sp & 1) * NS : 0); };
-  const char* const w3base = reinterpret_cast<const char*>(Wf3) + woff;
+  // W3 rows are permuted AT LOAD TIME: the lane that feeds MFMA row r = 8 q + 4 h + j of a 32-row block fetches the
+  // fragment slot of channel 16 h + 4 q + j (same 1-KiB fragment line, lanes permuted).  An accumulator lane (pixel
+  // li, half kh) holds rows 8 q + 4 kh + j in registers 4 q + j -- with the permutation these are the 16 CONSECUTIVE
+  // channels 16 kh + 0..15 of the block: 32 contiguous bytes per lane, 64 per pixel and lane pair, with no cross-lane
+  // movement at all (round 3 first used v_permlane32_swap pairs for 8 consecutive channels per lane)
+  const unsigned woff3 = (unsigned)((kh << 5) | (((li >> 2) & 1) << 4) | ((li >> 3) << 2) | (li & 3)) * 16;
+  const char* const w3base = reinterpret_cast<const char*>(Wf3) + woff3;
   auto a_ptr = [&](int sp, int k, int ms) {         // fragment of k-step k, row block ms of sub-pass sp
     return w3base + (int64_t)(sub_rb(sp) + ms) * (CCH * 4096) + k * 1024;
   };
@@ -292,61 +293,70 @@ __global__ __launch_bounds__(THREADS, (CM == 256 ? 2 : 3)) void bottleneck_bf16_
         ar[k % RING][ms] = *reinterpret_cast<const f32x4*>(kn < KSTEPS ? a_ptr(sp, kn, ms) : a_ptr(sp + 1, kn - KSTEPS, ms));
     }
   };
-  // epilogue group g of sub-pass sp held in `c`: (ms, nj, s2) = 8 consecutive channels x 32 pixels after the swaps.
-  // s2 runs fastest: the two 32-byte pieces of a pixel's 64-byte sector are stored one group apart, not NS groups --
-  // L2 hands half-written sectors to the fabric as whole 64-byte writes quickly (WRITE_SIZE of a res4 launch of 8
-  // frames: 101 MB with nj fastest, 74 MB like this, 59 MB of output; tools/probe_store_order.sh)
-  bf16x8 rres[3];                                    // residual rows in flight (three groups ahead)
-  // addresses of the residual / output rows = a wave-uniform base (scalar registers: tile, pixel block, channel
-  // block) + a 32-bit lane offset (pixel li of the block, channels 8 kh ..): no 64-bit per-lane arithmetic in the loop.
-  // Pixels beyond the end read pixel 0 of their block (block 0 of the tensor when the whole block is beyond the end)
-  // and are not stored.
+  // epilogue: group grp = (nj, ms), ms fastest = one 32-row x 32-pixel accumulator block = 16 consecutive channels
+  // per lane; it is finished in two halves (registers 8 h .. 8 h + 7 = channels 16 kh + 8 h ..), one per two
+  // k-steps, and both 16-byte stores are issued TOGETHER after the second half: the lane pair of a pixel writes a
+  // whole 64-byte sector in back-to-back instructions, and the other half of the 128-byte line (ms + 1) follows one
+  // group later.  L2 hands part-written lines to the fabric quickly, each time as whole sectors: WRITE_SIZE of a
+  // res4 launch of 8 frames (59.0 MB of output) was 101 MB with 32-byte pieces two epilogue steps apart, 76 MB one
+  // step apart, 75 MB with whole sectors but the halves of a line two groups apart, 59.9 MB like this
+  // (tools/probe_store_order.sh).  The residual is read the same way, 32 contiguous bytes per lane, two groups ahead.
+  constexpr int NGRP = MS * NS;
+  static_assert(G == 2 * NGRP, "two epilogue halves per group");
+  bf16x8 rres[2][2];                                 // residual rows of two groups in flight: [grp % 2][half]
+  bf16x8 ohold;                                      // first half of the group being finished
+  // addresses of the residual / output rows = a wave-uniform base (tile, pixel block, channel block) + a 32-bit lane
+  // offset (pixel li of the block, channels 16 kh ..).  Pixels beyond the end read pixel 0 of their block (block 0 of
+  // the tensor when the whole block is beyond the end) and are not stored.
   unsigned okmask = 0;                               // bit b: pixel li of pixel block b of this tile exists
 #pragma unroll
   for (int b = 0; b < 4; ++b) okmask |= (n0 + b * 32 + li < npix ? 1u : 0u) << b;
-  const unsigned voff_in = (unsigned)(li * C4 + 8 * kh) * 2, voff_out = (unsigned)(8 * kh) * 2;
-  auto row_base = [&](int sp, int g) {               // uniform element offset of group g's rows
-    const int ms = g / (2 * NS), s2 = g & 1, nj = (g >> 1) % NS;
+  const unsigned voff_in = (unsigned)(li * C4 + 16 * kh) * 2, voff_out = (unsigned)(16 * kh) * 2;
+  auto row_base = [&](int sp, int grp) {             // uniform element offset of the group's rows
+    const int ms = grp % MS, nj = grp / MS;
     const int64_t pb = n0 + (sub_nb(sp) + nj) * 32;
-    return (pb < npix ? pb : 0) * C4 + 32 * (sub_rb(sp) + ms) + 16 * s2;
+    return (pb < npix ? pb : 0) * C4 + 32 * (sub_rb(sp) + ms);
   };
-  auto lane_off = [&](int sp, int g) {
-    const int nj = (g >> 1) % NS;
-    return ((okmask >> (sub_nb(sp) + nj)) & 1u) ? voff_in : voff_out;
-  };
-  auto res_issue = [&](int sp, auto g_tag) {
-    constexpr int g = decltype(g_tag)::value;
+  auto res_issue = [&](int sp, auto grp_tag) {
+    constexpr int grp = decltype(grp_tag)::value;
 #if defined(TSPN_BT_ABL_NORES)      // probe build: no residual traffic
     (void)sp;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) rres[g % 3][j] = (__bf16)0.f;
+    for (int j = 0; j < 8; ++j) rres[grp % 2][0][j] = rres[grp % 2][1][j] = (__bf16)0.f;
 #else
-    rres[g % 3] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(residual + row_base(sp, g)) + lane_off(sp, g));
+    const bool okp = (okmask >> (sub_nb(sp) + grp / MS)) & 1u;
+    const char* rp = reinterpret_cast<const char*>(residual + row_base(sp, grp)) + (okp ? voff_in : voff_out);
+    rres[grp % 2][0] = *reinterpret_cast<const bf16x8*>(rp);
+    rres[grp % 2][1] = *reinterpret_cast<const bf16x8*>(rp + 16);
 #endif
   };
   auto group_finish = [&](f32x16 (&c)[MS][NS], int sp, auto g_tag) {
     constexpr int g = decltype(g_tag)::value;
-    constexpr int ms = g / (2 * NS), s2 = g & 1, nj = (g >> 1) % NS;
-    const int chm = 32 * (sub_rb(sp) + ms) + 16 * s2 + 4 * kh;   // bias in the MFMA layout, before the swaps
+    constexpr int grp = g >> 1, h = g & 1, ms = grp % MS, nj = grp / MS;
+    const int chm = 32 * (sub_rb(sp) + ms) + 16 * kh + 8 * h;
     const float4 bv0 = *reinterpret_cast<const float4*>(bias3 + chm);
-    const float4 bv1 = *reinterpret_cast<const float4*>(bias3 + chm + 8);
-    float lo[4] = {c[ms][nj][8 * s2] + bv0.x, c[ms][nj][8 * s2 + 1] + bv0.y, c[ms][nj][8 * s2 + 2] + bv0.z,
-                   c[ms][nj][8 * s2 + 3] + bv0.w};
-    float hi[4] = {c[ms][nj][8 * s2 + 4] + bv1.x, c[ms][nj][8 * s2 + 5] + bv1.y, c[ms][nj][8 * s2 + 6] + bv1.z,
-                   c[ms][nj][8 * s2 + 7] + bv1.w};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) swap32(lo[e], hi[e]);
-    const bool okp = (okmask >> (sub_nb(sp) + nj)) & 1u;
-    const bf16x8 rv = rres[g % 3];
-    const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    const float4 bv1 = *reinterpret_cast<const float4*>(bias3 + chm + 4);
+    const float v[8] = {c[ms][nj][8 * h] + bv0.x,     c[ms][nj][8 * h + 1] + bv0.y, c[ms][nj][8 * h + 2] + bv0.z,
+                        c[ms][nj][8 * h + 3] + bv0.w, c[ms][nj][8 * h + 4] + bv1.x, c[ms][nj][8 * h + 5] + bv1.y,
+                        c[ms][nj][8 * h + 6] + bv1.z, c[ms][nj][8 * h + 7] + bv1.w};
+    const bf16x8 rv = rres[grp % 2][h];
     bf16x8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = (__bf16)fmaxf(v[j] + (float)rv[j], 0.f);
+    if constexpr (h == 0) {
+      ohold = o;
+    } else {
+      const bool okp = (okmask >> (sub_nb(sp) + nj)) & 1u;
+      char* op = reinterpret_cast<char*>(out + row_base(sp, grp)) + voff_in;
 #if defined(TSPN_BT_ABL_NOSTORE)    // probe build: results are computed but (almost) never stored
-    if (okp && o[0] == (__bf16)12345.f) *reinterpret_cast<bf16x8*>(reinterpret_cast<char*>(out + row_base(sp, g)) + voff_in) = o;
+      if (okp && o[0] == (__bf16)12345.f) {
 #else
-    if (okp) *reinterpret_cast<bf16x8*>(reinterpret_cast<char*>(out + row_base(sp, g)) + voff_in) = o;
+      if (okp) {
 #endif
+        *reinterpret_cast<bf16x8*>(op) = ohold;
+        *reinterpret_cast<bf16x8*>(op + 16) = o;
+      }
+    }
   };
   auto zero = [&](f32x16 (&c)[MS][NS]) {
 #pragma unroll
@@ -356,15 +366,14 @@ __global__ __launch_bounds__(THREADS, (CM == 256 ? 2 : 3)) void bottleneck_bf16_
 #pragma unroll
         for (int e = 0; e < 16; ++e) c[ms][nj][e] = 0.f;
   };
-  // sub-pass sp into `cur` while the epilogue of sub-pass sp - 1 (in `prev`) drains: group g is finished after k-step
-  // 2 g + 1, its residual row was requested three groups earlier
+  // sub-pass sp into `cur` while the epilogue of sub-pass sp - 1 (in `prev`) drains: half g is finished after k-step
+  // 2 g + 1; the residual rows of a group are requested when the group two before it has been stored
   auto subpass = [&](f32x16 (&cur)[MS][NS], f32x16 (&prev)[MS][NS], int sp, auto drain_tag) {
     constexpr bool DRAIN = decltype(drain_tag)::value;
     zero(cur);
     if constexpr (DRAIN) {
       res_issue(sp - 1, std::integral_constant<int, 0>{});
-      if constexpr (G > 1) res_issue(sp - 1, std::integral_constant<int, 1>{});
-      if constexpr (G > 2) res_issue(sp - 1, std::integral_constant<int, 2>{});
+      if constexpr (NGRP > 1) res_issue(sp - 1, std::integral_constant<int, 1>{});
     }
     auto two = [&](auto g_tag) {
       constexpr int g = decltype(g_tag)::value;
@@ -373,12 +382,12 @@ __global__ __launch_bounds__(THREADS, (CM == 256 ? 2 : 3)) void bottleneck_bf16_
       kstep(cur, sp, std::integral_constant<int, 2 * g + 1>{});
       if constexpr (DRAIN) {
         group_finish(prev, sp - 1, g_tag);
-        if constexpr (g + 3 < G) res_issue(sp - 1, std::integral_constant<int, g + 3>{});
+        if constexpr ((g & 1) && (g >> 1) + 2 < NGRP) res_issue(sp - 1, std::integral_constant<int, (g >> 1) + 2>{});
       }
       __builtin_amdgcn_sched_barrier(0);
     };
     two(std::integral_constant<int, 0>{});
-    if constexpr (G > 1) two(std::integral_constant<int, 1>{});
+    two(std::integral_constant<int, 1>{});
     if constexpr (G > 2) { two(std::integral_constant<int, 2>{}); two(std::integral_constant<int, 3>{}); }
     if constexpr (G > 4) {
       two(std::integral_constant<int, 4>{}); two(std::integral_constant<int, 5>{});
@@ -395,15 +404,14 @@ __global__ __launch_bounds__(THREADS, (CM == 256 ? 2 : 3)) void bottleneck_bf16_
   {
     constexpr int sp = NSUB - 1;
     res_issue(sp, std::integral_constant<int, 0>{});
-    if constexpr (G > 1) res_issue(sp, std::integral_constant<int, 1>{});
-    if constexpr (G > 2) res_issue(sp, std::integral_constant<int, 2>{});
+    if constexpr (NGRP > 1) res_issue(sp, std::integral_constant<int, 1>{});
     auto fin = [&](auto g_tag) {
       constexpr int g = decltype(g_tag)::value;
       group_finish(accB, sp, g_tag);
-      if constexpr (g + 3 < G) res_issue(sp, std::integral_constant<int, g + 3>{});
+      if constexpr ((g & 1) && (g >> 1) + 2 < NGRP) res_issue(sp, std::integral_constant<int, (g >> 1) + 2>{});
     };
     fin(std::integral_constant<int, 0>{});
-    if constexpr (G > 1) fin(std::integral_constant<int, 1>{});
+    fin(std::integral_constant<int, 1>{});
     if constexpr (G > 2) { fin(std::integral_constant<int, 2>{}); fin(std::integral_constant<int, 3>{}); }
     if constexpr (G > 4) {
       fin(std::integral_constant<int, 4>{}); fin(std::integral_constant<int, 5>{});
