@@ -492,13 +492,18 @@ int tspn_bottleneck_tail_bf16(const uint16_t* h1, int64_t NB, int64_t H, int64_t
  * accumulation, relu(acc + bias) rounded to bf16 once.  x fp32 [NB,H,W,3] -> out bf16 [NB,OH,OW,Cout],
  * OH = (H - 1) / 2 + 1.  Cout = 32 or 64.  `frag` = tspn_pack_stem_bf16(w fp32 [Cout,3,7,7]) (Cout * 256 bf16);
  * `workspace` (tspn_stem_bf16_workspace_bytes) holds the 2x2 space-to-depth image the conv kernel streams.
- * tspn_max_pool_nhwc_bf16: max_pool2d(k, stride, pad) on a bf16 channels-last map (C % 8 == 0). */
+ * tspn_max_pool_nhwc_bf16: max_pool2d(k, stride, pad) on a bf16 channels-last map (C % 8 == 0).
+ * tspn_stem_pool_bf16: BasicStem.forward whole (conv + FrozenBN + ReLU, then max_pool2d(3, 2, 1)) in one conv
+ * launch: out bf16 [NB,PH,PW,Cout], PH = (OH - 1) / 2 + 1; bit-identical to tspn_max_pool_nhwc_bf16(3, 2, 1) of
+ * tspn_stem_conv_bf16, whose map it never writes.  Same operands and workspace as tspn_stem_conv_bf16. */
 size_t tspn_stem_bf16_workspace_bytes(int64_t NB, int64_t H, int64_t W);
 int tspn_pack_stem_bf16(const float* w, int64_t Cout, uint16_t* frag, void* stream);
 int tspn_stem_conv_bf16(const float* x, int64_t NB, int64_t H, int64_t W, const uint16_t* frag, int64_t Cout,
                         const float* bias, void* workspace, size_t workspace_bytes, uint16_t* out, void* stream);
 int tspn_max_pool_nhwc_bf16(const uint16_t* x, int64_t NB, int64_t H, int64_t W, int64_t C, int64_t k,
                             int64_t stride, int64_t pad, uint16_t* out, void* stream);
+int tspn_stem_pool_bf16(const float* x, int64_t NB, int64_t H, int64_t W, const uint16_t* frag, int64_t Cout,
+                        const float* bias, void* workspace, size_t workspace_bytes, uint16_t* out, void* stream);
 
 #ifdef __cplusplus
 }

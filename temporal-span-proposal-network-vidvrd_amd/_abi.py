@@ -120,6 +120,7 @@ PROTOTYPES = {
     "tspn_pack_stem_bf16": (_int, [_vp, _i64, _vp, _vp]),
     "tspn_stem_conv_bf16": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _sz, _vp, _vp]),
     "tspn_max_pool_nhwc_bf16": (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "tspn_stem_pool_bf16": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _sz, _vp, _vp]),
     "tspn_roi_align_nhwc_bf16": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, ctypes.c_float, _int, _int,
                                         _int, _vp, _vp]),
     "tspn_roi_align_nhwc_f32_bf16out": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, ctypes.c_float, _int, _int,

@@ -26,6 +26,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int KS = 7, KPAD = 3;           // the stem's kernel size and padding (stride 2)
 constexpr int TPX = 128;                  // output pixels per tile
@@ -182,6 +183,159 @@ __global__ __launch_bounds__(256, 2) void stem_conv_bf16_kernel(const __bf16* __
   }
 }
 
+// The stem conv AND its 3x3 / stride 2 / pad 1 max pool in one kernel: the conv map (236 MB per 8 frames of 720p) is
+// never written, and the pool's 1.5x re-read of it disappears.  Work item = one POOLED row (nb, ph); a persistent
+// workgroup walks it left to right in tiles of 64 pooled pixels = conv rows 2 ph - 1 .. 2 ph + 1 x 128 conv columns:
+//   * operand = 6 rows x 131 s2d pixels (25.3 KB) by LDS-DMA one tile ahead, double-buffered;
+//   * the three conv rows run one after the other through the same 16-k-step MFMA loop as above and are reduced to
+//     their elementwise maximum in the accumulator layout (rows outside the map are skipped: wave-uniform);
+//   * relu(max + bias) is rounded to bf16 and written as [conv column][channel] into an LDS slab of 1 + 128 columns;
+//     slot 0 holds conv column -1 of the tile = column 127 of the previous tile of the row (copied after use), zero
+//     at the start of a row;
+//   * a lane takes the maximum of columns 2 i - 1, 2 i, 2 i + 1 for 8 channels and stores 16 bytes: a pooled pixel
+//     leaves as one 128-byte line.
+// x + bias, ReLU and the rounding are monotonic, so "max first, then bias / ReLU / round" gives bit for bit
+// pool(round(relu(conv + bias))).  Every odd conv row is computed twice (1.5x the MFMAs of the stem, which are 2 % of
+// the backbone's); 69.3 KB of LDS, two workgroups per CU.
+constexpr int PROWS = 6;
+constexpr int PSTAGE_BYTES = PROWS * SROW * 32;
+
+template <int MB>
+__global__ __launch_bounds__(256, 2) void stem_pool_bf16_kernel(const __bf16* __restrict__ S, const __bf16* __restrict__ Wf,
+                                                                const float* __restrict__ bias, __bf16* __restrict__ out,
+                                                                int SH, int SW, int OH, int OW, int PH, int PW,
+                                                                int tiles_w, int64_t nrows) {
+  constexpr int COUT = 32 * MB;
+  constexpr int PITCHB = COUT * 2 + 16;       // bytes per conv column of the slab
+  constexpr int CPL = COUT / 8;               // lanes per pooled pixel (16 bytes each)
+  constexpr int PPP = 64 / CPL;               // pooled pixels per pass
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages + the slab
+  char* stage = smem;
+  char* slab = smem + 2 * PSTAGE_BYTES;       // (1 + TPX) columns
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kh = lane >> 5;
+
+  f32x4 a[16][MB];
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi)
+      a[ks][mi] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(Wf) + ((mi * 16 + ks) * 64 + lane) * 16);
+
+  // item it of this workgroup: pooled row blockIdx.x + (it / tiles_w) * gridDim.x, tile it % tiles_w
+  const int64_t rows_mine = blockIdx.x < nrows ? (nrows - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+  const int64_t nitems = rows_mine * tiles_w;
+  // wave w stages s2d rows w and w + 4 of the six
+  auto stage_item = [&](int64_t it, int buf) {
+    const int tw = (int)(it % tiles_w);
+    const int64_t row = blockIdx.x + (it / tiles_w) * gridDim.x;
+    const int ph = (int)(row % PH);
+    const int64_t nb = row / PH;
+    const int c0 = tw * TPX;
+    const int npiece = 2 * min(TPX + 3, SW - c0);
+    for (int j = wave; j < PROWS; j += 4) {
+      const int sr = 2 * ph - 1 + j;
+      if (sr < 0 || sr >= SH) continue;                  // rows of conv rows outside the map: never read
+      const char* src = reinterpret_cast<const char*>(S) + (((nb * SH + sr) * (int64_t)SW + c0) * 32);
+      char* dst = stage + buf * PSTAGE_BYTES + j * (SROW * 32);
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const int p = k * 64 + lane;
+        if (p < npiece) glds16(src + p * 16, dst + k * 1024);
+      }
+    }
+  };
+
+  if (nitems == 0) return;
+  stage_item(0, 0);
+  int buf = 0;
+  for (int64_t it = 0; it < nitems; ++it, buf ^= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's rows of the item have landed
+    __syncthreads();                                     // ... everybody's; the slab of the previous item is free
+    if (it + 1 < nitems) stage_item(it + 1, buf ^ 1);
+    const int tw = (int)(it % tiles_w);
+    const int64_t row = blockIdx.x + (it / tiles_w) * gridDim.x;
+    const int ph = (int)(row % PH);
+
+    f32x16 vmax[MB];
+    bool have = false;
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) {
+      const int r = 2 * ph - 1 + rr;
+      if (r < 0 || r >= OH) continue;
+      f32x16 acc[MB];
+#pragma unroll
+      for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[mi][e] = 0.f;
+      const char* Bb = stage + buf * PSTAGE_BYTES + (rr * SROW + 32 * wave + li) * 32 + 16 * kh;
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(Bb + ((ks >> 2) * SROW + (ks & 3)) * 32);
+#pragma unroll
+        for (int mi = 0; mi < MB; ++mi)
+          acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ks][mi]), b, acc[mi], 0, 0, 0);
+      }
+      if (!have) {
+#pragma unroll
+        for (int mi = 0; mi < MB; ++mi) vmax[mi] = acc[mi];
+        have = true;
+      } else {
+#pragma unroll
+        for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) vmax[mi][e] = fmaxf(vmax[mi][e], acc[mi][e]);
+      }
+    }
+
+    // relu(max + bias) -> bf16 -> slab[1 + conv column][channel]; columns beyond the map are zero (below every ReLU output)
+    const bool colok = tw * TPX + 32 * wave + li < OW;
+    char* sp = slab + (1 + 32 * wave + li) * PITCHB;
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int ch = mi * 32 + 8 * q + 4 * kh;
+        const float4 bv = *reinterpret_cast<const float4*>(bias + ch);
+        bf16x4 v;
+        v[0] = (__bf16)(colok ? fmaxf(vmax[mi][4 * q] + bv.x, 0.f) : 0.f);
+        v[1] = (__bf16)(colok ? fmaxf(vmax[mi][4 * q + 1] + bv.y, 0.f) : 0.f);
+        v[2] = (__bf16)(colok ? fmaxf(vmax[mi][4 * q + 2] + bv.z, 0.f) : 0.f);
+        v[3] = (__bf16)(colok ? fmaxf(vmax[mi][4 * q + 3] + bv.w, 0.f) : 0.f);
+        *reinterpret_cast<bf16x4*>(sp + ch * 2) = v;
+      }
+    __syncthreads();
+
+    // pooled pixel 16 wave + i of the tile = conv columns 32 wave + 2 i - 1 .. + 1 = slab slots 32 wave + 2 i .. + 2
+    const int pl = lane / CPL, cg = lane - pl * CPL;
+#pragma unroll
+    for (int pass = 0; pass < 16 / PPP; ++pass) {
+      const int i = pass * PPP + pl;
+      const char* cp = slab + (32 * wave + 2 * i) * PITCHB + cg * 16;
+      bf16x8 l = *reinterpret_cast<const bf16x8*>(cp);
+      const bf16x8 m = *reinterpret_cast<const bf16x8*>(cp + PITCHB);
+      const bf16x8 r = *reinterpret_cast<const bf16x8*>(cp + 2 * PITCHB);
+      if (tw == 0 && wave == 0 && i == 0) {              // conv column -1 of the row: padding
+#pragma unroll
+        for (int k = 0; k < 8; ++k) l[k] = (__bf16)0.f;
+      }
+      const int pw = tw * (TPX / 2) + 16 * wave + i;
+      if (pw < PW) {
+        bf16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (__bf16)fmaxf(fmaxf((float)l[k], (float)m[k]), (float)r[k]);
+        *reinterpret_cast<bf16x8*>(out + (row * PW + pw) * COUT + 8 * cg) = o;
+      }
+    }
+    __syncthreads();
+    if (tid < CPL)                                       // column 127 becomes column -1 of the next tile of the row
+      *reinterpret_cast<bf16x8*>(slab + tid * 16) = *reinterpret_cast<const bf16x8*>(slab + TPX * PITCHB + tid * 16);
+  }
+}
+
 // max_pool2d(k, stride, pad) on a channels-last bf16 map; a thread = 8 channels (16 bytes) of one output pixel
 __global__ __launch_bounds__(256) void max_pool_nhwc_bf16_kernel(const __bf16* __restrict__ x, int64_t NB, int H, int W,
                                                                  int C, int k, int stride, int pad, int OH, int OW,
@@ -276,6 +430,54 @@ extern "C" int tspn_stem_conv_bf16(const float* x, int64_t NB, int64_t H, int64_
                        (int)OW, (int)tiles_w, ntiles);
   }
   return tspn::check_launch("tspn_stem_conv_bf16");
+}
+
+extern "C" int tspn_stem_pool_bf16(const float* x, int64_t NB, int64_t H, int64_t W, const uint16_t* frag, int64_t Cout,
+                                   const float* bias, void* workspace, size_t workspace_bytes, uint16_t* out,
+                                   void* stream) {
+  TSPN_REQUIRE(NB >= 0 && H > 0 && W > 0, TSPN_EINVAL, "tspn_stem_pool_bf16: bad sizes");
+  TSPN_REQUIRE(Cout == 32 || Cout == 64, TSPN_EUNSUPPORTED, "tspn_stem_pool_bf16: Cout must be 32 or 64 (got %lld)",
+               (long long)Cout);
+  if (NB == 0) return TSPN_OK;
+  TSPN_REQUIRE(x && frag && bias && workspace && out, TSPN_EINVAL, "tspn_stem_pool_bf16: null pointer");
+  const int64_t OH = out_dim(H), OW = out_dim(W), SH = OH + 3, SW = OW + 3;
+  const int64_t PH = (OH - 1) / 2 + 1, PW = (OW - 1) / 2 + 1;     // max_pool2d(3, 2, 1)
+  TSPN_REQUIRE(H < (1 << 20) && W < (1 << 20) && NB * SH * SW < (1LL << 40), TSPN_EUNSUPPORTED,
+               "tspn_stem_pool_bf16: image too large");
+  const size_t need = tspn_stem_bf16_workspace_bytes(NB, H, W);
+  TSPN_REQUIRE(workspace_bytes >= need, TSPN_EWORKSPACE, "tspn_stem_pool_bf16: workspace %zu < %zu bytes", workspace_bytes,
+               need);
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  TSPN_REQUIRE(al16(frag) && al16(bias) && al16(workspace) && al16(out), TSPN_EUNSUPPORTED,
+               "tspn_stem_pool_bf16: operands must be 16-byte aligned");
+  __bf16* S = static_cast<__bf16*>(workspace);
+  hipStream_t s = TSPN_STREAM(stream);
+  const int64_t npx = NB * SH * SW;
+  hipLaunchKernelGGL(stem_s2d_bf16_kernel, dim3((unsigned)std::min<int64_t>(tspn::ceil_div(npx, 256), 1 << 20)), dim3(256),
+                     0, s, x, NB, (int)H, (int)W, (int)SH, (int)SW, S);
+  if (int rc = tspn::check_launch("tspn_stem_pool_bf16 (space-to-depth)")) return rc;
+  const int64_t tiles_w = tspn::ceil_div(OW, TPX), nrows = NB * PH;
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  // whole pooled rows per workgroup, as evenly as the row count allows (1440 rows of 8 frames of 720p: 480 x 3)
+  const int64_t slots = 2LL * cus, per = tspn::ceil_div(nrows, slots);
+  const unsigned grid = (unsigned)tspn::ceil_div(nrows, per);
+  const __bf16* Wf = reinterpret_cast<const __bf16*>(frag);
+  __bf16* o = reinterpret_cast<__bf16*>(out);
+  const size_t smem = 2 * PSTAGE_BYTES + (size_t)(1 + TPX) * ((size_t)Cout * 2 + 16);
+  if (Cout == 64) {
+    static tspn::LdsLimit lds;
+    if (int rc = lds.ensure(reinterpret_cast<const void*>(stem_pool_bf16_kernel<2>), smem, "tspn_stem_pool_bf16")) return rc;
+    hipLaunchKernelGGL(stem_pool_bf16_kernel<2>, dim3(grid), dim3(256), smem, s, S, Wf, bias, o, (int)SH, (int)SW, (int)OH,
+                       (int)OW, (int)PH, (int)PW, (int)tiles_w, nrows);
+  } else {
+    static tspn::LdsLimit lds;
+    if (int rc = lds.ensure(reinterpret_cast<const void*>(stem_pool_bf16_kernel<1>), smem, "tspn_stem_pool_bf16")) return rc;
+    hipLaunchKernelGGL(stem_pool_bf16_kernel<1>, dim3(grid), dim3(256), smem, s, S, Wf, bias, o, (int)SH, (int)SW, (int)OH,
+                       (int)OW, (int)PH, (int)PW, (int)tiles_w, nrows);
+  }
+  return tspn::check_launch("tspn_stem_pool_bf16");
 }
 
 extern "C" int tspn_max_pool_nhwc_bf16(const uint16_t* x, int64_t NB, int64_t H, int64_t W, int64_t C, int64_t k,

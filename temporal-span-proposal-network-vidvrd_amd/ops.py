@@ -19,7 +19,7 @@ __all__ = [
     "transpose_cast_bf16", "temporal_encoder_heads_bf16",
     "temporal_mean_bf16", "forward_fused_bf16", "span_predicate",
     "proposal_pair_filter", "gather_rows",
-    "pack_conv2d", "pack_conv2d_frag", "conv2d_nhwc", "roi_align_nhwc", "pack_conv2d_frag_bf16", "conv2d_nhwc_bf16", "max_pool_nhwc", "pack_conv2d_frag_cin4", "conv2d_nhwc_cin4", "max_pool_nhwc_bf16", "pack_stem_bf16", "stem_conv_bf16", "bottleneck_tail_bf16",
+    "pack_conv2d", "pack_conv2d_frag", "conv2d_nhwc", "roi_align_nhwc", "pack_conv2d_frag_bf16", "conv2d_nhwc_bf16", "max_pool_nhwc", "pack_conv2d_frag_cin4", "conv2d_nhwc_cin4", "max_pool_nhwc_bf16", "pack_stem_bf16", "stem_conv_bf16", "stem_pool_bf16", "bottleneck_tail_bf16",
 ]
 
 
@@ -980,6 +980,30 @@ def stem_conv_bf16(x, frag, bias, workspace=None):
         raise ValueError("stem_conv_bf16: workspace too small")
     out = torch.empty((NB, OH, OW, Cout), dtype=torch.bfloat16, device=x.device)
     _abi.check(l.tspn_stem_conv_bf16(_p(x), NB, H, W, _p(frag), Cout, _p(bias), _p(workspace),
+                                     workspace.numel() * workspace.element_size(), _p(out), _stream()))
+    return out
+
+
+def stem_pool_bf16(x, frag, bias, workspace=None):
+    """BasicStem.forward on bf16 operands in one conv launch: max_pool2d(relu(conv7x7/2/pad3(x) + bias), 3, 2, 1),
+    x fp32 [NB,H,W,3] -> bf16 [NB,PH,PW,Cout] (tspn_stem_pool_bf16); bit-identical to
+    max_pool_nhwc_bf16(stem_conv_bf16(x, frag, bias), 3, 2, 1) without writing the conv map."""
+    _dev(x, "x"); _dev(frag, "frag", torch.bfloat16); _dev(bias, "bias")
+    if x.dim() != 4 or x.shape[3] != 3 or frag.dim() != 4 or tuple(frag.shape[1:]) != (16, 64, 8):
+        raise ValueError("stem_pool_bf16: x must be [NB,H,W,3] and frag = pack_stem_bf16(weight)")
+    NB, H, W, _ = x.shape
+    Cout = frag.shape[0] * 32
+    if bias.shape != (Cout,):
+        raise ValueError("stem_pool_bf16: bias shape mismatch")
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    l = _abi.lib()
+    need = l.tspn_stem_bf16_workspace_bytes(NB, H, W)
+    if workspace is None:
+        workspace = _ws(need, x.device)
+    elif workspace.numel() * workspace.element_size() < need:
+        raise ValueError("stem_pool_bf16: workspace too small")
+    out = torch.empty((NB, (OH - 1) // 2 + 1, (OW - 1) // 2 + 1, Cout), dtype=torch.bfloat16, device=x.device)
+    _abi.check(l.tspn_stem_pool_bf16(_p(x), NB, H, W, _p(frag), Cout, _p(bias), _p(workspace),
                                      workspace.numel() * workspace.element_size(), _p(out), _stream()))
     return out
 

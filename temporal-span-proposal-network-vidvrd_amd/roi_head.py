@@ -228,6 +228,7 @@ class BasicStem(nn.Module):
         super().__init__()
         self.conv1 = ConvFrozenBN(in_channels, out_channels, 7, 2, 3, pad_cin_to=16)
         self.in_channels = in_channels
+        self.fuse_pool = True               # bf16 path: conv + max pool in one kernel (ops.stem_pool_bf16)
 
     def _folded_cin4(self, dev):
         c = self.conv1
@@ -254,11 +255,14 @@ class BasicStem(nn.Module):
         if out_bf16:
             # bf16 backbone: the stem is a bf16-operand conv like every other layer (image and folded weights rounded
             # to bf16, fp32 accumulation, one rounding of relu(acc + bias)); 7x7/2 as a 4x4/1 conv on the 2x2
-            # space-to-depth image (csrc/tspn_stem_bf16.hip), then the 3x3/2 max pool on the bf16 map
+            # space-to-depth image (csrc/tspn_stem_bf16.hip) with the 3x3/2 max pool inside the conv kernel
+            # (`fuse_pool`; off: the conv map is written and pooled by a second kernel - same bits)
             if self.in_channels != 3 or c.kernel_size != 7 or c.stride != 2 or c.padding != 3 or c.weight.shape[0] not in (32, 64):
                 raise ValueError("the bf16 backbone needs detectron2's BasicStem: 7x7 / stride 2 / padding 3 on 3 channels, "
                                  f"32 or 64 output channels (got {tuple(c.weight.shape)}, stride {c.stride}, padding {c.padding})")
             frag, bias = self._folded_bf16(x.device)
+            if self.fuse_pool:
+                return ops.stem_pool_bf16(x.contiguous(), frag, bias)
             return ops.max_pool_nhwc_bf16(ops.stem_conv_bf16(x.contiguous(), frag, bias), 3, 2, 1)
         if self.in_channels <= 4 and c.weight.shape[0] % 32 == 0:
             # stem form: RGB + zero channel, one K chunk = four taps (13 chunks for 7x7 instead of 49)

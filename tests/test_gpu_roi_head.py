@@ -328,6 +328,25 @@ def test_stem_bf16_vs_oracle(tspn, device, NB, H, W, Cout):
     assert torch.equal(tspn.ops.stem_conv_bf16(t(x).to(device), frag, t(b).to(device)), y)      # deterministic
 
 
+@pytest.mark.parametrize("NB,H,W,Cout", [(2, 30, 41, 64), (1, 7, 7, 32), (3, 64, 300, 64), (1, 33, 515, 32), (2, 16, 258, 64),
+                                         (1, 1, 1, 64), (1, 2, 513, 64), (5, 440, 70, 64), (1, 720, 1280, 64),
+                                         (2, 257, 1027, 32)])
+def test_stem_pool_fused_bit_identical_to_conv_then_pool(tspn, device, NB, H, W, Cout):
+    """tspn_stem_pool_bf16 (the 3x3/2 max pool inside the stem conv kernel: three conv rows per pooled row reduced in
+    the accumulator layout, columns through an LDS slab that carries column -1 from tile to tile) == the conv launch
+    followed by the pool launch, BIT FOR BIT: odd sizes, one-pixel images, rows of several 128-column tiles with a
+    ragged last one, more pooled rows than workgroup slots (several rows per persistent workgroup), 720p."""
+    x = t(tspn.hashrng.uniform(89, "x", (NB, H, W, 3), -2, 2)).to(device)
+    w = tspn.hashrng.normal(89, "w", (Cout, 3, 7, 7), std=0.1)
+    b = t(tspn.hashrng.normal(89, "b", (Cout,), std=0.1)).to(device)
+    frag = tspn.ops.pack_stem_bf16(t(w).to(device))
+    want = tspn.ops.max_pool_nhwc_bf16(tspn.ops.stem_conv_bf16(x, frag, b), 3, 2, 1)
+    got = tspn.ops.stem_pool_bf16(x, frag, b)
+    assert got.dtype == torch.bfloat16 and tuple(got.shape) == tuple(want.shape)
+    assert torch.equal(got, want)
+    assert torch.equal(tspn.ops.stem_pool_bf16(x, frag, b), got)       # deterministic
+
+
 def test_stem_bf16_errors(tspn, device):
     with pytest.raises(ValueError):
         tspn.ops.pack_stem_bf16(torch.zeros((48, 3, 7, 7), device=device))
@@ -338,6 +357,9 @@ def test_stem_bf16_errors(tspn, device):
     assert y.shape == (0, 4, 4, 64)
     with pytest.raises(ValueError):
         tspn.ops.stem_conv_bf16(torch.zeros((1, 8, 8, 4), device=device), frag, torch.zeros(64, device=device))
+    assert tspn.ops.stem_pool_bf16(torch.zeros((0, 8, 8, 3), device=device), frag, torch.zeros(64, device=device)).shape == (0, 2, 2, 64)
+    with pytest.raises(ValueError):
+        tspn.ops.stem_pool_bf16(torch.zeros((1, 8, 8, 4), device=device), frag, torch.zeros(64, device=device))
     net = tspn.ResNetC4(stem_out=16, res2_out=64, blocks=(1, 1, 1)).to(device)
     with pytest.raises(ValueError):          # the bf16 backbone needs a 32- or 64-channel detectron2 stem
         net(torch.zeros((1, 32, 32, 3), device=device), bf16=True)
@@ -476,3 +498,6 @@ def test_bottleneck_tail_and_stem_random_shapes(tspn, device, seed):
     assert tuple(y.shape) == tuple(ref.shape), (IH, IW, Cout)
     err = (y.cpu().double() - ref).abs()
     assert float(err.max()) <= 2.0 ** -8 * max(float(ref.abs().max()), 1e-3), (IH, IW, Cout, float(err.max()))
+    frag = tspn.ops.pack_stem_bf16(t(w).to(device))
+    assert torch.equal(tspn.ops.stem_pool_bf16(t(x).to(device), frag, t(b).to(device)),
+                       tspn.ops.max_pool_nhwc_bf16(y, 3, 2, 1)), (IH, IW, Cout)
