@@ -241,20 +241,36 @@ __global__ __launch_bounds__(THREADS, (CM == 256 ? 2 : 3)) void bottleneck_bf16_
   // ---------------------------------------------------------------- phase 3: 1x1 expand, K = CM, software-pipelined
   // Eight sub-passes per wave, each a [32 MS rows x 32 NS pixels] accumulator set (half of what the wave owns in a pass
   // of CM rows); two sets alternate: while the MFMAs of sub-pass i + 1 run, the epilogue of sub-pass i -- bias,
-  // residual, ReLU, rounding, 16-byte stores -- is fed into the gaps half a group per two k-steps,
-  // its residual rows requested two groups ahead.  The W3 fragments are one continuous stream through a 4-deep
-  // register ring that runs across sub-pass boundaries.
+  // residual, ReLU, rounding, 16-byte stores -- is fed into the gaps half a group per two k-steps.  The W3 fragments
+  // are one continuous stream through a register ring that runs across sub-pass boundaries, the residual rows a
+  // second ring of NRES groups requested NRES groups before their use.  At CM = 64 a sub-pass is only four MFMAs, so
+  // both rings are FOUR sub-passes deep there (16 k-steps of W3, 4 residual groups: 96 KB of residual rows in flight
+  // per CU): with one sub-pass of lookahead every sub-pass waited a full memory latency and the res2 tails ran at
+  // 2.2 TB/s.  (Loads return in order: a residual row requested before a W3 fragment has to land before that fragment
+  // is used, so the W3 ring must be as deep as the residual lookahead.)
   constexpr int KSTEPS = CM / 16;
   constexpr int MS = CM >= 128 ? 2 : 1;            // row blocks per sub-pass
   constexpr int NS = CM == 256 ? 2 : 1;            // pixel blocks per sub-pass
   constexpr int NSUB = 8;
-  constexpr int G = MS * 2 * NS;                   // epilogue groups per sub-pass (8 channels x 32 pixels per lane-row)
-  constexpr int RING = 4;
-  static_assert(KSTEPS == 2 * G && KSTEPS >= RING, "phase-3 schedule: one epilogue group per two k-steps");
+  constexpr int G = MS * 2 * NS;                   // epilogue halves per sub-pass (8 channels x 32 pixels per lane-row)
+  constexpr int NGRP = MS * NS;                    // epilogue groups per sub-pass (16 channels per lane)
+  constexpr int RING = CM == 64 ? 16 : 4;          // W3 ring, k-steps
+  constexpr int NRES = CM == 64 ? 4 : 2;           // residual ring, groups
+  constexpr bool UNROLLED = CM == 64;              // sub-pass index known at compile time (ring slots depend on it)
+  static_assert(KSTEPS == 2 * G, "phase-3 schedule: one epilogue half per two k-steps");
+  static_assert(UNROLLED || (KSTEPS % RING == 0 && NGRP % NRES == 0), "ring slots must not depend on a run-time sub-pass");
   const char* Hb = Bs + (kh * SLP + li) * 16;
   // sub-pass sp = 2 pass + part: rows (wm 4 + pass) MI + mi0 .., pixel blocks wn NI + ni0 ..
   auto sub_rb = [&](int sp) { return (wm * 4 + (sp >> 1)) * MI + (NS < NI ? 0 : (sp & 1) * MS); };
   auto sub_nb = [&](int sp) { return wn * NI + (NS < NI ? (sp & 1) * NS : 0); };
+  // a sub-pass index is either an int (run-time loop, CM >= 128) or an integral_constant (CM = 64, fully unrolled)
+  auto cval = [](auto sp) constexpr {              // its compile-time value; 0 when the ring slots do not depend on it
+    if constexpr (std::is_integral_v<decltype(sp)>) return 0; else return decltype(sp)::value;
+  };
+  auto plus = [](auto sp, auto d) {                // sp + d, keeping the kind
+    if constexpr (std::is_integral_v<decltype(sp)>) return sp + (int)decltype(d)::value;
+    else return std::integral_constant<int, decltype(sp)::value + decltype(d)::value>{};
+  };
   // W3 rows are permuted AT LOAD TIME: the lane that feeds MFMA row r = 8 q + 4 h + j of a 32-row block fetches the
   // fragment slot of channel 16 h + 4 q + j (same 1-KiB fragment line, lanes permuted).  An accumulator lane (pixel
   // li, half kh) holds rows 8 q + 4 kh + j in registers 4 q + j -- with the permutation these are the 16 CONSECUTIVE
@@ -267,14 +283,15 @@ __global__ __launch_bounds__(THREADS, (CM == 256 ? 2 : 3)) void bottleneck_bf16_
   };
   f32x4 ar[RING][MS];
 #pragma unroll
-  for (int k = 0; k < RING; ++k)
+  for (int j = 0; j < RING; ++j)
 #pragma unroll
-    for (int ms = 0; ms < MS; ++ms) ar[k][ms] = *reinterpret_cast<const f32x4*>(a_ptr(0, k, ms));
+    for (int ms = 0; ms < MS; ++ms) ar[j][ms] = *reinterpret_cast<const f32x4*>(a_ptr(j / KSTEPS, j % KSTEPS, ms));
   f32x16 accA[MS][NS], accB[MS][NS];
 
   // one k-step of sub-pass sp into `c`; refills the ring slot with the fragment RING k-steps ahead in the stream
-  auto kstep = [&](f32x16 (&c)[MS][NS], int sp, auto k_tag) {
+  auto kstep = [&](f32x16 (&c)[MS][NS], auto sp, auto k_tag) {
     constexpr int k = decltype(k_tag)::value;
+    constexpr int slot = (cval(decltype(sp){}) * KSTEPS + k) % RING;
     const int nb = sub_nb(sp);
     bf16x8 b[NS];
 #pragma unroll
@@ -282,15 +299,14 @@ __global__ __launch_bounds__(THREADS, (CM == 256 ? 2 : 3)) void bottleneck_bf16_
       b[nj] = *reinterpret_cast<const bf16x8*>(Hb + ((2 * k) * SLP + (nb + nj) * 32) * 16);
 #pragma unroll
     for (int ms = 0; ms < MS; ++ms) {
-      const bf16x8 av = __builtin_bit_cast(bf16x8, ar[k % RING][ms]);
+      const bf16x8 av = __builtin_bit_cast(bf16x8, ar[slot][ms]);
 #pragma unroll
       for (int nj = 0; nj < NS; ++nj) c[ms][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b[nj], c[ms][nj], 0, 0, 0);
     }
-    constexpr int kn = k + RING;                     // position in the stream of the fragment that takes this slot
-    if (kn < KSTEPS || sp + 1 < NSUB) {
+    constexpr int dsp = (k + RING) / KSTEPS, kn = (k + RING) % KSTEPS;   // the fragment that takes this slot
+    if ((int)sp + dsp < NSUB) {
 #pragma unroll
-      for (int ms = 0; ms < MS; ++ms)
-        ar[k % RING][ms] = *reinterpret_cast<const f32x4*>(kn < KSTEPS ? a_ptr(sp, kn, ms) : a_ptr(sp + 1, kn - KSTEPS, ms));
+      for (int ms = 0; ms < MS; ++ms) ar[slot][ms] = *reinterpret_cast<const f32x4*>(a_ptr((int)sp + dsp, kn, ms));
     }
   };
   // epilogue: group grp = (nj, ms), ms fastest = one 32-row x 32-pixel accumulator block = 16 consecutive channels
@@ -300,10 +316,8 @@ __global__ __launch_bounds__(THREADS, (CM == 256 ? 2 : 3)) void bottleneck_bf16_
   // group later.  L2 hands part-written lines to the fabric quickly, each time as whole sectors: WRITE_SIZE of a
   // res4 launch of 8 frames (59.0 MB of output) was 101 MB with 32-byte pieces two epilogue steps apart, 76 MB one
   // step apart, 75 MB with whole sectors but the halves of a line two groups apart, 59.9 MB like this
-  // (tools/probe_store_order.sh).  The residual is read the same way, 32 contiguous bytes per lane, two groups ahead.
-  constexpr int NGRP = MS * NS;
-  static_assert(G == 2 * NGRP, "two epilogue halves per group");
-  bf16x8 rres[2][2];                                 // residual rows of two groups in flight: [grp % 2][half]
+  // (tools/probe_store_order.sh).  The residual is read the same way, 32 contiguous bytes per lane.
+  bf16x8 rres[NRES][2];                              // residual rows in flight: [group in the stream % NRES][half]
   bf16x8 ohold;                                      // first half of the group being finished
   // addresses of the residual / output rows = a wave-uniform base (tile, pixel block, channel block) + a 32-bit lane
   // offset (pixel li of the block, channels 16 kh ..).  Pixels beyond the end read pixel 0 of their block (block 0 of
@@ -317,37 +331,46 @@ __global__ __launch_bounds__(THREADS, (CM == 256 ? 2 : 3)) void bottleneck_bf16_
     const int64_t pb = n0 + (sub_nb(sp) + nj) * 32;
     return (pb < npix ? pb : 0) * C4 + 32 * (sub_rb(sp) + ms);
   };
-  auto res_issue = [&](int sp, auto grp_tag) {
+  // group gg = e NGRP + grp of the stream of epilogue groups (e = the sub-pass whose results it finishes)
+  auto res_issue = [&](auto e, auto grp_tag) {
     constexpr int grp = decltype(grp_tag)::value;
+    constexpr int slot = (cval(decltype(e){}) * NGRP + grp) % NRES;
 #if defined(TSPN_BT_ABL_NORES)      // probe build: no residual traffic
-    (void)sp;
+    (void)e;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) rres[grp % 2][0][j] = rres[grp % 2][1][j] = (__bf16)0.f;
+    for (int j = 0; j < 8; ++j) rres[slot][0][j] = rres[slot][1][j] = (__bf16)0.f;
 #else
-    const bool okp = (okmask >> (sub_nb(sp) + grp / MS)) & 1u;
-    const char* rp = reinterpret_cast<const char*>(residual + row_base(sp, grp)) + (okp ? voff_in : voff_out);
-    rres[grp % 2][0] = *reinterpret_cast<const bf16x8*>(rp);
-    rres[grp % 2][1] = *reinterpret_cast<const bf16x8*>(rp + 16);
+    const bool okp = (okmask >> (sub_nb(e) + grp / MS)) & 1u;
+    const char* rp = reinterpret_cast<const char*>(residual + row_base(e, grp)) + (okp ? voff_in : voff_out);
+    rres[slot][0] = *reinterpret_cast<const bf16x8*>(rp);
+    rres[slot][1] = *reinterpret_cast<const bf16x8*>(rp + 16);
 #endif
   };
-  auto group_finish = [&](f32x16 (&c)[MS][NS], int sp, auto g_tag) {
+  // the group NRES after (e, grp) in the stream, if there is one
+  auto res_issue_ahead = [&](auto e, auto grp_tag) {
+    constexpr int grp = decltype(grp_tag)::value;
+    constexpr int de = (grp + NRES) / NGRP, gn = (grp + NRES) % NGRP;
+    if ((int)e + de < NSUB) res_issue(plus(e, std::integral_constant<int, de>{}), std::integral_constant<int, gn>{});
+  };
+  auto group_finish = [&](f32x16 (&c)[MS][NS], auto e, auto g_tag) {
     constexpr int g = decltype(g_tag)::value;
     constexpr int grp = g >> 1, h = g & 1, ms = grp % MS, nj = grp / MS;
-    const int chm = 32 * (sub_rb(sp) + ms) + 16 * kh + 8 * h;
+    constexpr int slot = (cval(decltype(e){}) * NGRP + grp) % NRES;
+    const int chm = 32 * (sub_rb(e) + ms) + 16 * kh + 8 * h;
     const float4 bv0 = *reinterpret_cast<const float4*>(bias3 + chm);
     const float4 bv1 = *reinterpret_cast<const float4*>(bias3 + chm + 4);
     const float v[8] = {c[ms][nj][8 * h] + bv0.x,     c[ms][nj][8 * h + 1] + bv0.y, c[ms][nj][8 * h + 2] + bv0.z,
                         c[ms][nj][8 * h + 3] + bv0.w, c[ms][nj][8 * h + 4] + bv1.x, c[ms][nj][8 * h + 5] + bv1.y,
                         c[ms][nj][8 * h + 6] + bv1.z, c[ms][nj][8 * h + 7] + bv1.w};
-    const bf16x8 rv = rres[grp % 2][h];
+    const bf16x8 rv = rres[slot][h];
     bf16x8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = (__bf16)fmaxf(v[j] + (float)rv[j], 0.f);
     if constexpr (h == 0) {
       ohold = o;
     } else {
-      const bool okp = (okmask >> (sub_nb(sp) + nj)) & 1u;
-      char* op = reinterpret_cast<char*>(out + row_base(sp, grp)) + voff_in;
+      const bool okp = (okmask >> (sub_nb(e) + nj)) & 1u;
+      char* op = reinterpret_cast<char*>(out + row_base(e, grp)) + voff_in;
 #if defined(TSPN_BT_ABL_NOSTORE)    // probe build: results are computed but (almost) never stored
       if (okp && o[0] == (__bf16)12345.f) {
 #else
@@ -356,6 +379,7 @@ __global__ __launch_bounds__(THREADS, (CM == 256 ? 2 : 3)) void bottleneck_bf16_
         *reinterpret_cast<bf16x8*>(op) = ohold;
         *reinterpret_cast<bf16x8*>(op + 16) = o;
       }
+      res_issue_ahead(e, std::integral_constant<int, grp>{});   // its ring slot is free now
     }
   };
   auto zero = [&](f32x16 (&c)[MS][NS]) {
@@ -366,24 +390,18 @@ __global__ __launch_bounds__(THREADS, (CM == 256 ? 2 : 3)) void bottleneck_bf16_
 #pragma unroll
         for (int e = 0; e < 16; ++e) c[ms][nj][e] = 0.f;
   };
+  using M1 = std::integral_constant<int, -1>;
   // sub-pass sp into `cur` while the epilogue of sub-pass sp - 1 (in `prev`) drains: half g is finished after k-step
-  // 2 g + 1; the residual rows of a group are requested when the group two before it has been stored
-  auto subpass = [&](f32x16 (&cur)[MS][NS], f32x16 (&prev)[MS][NS], int sp, auto drain_tag) {
+  // 2 g + 1
+  auto subpass = [&](f32x16 (&cur)[MS][NS], f32x16 (&prev)[MS][NS], auto sp, auto drain_tag) {
     constexpr bool DRAIN = decltype(drain_tag)::value;
     zero(cur);
-    if constexpr (DRAIN) {
-      res_issue(sp - 1, std::integral_constant<int, 0>{});
-      if constexpr (NGRP > 1) res_issue(sp - 1, std::integral_constant<int, 1>{});
-    }
     auto two = [&](auto g_tag) {
       constexpr int g = decltype(g_tag)::value;
       kstep(cur, sp, std::integral_constant<int, 2 * g>{});
       __builtin_amdgcn_sched_barrier(0);
       kstep(cur, sp, std::integral_constant<int, 2 * g + 1>{});
-      if constexpr (DRAIN) {
-        group_finish(prev, sp - 1, g_tag);
-        if constexpr ((g & 1) && (g >> 1) + 2 < NGRP) res_issue(sp - 1, std::integral_constant<int, (g >> 1) + 2>{});
-      }
+      if constexpr (DRAIN) group_finish(prev, plus(sp, M1{}), g_tag);
       __builtin_amdgcn_sched_barrier(0);
     };
     two(std::integral_constant<int, 0>{});
@@ -394,21 +412,40 @@ __global__ __launch_bounds__(THREADS, (CM == 256 ? 2 : 3)) void bottleneck_bf16_
       two(std::integral_constant<int, 6>{}); two(std::integral_constant<int, 7>{});
     }
   };
-  subpass(accA, accB, 0, std::false_type{});
+  // the first NRES groups of the stream
+  {
+    auto first = [&](auto gg_tag) {
+      constexpr int gg = decltype(gg_tag)::value;
+      if constexpr (gg < NRES) {
+        if constexpr (UNROLLED) res_issue(std::integral_constant<int, gg / NGRP>{}, std::integral_constant<int, gg % NGRP>{});
+        else res_issue((int)(gg / NGRP), std::integral_constant<int, gg % NGRP>{});
+      }
+    };
+    first(std::integral_constant<int, 0>{}); first(std::integral_constant<int, 1>{});
+    first(std::integral_constant<int, 2>{}); first(std::integral_constant<int, 3>{});
+  }
+  if constexpr (UNROLLED) {
+    subpass(accA, accB, std::integral_constant<int, 0>{}, std::false_type{});
+    subpass(accB, accA, std::integral_constant<int, 1>{}, std::true_type{});
+    subpass(accA, accB, std::integral_constant<int, 2>{}, std::true_type{});
+    subpass(accB, accA, std::integral_constant<int, 3>{}, std::true_type{});
+    subpass(accA, accB, std::integral_constant<int, 4>{}, std::true_type{});
+    subpass(accB, accA, std::integral_constant<int, 5>{}, std::true_type{});
+    subpass(accA, accB, std::integral_constant<int, 6>{}, std::true_type{});
+    subpass(accB, accA, std::integral_constant<int, 7>{}, std::true_type{});
+  } else {
+    subpass(accA, accB, 0, std::false_type{});
 #pragma unroll 1
-  for (int sp = 1; sp < NSUB; sp += 2) {
-    subpass(accB, accA, sp, std::true_type{});
-    if (sp + 1 < NSUB) subpass(accA, accB, sp + 1, std::true_type{});
+    for (int sp = 1; sp < NSUB; sp += 2) {
+      subpass(accB, accA, sp, std::true_type{});
+      if (sp + 1 < NSUB) subpass(accA, accB, sp + 1, std::true_type{});
+    }
   }
   // the last sub-pass (odd, in accB) drains on its own
   {
-    constexpr int sp = NSUB - 1;
-    res_issue(sp, std::integral_constant<int, 0>{});
-    if constexpr (NGRP > 1) res_issue(sp, std::integral_constant<int, 1>{});
     auto fin = [&](auto g_tag) {
-      constexpr int g = decltype(g_tag)::value;
-      group_finish(accB, sp, g_tag);
-      if constexpr ((g & 1) && (g >> 1) + 2 < NGRP) res_issue(sp, std::integral_constant<int, (g >> 1) + 2>{});
+      if constexpr (UNROLLED) group_finish(accB, std::integral_constant<int, NSUB - 1>{}, g_tag);
+      else group_finish(accB, (int)(NSUB - 1), g_tag);
     };
     fin(std::integral_constant<int, 0>{});
     fin(std::integral_constant<int, 1>{});
