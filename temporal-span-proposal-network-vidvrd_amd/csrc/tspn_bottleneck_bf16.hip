@@ -155,65 +155,154 @@ __global__ __launch_bounds__(THREADS, (CM == 256 ? 2 : 3)) void bottleneck_bf16_
     for (int mi = 0; mi < MI; ++mi) wbase[mi] += 4096;
   };
 
-  static_assert(NCHUNKS > DIST, "ring prologue");
+  if constexpr (CM != 64) {
+    static_assert(NCHUNKS > DIST, "ring prologue");
 #pragma unroll
-  for (int i = 0; i < DIST; ++i) stage_x(i, i);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  load_step(K0{}); load_step(K1{}); load_step(K2{}); load_step(K3{});
-  bump();
-  __builtin_amdgcn_sched_barrier(0);
+    for (int i = 0; i < DIST; ++i) stage_x(i, i);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    load_step(K0{}); load_step(K1{}); load_step(K2{}); load_step(K3{});
+    bump();
+    __builtin_amdgcn_sched_barrier(0);
 
-  // lane's fragment base inside a stage: slot = pixel block offset + li, channel-group half kh
-  const int bofs = ((kh * SLP) + wn * NI * 32 + li) * 16;
-  // chunk i.  VMEM issue order: [x_{i+DIST}: 4 pieces] a0' | a1' | a2' | a3' (MI loads each, the weights of chunk
-  // i + 1); counts = YOUNGER operations at each wait.  x_{i+1} was requested DIST - 1 >= 1 chunks ago, BEFORE the
-  // weights of this chunk: in-order VMEM return makes the wait for a3 of this chunk the wait for x_{i+1} as well.
-  auto chunk_body = [&](int i, int buf, auto stage_tag, auto more_tag) {
-    constexpr bool STAGE = decltype(stage_tag)::value, MORE = decltype(more_tag)::value;
-    constexpr int NX = STAGE ? 4 : 0, R = MORE ? MI : 0, L = MI;
-    const char* Bb = Bs + buf * B_ST + bofs;
-    bf16x8 b0[NI], b1[NI];
-    wait_w<3 * L>(a[0][0], a[0][1]);
-    if (STAGE) stage_x(buf >= 1 ? buf - 1 : NST - 1, i + DIST);      // the stage chunk i - 1 has just left
-    __builtin_amdgcn_sched_barrier(0);
-    read_b(Bb, 0, b0);
-    read_b(Bb, 2, b1);
-    mfma_step(acc, a[0], b0);
-    if (MORE) load_step(K0{});
-    __builtin_amdgcn_sched_barrier(0);
-    wait_w<2 * L + NX + R>(a[1][0], a[1][1]);
-    read_b(Bb, 4, b0);
-    mfma_step(acc, a[1], b1);
-    if (MORE) load_step(K1{});
-    __builtin_amdgcn_sched_barrier(0);
-    wait_w<L + NX + 2 * R>(a[2][0], a[2][1]);
-    read_b(Bb, 6, b1);
-    mfma_step(acc, a[2], b0);
-    if (MORE) load_step(K2{});
-    __builtin_amdgcn_sched_barrier(0);
-    wait_w<NX + 3 * R>(a[3][0], a[3][1]);
-    mfma_step(acc, a[3], b1);
-    if (MORE) { load_step(K3{}); bump(); }
-    __builtin_amdgcn_sched_barrier(0);
-    // every LDS read of this chunk has returned; x_{i+1} landed with a3 (see above); the last chunk drains everything
-    if (MORE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // lane's fragment base inside a stage: slot = pixel block offset + li, channel-group half kh
+    const int bofs = ((kh * SLP) + wn * NI * 32 + li) * 16;
+    // chunk i.  VMEM issue order: [x_{i+DIST}: 4 pieces] a0' | a1' | a2' | a3' (MI loads each, the weights of chunk
+    // i + 1); counts = YOUNGER operations at each wait.  x_{i+1} was requested DIST - 1 >= 1 chunks ago, BEFORE the
+    // weights of this chunk: in-order VMEM return makes the wait for a3 of this chunk the wait for x_{i+1} as well.
+    auto chunk_body = [&](int i, int buf, auto stage_tag, auto more_tag) {
+      constexpr bool STAGE = decltype(stage_tag)::value, MORE = decltype(more_tag)::value;
+      constexpr int NX = STAGE ? 4 : 0, R = MORE ? MI : 0, L = MI;
+      const char* Bb = Bs + buf * B_ST + bofs;
+      bf16x8 b0[NI], b1[NI];
+      wait_w<3 * L>(a[0][0], a[0][1]);
+      if (STAGE) stage_x(buf >= 1 ? buf - 1 : NST - 1, i + DIST);      // the stage chunk i - 1 has just left
+      __builtin_amdgcn_sched_barrier(0);
+      read_b(Bb, 0, b0);
+      read_b(Bb, 2, b1);
+      mfma_step(acc, a[0], b0);
+      if (MORE) load_step(K0{});
+      __builtin_amdgcn_sched_barrier(0);
+      wait_w<2 * L + NX + R>(a[1][0], a[1][1]);
+      read_b(Bb, 4, b0);
+      mfma_step(acc, a[1], b1);
+      if (MORE) load_step(K1{});
+      __builtin_amdgcn_sched_barrier(0);
+      wait_w<L + NX + 2 * R>(a[2][0], a[2][1]);
+      read_b(Bb, 6, b1);
+      mfma_step(acc, a[2], b0);
+      if (MORE) load_step(K2{});
+      __builtin_amdgcn_sched_barrier(0);
+      wait_w<NX + 3 * R>(a[3][0], a[3][1]);
+      mfma_step(acc, a[3], b1);
+      if (MORE) { load_step(K3{}); bump(); }
+      __builtin_amdgcn_sched_barrier(0);
+      // every LDS read of this chunk has returned; x_{i+1} landed with a3 (see above); the last chunk drains everything
+      if (MORE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    {
+      int buf = 0;
+      int i = 0;
+      for (; i + DIST < NCHUNKS; ++i) {
+        chunk_body(i, buf, std::true_type{}, std::true_type{});
+        buf = buf + 1 == NST ? 0 : buf + 1;
+      }
+      for (; i + 1 < NCHUNKS; ++i) {
+        chunk_body(i, buf, std::false_type{}, std::true_type{});
+        buf = buf + 1 == NST ? 0 : buf + 1;
+      }
+      chunk_body(i, buf, std::false_type{}, std::false_type{});   // ends with a barrier: nobody reads the stages any more
+    }
+  } else {
+    // ---- CM = 64: one chunk per tap is only 8 MFMAs per wave -- a barrier, a DMA hand-over and an L2 round trip
+    // for the weights per 8 MFMAs left the MFMA pipe idle two thirds of phase 2 (109 us per 8 frames of 720p against
+    // 28 at the rate of the wide layers).  Here the operand of ALL nine taps is staged ONCE: tap (a, b) of pixel n is
+    // pixel n + (a - 1) W + (b - 1) of the channels-last map, so three LINEAR ranges of 130 pixels -- stage a =
+    // pixels n0 + (a - 1) W - 1 .. + 129 -- hold everything (same 16.9 KB per stage as a tap's chunk; slots 128, 129
+    // in a 768-byte side region, the DMA writes 64 consecutive slots per instruction); a tap reads its stage at a
+    // slot offset, and taps that fall off the image are zeroed AT THE READ by the lane's own tap mask (the ranges
+    // run across row and image boundaries).  One barrier, then 36 k-steps back to back; the weights stream through a
+    // ring of 12 k-steps = three taps of lookahead, counted vmcnt.
+    constexpr int RW = 12;
+    static_assert(NST >= 3 && MI == 2 && NI == 1 && WM == 1, "CM = 64 form");
+    char* const extra = Bs + 3 * B_ST;
+    auto tap_mask = [&](int64_t n) {
+      unsigned m = 0;
+      const bool okn = n < npix;
+      const int64_t nc = okn ? n : 0;
+      const int64_t nb = nc / ((int64_t)H * W);
+      const int r = (int)(nc - nb * H * W);
+      const int oh = r / W, ow = r - oh * W;
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b)
+          if (okn && oh - 1 + a >= 0 && oh - 1 + a < H && ow - 1 + b >= 0 && ow - 1 + b < W) m |= 1u << (a * 3 + b);
+      return m;
+    };
+    const unsigned rmask = tap_mask(n0 + wn * 32 + li);      // of the pixel this lane reads as its B column
+#pragma unroll
+    for (int ra = 0; ra < 3; ++ra) {
+      const int64_t q = n0 + (int64_t)(ra - 1) * W - 1 + slot;
+      const __bf16* xs = (q >= 0 && q < npix) ? h1 + q * CM + 8 * bg : g_zero_page_bt + 8 * bg;
+      char* dst = Bs + ra * B_ST + (bg * SLP + 64 * (wave & 1)) * 16;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) glds16(xs + 16 * p, dst + 2 * p * SLP * 16);
+    }
+    if (wave == 0 && lane < 48) {                            // slots 128, 129 of the three ranges: [range][group][2]
+      const int ra = lane >> 4, g = (lane >> 1) & 7, e = lane & 1;
+      const int64_t q = n0 + (int64_t)(ra - 1) * W - 1 + 128 + e;
+      const __bf16* xs = (q >= 0 && q < npix) ? h1 + q * CM + 8 * g : g_zero_page_bt + 8 * g;
+      glds16(xs, extra);                                     // the DMA adds lane * 16
+    }
+    f32x4 aw[RW][MI];
+    const char* wl[MI] = {wbase[0], wbase[1]};
+    auto load_k = [&](auto j_tag) {                          // k-step j of the 36 into its ring slot
+      constexpr int j = decltype(j_tag)::value;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) load_wfrag<1024 * (j % 4)>(aw[j % RW][mi], woff, wl[mi]);
+      if constexpr (j % 4 == 3) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) wl[mi] += 4096;
+      }
+    };
+    auto step = [&](auto j_tag) {
+      constexpr int j = decltype(j_tag)::value;
+      constexpr int tap = j / 4, ks = j % 4, ra = tap / 3, rb = tap % 3;
+      // younger loads at this wait: the ring runs RW - 1 k-steps ahead until k-step 24 issued the last refill
+      constexpr int YOUNGER = MI * (RW - 1 - (j > 24 ? j - 24 : 0));
+      wait_w<YOUNGER>(aw[j % RW][0], aw[j % RW][1]);
+      const int g = 2 * ks + kh, sl = wn * 32 + li + rb;
+      const char* bp = Bs + ra * B_ST + (g * SLP + sl) * 16;
+      if (wn == 3 && sl >= 128) bp = extra + ((ra * 8 + g) * 2 + (sl - 128)) * 16;
+      f32x4 bv = *reinterpret_cast<const f32x4*>(bp);
+      if (!((rmask >> tap) & 1u)) bv = f32x4{0.f, 0.f, 0.f, 0.f};
+      const bf16x8 b = __builtin_bit_cast(bf16x8, bv);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+        acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aw[j % RW][mi]), b, acc[mi][0], 0, 0, 0);
+      if constexpr (j + RW < 36) load_k(std::integral_constant<int, j + RW>{});
+    };
+    auto four = [&](auto t_tag) {
+      constexpr int t = decltype(t_tag)::value;
+      step(std::integral_constant<int, 4 * t>{});     step(std::integral_constant<int, 4 * t + 1>{});
+      step(std::integral_constant<int, 4 * t + 2>{}); step(std::integral_constant<int, 4 * t + 3>{});
+    };
+    auto prologue = [&](auto t_tag) {
+      constexpr int t = decltype(t_tag)::value;
+      load_k(std::integral_constant<int, 4 * t>{});     load_k(std::integral_constant<int, 4 * t + 1>{});
+      load_k(std::integral_constant<int, 4 * t + 2>{}); load_k(std::integral_constant<int, 4 * t + 3>{});
+    };
+    prologue(std::integral_constant<int, 0>{}); prologue(std::integral_constant<int, 1>{}); prologue(std::integral_constant<int, 2>{});
+    // the DMA pieces are OLDER than the 24 weight loads: in-order return makes this the wait for the staged ranges
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MI * RW) : "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-  };
-  {
-    int buf = 0;
-    int i = 0;
-    for (; i + DIST < NCHUNKS; ++i) {
-      chunk_body(i, buf, std::true_type{}, std::true_type{});
-      buf = buf + 1 == NST ? 0 : buf + 1;
-    }
-    for (; i + 1 < NCHUNKS; ++i) {
-      chunk_body(i, buf, std::false_type{}, std::true_type{});
-      buf = buf + 1 == NST ? 0 : buf + 1;
-    }
-    chunk_body(i, buf, std::false_type{}, std::false_type{});   // ends with a barrier: nobody reads the stages any more
+    four(std::integral_constant<int, 0>{}); four(std::integral_constant<int, 1>{}); four(std::integral_constant<int, 2>{});
+    four(std::integral_constant<int, 3>{}); four(std::integral_constant<int, 4>{}); four(std::integral_constant<int, 5>{});
+    four(std::integral_constant<int, 6>{}); four(std::integral_constant<int, 7>{}); four(std::integral_constant<int, 8>{});
+    __syncthreads();                                         // nobody reads the stages any more
   }
 
   // ---------------------------------------------------------------- h2 = relu(acc + b2) -> bf16 -> LDS (B-operand image)
@@ -464,7 +553,7 @@ int launch(const uint16_t* h1, int64_t NB, int64_t H, int64_t W, const uint16_t*
   const int64_t tiles = tspn::ceil_div(npix, BN);
   TSPN_REQUIRE(tiles < (1LL << 31), TSPN_EUNSUPPORTED, "tspn_bottleneck_tail_bf16: grid too large");
   constexpr int nst = CM == 256 ? 4 : 3;
-  constexpr size_t smem = (size_t)(CM / KC > nst ? CM / KC : nst) * B_ST;
+  constexpr size_t smem = (size_t)(CM / KC > nst ? CM / KC : nst) * B_ST + (CM == 64 ? 1024 : 0);   // + slots 128, 129 (CM = 64 form)
   static tspn::LdsLimit lds;
   if (int rc = lds.ensure(reinterpret_cast<const void*>(bottleneck_bf16_kernel<CM>), smem, "tspn_bottleneck_tail_bf16"))
     return rc;
