@@ -919,10 +919,11 @@ def max_pool_nhwc(x, kernel_size=3, stride=2, padding=1, out_bf16=False):
     return out
 
 
-def bottleneck_tail_bf16(h1, frag2, bias2, frag3, bias3, residual):
+def bottleneck_tail_bf16(h1, frag2, bias2, frag3, bias3, residual, out=None):
     """relu(conv1x1(relu(conv3x3(h1) + b2)) + b3 + residual) in one launch (tspn_bottleneck_tail_bf16): h1 bf16
     [NB,H,W,CM], CM in (64, 128, 256); frag2 / frag3 = pack_conv2d_frag_bf16 of the folded conv2 / conv3 weights;
-    residual bf16 [NB,H,W,4 CM] -> bf16 [NB,H,W,4 CM]."""
+    residual bf16 [NB,H,W,4 CM] -> bf16 [NB,H,W,4 CM] (written into `out` when given: a contiguous tensor of that
+    shape, e.g. a slice of the caller's result along the first dimension)."""
     _dev(h1, "h1", torch.bfloat16); _dev(frag2, "frag2", torch.bfloat16); _dev(frag3, "frag3", torch.bfloat16)
     _dev(bias2, "bias2"); _dev(bias3, "bias3"); _dev(residual, "residual", torch.bfloat16)
     NB, H, W, CM = h1.shape
@@ -932,7 +933,12 @@ def bottleneck_tail_bf16(h1, frag2, bias2, frag3, bias3, residual):
         raise ValueError("bottleneck_tail_bf16: frag2 / frag3 must be pack_conv2d_frag_bf16 of [CM,CM,3,3] / [4CM,CM,1,1]")
     if bias2.shape != (CM,) or bias3.shape != (4 * CM,) or tuple(residual.shape) != (NB, H, W, 4 * CM):
         raise ValueError("bottleneck_tail_bf16: bias / residual shape mismatch")
-    out = torch.empty((NB, H, W, 4 * CM), dtype=torch.bfloat16, device=h1.device)
+    if out is None:
+        out = torch.empty((NB, H, W, 4 * CM), dtype=torch.bfloat16, device=h1.device)
+    else:
+        _dev(out, "out", torch.bfloat16)
+        if tuple(out.shape) != (NB, H, W, 4 * CM):
+            raise ValueError(f"bottleneck_tail_bf16: out must be {(NB, H, W, 4 * CM)}, got {tuple(out.shape)}")
     _abi.check(_abi.lib().tspn_bottleneck_tail_bf16(_p(h1), NB, H, W, CM, _p(frag2), _p(bias2), _p(frag3), _p(bias3),
                                                     _p(residual), _p(out), _stream()))
     return out

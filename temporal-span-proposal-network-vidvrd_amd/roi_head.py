@@ -107,11 +107,13 @@ class BottleneckBlock(nn.Module):
         return (self.fuse_tail and x.dtype == torch.bfloat16 and cm in (64, 128, 256) and c2.weight.shape[1] == cm
                 and c3.weight.shape[0] == 4 * cm and c2.kernel_size == 3 and c2.stride == 1 and c2.padding == 1)
 
-    def forward(self, x, presampled=False):
+    def forward(self, x, presampled=False, out=None):
         """`presampled`: x already holds only the pixels the strided 1x1 convs (conv1, shortcut) read -- every
-        `stride`-th row and column -- so they run with stride 1 (Res5RoIHead lets ROIAlign produce just those bins)."""
+        `stride`-th row and column -- so they run with stride 1 (Res5RoIHead lets ROIAlign produce just those bins).
+        `out`: where to write the block's result (a contiguous tensor of its shape; the fused bf16 tail writes into it
+        directly, the other paths copy)."""
         st = 1 if presampled else None
-        out = self.conv1(x, relu=True, stride=st)
+        h = self.conv1(x, relu=True, stride=st)
         if self.shortcut is not None:
             sc = self.shortcut(x, stride=st)
         elif self.stride == 1:
@@ -121,9 +123,12 @@ class BottleneckBlock(nn.Module):
         if self._can_fuse(x):
             f2, b2 = self.conv2.folded_bf16(x.device)
             f3, b3 = self.conv3.folded_bf16(x.device)
-            return ops.bottleneck_tail_bf16(out, f2, b2, f3, b3, sc.contiguous())
-        out = self.conv2(out, relu=True)
-        return self.conv3(out, residual=sc, relu=True)
+            return ops.bottleneck_tail_bf16(h, f2, b2, f3, b3, sc.contiguous(), out=out)
+        y = self.conv3(self.conv2(h, relu=True), residual=sc, relu=True)
+        if out is None:
+            return y
+        out.copy_(y)
+        return out
 
 
 class Res5RoIHead(_CachedWeightsMixin, nn.Module):
@@ -329,11 +334,24 @@ class ResNetC4(_CachedWeightsMixin, nn.Module):
             imgs = _f32(images, dev)
             for st in side:
                 st.wait_stream(main)
+            res4 = list(self.res4)
+            last = res4[-1]
+            direct = last.stride == 1          # its output has the shape of its input: the chunk's last block writes
+            res = None                         # its frames of the result directly (no torch.cat of the chunks)
             for k, lo in enumerate(range(0, images.shape[0], self.frame_chunk)):
                 with torch.cuda.stream(side[k % ns]):
                     x = self.stem(imgs[lo:lo + self.frame_chunk], out_bf16=bf16)
-                    out.append(self.res4(self.res3(self.res2(x))))
+                    x = self.res3(self.res2(x))
+                    if not direct:
+                        out.append(self.res4(x))
+                        continue
+                    for blk in res4[:-1]:
+                        x = blk(x)
+                    if res is None:
+                        with torch.cuda.stream(main):      # the caller's stream owns the result
+                            res = torch.empty((images.shape[0],) + tuple(x.shape[1:3]) + (last.conv3.weight.shape[0],),
+                                              dtype=x.dtype, device=dev)
+                    last(x, out=res[lo:lo + x.shape[0]])
             for st in side:
                 main.wait_stream(st)
-            res = torch.cat(out)               # on the caller's stream, after both side streams
-            return res
+            return res if direct else torch.cat(out)
