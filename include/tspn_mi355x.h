@@ -37,8 +37,10 @@ extern "C" {
  * canonical_pairs in round 1 without a bump; round 2 adds the struct-size exports below, which the
  * host checks against its own view of the descriptors at load time; 3: tspn_fused_desc.ev_logits_ready;
  * 4 (round 3): the Winograd F(2,3) and the three F(4,3) temporal-conv generations and their pack / repack
- * entry points are gone, tspn_fused_desc.conv_algo is TSPN_CONV_DIRECT | TSPN_CONV_WINOGRAD63).            */
-#define TSPN_ABI_VERSION 4
+ * entry points are gone, tspn_fused_desc.conv_algo is TSPN_CONV_DIRECT | TSPN_CONV_WINOGRAD63;
+ * 5 (round 3): tspn_pack_conv2d_frag_bf16 lays the fragments out channel chunk by chunk (was tap by tap) and
+ * the bf16 convolutions contract in that order; tspn_stem_pool_bf16 added).                                  */
+#define TSPN_ABI_VERSION 5
 
 enum {
   TSPN_OK = 0,
@@ -443,8 +445,10 @@ int tspn_conv2d_nhwc_cin4_f32(const float* x, int64_t NB, int64_t H, int64_t W, 
 /* bf16-operand form (tspn_roi_bf16.hip; v_mfma_f32_32x32x16_bf16): x, residual, out are bf16 (uint16_t
  * bit patterns), bias fp32; products exact, fp32 accumulation, act(acc + bias + residual) rounded to bf16
  * once (round to nearest even).  Weights: tspn_pack_conv2d_frag_bf16 rounds the fp32 (BN-folded) weight
- * once into  frag[Cout/32][KH*KW][Cin/64][4 ks][64 lanes = 32 kh + li][8 j] =
- * bf16(w[32 mb + li][64 c + 16 ks + 8 kh + j][tap]).  Needs Cin % 64 == 0, Cout % 32 == 0. */
+ * once into  frag[Cout/32][Cin/64][KH*KW][4 ks][64 lanes = 32 kh + li][8 j] =
+ * bf16(w[32 mb + li][64 c + 16 ks + 8 kh + j][tap])  (ABI 5: channel chunk outermost -- the contraction runs chunk by
+ * chunk, all taps of a chunk in a row, in tspn_conv2d_nhwc_bf16 and in tspn_bottleneck_tail_bf16 alike).
+ * Needs Cin % 64 == 0, Cout % 32 == 0. */
 int tspn_pack_conv2d_frag_bf16(const float* w, int64_t Cout, int64_t Cin, int64_t KH, int64_t KW,
                                uint16_t* frag, void* stream);
 int tspn_conv2d_nhwc_bf16(const uint16_t* x, int64_t NB, int64_t H, int64_t W, int64_t Cin,

@@ -59,7 +59,7 @@ __device__ __forceinline__ void wait_w(f32x4& r0, f32x4& r1) {
   asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r0), "+v"(r1) : "n"(VM));
 }
 template <int CM>
-__global__ __launch_bounds__(THREADS, (CM == 256 ? 2 : 3)) void bottleneck_bf16_kernel(
+__global__ __launch_bounds__(THREADS, (CM == 64 ? 3 : 2)) void bottleneck_bf16_kernel(
     const __bf16* __restrict__ h1, const __bf16* __restrict__ Wf2, const float* __restrict__ bias2,
     const __bf16* __restrict__ Wf3, const float* __restrict__ bias3, const __bf16* __restrict__ residual,
     __bf16* __restrict__ out, int H, int W, int64_t npix) {
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(THREADS, (CM == 256 ? 2 : 3)) void bottleneck_bf16_
         if (okn && oh - 1 + a >= 0 && oh - 1 + a < H && ow - 1 + b >= 0 && ow - 1 + b < W) tapmask |= 1u << (a * 3 + b);
   }
   auto stage_x = [&](int buf, int i) {             // exactly four pieces per wave
-    const int tap = i / CCH, c = i - tap * CCH;
+    const int c = i / 9, tap = i - c * 9;          // chunk order of conv2d_nhwc_bf16: channel chunk by chunk, its taps in a row
     const int ta = tap / 3, tb = tap - ta * 3;
     const bool valid = (tapmask >> tap) & 1u;
     const __bf16* xs = valid ? h1 + pbase + ((int64_t)ta * W + tb) * CM + c * KC + 8 * bg : g_zero_page_bt + 8 * bg;
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(THREADS, (CM == 256 ? 2 : 3)) void bottleneck_bf16_
     for (int mi = 0; mi < MI; ++mi) wbase[mi] += 4096;
   };
 
-  if constexpr (CM != 64) {
+  if constexpr (CM > 128) {
     static_assert(NCHUNKS > DIST, "ring prologue");
 #pragma unroll
     for (int i = 0; i < DIST; ++i) stage_x(i, i);
@@ -217,17 +217,17 @@ __global__ __launch_bounds__(THREADS, (CM == 256 ? 2 : 3)) void bottleneck_bf16_
       chunk_body(i, buf, std::false_type{}, std::false_type{});   // ends with a barrier: nobody reads the stages any more
     }
   } else {
-    // ---- CM = 64: one chunk per tap is only 8 MFMAs per wave -- a barrier, a DMA hand-over and an L2 round trip
-    // for the weights per 8 MFMAs left the MFMA pipe idle two thirds of phase 2 (109 us per 8 frames of 720p against
-    // 28 at the rate of the wide layers).  Here the operand of ALL nine taps is staged ONCE: tap (a, b) of pixel n is
-    // pixel n + (a - 1) W + (b - 1) of the channels-last map, so three LINEAR ranges of 130 pixels -- stage a =
-    // pixels n0 + (a - 1) W - 1 .. + 129 -- hold everything (same 16.9 KB per stage as a tap's chunk; slots 128, 129
-    // in a 768-byte side region, the DMA writes 64 consecutive slots per instruction); a tap reads its stage at a
-    // slot offset, and taps that fall off the image are zeroed AT THE READ by the lane's own tap mask (the ranges
-    // run across row and image boundaries).  One barrier, then 36 k-steps back to back; the weights stream through a
-    // ring of 12 k-steps = three taps of lookahead, counted vmcnt.
-    constexpr int RW = 12;
-    static_assert(NST >= 3 && MI == 2 && NI == 1 && WM == 1, "CM = 64 form");
+    // ---- CM <= 128: a chunk (64 channels of one tap) is only 8 / 16 MFMAs per wave -- a barrier, a DMA hand-over and
+    // an L2 round trip for the weights per chunk left the MFMA pipe idle most of phase 2 (CM = 64: 109 us per 8 frames
+    // of 720p against 28 at the rate of the wide layers).  Here the operand of ALL nine taps of a 64-channel half is
+    // staged ONCE: tap (a, b) of pixel n is pixel n + (a - 1) W + (b - 1) of the channels-last map, so three LINEAR
+    // ranges of 130 pixels -- stage a = pixels n0 + (a - 1) W - 1 .. + 129 -- hold everything (the same 16.9 KB per
+    // stage as a tap's chunk; slots 128, 129 in a 768-byte side region: the DMA writes 64 consecutive slots per
+    // instruction); a tap reads its stage at a slot offset, and taps that fall off the image are zeroed AT THE READ by
+    // the lane's own tap mask (the ranges run across row and image boundaries).  One barrier, then 36 k-steps back to
+    // back per half; the weights stream through a ring of RW k-steps, counted vmcnt.
+    constexpr int RW = CM == 64 ? 12 : 8;
+    static_assert(NST >= 3 && MI == 2, "once-staged form");
     char* const extra = Bs + 3 * B_ST;
     auto tap_mask = [&](int64_t n) {
       unsigned m = 0;
@@ -241,47 +241,43 @@ __global__ __launch_bounds__(THREADS, (CM == 256 ? 2 : 3)) void bottleneck_bf16_
           if (okn && oh - 1 + a >= 0 && oh - 1 + a < H && ow - 1 + b >= 0 && ow - 1 + b < W) m |= 1u << (a * 3 + b);
       return m;
     };
-    const unsigned rmask = tap_mask(n0 + wn * 32 + li);      // of the pixel this lane reads as its B column
+    unsigned rmask[NI];                                      // of the pixels this lane reads as its B columns
 #pragma unroll
-    for (int ra = 0; ra < 3; ++ra) {
-      const int64_t q = n0 + (int64_t)(ra - 1) * W - 1 + slot;
-      const __bf16* xs = (q >= 0 && q < npix) ? h1 + q * CM + 8 * bg : g_zero_page_bt + 8 * bg;
-      char* dst = Bs + ra * B_ST + (bg * SLP + 64 * (wave & 1)) * 16;
-#pragma unroll
-      for (int p = 0; p < 4; ++p) glds16(xs + 16 * p, dst + 2 * p * SLP * 16);
-    }
-    if (wave == 0 && lane < 48) {                            // slots 128, 129 of the three ranges: [range][group][2]
-      const int ra = lane >> 4, g = (lane >> 1) & 7, e = lane & 1;
-      const int64_t q = n0 + (int64_t)(ra - 1) * W - 1 + 128 + e;
-      const __bf16* xs = (q >= 0 && q < npix) ? h1 + q * CM + 8 * g : g_zero_page_bt + 8 * g;
-      glds16(xs, extra);                                     // the DMA adds lane * 16
-    }
+    for (int ni = 0; ni < NI; ++ni) rmask[ni] = tap_mask(n0 + (wn * NI + ni) * 32 + li);
     f32x4 aw[RW][MI];
-    const char* wl[MI] = {wbase[0], wbase[1]};
-    auto load_k = [&](auto j_tag) {                          // k-step j of the 36 into its ring slot
+    const char* wl[MI];
+    auto load_k = [&](auto j_tag) {                          // k-step j of the 36 of a half into its ring slot
       constexpr int j = decltype(j_tag)::value;
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) load_wfrag<1024 * (j % 4)>(aw[j % RW][mi], woff, wl[mi]);
       if constexpr (j % 4 == 3) {
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) wl[mi] += 4096;
+        for (int mi = 0; mi < MI; ++mi) wl[mi] += 4096;          // the next tap of this half
       }
     };
     auto step = [&](auto j_tag) {
       constexpr int j = decltype(j_tag)::value;
       constexpr int tap = j / 4, ks = j % 4, ra = tap / 3, rb = tap % 3;
-      // younger loads at this wait: the ring runs RW - 1 k-steps ahead until k-step 24 issued the last refill
-      constexpr int YOUNGER = MI * (RW - 1 - (j > 24 ? j - 24 : 0));
+      // younger loads at this wait: the ring runs RW - 1 k-steps ahead until k-step 36 - RW issued the last refill
+      constexpr int YOUNGER = MI * (RW - 1 - (j > 36 - RW ? j - (36 - RW) : 0));
       wait_w<YOUNGER>(aw[j % RW][0], aw[j % RW][1]);
-      const int g = 2 * ks + kh, sl = wn * 32 + li + rb;
-      const char* bp = Bs + ra * B_ST + (g * SLP + sl) * 16;
-      if (wn == 3 && sl >= 128) bp = extra + ((ra * 8 + g) * 2 + (sl - 128)) * 16;
-      f32x4 bv = *reinterpret_cast<const f32x4*>(bp);
-      if (!((rmask >> tap) & 1u)) bv = f32x4{0.f, 0.f, 0.f, 0.f};
-      const bf16x8 b = __builtin_bit_cast(bf16x8, bv);
+      const int g = 2 * ks + kh;
+      bf16x8 b[NI];
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-        acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aw[j % RW][mi]), b, acc[mi][0], 0, 0, 0);
+      for (int ni = 0; ni < NI; ++ni) {
+        const int sl = (wn * NI + ni) * 32 + li + rb;
+        const char* bp = Bs + ra * B_ST + (g * SLP + sl) * 16;
+        if ((wn * NI + ni) == 3 && sl >= 128) bp = extra + ((ra * 8 + g) * 2 + (sl - 128)) * 16;
+        f32x4 bv = *reinterpret_cast<const f32x4*>(bp);
+        if (!((rmask[ni] >> tap) & 1u)) bv = f32x4{0.f, 0.f, 0.f, 0.f};
+        b[ni] = __builtin_bit_cast(bf16x8, bv);
+      }
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const bf16x8 av = __builtin_bit_cast(bf16x8, aw[j % RW][mi]);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b[ni], acc[mi][ni], 0, 0, 0);
+      }
       if constexpr (j + RW < 36) load_k(std::integral_constant<int, j + RW>{});
     };
     auto four = [&](auto t_tag) {
@@ -291,17 +287,42 @@ __global__ __launch_bounds__(THREADS, (CM == 256 ? 2 : 3)) void bottleneck_bf16_
     };
     auto prologue = [&](auto t_tag) {
       constexpr int t = decltype(t_tag)::value;
-      load_k(std::integral_constant<int, 4 * t>{});     load_k(std::integral_constant<int, 4 * t + 1>{});
-      load_k(std::integral_constant<int, 4 * t + 2>{}); load_k(std::integral_constant<int, 4 * t + 3>{});
+      if constexpr (4 * t < RW) {
+        load_k(std::integral_constant<int, 4 * t>{});     load_k(std::integral_constant<int, 4 * t + 1>{});
+        load_k(std::integral_constant<int, 4 * t + 2>{}); load_k(std::integral_constant<int, 4 * t + 3>{});
+      }
     };
-    prologue(std::integral_constant<int, 0>{}); prologue(std::integral_constant<int, 1>{}); prologue(std::integral_constant<int, 2>{});
-    // the DMA pieces are OLDER than the 24 weight loads: in-order return makes this the wait for the staged ranges
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MI * RW) : "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    four(std::integral_constant<int, 0>{}); four(std::integral_constant<int, 1>{}); four(std::integral_constant<int, 2>{});
-    four(std::integral_constant<int, 3>{}); four(std::integral_constant<int, 4>{}); four(std::integral_constant<int, 5>{});
-    four(std::integral_constant<int, 6>{}); four(std::integral_constant<int, 7>{}); four(std::integral_constant<int, 8>{});
+    auto do_half = [&](auto half_tag) {
+      constexpr int half = decltype(half_tag)::value;
+      if constexpr (half > 0) __syncthreads();               // everybody has read the previous half's ranges
+#pragma unroll
+      for (int ra = 0; ra < 3; ++ra) {
+        const int64_t q = n0 + (int64_t)(ra - 1) * W - 1 + slot;
+        const __bf16* xs = (q >= 0 && q < npix) ? h1 + q * CM + half * KC + 8 * bg : g_zero_page_bt + 8 * bg;
+        char* dst = Bs + ra * B_ST + (bg * SLP + 64 * (wave & 1)) * 16;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) glds16(xs + 16 * p, dst + 2 * p * SLP * 16);
+      }
+      if (wave == 0 && lane < 48) {                          // slots 128, 129 of the three ranges: [range][group][2]
+        const int ra = lane >> 4, g = (lane >> 1) & 7, e = lane & 1;
+        const int64_t q = n0 + (int64_t)(ra - 1) * W - 1 + 128 + e;
+        const __bf16* xs = (q >= 0 && q < npix) ? h1 + q * CM + half * KC + 8 * g : g_zero_page_bt + 8 * g;
+        glds16(xs, extra);                                   // the DMA adds lane * 16
+      }
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) wl[mi] = wbase[mi] + half * (9 * 4096);
+      prologue(std::integral_constant<int, 0>{}); prologue(std::integral_constant<int, 1>{}); prologue(std::integral_constant<int, 2>{});
+      // the DMA pieces are OLDER than the MI RW weight loads: in-order return makes this the wait for the staged ranges
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MI * RW) : "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      four(std::integral_constant<int, 0>{}); four(std::integral_constant<int, 1>{}); four(std::integral_constant<int, 2>{});
+      four(std::integral_constant<int, 3>{}); four(std::integral_constant<int, 4>{}); four(std::integral_constant<int, 5>{});
+      four(std::integral_constant<int, 6>{}); four(std::integral_constant<int, 7>{}); four(std::integral_constant<int, 8>{});
+    };
+    do_half(std::integral_constant<int, 0>{});
+    if constexpr (CCH > 1) do_half(std::integral_constant<int, 1>{});
+    static_assert(CCH <= 2, "once-staged form: one or two 64-channel halves");
     __syncthreads();                                         // nobody reads the stages any more
   }
 
@@ -553,7 +574,7 @@ int launch(const uint16_t* h1, int64_t NB, int64_t H, int64_t W, const uint16_t*
   const int64_t tiles = tspn::ceil_div(npix, BN);
   TSPN_REQUIRE(tiles < (1LL << 31), TSPN_EUNSUPPORTED, "tspn_bottleneck_tail_bf16: grid too large");
   constexpr int nst = CM == 256 ? 4 : 3;
-  constexpr size_t smem = (size_t)(CM / KC > nst ? CM / KC : nst) * B_ST + (CM == 64 ? 1024 : 0);   // + slots 128, 129 (CM = 64 form)
+  constexpr size_t smem = (size_t)(CM / KC > nst ? CM / KC : nst) * B_ST + (CM <= 128 ? 1024 : 0);   // + slots 128, 129 (once-staged form)
   static tspn::LdsLimit lds;
   if (int rc = lds.ensure(reinterpret_cast<const void*>(bottleneck_bf16_kernel<CM>), smem, "tspn_bottleneck_tail_bf16"))
     return rc;

@@ -11,8 +11,11 @@
 //   * K chunk = 64 channels of one tap = four MFMA k-steps of 16 channels (16 MFMAs per wave and chunk);
 //     a pixel's 64 channels are one 128-byte line of x, staged as eight 16-byte pieces
 //     [8 channel groups][132 slots][8 bf16];
-//   * weights  Wf[Cout/32][tap][Cin/64][ks = 0..3][lane = 32 kh + li][8] = w[32 mb + li][64 c + 16 ks + 8 kh + j][tap]:
+//   * weights  Wf[Cout/32][Cin/64][tap][ks = 0..3][lane = 32 kh + li][8] = w[32 mb + li][64 c + 16 ks + 8 kh + j][tap]:
 //     one global_load_dwordx4 per lane and k-step, refilled for the next chunk right after the k-step's MFMAs.
+//     The contraction runs in THIS order -- 64-channel chunk by chunk, all taps of a chunk in a row (chunk i = tap
+//     i % taps of channels 64 (i / taps) ..) -- so that the fused bottleneck tail, which stages all nine taps of a
+//     64-channel half at once (tspn_bottleneck_bf16.hip), adds the same products in the same order.
 //   * MI = 32-row blocks per wave (template): MI = 2 (tile 256 x 128, Cout % 64 == 0) shares every x fragment
 //     between two weight fragments -- 0.5 instead of 1 LDS fragment read per MFMA, which is what bounds
 //     the MI = 1 kernel (8 waves x 16 KB of ds_read_b128 per chunk against 1024 MFMA cycles per SIMD).
@@ -55,7 +58,7 @@ __device__ __forceinline__ void wait_w(f32x4& r0, f32x4& r1) {
   asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r0), "+v"(r1) : "n"(VM));
 }
 
-// w fp32 [Cout][Cin][KH][KW] -> bf16 fragment-major [Cout/32][taps][Cin/64][4][64][8]
+// w fp32 [Cout][Cin][KH][KW] -> bf16 fragment-major [Cout/32][Cin/64][taps][4][64][8]
 __global__ void pack_conv2d_frag_bf16_kernel(const float* __restrict__ w, int64_t Cout, int64_t Cin, int64_t ntaps,
                                              __bf16* __restrict__ packed) {
   const int64_t total = ntaps * Cin * Cout;
@@ -64,7 +67,7 @@ __global__ void pack_conv2d_frag_bf16_kernel(const float* __restrict__ w, int64_
        o += (int64_t)gridDim.x * blockDim.x) {
     const int j = (int)(o & 7), lane = (int)((o >> 3) & 63), ks = (int)((o >> 9) & 3);
     const int64_t q = o >> 11;
-    const int64_t c = q % cch, tap = (q / cch) % ntaps, mb = q / (cch * ntaps);
+    const int64_t tap = q % ntaps, c = (q / ntaps) % cch, mb = q / (cch * ntaps);
     const int64_t co = 32 * mb + (lane & 31), ci = KC * c + 16 * ks + 8 * (lane >> 5) + j;
     packed[o] = (__bf16)w[(co * Cin + ci) * ntaps + tap];
   }
@@ -132,7 +135,8 @@ __global__ __launch_bounds__(THREADS, (MI == 1 ? TSPN_ROI_BF16_MI1_WAVES : 2)) v
         if (okn && ih0 + a >= 0 && ih0 + a < H && iw0 + b >= 0 && iw0 + b < W) tapmask |= 1ull << (a * KW + b);
   }
   auto stage_x = [&](int buf, int i) {             // exactly four pieces per wave
-    const int tap = i / cchunks, c = i - tap * cchunks;
+    const int ntaps = KH * KW;
+    const int c = i / ntaps, tap = i - c * ntaps;
     const int ta = tap / KW, tb = tap - ta * KW;
     const bool valid = (tapmask >> tap) & 1ull;
     const __bf16* xs = valid ? x + pbase + ((int64_t)ta * W + tb) * Cin + c * KC + 8 * bg : g_zero_page_bf16 + 8 * bg;

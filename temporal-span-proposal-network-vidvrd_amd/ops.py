@@ -874,7 +874,7 @@ def pack_conv2d_frag_bf16(weight):
     Cout, Cin, KH, KW = weight.shape
     if Cout % 32 or Cin % 64:
         raise ValueError(f"pack_conv2d_frag_bf16: needs Cout % 32 == 0 and Cin % 64 == 0 (Cout={Cout}, Cin={Cin})")
-    frag = torch.empty((Cout // 32, KH * KW, Cin // 64, 4, 64, 8), dtype=torch.bfloat16, device=weight.device)
+    frag = torch.empty((Cout // 32, Cin // 64, KH * KW, 4, 64, 8), dtype=torch.bfloat16, device=weight.device)
     _abi.check(_abi.lib().tspn_pack_conv2d_frag_bf16(_p(weight), Cout, Cin, KH, KW, _p(frag), _stream()))
     return frag
 
@@ -886,7 +886,7 @@ def conv2d_nhwc_bf16(x, frag, kernel_size, stride=1, padding=0, bias=None, resid
     _dev(x, "x", torch.bfloat16); _dev(frag, "frag", torch.bfloat16)
     NB, H, W, Cin = x.shape
     KH, KW = kernel_size
-    if frag.dim() != 6 or tuple(frag.shape[1:]) != (KH * KW, Cin // 64, 4, 64, 8) or Cin % 64:
+    if frag.dim() != 6 or tuple(frag.shape[1:]) != (Cin // 64, KH * KW, 4, 64, 8) or Cin % 64:
         raise ValueError(f"conv2d_nhwc_bf16: weights {tuple(frag.shape)} do not match taps={KH * KW}, Cin={Cin}")
     Cout = frag.shape[0] * 32
     OH, OW = (H + 2 * padding - KH) // stride + 1, (W + 2 * padding - KW) // stride + 1
@@ -929,7 +929,7 @@ def bottleneck_tail_bf16(h1, frag2, bias2, frag3, bias3, residual, out=None):
     NB, H, W, CM = h1.shape
     if CM not in (64, 128, 256):
         raise ValueError(f"bottleneck_tail_bf16: bottleneck channels must be 64, 128 or 256 (got {CM})")
-    if tuple(frag2.shape) != (CM // 32, 9, CM // 64, 4, 64, 8) or tuple(frag3.shape) != (CM // 8, 1, CM // 64, 4, 64, 8):
+    if tuple(frag2.shape) != (CM // 32, CM // 64, 9, 4, 64, 8) or tuple(frag3.shape) != (CM // 8, CM // 64, 1, 4, 64, 8):
         raise ValueError("bottleneck_tail_bf16: frag2 / frag3 must be pack_conv2d_frag_bf16 of [CM,CM,3,3] / [4CM,CM,1,1]")
     if bias2.shape != (CM,) or bias3.shape != (4 * CM,) or tuple(residual.shape) != (NB, H, W, 4 * CM):
         raise ValueError("bottleneck_tail_bf16: bias / residual shape mismatch")

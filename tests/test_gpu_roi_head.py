@@ -153,8 +153,8 @@ def test_conv2d_nhwc_bf16_vs_fp64(tspn, device, NB, H, W, Cin, Cout, k, stride, 
     if fused:
         ref = torch.relu(ref + res.double())
     frag = tspn.ops.pack_conv2d_frag_bf16(t(w).to(device))
-    want = wb.view(torch.int16).numpy().reshape(Cout // 32, 32, Cin // 64, 4, 2, 8, k * k).transpose(0, 6, 2, 3, 4, 1, 5)
-    np.testing.assert_array_equal(frag.cpu().view(torch.int16).numpy().reshape(Cout // 32, k * k, Cin // 64, 4, 2, 32, 8), want)
+    want = wb.view(torch.int16).numpy().reshape(Cout // 32, 32, Cin // 64, 4, 2, 8, k * k).transpose(0, 2, 6, 3, 4, 1, 5)
+    np.testing.assert_array_equal(frag.cpu().view(torch.int16).numpy().reshape(Cout // 32, Cin // 64, k * k, 4, 2, 32, 8), want)
     y = tspn.ops.conv2d_nhwc_bf16(xb.to(device), frag, (k, k), stride, pad, bias=t(b).to(device) if fused else None,
                                   residual=res.to(device) if fused else None, relu=fused)
     assert y.dtype == torch.bfloat16 and tuple(y.shape) == tuple(ref.shape)
