@@ -130,8 +130,13 @@ __global__ __launch_bounds__(THREADS, (CM == 64 ? 3 : 2)) void bottleneck_bf16_k
 
   f32x4 a[4][MI];      // weight fragments of the four k-steps of a chunk
   auto read_b = [&](const char* Bb, int g2, bf16x8 (&b)[NI]) {   // fragments of channel groups g2 + kh of NI pixel blocks
+#if defined(TSPN_BT_ABL_NOB)        // probe build: no LDS fragment reads in phase 2 (registers keep whatever they hold)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) asm volatile("" : "+v"(b[ni]));
+#else
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const bf16x8*>(Bb + (g2 * SLP + ni * 32) * 16);
+#endif
   };
   auto mfma_step = [&](f32x16 (&c)[MI][NI], const f32x4 (&aw)[MI], const bf16x8 (&b)[NI]) {
 #pragma unroll
@@ -151,8 +156,10 @@ __global__ __launch_bounds__(THREADS, (CM == 64 ? 3 : 2)) void bottleneck_bf16_k
   using K2 = std::integral_constant<int, 2>;
   using K3 = std::integral_constant<int, 3>;
   auto bump = [&]() {
+#if !defined(TSPN_BT_ABL_NOBUMP)    // probe build: every chunk loads the first chunk's weights (L1-hot)
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) wbase[mi] += 4096;
+#endif
   };
 
   if constexpr (CM > 128) {
@@ -174,9 +181,13 @@ __global__ __launch_bounds__(THREADS, (CM == 64 ? 3 : 2)) void bottleneck_bf16_k
       constexpr bool STAGE = decltype(stage_tag)::value, MORE = decltype(more_tag)::value;
       constexpr int NX = STAGE ? 4 : 0, R = MORE ? MI : 0, L = MI;
       const char* Bb = Bs + buf * B_ST + bofs;
-      bf16x8 b0[NI], b1[NI];
+      bf16x8 b0[NI] = {}, b1[NI] = {};
       wait_w<3 * L>(a[0][0], a[0][1]);
+#if defined(TSPN_BT_ABL_NOX)        // probe build: the x ring is refilled from the first chunks' addresses (L2-hot)
+      if (STAGE) stage_x(buf >= 1 ? buf - 1 : NST - 1, (i + DIST) % DIST);
+#else
       if (STAGE) stage_x(buf >= 1 ? buf - 1 : NST - 1, i + DIST);      // the stage chunk i - 1 has just left
+#endif
       __builtin_amdgcn_sched_barrier(0);
       read_b(Bb, 0, b0);
       read_b(Bb, 2, b1);
