@@ -441,10 +441,13 @@ def test_roi_align_bin_stride_and_presampled_first_block(tspn, device):
         assert torch.equal(a, b)
 
 
-def test_backbone_and_roi_head_on_two_streams_equal_one(tspn, device):
+@pytest.mark.parametrize("blocks", [(1, 1, 2), (1, 1, 1)])
+def test_backbone_and_roi_head_on_two_streams_equal_one(tspn, device, blocks):
     """ResNetC4.streams / Res5RoIHead.streams: chunks alternating between HIP streams give the same maps and features
-    as one stream, bit for bit, also when the caller itself works on a non-default stream."""
-    net, _ = _backbone_and_weights(tspn, device, 64, 256, (1, 1, 2))
+    as one stream, bit for bit, also when the caller itself works on a non-default stream.  With more than one res4
+    block every chunk's last block writes its frames of the result in place (bf16: the fused tail's `out`; fp32: a
+    copy); a one-block res4 (its only block strided) takes the concatenating path."""
+    net, _ = _backbone_and_weights(tspn, device, 64, 256, blocks)
     net.frame_chunk = 2
     img = t(tspn.hashrng.uniform(96, "img", (7, 64, 96, 3), -1, 1)).to(device)
     head = tspn.Res5RoIHead(1024, 128, 512, roi_chunk=5).to(device)
