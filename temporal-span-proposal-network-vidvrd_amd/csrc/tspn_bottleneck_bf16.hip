@@ -56,7 +56,11 @@ __device__ __forceinline__ void load_wfrag(f32x4& dst, unsigned lane_off, const 
 }
 template <int VM>
 __device__ __forceinline__ void wait_w(f32x4& r0, f32x4& r1) {
+#if defined(TSPN_BT_ABL_NOWAIT)     // probe build: no counted waits in phase 2
+  asm volatile("" : "+v"(r0), "+v"(r1));
+#else
   asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r0), "+v"(r1) : "n"(VM));
+#endif
 }
 template <int CM>
 __global__ __launch_bounds__(THREADS, (CM == 64 ? 3 : 2)) void bottleneck_bf16_kernel(
@@ -148,8 +152,12 @@ __global__ __launch_bounds__(THREADS, (CM == 64 ? 3 : 2)) void bottleneck_bf16_k
   };
   auto load_step = [&](auto ks_tag) {
     constexpr int KS = decltype(ks_tag)::value;
+#if defined(TSPN_BT_ABL_NOLOAD)     // probe build: the weight registers keep what the prologue loaded
+    (void)KS;
+#else
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) load_wfrag<1024 * KS>(a[KS][mi], woff, wbase[mi]);
+#endif
   };
   using K0 = std::integral_constant<int, 0>;
   using K1 = std::integral_constant<int, 1>;
@@ -162,45 +170,105 @@ __global__ __launch_bounds__(THREADS, (CM == 64 ? 3 : 2)) void bottleneck_bf16_k
 #endif
   };
 
-  if constexpr (CM > 128) {
-    static_assert(NCHUNKS > DIST, "ring prologue");
+#ifndef TSPN_BT_ONCE_MAX
+#define TSPN_BT_ONCE_MAX 128       // largest CM that takes the once-staged form of phase 2 (probe knob)
+#endif
+  if constexpr (CM > TSPN_BT_ONCE_MAX) {
+    // ---- CM = 256: a ring of linear RANGES.  Tap (a, b) of pixel n is pixel n + (a - 1) W + (b - 1) of the
+    // channels-last map, so ONE staged range -- pixels n0 + (a - 1) W - 1 .. + 129 of a 64-channel part -- serves the
+    // three taps (a, 0..2) at slot offsets 0..2: a chunk of the ring is a range = 12 k-steps = 96 MFMAs per wave, a
+    // tile streams 12 ranges (203 KB) instead of 36 tap chunks (576 KB) through the LDS-DMA and meets at 12 barriers
+    // instead of 36 (probe builds: the x DMA cost 13 of the phase's 80 us per 16 frames, profiles/r3/
+    // bottleneck_tail_ablation.md).  Slots 128, 129 of a range live in a 256-byte side region per stage; taps that fall
+    // off the image are zeroed AT THE READ by the lane's own tap mask (a range runs across row and image boundaries).
+    // Same contraction order as before: channel part by part, its nine taps in a row.
+    constexpr int NRNG = 3 * CCH;
+    static_assert(NRNG > DIST && NI == 4 && WN == 1, "range ring");
+    char* const extra = Bs + NST * B_ST;                     // [stage][8 groups][2 slots] x 16 B
+    auto tap_mask = [&](int64_t n) {
+      unsigned m = 0;
+      const bool okn = n < npix;
+      const int64_t nc = okn ? n : 0;
+      const int64_t nb = nc / ((int64_t)H * W);
+      const int r = (int)(nc - nb * H * W);
+      const int oh = r / W, ow = r - oh * W;
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b)
+          if (okn && oh - 1 + a >= 0 && oh - 1 + a < H && ow - 1 + b >= 0 && ow - 1 + b < W) m |= 1u << (a * 3 + b);
+      return m;
+    };
+    unsigned rmask[NI];                                      // of the pixels this lane reads as its B columns
 #pragma unroll
-    for (int i = 0; i < DIST; ++i) stage_x(i, i);
+    for (int ni = 0; ni < NI; ++ni) rmask[ni] = tap_mask(n0 + ni * 32 + li);
+    auto stage_r = [&](int buf, int i) {                     // range i = 3 c + ra: four pieces per wave (+ one: wave 0)
+#if defined(TSPN_BT_ABL_NODMA)      // probe build: no x DMA in the loop at all
+      if (i >= DIST) return;
+#endif
+      const int c = i / 3, ra = i - 3 * c;
+      const int64_t q = n0 + (int64_t)(ra - 1) * W - 1 + slot;
+      const __bf16* xs = (q >= 0 && q < npix) ? h1 + q * CM + c * KC + 8 * bg : g_zero_page_bt + 8 * bg;
+      char* dst = Bs + buf * B_ST + (bg * SLP + 64 * (wave & 1)) * 16;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) glds16(xs + 16 * p, dst + 2 * p * SLP * 16);
+      if (wave == 0 && lane < 16) {                          // slots 128, 129: [group][2]
+        const int g = lane >> 1, e = lane & 1;
+        const int64_t q2 = n0 + (int64_t)(ra - 1) * W - 1 + 128 + e;
+        const __bf16* xs2 = (q2 >= 0 && q2 < npix) ? h1 + q2 * CM + c * KC + 8 * g : g_zero_page_bt + 8 * g;
+        glds16(xs2, extra + buf * 256);                      // the DMA adds lane * 16
+      }
+    };
+#pragma unroll
+    for (int i = 0; i < DIST; ++i) stage_r(i, i);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     load_step(K0{}); load_step(K1{}); load_step(K2{}); load_step(K3{});
     bump();
     __builtin_amdgcn_sched_barrier(0);
 
-    // lane's fragment base inside a stage: slot = pixel block offset + li, channel-group half kh
-    const int bofs = ((kh * SLP) + wn * NI * 32 + li) * 16;
-    // chunk i.  VMEM issue order: [x_{i+DIST}: 4 pieces] a0' | a1' | a2' | a3' (MI loads each, the weights of chunk
-    // i + 1); counts = YOUNGER operations at each wait.  x_{i+1} was requested DIST - 1 >= 1 chunks ago, BEFORE the
-    // weights of this chunk: in-order VMEM return makes the wait for a3 of this chunk the wait for x_{i+1} as well.
-    auto chunk_body = [&](int i, int buf, auto stage_tag, auto more_tag) {
-      constexpr bool STAGE = decltype(stage_tag)::value, MORE = decltype(more_tag)::value;
+    // fragment of channel groups g2 + kh of the NI pixel blocks at slot offset rb of a stage, masked by tap 3 ra + rb
+    auto read_r = [&](int buf, int tap, int rb, int g2, bf16x8 (&b)[NI]) {
+#if defined(TSPN_BT_ABL_NOB)        // probe build: no LDS fragment reads in phase 2
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) asm volatile("" : "+v"(b[ni]));
+      (void)buf; (void)tap; (void)rb; (void)g2;
+#else
+      const char* Bb = Bs + buf * B_ST + ((g2 + kh) * SLP + li + rb) * 16;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const char* bp = Bb + ni * 32 * 16;
+        if (ni == 3) bp = (li + rb >= 32) ? extra + buf * 256 + ((g2 + kh) * 2 + (li + rb - 32)) * 16 : bp;
+        f32x4 bv = *reinterpret_cast<const f32x4*>(bp);
+        if (!((rmask[ni] >> tap) & 1u)) bv = f32x4{0.f, 0.f, 0.f, 0.f};
+        b[ni] = __builtin_bit_cast(bf16x8, bv);
+      }
+#endif
+    };
+    // one round = the four k-steps of tap (ra, rb) of range i.  VMEM issue order as in the tap ring: [range i + DIST:
+    // 4 pieces, first round only] a0' | a1' | a2' | a3' (MI loads each, the weights four k-steps ahead); counts =
+    // YOUNGER operations at each wait (wave 0 issues one piece more: its waits are one operation stricter than needed).
+    // The range requested DIST - 1 >= 1 ranges ago precedes every weight load of this range: in-order VMEM return makes
+    // any of these waits the wait for it as well.
+    auto round_body = [&](int i, int buf, int ra, auto rb_tag, auto stage_tag, auto more_tag, auto last_tag) {
+      constexpr int rb = decltype(rb_tag)::value;
+      constexpr bool STAGE = decltype(stage_tag)::value, MORE = decltype(more_tag)::value, LAST = decltype(last_tag)::value;
       constexpr int NX = STAGE ? 4 : 0, R = MORE ? MI : 0, L = MI;
-      const char* Bb = Bs + buf * B_ST + bofs;
+      const int tap = 3 * ra + rb;
       bf16x8 b0[NI] = {}, b1[NI] = {};
       wait_w<3 * L>(a[0][0], a[0][1]);
-#if defined(TSPN_BT_ABL_NOX)        // probe build: the x ring is refilled from the first chunks' addresses (L2-hot)
-      if (STAGE) stage_x(buf >= 1 ? buf - 1 : NST - 1, (i + DIST) % DIST);
-#else
-      if (STAGE) stage_x(buf >= 1 ? buf - 1 : NST - 1, i + DIST);      // the stage chunk i - 1 has just left
-#endif
+      if (STAGE) stage_r(buf >= 1 ? buf - 1 : NST - 1, i + DIST);      // the stage range i - 1 has just left
       __builtin_amdgcn_sched_barrier(0);
-      read_b(Bb, 0, b0);
-      read_b(Bb, 2, b1);
+      read_r(buf, tap, rb, 0, b0);
+      read_r(buf, tap, rb, 2, b1);
       mfma_step(acc, a[0], b0);
       if (MORE) load_step(K0{});
       __builtin_amdgcn_sched_barrier(0);
       wait_w<2 * L + NX + R>(a[1][0], a[1][1]);
-      read_b(Bb, 4, b0);
+      read_r(buf, tap, rb, 4, b0);
       mfma_step(acc, a[1], b1);
       if (MORE) load_step(K1{});
       __builtin_amdgcn_sched_barrier(0);
       wait_w<L + NX + 2 * R>(a[2][0], a[2][1]);
-      read_b(Bb, 6, b1);
+      read_r(buf, tap, rb, 6, b1);
       mfma_step(acc, a[2], b0);
       if (MORE) load_step(K2{});
       __builtin_amdgcn_sched_barrier(0);
@@ -208,24 +276,38 @@ __global__ __launch_bounds__(THREADS, (CM == 64 ? 3 : 2)) void bottleneck_bf16_k
       mfma_step(acc, a[3], b1);
       if (MORE) { load_step(K3{}); bump(); }
       __builtin_amdgcn_sched_barrier(0);
-      // every LDS read of this chunk has returned; x_{i+1} landed with a3 (see above); the last chunk drains everything
-      if (MORE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
+      if (LAST) {      // every LDS read of this range has returned; the next range has landed (see above)
+        if (MORE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
     };
+    using T = std::true_type;
+    using F = std::false_type;
+    using R0 = std::integral_constant<int, 0>;
+    using R1 = std::integral_constant<int, 1>;
+    using R2 = std::integral_constant<int, 2>;
     {
-      int buf = 0;
+      int buf = 0, ra = 0;
       int i = 0;
-      for (; i + DIST < NCHUNKS; ++i) {
-        chunk_body(i, buf, std::true_type{}, std::true_type{});
+      for (; i + DIST < NRNG; ++i) {
+        round_body(i, buf, ra, R0{}, T{}, T{}, F{});
+        round_body(i, buf, ra, R1{}, F{}, T{}, F{});
+        round_body(i, buf, ra, R2{}, F{}, T{}, T{});
         buf = buf + 1 == NST ? 0 : buf + 1;
+        ra = ra == 2 ? 0 : ra + 1;
       }
-      for (; i + 1 < NCHUNKS; ++i) {
-        chunk_body(i, buf, std::false_type{}, std::true_type{});
+      for (; i + 1 < NRNG; ++i) {
+        round_body(i, buf, ra, R0{}, F{}, T{}, F{});
+        round_body(i, buf, ra, R1{}, F{}, T{}, F{});
+        round_body(i, buf, ra, R2{}, F{}, T{}, T{});
         buf = buf + 1 == NST ? 0 : buf + 1;
+        ra = ra == 2 ? 0 : ra + 1;
       }
-      chunk_body(i, buf, std::false_type{}, std::false_type{});   // ends with a barrier: nobody reads the stages any more
+      round_body(i, buf, ra, R0{}, F{}, T{}, F{});
+      round_body(i, buf, ra, R1{}, F{}, T{}, F{});
+      round_body(i, buf, ra, R2{}, F{}, F{}, T{});            // ends with a barrier: nobody reads the stages any more
     }
   } else {
     // ---- CM <= 128: a chunk (64 channels of one tap) is only 8 / 16 MFMAs per wave -- a barrier, a DMA hand-over and
@@ -237,7 +319,7 @@ __global__ __launch_bounds__(THREADS, (CM == 64 ? 3 : 2)) void bottleneck_bf16_k
     // instruction); a tap reads its stage at a slot offset, and taps that fall off the image are zeroed AT THE READ by
     // the lane's own tap mask (the ranges run across row and image boundaries).  One barrier, then 36 k-steps back to
     // back per half; the weights stream through a ring of RW k-steps, counted vmcnt.
-    constexpr int RW = CM == 64 ? 12 : 8;
+    constexpr int RW = CM == 64 ? 12 : (CM == 128 ? 8 : 4);
     static_assert(NST >= 3 && MI == 2, "once-staged form");
     char* const extra = Bs + 3 * B_ST;
     auto tap_mask = [&](int64_t n) {
@@ -333,7 +415,8 @@ __global__ __launch_bounds__(THREADS, (CM == 64 ? 3 : 2)) void bottleneck_bf16_k
     };
     do_half(std::integral_constant<int, 0>{});
     if constexpr (CCH > 1) do_half(std::integral_constant<int, 1>{});
-    static_assert(CCH <= 2, "once-staged form: one or two 64-channel halves");
+    if constexpr (CCH > 2) { do_half(std::integral_constant<int, 2>{}); do_half(std::integral_constant<int, 3>{}); }
+    static_assert(CCH <= 4, "once-staged form: up to four 64-channel parts");
     __syncthreads();                                         // nobody reads the stages any more
   }
 
@@ -585,7 +668,7 @@ int launch(const uint16_t* h1, int64_t NB, int64_t H, int64_t W, const uint16_t*
   const int64_t tiles = tspn::ceil_div(npix, BN);
   TSPN_REQUIRE(tiles < (1LL << 31), TSPN_EUNSUPPORTED, "tspn_bottleneck_tail_bf16: grid too large");
   constexpr int nst = CM == 256 ? 4 : 3;
-  constexpr size_t smem = (size_t)(CM / KC > nst ? CM / KC : nst) * B_ST + (CM <= 128 ? 1024 : 0);   // + slots 128, 129 (once-staged form)
+  constexpr size_t smem = (size_t)(CM / KC > nst ? CM / KC : nst) * B_ST + 1024;   // + slots 128, 129 (once-staged form)
   static tspn::LdsLimit lds;
   if (int rc = lds.ensure(reinterpret_cast<const void*>(bottleneck_bf16_kernel<CM>), smem, "tspn_bottleneck_tail_bf16"))
     return rc;
