@@ -77,14 +77,19 @@ __global__ void pack_conv2d_frag_bf16_kernel(const float* __restrict__ w, int64_
 #ifndef TSPN_ROI_BF16_MI1_WAVES
 #define TSPN_ROI_BF16_MI1_WAVES 3
 #endif
-template <int MI>
+// RNG (3x3 / stride 1 / pad 1 only): the x stages are LINEAR RANGES instead of tap chunks -- tap (a, b) of output pixel
+// n is input pixel n + (a - 1) W + (b - 1), so one staged range (pixels n0 + (a - 1) W - 1 .. + 129 of a 64-channel
+// part) serves the three taps (a, 0..2) at slot offsets 0..2: a third of the DMA volume and of the barriers; slots
+// 128, 129 in a 256-byte side region per stage; taps off the image are zeroed at the read by the lane's tap mask.
+// Same contraction order (tspn_bottleneck_bf16.hip does the same: the two stay bit-identical).
+template <int MI, bool RNG>
 __global__ __launch_bounds__(THREADS, (MI == 1 ? TSPN_ROI_BF16_MI1_WAVES : 2)) void conv2d_nhwc_bf16_kernel(
     const __bf16* __restrict__ x, const __bf16* __restrict__ Wf, const float* __restrict__ bias,
     const __bf16* __restrict__ residual, __bf16* __restrict__ out, int H, int W, int Cin, int Cout, int KH,
     int KW, int stride, int pad, int OH, int OW, int64_t npix, int tiles_m, int tiles_n, int relu) {
   constexpr int BM = 128 * MI;
   constexpr int EPI_BYTES = 4 * 32 * (32 * MI + 4) * 4;   // epilogue transpose: 4 waves x 32 pixels x padded row
-  __shared__ __attribute__((aligned(16))) char Bs[2 * B_ST > EPI_BYTES ? 2 * B_ST : EPI_BYTES];
+  __shared__ __attribute__((aligned(16))) char Bs[2 * B_ST + 512 > EPI_BYTES ? 2 * B_ST + 512 : EPI_BYTES];
 
   const int nwg = gridDim.x;
   const int bid = blockIdx.x;
@@ -186,6 +191,108 @@ __global__ __launch_bounds__(THREADS, (MI == 1 ? TSPN_ROI_BF16_MI1_WAVES : 2)) v
     for (int mi = 0; mi < MI; ++mi) wbase[mi] += 4096;
   };
 
+  if constexpr (RNG) {
+    char* const extra = Bs + 2 * B_ST;                       // [stage][8 groups][2 slots] x 16 B
+    unsigned rmask[4];                                       // tap masks of the pixels this lane reads as its B columns
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int64_t n = n0 + ni * 32 + li;
+      const bool okn = n < npix;
+      const int64_t nc = okn ? n : 0;
+      const int64_t nb = nc / ((int64_t)OH * OW);
+      const int r = (int)(nc - nb * OH * OW);
+      const int oh = r / OW, ow = r - oh * OW;
+      unsigned m = 0;
+      for (int ta = 0; ta < 3; ++ta)
+        for (int tb = 0; tb < 3; ++tb)
+          if (okn && oh - 1 + ta >= 0 && oh - 1 + ta < H && ow - 1 + tb >= 0 && ow - 1 + tb < W) m |= 1u << (ta * 3 + tb);
+      rmask[ni] = m;
+    }
+    const int64_t npin = npix;                               // stride 1, pad 1: input pixels = output pixels
+    auto stage_r = [&](int buf, int i) {                     // range i = 3 c + ra
+      const int c = i / 3, ra = i - 3 * c;
+      const int64_t q = n0 + (int64_t)(ra - 1) * W - 1 + slot;
+      const __bf16* xs = (q >= 0 && q < npin) ? x + q * Cin + c * KC + 8 * bg : g_zero_page_bf16 + 8 * bg;
+      char* dst = Bs + buf * B_ST + (bg * SLP + 64 * (wave & 1)) * 16;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) glds16(xs + 16 * p, dst + 2 * p * SLP * 16);
+      if (wave == 0 && lane < 16) {                          // slots 128, 129: [group][2]
+        const int g = lane >> 1, e = lane & 1;
+        const int64_t q2 = n0 + (int64_t)(ra - 1) * W - 1 + 128 + e;
+        const __bf16* xs2 = (q2 >= 0 && q2 < npin) ? x + q2 * Cin + c * KC + 8 * g : g_zero_page_bf16 + 8 * g;
+        glds16(xs2, extra + buf * 256);                      // the DMA adds lane * 16
+      }
+    };
+    auto read_r = [&](int buf, int tap, int rb, int ks, bf16x8 (&b)[4]) {
+      const char* Bb = Bs + buf * B_ST + ((2 * ks + kh) * SLP + li + rb) * 16;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const char* bp = Bb + ni * 32 * 16;
+        if (ni == 3) bp = (li + rb >= 32) ? extra + buf * 256 + ((2 * ks + kh) * 2 + (li + rb - 32)) * 16 : bp;
+        f32x4 bv = *reinterpret_cast<const f32x4*>(bp);
+        if (!((rmask[ni] >> tap) & 1u)) bv = f32x4{0.f, 0.f, 0.f, 0.f};
+        b[ni] = __builtin_bit_cast(bf16x8, bv);
+      }
+    };
+    const int nrng = 3 * cchunks;
+    stage_r(0, 0);
+    __syncthreads();
+    load_step(K0{}); load_step(K1{}); load_step(K2{}); load_step(K3{});
+    bump();
+    __builtin_amdgcn_sched_barrier(0);
+    // one round = the four k-steps of tap (ra, rb) of range i; VMEM issue order and counts as in chunk_body below, the
+    // x pieces (4; wave 0 issues 5: its waits are one operation stricter than needed) only in the first round
+    auto round_body = [&](int i, int ra, auto rb_tag, auto stage_tag, auto more_tag, auto last_tag) {
+      constexpr int rb = decltype(rb_tag)::value;
+      constexpr bool STAGE = decltype(stage_tag)::value, MORE = decltype(more_tag)::value, LAST = decltype(last_tag)::value;
+      constexpr int NX = STAGE ? 4 : 0, R = MORE ? MI : 0, L = MI;
+      const int buf = i & 1, tap = 3 * ra + rb;
+      bf16x8 b0[4], b1[4];
+      wait_step(std::integral_constant<int, 3 * L>{}, 0);
+      if (STAGE) stage_r(buf ^ 1, i + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      read_r(buf, tap, rb, 0, b0);
+      read_r(buf, tap, rb, 1, b1);
+      mfma_step(a[0], b0);
+      if (MORE) load_step(K0{});
+      __builtin_amdgcn_sched_barrier(0);
+      wait_step(std::integral_constant<int, 2 * L + NX + R>{}, 1);
+      read_r(buf, tap, rb, 2, b0);
+      mfma_step(a[1], b1);
+      if (MORE) load_step(K1{});
+      __builtin_amdgcn_sched_barrier(0);
+      wait_step(std::integral_constant<int, L + NX + 2 * R>{}, 2);
+      read_r(buf, tap, rb, 3, b1);
+      mfma_step(a[2], b0);
+      if (MORE) load_step(K2{});
+      __builtin_amdgcn_sched_barrier(0);
+      wait_step(std::integral_constant<int, NX + 3 * R>{}, 3);
+      mfma_step(a[3], b1);
+      if (MORE) { load_step(K3{}); bump(); }
+      __builtin_amdgcn_sched_barrier(0);
+      if (LAST) {      // the next range has landed (older than the weight loads in flight), every LDS read has returned
+        if (MORE) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * MI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    using R0 = std::integral_constant<int, 0>;
+    using R1 = std::integral_constant<int, 1>;
+    using R2 = std::integral_constant<int, 2>;
+    int ra = 0;
+    for (int i = 0; i + 1 < nrng; ++i) {
+      round_body(i, ra, R0{}, T{}, T{}, F{});
+      round_body(i, ra, R1{}, F{}, T{}, F{});
+      round_body(i, ra, R2{}, F{}, T{}, T{});
+      ra = ra == 2 ? 0 : ra + 1;
+    }
+    round_body(nrng - 1, ra, R0{}, F{}, T{}, F{});
+    round_body(nrng - 1, ra, R1{}, F{}, T{}, F{});
+    round_body(nrng - 1, ra, R2{}, F{}, F{}, T{});
+  } else {
   // ---- prologue: x_0 landed; the weights of chunk 0 are the youngest VMEM operations
   stage_x(0, 0);
   __syncthreads();
@@ -231,6 +338,7 @@ __global__ __launch_bounds__(THREADS, (MI == 1 ? TSPN_ROI_BF16_MI1_WAVES : 2)) v
   };
   for (int i = 0; i + 1 < nchunks; ++i) chunk_body(i, std::true_type{});
   chunk_body(nchunks - 1, std::false_type{});
+  }
 
   // ---- epilogue.  A lane holds 4 consecutive channels of ONE pixel per register quad, so direct stores would
   // write 8-byte fragments to 32 different rows per instruction (measured: the 1x1 convs of the backbone ran at
@@ -373,6 +481,8 @@ extern "C" int tspn_conv2d_nhwc_bf16(const uint16_t* x, int64_t NB, int64_t H, i
                        (int)Cin, (int)Cout, (int)KH, (int)KW, (int)stride, (int)pad, (int)OH, (int)OW, npix,
                        (int)tiles_m, (int)tiles_n, relu);
   };
-  if (mi == 2) launch(conv2d_nhwc_bf16_kernel<2>); else launch(conv2d_nhwc_bf16_kernel<1>);
+  const bool rng = KH == 3 && KW == 3 && stride == 1 && pad == 1;
+  if (mi == 2) { if (rng) launch(conv2d_nhwc_bf16_kernel<2, true>); else launch(conv2d_nhwc_bf16_kernel<2, false>); }
+  else { if (rng) launch(conv2d_nhwc_bf16_kernel<1, true>); else launch(conv2d_nhwc_bf16_kernel<1, false>); }
   return tspn::check_launch("tspn_conv2d_nhwc_bf16");
 }
