@@ -4,13 +4,15 @@
 // W / b by the caller).  Round 2 ran the two convolutions as separate launches: the 3x3 is MFMA-bound, the 1x1
 // expand (K = 64..256, an output four times its input plus a residual read) is bound by its 8-byte-per-lane
 // epilogue traffic (3.3 TB/s at res4, 374 TFLOP/s), and h2 made a round trip through HBM in between.  Here:
-//   phase 2  the 3x3 conv exactly as conv2d_nhwc_bf16_kernel does it (implicit GEMM, M = CM output channels, N = 128
-//            pixels per workgroup, K = 9 taps x CM in chunks of 64 channels of one tap; x through LDS by DMA with a
-//            zero page for padding taps, fragment-major weights straight into MFMA operand registers, counted
-//            vmcnt, one bare s_barrier per chunk) but with the x stages as a ring filled 2-3 chunks ahead -- the
-//            WHOLE channel range of the tile stays in one workgroup:
-//            wave (wm, wn) owns rows [64 wm, 64 wm + 64) x pixel blocks [NI wn, NI wn + NI), with
-//            (WM, WN) = (4, 1) / (2, 2) / (1, 4) for CM = 256 / 128 / 64;
+//   phase 2  the 3x3 conv as conv2d_nhwc_bf16_kernel does it in its range mode (implicit GEMM, M = CM output
+//            channels, N = 128 pixels per workgroup, K = CM / 64 channel parts x 9 taps x 64 channels; fragment-major
+//            weights straight into MFMA operand registers, counted vmcnt, bare s_barrier) with the WHOLE channel
+//            range of the tile in one workgroup: wave (wm, wn) owns rows [64 wm, 64 wm + 64) x pixel blocks
+//            [NI wn, NI wn + NI), (WM, WN) = (4, 1) / (2, 2) / (1, 4) for CM = 256 / 128 / 64.  The x operand goes
+//            through LDS as LINEAR RANGES of 130 pixels of a 64-channel part: tap (a, b) of pixel n is pixel
+//            n + (a - 1) W + (b - 1), so one range serves the three taps of a row at slot offsets 0..2, taps off the
+//            image zeroed at the read by the lane's tap mask -- a ring of four range stages at CM = 256 (12 chunks
+//            of 12 k-steps per tile), all three ranges of a part staged at once at CM <= 128 (comments at the code);
 //   h2       relu(acc + b2) is rounded to bf16 ONCE (the same rounding point as the unfused chain) and written
 //            into the now idle stage memory in the B-operand layout [CM / 8 groups][132 slots][8 bf16];
 //   phase 3  the 1x1 expand (M = 4 CM rows, K = CM) as eight sub-passes per wave on two alternating accumulator
