@@ -104,6 +104,8 @@ def parse(argv=None):
                          "BaseModel.decode on PairLists (the default)")
     ap.add_argument("--frames", type=int, default=None, help="cfg5: frames per video (default 900)")
     ap.add_argument("--tracklets", type=int, default=None, help="cfg5: tracklets per video (default 64)")
+    ap.add_argument("--roi-streams", type=int, default=0,
+                    help="cfg5: HIP streams the RoI head alternates its RoI chunks between (0 = the class default)")
     ap.add_argument("--fused-bottleneck", choices=["auto", "off"], default="auto",
                     help="cfg5: `off` runs every backbone convolution as its own launch (the round-2 path)")
     ap.add_argument("--serial-tail", action="store_true",
@@ -698,6 +700,8 @@ class Cfg5Workload:
         self.head = tspn.Res5RoIHead()
         self.head.load_state_dict(t(self.r5_sd))
         self.head = self.head.to(dev)
+        if getattr(args, "roi_streams", 0) > 0:
+            self.head.streams = args.roi_streams
         cfg = tspn.load_cfg(None, **{"RELPN.USE_PPN": True, "RELPN.USE_DPN": True, "RELPN.DPN.IN_CHANNELS": 2 * D,
                                      "PREDICT.FEATURE_DIM": 2 * D, "RELPN.DPN.NUM_ANCHORS_PER_LOCATION": A_ANCH,
                                      "PREDICT.PREDICATE_NUM": K_PRED, "RELPN.PPN.NUM_PAIR_PROPOSALS": TOPK_PPN})
