@@ -368,8 +368,8 @@ def test_stem_bf16_errors(tspn, device):
 @pytest.mark.parametrize("CM,NB,H,W", [(64, 2, 9, 13), (128, 1, 16, 16), (256, 3, 7, 11), (64, 1, 1, 1), (256, 1, 45, 80),
                                       (128, 2, 30, 17)])
 def test_bottleneck_tail_fused_bit_identical_to_two_convs(tspn, device, CM, NB, H, W):
-    """tspn_bottleneck_tail_bf16 (3x3 conv + 1x1 expand + residual + ReLU in one launch, h2 in LDS, half-wave-swapped
-    16-byte epilogue) == tspn_conv2d_nhwc_bf16 applied twice, BIT FOR BIT (same contraction order, same rounding
+    """tspn_bottleneck_tail_bf16 (3x3 conv + 1x1 expand + residual + ReLU in one launch, h2 in LDS, 32 contiguous bytes
+    per lane in the epilogue) == tspn_conv2d_nhwc_bf16 applied twice, BIT FOR BIT (same contraction order, same rounding
     points), and == the float64 restatement within bf16 rounding: pixel counts that are not a multiple of the 128-pixel
     tile, images smaller than the 3x3 halo, all three channel widths (wave tilings 1x4 / 2x2 / 4x1)."""
     h1 = tspn.hashrng.uniform(90, "h1", (NB, H, W, CM), 0, 1)
@@ -386,6 +386,12 @@ def test_bottleneck_tail_fused_bit_identical_to_two_convs(tspn, device, CM, NB, 
     got = tspn.ops.bottleneck_tail_bf16(h1d, f2, d(b2), f3, d(b3), resd)
     assert got.dtype == torch.bfloat16 and tuple(got.shape) == (NB, H, W, 4 * CM)
     assert torch.equal(got, want), f"max diff {float((got.float() - want.float()).abs().max())}"
+    big = torch.zeros((NB + 2, H, W, 4 * CM), dtype=torch.bfloat16, device=device)      # `out`: a slice of a larger result
+    ret = tspn.ops.bottleneck_tail_bf16(h1d, f2, d(b2), f3, d(b3), resd, out=big[1:NB + 1])
+    assert ret.data_ptr() == big[1:].data_ptr() and torch.equal(big[1:NB + 1], want)
+    assert not bool(big[0].any()) and not bool(big[NB + 1].any())
+    with pytest.raises(ValueError):
+        tspn.ops.bottleneck_tail_bf16(h1d, f2, d(b2), f3, d(b3), resd, out=big)
     r2 = ro.conv2d_bf16(h1d.cpu().float().permute(0, 3, 1, 2), t(w2), t(b2), padding=1, relu=True)
     ref = ro.conv2d_bf16(r2, t(w3), t(b3), residual=resd.cpu().float().permute(0, 3, 1, 2), relu=True).permute(0, 2, 3, 1)
     err = (got.cpu().double() - ref).abs()
