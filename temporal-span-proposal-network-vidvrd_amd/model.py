@@ -53,6 +53,8 @@ def invalidate_caches(module):
         for cache in vars(m).values():
             if isinstance(cache, _DeviceCache):
                 cache.clear()
+        if hasattr(m, "_logits_token"):
+            m._logits_token = None       # never let a decode ride the ready-event of a pass made with other weights
 
 
 class _CachedWeightsMixin:
@@ -326,11 +328,17 @@ class PPN(nn.Module):
             batch_size_per_image=self.batch_size_per_segment, positive_fraction=self.positive_fraction)
         self._cache = _DeviceCache()
 
+    def device_weights(self, dev):
+        """Device-resident copies of the two MLPs (cached).  BaseModel calls this on the CALLER's stream before it
+        sends `propose` to its side stream, so the copies are made, and their memory owned, by the caller's stream."""
+        names, params = self.ppn_head.weights()
+        return self._cache.get("ppn", params, dev, lambda ts: dict(zip(names, ts)))
+
     def propose(self, cls_logits):
         """Eval: one fused HIP launch per group of equal-N segments -> (matrices, top-k indices)."""
-        names, params = self.ppn_head.weights()
+        _, params = self.ppn_head.weights()
         dev = _compute_device(*cls_logits, params[0])
-        w = self._cache.get("ppn", params, dev, lambda ts: dict(zip(names, ts)))
+        w = self.device_weights(dev)
         mats, idxs = [None] * len(cls_logits), [None] * len(cls_logits)
         groups = {}
         for i, c in enumerate(cls_logits):
@@ -697,6 +705,19 @@ class BaseModel(_CachedWeightsMixin, nn.Module):
         overlap = self.overlap_tail and all(p.get_field("tracklet_feats").is_cuda for p in pair_list)
         side, ev_logits = self._side_stream(dev) if overlap else (None, None)
         if side is not None:
+            # everything the side stream reads that THIS call may build lazily is built here, on the caller's stream,
+            # before the side stream is made to wait for it: the PPN weight copies and the canonical pair tables of
+            # every group (read by the pair-geometry launch here and by `decode` later)
+            if self.use_ppn:
+                self.relpn.pair_proposal_network.device_weights(dev)
+            shapes = {}
+            for p in pair_list:
+                f = p.get_field("tracklet_feats")
+                if not (p.has_field("tracklet_pairs") and p.get_field("tracklet_pairs") is not None):
+                    k = (tuple(f.shape), f.dtype == torch.bfloat16)
+                    shapes[k] = shapes.get(k, 0) + 1
+            for (shape, _), cnt in shapes.items():
+                self._canonical_pairs(dev, cnt, shape[0])
             side.wait_stream(main)                 # class logits / boxes may have been produced on the caller's stream
         pair_proposals = None
         if self.use_ppn:
@@ -770,6 +791,8 @@ class BaseModel(_CachedWeightsMixin, nn.Module):
                         pairs.append(p.to(dev) + k * n)
                     counts = [p.shape[0] for p in pairs]
                     allp = torch.cat(pairs).contiguous()
+                    if side is not None and self.pair_geometry_in_forward:
+                        side.wait_stream(main)     # the geometry launch on the side stream reads this table
                 # temporal conv algorithm: RELPN.DPN.CONV_ALGO = "auto" (Winograd F(6,3) when D % 32 == 0: 4/9 of the
                 # MFMA work; its fp32 error bound is in DESIGN.md §4) or "direct" (the k=3 taps as one implicit GEMM)
                 packed, cbias = dpn._conv_split(dev, winograd=(self.conv_algo == "auto" and d % 32 == 0))
@@ -824,7 +847,7 @@ class BaseModel(_CachedWeightsMixin, nn.Module):
         _, geom = ops.pair_gather(None, boxes, allp, want_feat=False, check_pairs=False)   # allp was validated above
         return geom
 
-    def decode(self, pair_list, rel_logits, topk_per_pair=20, topk_per_seg=200, num_obj=35):
+    def decode(self, pair_list, rel_logits, topk_per_pair=20, topk_per_seg=200, num_obj=35, overlap=True):
         """Top-k triplet decode of `forward`'s rel_logits on the GPU (replaces the Python of
         reference lib/modeling/predict.py:59-117).  Per segment returns
         (scores [M], triplets int64 [M,3] = (subject class, predicate, object class), pair_tids [M,2]).
@@ -832,7 +855,14 @@ class BaseModel(_CachedWeightsMixin, nn.Module):
         Baseline segments (2-D `features` [P,F>=70]) reproduce predict.py:88-89 as is: class =
         argmax of feature row (N-1)*tid, columns 0:35 / 35:70.  Tracklet segments use
         'track_cls_logits' [N,35] directly.  Segments with < 2 tracklets yield empty results
-        (predict.py:61-64 skips them)."""
+        (predict.py:61-64 skips them).
+
+        Stream contract of the overlapped tail (`RELPN.OVERLAP_TAIL`): when `rel_logits` are the very tensors the last
+        `forward` on this stream returned, the decode runs on the module's side stream behind that forward's
+        logits-ready event, i.e. under its encoder.  The side stream was ordered after the caller's stream at the START
+        of that forward, so `pair_list`'s fields must be the ones that forward was given; class logits (re)written on
+        the caller's stream BETWEEN forward and decode are not waited for — pass `overlap=False` (or set
+        `model.overlap_tail = False`) for such a decode."""
         out = [None] * len(pair_list)
         groups = {}
         for i, (plist, lg) in enumerate(zip(pair_list, rel_logits)):
@@ -856,7 +886,7 @@ class BaseModel(_CachedWeightsMixin, nn.Module):
             custom = [pair_list[i].has_field("tracklet_pairs") and pair_list[i].get_field("tracklet_pairs") is not None
                       for i in members]
             side, tok = None, self._logits_token
-            if (self.overlap_tail and tok is not None and tok[0] == dev.index and tok[2] == main.cuda_stream
+            if (overlap and self.overlap_tail and tok is not None and tok[0] == dev.index and tok[2] == main.cuda_stream
                     and tok[1].data_ptr() == lg.data_ptr() and tok[1].numel() == lg.numel() and not quirk
                     and not any(custom) and all(pair_list[i].get_field("track_cls_logits").is_cuda for i in members)):
                 side, ev_logits = self._side_stream(dev)
@@ -894,15 +924,20 @@ class BaseModel(_CachedWeightsMixin, nn.Module):
                                       topk_per_pair=topk_per_pair, topk_per_seg=topk_per_seg, check_pairs=not trusted)
             else:
                 cshape = tuple(pair_list[members[0]].get_field("track_cls_logits").shape)
-                cls = _batch_rows([pair_list[i].get_field("track_cls_logits") for i in members], dev).view((nm,) + cshape)
+                cls_src = [pair_list[i].get_field("track_cls_logits") for i in members]
                 if side is not None:
                     with torch.cuda.stream(side):
+                        # the class logits are batched UNDER the side stream: when they are not consecutive slices of
+                        # one allocation this is a cat / cast kernel, which on the caller's stream would sit behind the
+                        # whole encoder while the decode launch on the side stream read its (unwritten) result
+                        cls = _batch_rows(cls_src, dev).view((nm,) + cshape)
                         res = ops.decode_topk(lg, pairs, cls, row_mul=1, num_obj=num_obj, topk_per_pair=topk_per_pair,
                                               topk_per_seg=topk_per_seg, check_pairs=not trusted)
                         for r in res:
                             r.record_stream(main)      # allocated under the side stream, consumed on the caller's
                     main.wait_stream(side)             # the caller's stream sees complete results from here on
                 else:
+                    cls = _batch_rows(cls_src, dev).view((nm,) + cshape)
                     res = ops.decode_topk(lg, pairs, cls, row_mul=1, num_obj=num_obj, topk_per_pair=topk_per_pair,
                                           topk_per_seg=topk_per_seg, check_pairs=not trusted)
             for k, i in enumerate(members):

@@ -131,6 +131,27 @@ class BottleneckBlock(nn.Module):
         return out
 
 
+def _warm_conv_weights(module, dev, bf16):
+    """Fold + pack the weights of every ConvFrozenBN under `module` on the CURRENT (the caller's) stream.  The
+    multi-stream forwards call this before their side streams are made to wait for the caller's: `_DeviceCache` has no
+    stream ordering of its own, so a cache filled lazily by the first chunk on side stream 0 could be read half-built
+    by side stream 1.  A cache hit costs a few microseconds per conv, so this runs on every forward and
+    also catches weights that changed since the last one."""
+    for m in module.modules():
+        if isinstance(m, BasicStem):
+            c = m.conv1
+            if bf16:
+                m._folded_bf16(dev)
+            elif m.in_channels <= 4 and c.weight.shape[0] % 32 == 0:
+                m._folded_cin4(dev)
+            else:
+                c.folded(dev)
+        elif isinstance(m, BottleneckBlock):
+            for c in (m.conv1, m.conv2, m.conv3, m.shortcut):
+                if c is not None:
+                    c.folded_bf16(dev) if bf16 else c.folded(dev)
+
+
 class Res5RoIHead(_CachedWeightsMixin, nn.Module):
     """ROIAlign + res5 + spatial mean (detectron2 Res5ROIHeads._shared_roi_transform, then .mean([2,3])).
 
@@ -189,6 +210,7 @@ class Res5RoIHead(_CachedWeightsMixin, nn.Module):
             side = None
             if ns > 1:
                 side = self._side_streams.setdefault((dev.index, ns), [torch.cuda.Stream(device=dev) for _ in range(ns)])
+                _warm_conv_weights(self, dev, bf16)      # packed weights exist before any side stream may read them
                 for st in side:
                     st.wait_stream(main)
             # res5's first block reads its input only through 1x1 convs of stride s (stride_in_1x1: conv1 and the
@@ -332,6 +354,7 @@ class ResNetC4(_CachedWeightsMixin, nn.Module):
             main = torch.cuda.current_stream(dev)
             side = self._side_streams.setdefault((dev.index, ns), [torch.cuda.Stream(device=dev) for _ in range(ns)])
             imgs = _f32(images, dev)
+            _warm_conv_weights(self, dev, bf16)          # packed weights exist before any side stream may read them
             for st in side:
                 st.wait_stream(main)
             res4 = list(self.res4)

@@ -10,6 +10,8 @@ What is imported from the reference (torch + numpy only):
     lib.modeling.model            BaseModel, RelationPredictor
     lib.modeling.relpn.ppn        PPN, PPNHead
     lib.modeling.relpn.dpn        DPNHead
+    relpn/dpn_anchor.py           DPNHead with relness_pred + duration_pred (the file uses sibling-relative imports
+                                  `from rel_nms import ...`, so its directory goes on sys.path; g11)
     lib.modeling.relpn.anchor_generator   AnchorGenerator
     lib.modeling.relpn.sampler    BalancedPositiveNegativePairSampler
     lib.modeling.trajectory       cubic_iou
@@ -97,6 +99,8 @@ from lib.dataset.list_pair import PairList as RefPairList  # noqa: E402
 from lib.dataset.list_target import TargetList as RefTargetList  # noqa: E402
 from lib.dataset.vrdataset import VRDataset as RefVRDataset  # noqa: E402
 import lib.modeling.predict as ref_predict  # noqa: E402
+sys.path.insert(0, os.path.join(REF, "lib", "modeling", "relpn"))   # dpn_anchor.py imports its siblings by bare name
+from dpn_anchor import DPNHead as RefAnchorDPNHead  # noqa: E402
 
 torch.manual_seed(0)
 torch.set_num_threads(8)
@@ -353,6 +357,33 @@ def g7_misc():
     save("g7_misc.npz", sampler_counts=np.array([int(pos[0].sum()), int(neg[0].sum())]), **segs, **masks)
 
 
+def g11_relness():
+    """The relationness head as the reference states it: relpn/dpn_anchor.py:82-108 `DPNHead(in_channels, num_anchors)`
+    = conv + ReLU, then `relness_pred` Conv1d(C, A, 1) AND `duration_pred` Conv1d(C, 2A, 1), looping over a list of
+    feature maps.  Run at the two G3 shapes in fp32 and cast with .bfloat16() (torch CPU bf16 kernels); both outputs
+    fp32 / bf16 relness stored.  Its `duration` must equal g3 / g8's (same weights, same arithmetic) - asserted here."""
+    out = {}
+    pre = "relpn.duration_proposal_network.dpn_head."
+    g3 = np.load(os.path.join(HERE, "g3_dpn_head.npz"))
+    g8 = np.load(os.path.join(HERE, "g8_bf16.npz"))
+    for tag in cases.G3_SHAPES:
+        c = cases.g3_inputs(tag)
+        head = RefAnchorDPNHead(c["c"], 4)
+        head.load_state_dict({k[len(pre):]: t(v) for k, v in c["state_dict"].items() if k.startswith(pre)}, strict=True)
+        with torch.no_grad():
+            rel, dur = head([t(c["x"])])
+        assert len(rel) == 1 and len(dur) == 1
+        assert np.array_equal(dur[0].numpy(), g3[f"{tag}_duration"])
+        out[f"{tag}_relness"] = rel[0].numpy()       # duration: identical to g3 (asserted above), not stored twice
+        head = head.bfloat16()
+        with torch.no_grad():
+            rel, dur = head([t(c["x"]).bfloat16()])
+        assert rel[0].dtype == torch.bfloat16
+        assert np.array_equal(dur[0].float().numpy(), g8[f"{tag}_duration"])
+        out[f"{tag}_relness_bf16"] = rel[0].float().numpy()
+    save("g11_relness_head.npz", **out)
+
+
 def g8_bf16():
     """The reference's own DPNHead and RelationPredictor cast with .bfloat16() and run by torch's CPU
     bf16 kernels on the (bf16-rounded) g3 / g1 inputs: pins the rounding points of the build's bf16
@@ -425,6 +456,7 @@ def main():
     g6_decode()
     g7_misc()
     g8_bf16()
+    g11_relness()
     g9_association()
     g10_dataset_and_predict()
 

@@ -388,12 +388,12 @@ def test_dense_bf16_encoder_heads_vs_reference_bf16_modules_g8(tspn, device, tag
         d(x), tspn.ops.pack_conv3_bf16(d(sd[DPN_PRE + "conv.weight"])), d(r16(sd[DPN_PRE + "conv.bias"])),
         tspn.ops.pack_heads_bf16(d(hw)), d(r16(hb)), 3 * A).cpu()
     assert out.shape == (P, 3 * A, T)
-    ref = g[f"{tag}_duration"]
-    dur = out[:, A:]
-    same = (oracle.bf16_round(dur).numpy() == ref).mean()
-    assert same > 0.999, same
-    ulp = np.maximum(np.abs(ref), 2.0 ** -126) * 2.0 ** -7
-    assert np.all(np.abs(dur.numpy() - ref) <= 2 * ulp)
+    g11 = cases.load("g11_relness_head.npz")   # dpn_anchor.py:82-108's DPNHead.bfloat16(): the relationness leg
+    for got, ref in ((out[:, A:], g[f"{tag}_duration"]), (out[:, :A], g11[f"{tag}_relness_bf16"])):
+        same = (oracle.bf16_round(got).numpy() == ref).mean()
+        assert same > 0.999, same
+        ulp = np.maximum(np.abs(ref), 2.0 ** -126) * 2.0 ** -7
+        assert np.all(np.abs(got.numpy() - ref) <= 2 * ulp)
     rel_o, dur_o, _ = oracle.dpn_head_bf16(x, sd[DPN_PRE + "conv.weight"], sd[DPN_PRE + "conv.bias"],
                                            sd[DPN_PRE + "duration_pred.weight"], sd[DPN_PRE + "duration_pred.bias"],
                                            sd[DPN_PRE + "relness_pred.weight"], sd[DPN_PRE + "relness_pred.bias"])

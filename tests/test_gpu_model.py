@@ -559,6 +559,59 @@ def test_forward_on_slices_of_one_batched_tensor_is_zero_copy_and_equal(tspn, de
     np.testing.assert_allclose(dp[1].duration.cpu().numpy(), ref["duration"].numpy(), rtol=0, atol=1e-5)
 
 
+
+def test_overlapped_decode_with_separately_allocated_class_logits(tspn, device):
+    """with per-video class logits that are NOT consecutive slices of one allocation (and not fp32),
+    batching them is a cat / cast kernel; it has to run on the stream that decodes.  Sizes at which the encoder takes
+    milliseconds, so that a cat queued behind it on the caller's stream would lose the race every time.  Also covers an
+    explicit pair table with the geometry launch on the side stream (the table is built on the caller's stream)."""
+    D, N, T, B = 512, 24, 150, 6
+    sd = tspn.synth.make_weights(9, c=2 * D, bias_std=0.05)
+    models = []
+    for ov in (True, False):
+        cfg = cases.baseline_cfg(**{"RELPN.USE_PPN": True, "RELPN.USE_DPN": True, "RELPN.DPN.IN_CHANNELS": 2 * D,
+                                    "PREDICT.FEATURE_DIM": 2 * D, "RELPN.OVERLAP_TAIL": ov,
+                                    "RELPN.DPN.PAIR_GEOMETRY": True})
+        m = tspn.BaseModel(cfg)
+        load(m, sd)
+        m.eval()
+        models.append(m)
+    for step in range(3):
+        vids = [tspn.synth.make_video(700 + 10 * step + b, N, T, D) for b in range(B)]
+        big = torch.cat([t(v["tracklet_feats"]) for v in vids]).to(device)
+        boxes = torch.cat([t(v["tracklet_boxes"]) for v in vids]).to(device)
+        pad = []
+        plists = []
+        for b, v in enumerate(vids):
+            c = (8.0 * t(v["track_cls_logits"])).double().to(device)      # own allocation, needs a cast
+            pad.append(torch.empty(1000 + 37 * b, device=device))            # keeps the allocations apart
+            plists.append(tspn.PairList.from_tracklets(big[b * N:(b + 1) * N], boxes[b * N:(b + 1) * N], c))
+        torch.cuda.synchronize()
+        outs = []
+        for m in models:
+            pp, dp, lg = m(plists, None)
+            dec = m.decode(plists, lg)
+            torch.cuda.synchronize()
+            outs.append((pp, dp, lg, dec))
+        (pp0, dp0, lg0, d0), (pp1, dp1, lg1, d1) = outs
+        for b in range(B):
+            assert torch.equal(pp0[b], pp1[b]) and torch.equal(lg0[b], lg1[b])
+            assert torch.equal(dp0[b].geom, dp1[b].geom)
+            assert all(torch.equal(x, y) for x, y in zip(d0[b], d1[b]))
+    # one segment with its own pair table: first use of that table is the geometry launch on the side stream
+    v = tspn.synth.make_video(990, N, T, D)
+    tab = torch.from_numpy(np.array([(i, j) for i in range(N) for j in range(N) if i != j][::3], dtype=np.int64))
+    res = []
+    for m in models:
+        pl = tspn.PairList.from_tracklets(t(v["tracklet_feats"]).to(device), t(v["tracklet_boxes"]).to(device),
+                                          (8.0 * t(v["track_cls_logits"])).to(device))
+        pl.add_field("tracklet_pairs", tab)
+        _, dp, lg = m([pl], None)
+        torch.cuda.synchronize()
+        res.append((dp[0].geom, lg[0]))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
 @pytest.mark.parametrize("bf16", [False, True])
 def test_overlapped_tail_equals_serial(tspn, device, bf16):
     """RELPN.OVERLAP_TAIL (default on): PPN and the top-k decode run on a second HIP stream under the encoder of the

@@ -275,8 +275,10 @@ def test_conv3_split_pack(tspn, device):
 
 
 def test_dpn_head_golden(tspn, device):
-    """DPNHead.forward of the reference (golden G3) through the dense HIP path."""
+    """DPNHead.forward of the reference through the dense HIP path: duration against golden G3 (relpn/dpn.py:55-73),
+    relationness against golden G11 (relpn/dpn_anchor.py:82-108, the reference's own two-headed DPNHead)."""
     g = cases.load("g3_dpn_head.npz")
+    g11 = cases.load("g11_relness_head.npz")
     for tag in cases.G3_SHAPES:
         c = cases.g3_inputs(tag)
         sd = dev_sd(c["state_dict"], device)
@@ -292,6 +294,7 @@ def test_dpn_head_golden(tspn, device):
                                     cpu[DPN_PRE + "duration_pred.weight"], cpu[DPN_PRE + "duration_pred.bias"],
                                     cpu[DPN_PRE + "relness_pred.weight"], cpu[DPN_PRE + "relness_pred.bias"])
         np.testing.assert_allclose(out[:, :4].cpu().numpy(), rel.numpy(), rtol=0, atol=5e-6)
+        np.testing.assert_allclose(out[:, :4].cpu().numpy(), g11[f"{tag}_relness"], rtol=0, atol=5e-6)
 
 
 @pytest.mark.parametrize("P,C,T,H", [(1, 1, 1, 1), (3, 5, 7, 12), (9, 64, 30, 12), (6, 130, 33, 16), (11, 96, 150, 3)])

@@ -479,6 +479,33 @@ def test_backbone_and_roi_head_on_two_streams_equal_one(tspn, device, blocks):
     assert torch.equal(m32, net(img, bf16=False))
 
 
+def test_first_forward_on_two_streams_behind_a_busy_gpu(tspn, device):
+    """the very FIRST forward of a fresh backbone / RoI head with streams = 2, queued behind a
+    long-running kernel so that both side streams are released together: the folded / packed weights must have been
+    built on the caller's stream before either side stream may read them.  Reference result: a second, identical
+    module on one stream."""
+    nets = [_backbone_and_weights(tspn, device, 64, 256, (1, 1, 2))[0] for _ in range(2)]
+    heads = [tspn.Res5RoIHead(1024, 128, 512, roi_chunk=5).to(device) for _ in range(2)]
+    heads[1].load_state_dict(heads[0].state_dict())
+    img = t(tspn.hashrng.uniform(97, "img", (6, 64, 96, 3), -1, 1)).to(device)
+    boxes = t(tspn.hashrng.uniform(97, "bx", (3, 6, 2), 0, 30)).to(device)
+    boxes = torch.cat([boxes, boxes + 25], dim=2).contiguous()
+    for net in nets:
+        net.frame_chunk = 2
+    nets[0].streams, heads[0].streams = 1, 1
+    ref_m = nets[0](img, bf16=True)
+    ref_f = heads[0](ref_m, boxes)
+    torch.cuda.synchronize()
+    nets[1].streams, heads[1].streams = 2, 2
+    busy = torch.randn(8192, 8192, device=device)
+    for _ in range(6):
+        busy = busy @ busy * 1e-4              # tens of milliseconds of queued work on the caller's stream
+    m = nets[1](img, bf16=True)                # caches are cold here
+    f = heads[1](m, boxes)
+    torch.cuda.synchronize()
+    assert torch.equal(m, ref_m) and torch.equal(f, ref_f)
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_bottleneck_tail_and_stem_random_shapes(tspn, device, seed):
     """Shape fuzz of the two round-3 backbone kernels (hash-RNG shapes): the fused tail against the two conv launches

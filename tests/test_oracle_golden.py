@@ -52,7 +52,10 @@ def test_g2_ppn_matrix_and_topk():
 
 
 def test_g3_dpn_head():
+    """duration: reference relpn/dpn.py:55-73 (g3); relness: reference relpn/dpn_anchor.py:82-108 (g11) - both legs of
+    oracle.dpn_head are pinned by the reference's own modules."""
     g = cases.load("g3_dpn_head.npz")
+    g11 = cases.load("g11_relness_head.npz")
     for tag in cases.G3_SHAPES:
         c = cases.g3_inputs(tag)
         sd = sd_t(c["state_dict"])
@@ -61,6 +64,7 @@ def test_g3_dpn_head():
                                       sd[DPN_PRE + "relness_pred.weight"], sd[DPN_PRE + "relness_pred.bias"])
         np.testing.assert_allclose(dur.numpy(), g[f"{tag}_duration"], rtol=0, atol=1e-6)
         assert rel.shape == (c["x"].shape[0], 4, c["x"].shape[2])
+        np.testing.assert_allclose(rel.numpy(), g11[f"{tag}_relness"], rtol=0, atol=1e-6)
 
 
 def test_g4_cubic_iou_bit_exact():
@@ -188,19 +192,20 @@ def test_g8_bf16_semantics_pinned_by_reference_bf16_modules():
     bf16 kernels): rounding the oracle's unrounded output to bf16 reproduces the reference's output
     on (nearly) every element, and never differs by more than two bf16 ulps."""
     g = cases.load("g8_bf16.npz")
+    g11 = cases.load("g11_relness_head.npz")
     for tag in cases.G3_SHAPES:
         c = cases.g3_inputs(tag)
         sd = sd_t(c["state_dict"])
         rel, dur, h = oracle.dpn_head_bf16(t(c["x"]), sd[DPN_PRE + "conv.weight"], sd[DPN_PRE + "conv.bias"],
                                            sd[DPN_PRE + "duration_pred.weight"], sd[DPN_PRE + "duration_pred.bias"],
                                            sd[DPN_PRE + "relness_pred.weight"], sd[DPN_PRE + "relness_pred.bias"])
-        ref = g[f"{tag}_duration"]
-        same = (oracle.bf16_round(dur).numpy() == ref).mean()
-        assert same > 0.999, same
-        ulp = np.maximum(np.abs(ref), 2.0 ** -126) * 2.0 ** -7   # spacing of bf16 at |ref| (upper bound)
-        assert np.all(np.abs(dur.numpy() - ref) <= 2 * ulp)
+        # duration: dpn.py's DPNHead.bfloat16() (g8); relness: dpn_anchor.py's DPNHead.bfloat16() (g11)
+        for got, ref in ((dur, g[f"{tag}_duration"]), (rel, g11[f"{tag}_relness_bf16"])):
+            same = (oracle.bf16_round(got).numpy() == ref).mean()
+            assert same > 0.999, same
+            ulp = np.maximum(np.abs(ref), 2.0 ** -126) * 2.0 ** -7   # spacing of bf16 at |ref| (upper bound)
+            assert np.all(np.abs(got.numpy() - ref) <= 2 * ulp)
         np.testing.assert_array_equal(oracle.bf16_round(h).numpy(), h.numpy())   # activation is bf16
-        assert rel.shape == (c["x"].shape[0], 4, c["x"].shape[2])
     c = cases.g1_inputs()
     feats = oracle.feature_preprocess(t(c["raw"].copy()))
     lg = oracle.predicate_head_bf16(feats, t(c["state_dict"]["classifier.rel_predictor.weight"]),
