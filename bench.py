@@ -46,7 +46,7 @@ Printed JSON (rank 0): see the task contract; extras:
 
 `--stub-gpu` (CPU rehearsal, used by tests/test_dist_gloo.py): the rank body of this file — rendezvous, warm-up,
 barrier-bracketed timed loop, the decoded-result all-gather of every step, max-over-ranks time, the
-`gathered[rank*B:(rank+1)*B] == local` check, the JSON line — with the GPU step replaced by recorded decoded
+`gathered[lo:hi] == local` check (lo, hi = this rank's block, ragged under `--total-videos`), the JSON line — with the GPU step replaced by recorded decoded
 rows and `gloo` in place of RCCL.  Its JSON says `"stub": true`; it measures nothing.
 """
 import argparse
@@ -80,6 +80,9 @@ def parse(argv=None):
     ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default: 5; cfg4 2; cfg5 1)")
     ap.add_argument("--videos", type=int, default=None,
                     help="videos per GPU per step (default: 16 for cfg2, 64 for cfg4, 4 for cfg3, 1 for cfg5)")
+    ap.add_argument("--total-videos", type=int, default=None,
+                    help="videos per step over ALL ranks, block-sharded with dist.shard_range (ragged when it does not "
+                         "divide: 509 over 8 ranks = 64,64,64,64,64,63,63,63); overrides --videos")
     ap.add_argument("--batches", type=int, default=2,
                     help="different input batches resident in HBM, rotated step by step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -368,21 +371,49 @@ def launch_check(args):
 # ------------------------------------------------------------------------------------------------ workloads
 class Gatherer:
     """The one collective of the path: all-gather of per-video results at the end of a step (RCCL; gloo in the
-    CPU rehearsal).  Keeps the last local and gathered rows for the post-run check."""
+    CPU rehearsal).  Keeps the last local and gathered rows for the post-run check, and times the collective itself:
+    HIP events on the stream it is issued from (RCCL runs on its own stream; torch makes the issuing stream wait for
+    it, so the second event fires when the gathered rows are usable), wall clock under gloo."""
 
-    def __init__(self, tspn, args, world, use_dist):
-        self.tspn, self.args, self.world, self.use_dist = tspn, args, world, use_dist
+    def __init__(self, tspn, args, world, use_dist, rank=0, torch=None, on_gpu=False):
+        self.tspn, self.args, self.world, self.use_dist, self.rank = tspn, args, world, use_dist, rank
         self.last, self.gathered = None, None
+        self.total = args.total_videos          # None: every rank holds the same number of videos
+        self.torch, self.on_gpu = torch, on_gpu
+        self.events, self.wall = [], []
+
+    def shard(self, default_b):
+        """(first global video, videos of this rank, videos over all ranks) per step."""
+        if self.total is None:
+            return self.rank * default_b, default_b, self.world * default_b
+        lo, hi = self.tspn.dist.shard_range(self.total, self.rank, self.world)
+        return lo, hi - lo, self.total
 
     def __call__(self, sc, trip, tid, idx, logits=None):
         b = sc.shape[0]
+        num = self.total if self.total is not None else self.world * b
         if self.use_dist:
-            if self.args.gather == "decoded" or logits is None:
-                self.gathered = self.tspn.dist.gather_decoded(sc, trip, tid, self.world * b, pair_proposals=idx, force=True)
+            if self.on_gpu:
+                e0, e1 = (self.torch.cuda.Event(enable_timing=True) for _ in range(2))
+                e0.record()
             else:
-                self.tspn.dist.gather_results(logits, self.world * b, force=True)
-                self.tspn.dist.gather_results(idx, self.world * b, force=True)
+                t0 = time.perf_counter()
+            if self.args.gather == "decoded" or logits is None:
+                self.gathered = self.tspn.dist.gather_decoded(sc, trip, tid, num, pair_proposals=idx, force=True)
+            else:
+                self.tspn.dist.gather_results(logits, num, force=True)
+                self.tspn.dist.gather_results(idx, num, force=True)
+            if self.on_gpu:
+                e1.record()
+                self.events.append((e0, e1))
+            else:
+                self.wall.append((time.perf_counter() - t0) * 1e3)
         self.last = (sc, trip, tid, idx)
+
+    def gather_ms(self, skip):
+        """Mean time of the collective over the timed steps (the first `skip` calls are warm-up); call after a sync."""
+        ms = [a.elapsed_time(b) for a, b in self.events[skip:]] if self.on_gpu else self.wall[skip:]
+        return float(sum(ms) / len(ms)) if ms else None
 
     def check(self, rank):
         """Every rank holds every video's decoded rows, in global order; its own block equals what it computed."""
@@ -390,31 +421,41 @@ class Gatherer:
         if not self.use_dist or self.gathered is None:
             return
         g, b = self.gathered, self.last[0].shape[0]
-        assert g["scores"].shape == (self.world * b, self.last[0].shape[1]), g["scores"].shape
-        assert g["pair_proposals"].shape == (self.world * b, self.last[3].shape[1]), g["pair_proposals"].shape
-        assert torch.equal(g["scores"][rank * b:(rank + 1) * b], self.last[0]), "gathered scores differ from the local block"
-        assert torch.equal(g["triplets"][rank * b:(rank + 1) * b], self.last[1]), "gathered triplets differ"
-        assert torch.equal(g["pair_proposals"][rank * b:(rank + 1) * b], self.last[3]), "gathered pair proposals differ"
+        lo, cnt, num = self.shard(b)
+        assert cnt == b, (cnt, b)
+        assert g["scores"].shape == (num, self.last[0].shape[1]), g["scores"].shape
+        assert g["pair_proposals"].shape == (num, self.last[3].shape[1]), g["pair_proposals"].shape
+        assert torch.equal(g["scores"][lo:lo + b], self.last[0]), "gathered scores differ from the local block"
+        assert torch.equal(g["triplets"][lo:lo + b], self.last[1]), "gathered triplets differ"
+        assert torch.equal(g["pair_proposals"][lo:lo + b], self.last[3]), "gathered pair proposals differ"
 
 
 class StubWorkload:
-    """--stub-gpu: recorded decoded rows (deterministic per global video index) in place of the GPU step."""
+    """--stub-gpu: recorded decoded rows (deterministic per global video index) in place of the GPU step.
+    `--workload cfg5` rehearses that workload's shape: ONE video of 64 tracklets per rank per step."""
 
     def __init__(self, args, tspn, torch, np, dev, world, rank, gather):
         self.args, self.world, self.rank, self.gather = args, world, rank, gather
-        self.B = args.videos if args.videos is not None else 4
-        self.units_per_step = self.B * N_TRK * (N_TRK - 1)
+        cfg5 = args.workload == "cfg5"
+        n_trk = self.n_trk = CFG5[0] if cfg5 else (CFG3[0] if args.workload == "cfg3" else N_TRK)
+        first, self.B, self.total_videos = gather.shard(args.videos if args.videos is not None else (1 if cfg5 else 4))
+        self.units_per_step = self.B * n_trk * (n_trk - 1)
+        self.total_units_per_step = self.total_videos * n_trk * (n_trk - 1)
         rows = []
         for b in range(self.B):
-            g = rank * self.B + b     # global video index
+            g = first + b     # global video index
             sc = np.sort(tspn.hashrng.uniform(1000 + g, "sc", (TOPK_SEG,)))[::-1].copy()
             trip = np.stack([tspn.hashrng.integers(1000 + g, "s", (TOPK_SEG,), 0, 35),
                              tspn.hashrng.integers(1000 + g, "p", (TOPK_SEG,), 0, K_PRED),
                              tspn.hashrng.integers(1000 + g, "o", (TOPK_SEG,), 0, 35)], axis=1).astype(np.int64)
-            tid = tspn.hashrng.integers(1000 + g, "t", (TOPK_SEG, 2), 0, N_TRK).astype(np.int64)
-            idx = tspn.hashrng.integers(1000 + g, "i", (TOPK_PPN,), 0, N_TRK * N_TRK).astype(np.int64)
+            tid = tspn.hashrng.integers(1000 + g, "t", (TOPK_SEG, 2), 0, n_trk).astype(np.int64)
+            idx = tspn.hashrng.integers(1000 + g, "i", (TOPK_PPN,), 0, n_trk * n_trk).astype(np.int64)
             rows.append((sc, trip, tid, idx))
-        self.rows = tuple(torch.from_numpy(np.stack([r[k] for r in rows])) for k in range(4))
+        if rows:
+            self.rows = tuple(torch.from_numpy(np.stack([r[k] for r in rows])) for k in range(4))
+        else:               # an empty shard still takes part in the collective
+            self.rows = (torch.zeros((0, TOPK_SEG)), torch.zeros((0, TOPK_SEG, 3), dtype=torch.int64),
+                         torch.zeros((0, TOPK_SEG, 2), dtype=torch.int64), torch.zeros((0, TOPK_PPN), dtype=torch.int64))
 
     def step(self, i):
         self.gather(*self.rows)
@@ -423,9 +464,10 @@ class StubWorkload:
         pass
 
     def report(self, elapsed, clock_mhz):
-        return {"metric": f"tracklet-pairs/sec scored (N={N_TRK}, T={T_FRAMES}, D={D_ROI})", "dtype": "none", "stub": True,
-                "config": {"workload": "STUB: recorded decoded rows instead of the GPU step (CPU rehearsal of the rank "
-                                       "body over gloo; measures nothing)", "videos_per_gpu_per_step": self.B},
+        return {"metric": f"tracklet-pairs/sec scored (N={self.n_trk}, T={T_FRAMES}, D={D_ROI})", "dtype": "none", "stub": True,
+                "config": {"workload": f"STUB ({self.args.workload} shape): recorded decoded rows instead of the GPU step (CPU "
+                                       "rehearsal of the rank body over gloo; measures nothing)",
+                           "videos_per_gpu_per_step": self.B, "videos_per_step": self.total_videos},
                 "roofline": None}
 
     def cpu_baseline(self):
@@ -441,10 +483,15 @@ class ScoringWorkload:
         bf16 = self.bf16 = args.workload == "cfg3"
         N, T, D = self.N, self.T, self.D = CFG3 if bf16 else (N_TRK, T_FRAMES, D_ROI)
         C = self.C = 2 * D
-        B = self.B = args.videos if args.videos is not None else {"cfg2": 16, "cfg4": 64, "cfg3": 4}[args.workload]
+        first, B, self.total_videos = gather.shard(args.videos if args.videos is not None else
+                                                   {"cfg2": 16, "cfg4": 64, "cfg3": 4}[args.workload])
+        self.B = B
+        if B < 1:
+            raise SystemExit(f"bench.py: rank {rank} got no video of --total-videos {args.total_videos}; give every rank one")
         self.P_vid = N * (N - 1)
         self.P = B * self.P_vid
         self.units_per_step = self.P
+        self.total_units_per_step = self.total_videos * self.P_vid
         self.via_model = not args.ops_level
         total_steps = args.warmup + args.steps
 
@@ -457,7 +504,7 @@ class ScoringWorkload:
         nb = self.nb = max(1, args.batches)
         gen = torch.Generator(device=dev).manual_seed(1234 + rank)
         hashed = min(B, 16)
-        vids = [tspn.synth.make_video(1 + rank * B + b, N, T, D) for b in range(hashed)]
+        vids = [tspn.synth.make_video(1 + first + b, N, T, D) for b in range(hashed)]
         self.feats_all, self.cls_all, self.boxes_all = [], [], []
         for k in range(nb):
             f = torch.rand((B * N, T, D), device=dev, generator=gen)
@@ -682,12 +729,13 @@ class Cfg5Workload:
         N = self.N = args.tracklets or N
         T = self.T = args.frames or T
         self.H, self.W = H, W
-        self.B = args.videos if args.videos is not None else 1
+        _, self.B, self.total_videos = gather.shard(args.videos if args.videos is not None else 1)
         if self.B != 1:
-            raise SystemExit("bench.py --workload cfg5 scores one video per GPU per step (--videos 1)")
+            raise SystemExit("bench.py --workload cfg5 scores one video per GPU per step (--videos 1, --total-videos = --gpus)")
         D = self.D = 2048
         self.P_vid = N * (N - 1)
         self.units_per_step = self.P_vid
+        self.total_units_per_step = self.total_videos * self.P_vid
         t = lambda sd: {k: torch.from_numpy(v) for k, v in sd.items()}  # noqa: E731
         self.bb_sd = tspn.synth.make_backbone_weights(0)
         self.r5_sd = tspn.synth.make_res5_weights(0)
@@ -834,7 +882,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         assert dist.get_world_size() == args.gpus
 
-    gather = Gatherer(tspn, args, world, use_dist)
+    gather = Gatherer(tspn, args, world, use_dist, rank=rank, torch=torch, on_gpu=not stub)
     wl_cls = StubWorkload if stub else (Cfg5Workload if args.workload == "cfg5" else ScoringWorkload)
     wl = wl_cls(args, tspn, torch, np, dev, world, rank, gather)
     total_steps = args.warmup + args.steps
@@ -858,17 +906,31 @@ def main():
     wl.sync()
     elapsed = time.perf_counter() - t0
     clock_mhz = clock.stop() if clock is not None else None
+    per_rank = None
     if use_dist:
+        # every rank's own elapsed time and its mean time inside the collective travel to rank 0 with the maximum: the
+        # first multi-GPU run then says by itself whether a shortfall is a slow rank, the gather, or the hosts' cores
+        gms = gather.gather_ms(args.warmup)
+        mine = torch.tensor([elapsed, gms if gms is not None else -1.0, float(wl.units_per_step)], dtype=torch.float64, device=dev)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)   # the slowest rank sets the job's time
         elapsed = float(tmax.item())
+        rows = [[float(v) for v in r.tolist()] for r in allr]
+        ms = [r[0] / args.steps * 1e3 for r in rows]
+        per_rank = {"ms_per_step": [round(v, 4) for v in ms], "ms_per_step_min": min(ms), "ms_per_step_max": max(ms),
+                    "gather_ms": [round(r[1], 4) for r in rows], "gather_ms_max": max(r[1] for r in rows),
+                    "units_per_step": [int(r[2]) for r in rows],
+                    "note": "gather_ms = the all-gather of the decoded rows alone (HIP events on the issuing stream; wall "
+                            "clock under gloo), inside ms_per_step; a rank that waits for a slower one shows it here"}
         gather.check(rank)
 
     if rank == 0:
         rep = wl.report(elapsed, clock_mhz)
         out = {
             "metric": rep["metric"],
-            "value": world * wl.units_per_step * args.steps / elapsed,
+            "value": wl.total_units_per_step * args.steps / elapsed,
             "unit": "tracklet-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -879,6 +941,8 @@ def main():
         }
         if rep.get("stub"):
             out["stub"] = True
+        if per_rank is not None:
+            out["per_rank"] = per_rank
         if world == 1 and not args.no_cpu_baseline and not stub:
             out["cpu_baseline"] = wl.cpu_baseline()
         sys.stdout.flush()

@@ -138,7 +138,7 @@ def test_bench_self_launches_its_ranks():
 def test_bench_rank_body_world2_with_stubbed_gpu_step():
     """the REAL rank body of bench.py on two gloo ranks — self-launch of torch.distributed.run,
     rendezvous, warm-up, barrier-bracketed timed loop with the decoded-result all-gather in every step, the
-    max-over-ranks time (all_reduce MAX), the `gathered[rank*B:(rank+1)*B] == local` check on every rank, ONE JSON
+    max-over-ranks time (all_reduce MAX), the `gathered[lo:hi] == local` check on every rank, ONE JSON
     line from rank 0 — with only the GPU step replaced by recorded decoded rows (`--stub-gpu`).  Whole-job value =
     world x units per step x steps / max time."""
     import json
@@ -163,6 +163,49 @@ def test_bench_rank_body_world2_with_stubbed_gpu_step():
                             + extra, capture_output=True, text=True, timeout=300, env=env)
         assert r1.returncode == 0, r1.stderr[-3000:]
         assert json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][0])["n_gpus"] == 1
+
+
+def _run_bench(*flags, timeout=600):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    env["OMP_NUM_THREADS"] = "1"          # eight rank processes on this container's eight cores
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(flags), capture_output=True, text=True,
+                       timeout=timeout, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_rank_body_world8_ragged_shard_with_per_rank_diagnosis():
+    """the rank body on EIGHT gloo ranks with a video count that does not divide (509 over 8 =
+    5 x 64 + 3 x 63, dist.shard_range): the pad-to-max all-gather restores global order on every rank (checked inside
+    bench.py: gathered[lo:hi] == local), the whole-job value counts the 509 videos once, and rank 0's line carries every
+    rank's own ms_per_step and its time inside the collective."""
+    out = _run_bench("--gpus", "8", "--stub-gpu", "--steps", "3", "--warmup", "1", "--total-videos", "509")
+    assert out["stub"] is True and out["n_gpus"] == 8 and out["config"]["videos_per_step"] == 509
+    pr = out["per_rank"]
+    assert pr["units_per_step"] == [64 * 992] * 5 + [63 * 992] * 3
+    assert len(pr["ms_per_step"]) == 8 and len(pr["gather_ms"]) == 8
+    assert pr["ms_per_step_max"] <= out["ms_per_step"] * (1 + 1e-9) and pr["ms_per_step_min"] > 0
+    assert all(0 < g <= m * (1 + 1e-9) for g, m in zip(pr["gather_ms"], pr["ms_per_step"]))
+    pairs = 509 * 32 * 31 * 3
+    assert abs(out["value"] * out["ms_per_step"] * 1e-3 * 3 - pairs) < 1e-6 * pairs
+
+
+def test_bench_rank_body_cfg5_shape_one_video_per_rank():
+    """cfg5's N > 1 form (one VidOR-scale video of 64 tracklets per rank per step) through the same rank body, four
+    gloo ranks; and a shard that leaves one rank of three with a single video while the others hold two."""
+    out = _run_bench("--gpus", "4", "--stub-gpu", "--workload", "cfg5", "--steps", "2", "--warmup", "1")
+    assert out["n_gpus"] == 4 and out["config"]["videos_per_gpu_per_step"] == 1 and out["config"]["videos_per_step"] == 4
+    assert out["per_rank"]["units_per_step"] == [64 * 63] * 4
+    pairs = 4 * 64 * 63 * 2
+    assert abs(out["value"] * out["ms_per_step"] * 1e-3 * 2 - pairs) < 1e-6 * pairs
+    out = _run_bench("--gpus", "3", "--stub-gpu", "--steps", "2", "--warmup", "0", "--total-videos", "5")
+    assert out["per_rank"]["units_per_step"] == [2 * 992, 2 * 992, 1 * 992]
 
 
 def test_bench_refuses_more_ranks_than_devices():
