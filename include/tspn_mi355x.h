@@ -147,6 +147,19 @@ int tspn_ppn_pair_matrix_topk_f32(const float* cls, int64_t B, int64_t N, int64_
 int tspn_traj_iou_f32(const float* boxes1, int64_t N1, const float* boxes2, int64_t N2,
                       int64_t B, int64_t T, float* out, void* stream);
 
+/* ---- f3: association-time trajectory IoU, batched ------------------------
+ * Replaces the per-candidate `_traj_iou(r.straj, straj)` / `_traj_iou(r.otraj, otraj)` calls of
+ * lib/modeling/association.py:35-48,101-106 (-> trajectory.py:144-158 traj_iou -> cubic_iou on float64
+ * boxes) by one launch per segment: a [U,L,4] = every distinct trajectory the previous segment's relations
+ * hold, from the current segment's first frame on; len_a[U] int32 = how many of those frames each has (its
+ * common frames with the segment's tracklets; 0 = no overlap -> IoU 0, association.py:36-37; the caller
+ * guarantees len_a[u] <= L); b [N,L,4] = the current segment's tracklets; out [U,N] float32.  Rounding
+ * recipe of the reference chain kept to the bit: coordinates max/min stored as float32, intersection in
+ * float32 in frame order, areas float64 in numpy's pairwise summation order, quotient in float64 stored as
+ * float32.  The length check is the caller's: this function reads len_a[u] frames of both rows.           */
+int tspn_traj_iou_tail_f64(const double* a, const int32_t* len_a, const double* b, int64_t U, int64_t N,
+                           int64_t L, float* out, void* stream);
+
 /* ---- pair order ---------------------------------------------------------
  * All ordered pairs (i,j), i != j, i-major (lib/modeling/predict.py:133-140):
  * pairs[N*(N-1), 2] int64, tracklet ids offset by `base`.                   */

@@ -81,6 +81,7 @@ PROTOTYPES = {
                                              _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                              _i64, _vp, _vp, _vp]),
     "tspn_traj_iou_f32": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp]),
+    "tspn_traj_iou_tail_f64": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "tspn_pair_index_i64": (_int, [_i64, _i64, _vp, _vp]),
     "tspn_pair_gather_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp]),
     "tspn_pack_conv3_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),

@@ -3,8 +3,16 @@
 Host-side mirror of the reference's `lib/modeling/association.py` (same entry point, same argument
 meaning, same output dicts) without dlib: trajectories are plain lists of (left, top, right, bottom)
 float tuples.  It is downstream of the GPU path: the inputs are the per-segment
-top-k triplets of `BaseModel.decode` / predict.py:59-117, a few hundred small items per video, and the
-algorithm is sequential by construction, so it stays on the host.
+top-k triplets of `BaseModel.decode` / predict.py:59-117.  The greedy loop is sequential by construction
+and stays on the host; its arithmetic - the trajectory IoUs, two per (prediction, candidate relation) in
+the reference - is batched: with `device=` every live trajectory of the previous segment's relations
+meets every tracklet of the current segment in ONE launch of `tspn_traj_iou_tail_f64` per segment
+(csrc/tspn_iou.hip, the reference chain's float32 / float64 roundings kept to the bit), and only rows
+whose trajectory a merge has changed since are recomputed, again in one launch.  Two things the
+reference does per prediction are done once per segment because they cannot change in between: the
+stable sort of the previous segment's relations by mean confidence (a relation's confidences change only
+when it is extended, and then it leaves that list), and the scan for relations with the same triplet
+(grouped once, order kept).  Without `device` the same loop calls the host IoU per candidate.
 
 Behaviour reproduced as is (each checked against the reference's own code by tests/golden/g9):
   * segments are visited in order of `int(fstart)`; per segment the predictions are sorted by score,
@@ -33,7 +41,7 @@ __all__ = ["Track", "VideoRelation", "greedy_relational_association", "load_traj
 class Track:
     """Box trajectory over frames [pstart, pend) (reference lib/modeling/trajectory.py:12-83)."""
 
-    __slots__ = ("pstart", "pend", "rois", "score", "category", "classeme", "vsig", "gt_trackid")
+    __slots__ = ("pstart", "pend", "rois", "score", "category", "classeme", "vsig", "gt_trackid", "_ver")
 
     def __init__(self, pstart, pend, rois, score=0.0, category=-1, classeme=(), vsig=None, gt_trackid=-1):
         rois = [tuple(float(v) for v in r) for r in rois]
@@ -42,6 +50,7 @@ class Track:
         self.pstart, self.pend, self.rois = int(pstart), int(pend), rois
         self.score, self.category, self.classeme = score, category, classeme
         self.vsig, self.gt_trackid = vsig, gt_trackid
+        self._ver = 0          # bumped by every in-place merge: the batched IoU rows of this trajectory are stale
 
     def length(self):
         return self.pend - self.pstart
@@ -90,6 +99,7 @@ def _merge_trajs(t1, t2):
     for i in range(overlap, t2.length()):
         t1.rois.append(t2.rois[i])
         t1.pend += 1
+    t1._ver += 1
     return t1
 
 
@@ -106,9 +116,15 @@ class VideoRelation:
         return (self.s_cid, self.pid, self.o_cid)
 
     def mean_confs(self):
-        return np.mean(self.confs_list)
+        # np.mean as in the reference (association.py:84-85; its summation order decides ties), cached per list length
+        n = len(self.confs_list)
+        if getattr(self, "_mean_n", -1) != n:
+            self._mean, self._mean_n = np.mean(self.confs_list), n
+        return self._mean
 
-    def both_overlap(self, straj, otraj, iou_thr=0.5):
+    def both_overlap(self, straj, otraj, iou_thr=0.5, table=None, s_idx=None, o_idx=None):
+        if table is not None:      # batched device IoUs of this segment (same values, same short circuit)
+            return bool(table.iou(self.straj, s_idx) >= iou_thr and table.iou(self.otraj, o_idx) >= iou_thr)
         return bool(_traj_iou(self.straj, straj) >= iou_thr and _traj_iou(self.otraj, otraj) >= iou_thr)
 
     def extend(self, straj, otraj, confs):
@@ -151,7 +167,73 @@ def _as_tracks(trajs, fstart, fend):
     return out
 
 
-def greedy_relational_association(dataset, short_term_relations, max_traj_num_in_clip=100, trajectories=None):
+class _SegmentIoUTable:
+    """IoUs of a segment: (live trajectory of an earlier segment) x (tracklet of this segment), on their common
+    frames, computed on the device in one launch for all pairs (`ops.traj_iou_tail`) and again - one launch for
+    every stale row at once - when a merge has changed trajectories since.  Values equal `_traj_iou`'s bit for bit."""
+
+    def __init__(self, device, cur_tracks, fstart, fend):
+        import torch
+
+        from . import ops
+        self._torch, self._ops = torch, ops
+        self.device = torch.device(device)
+        self.fstart, self.fend, self.L = int(fstart), int(fend), int(fend) - int(fstart)
+        b = np.empty((len(cur_tracks), self.L, 4), dtype=np.float64)
+        for j, t in enumerate(cur_tracks):
+            if len(t.rois) != self.L:
+                raise ValueError(f"tracklet {j} of segment [{fstart}, {fend}) has {len(t.rois)} boxes")
+            b[j] = t.rois
+        self.n = len(cur_tracks)
+        self.b = torch.from_numpy(b).to(self.device)
+        self.live = {}         # id(track) -> track
+        self.rows = {}         # id(track) -> (version, float32 [N] or AssertionError)
+        self.launches = 0
+
+    def add(self, tracks):
+        for t in tracks:
+            self.live[id(t)] = t
+
+    def _refresh(self):
+        stale = [t for k, t in self.live.items() if self.rows.get(k, (None,))[0] != t._ver]
+        if not stale or self.n == 0:
+            for t in stale:
+                self.rows[id(t)] = (t._ver, np.zeros((0,), dtype=np.float32))
+            return
+        torch = self._torch
+        a = np.zeros((len(stale), self.L, 4), dtype=np.float64)
+        ln = np.zeros((len(stale),), dtype=np.int32)
+        bad = {}
+        for u, t in enumerate(stale):
+            if t.pstart > self.fstart:
+                raise AssertionError("segments out of order")       # cannot happen after the sort by fstart
+            k = t.pend - self.fstart                                 # common frames [fstart, t.pend)
+            if k <= 0:
+                continue                                             # no overlap -> 0 (association.py:36-37)
+            if k > self.L:
+                bad[u] = AssertionError("trajectories of different length")    # trajectory.py:89, raised on use
+                continue
+            a[u, :k] = t.rois[self.fstart - t.pstart:t.pend - t.pstart]
+            ln[u] = k
+        out = self._ops.traj_iou_tail(torch.from_numpy(a).to(self.device), torch.from_numpy(ln).to(self.device), self.b)
+        out = out.cpu().numpy()
+        self.launches += 1
+        for u, t in enumerate(stale):
+            self.rows[id(t)] = (t._ver, bad.get(u, out[u]))
+
+    def iou(self, track, j):
+        ent = self.rows.get(id(track))
+        if ent is None or ent[0] != track._ver:
+            self.live[id(track)] = track
+            self._refresh()
+            ent = self.rows[id(track)]
+        if isinstance(ent[1], AssertionError):
+            raise ent[1]
+        return ent[1][int(j)]
+
+
+def greedy_relational_association(dataset, short_term_relations, max_traj_num_in_clip=100, trajectories=None,
+                                  device=None, stats=None):
     """Reference `greedy_relational_association` (association.py:117-175).
 
     `short_term_relations`: list of `((vid, fstart, fend), (pred_list, iou, trackid))` with
@@ -159,6 +241,9 @@ def greedy_relational_association(dataset, short_term_relations, max_traj_num_in
     `trajectories`: callable `(vid, fstart, fend) -> tracklets` (Track objects, `traj_cls` dicts or
     [L,4] box arrays, indexed like the predictions' tracklet ids) or a dict keyed by that triple;
     default = the reference's on-disk proposals (`load_trajectories`).
+    `device`: a HIP device ("cuda", "cuda:0", torch.device): the trajectory IoUs of a segment come from one
+    batched launch (module docstring) instead of one numpy evaluation per (prediction, candidate); same results.
+    `stats`: optional dict, receives counters (`iou_launches`, `iou_lookups`, `segments`).
     Returns the list of serialised video relations (`dataset` supplies the names; None keeps ids)."""
     if trajectories is None:
         provider = load_trajectories
@@ -169,6 +254,7 @@ def greedy_relational_association(dataset, short_term_relations, max_traj_num_in
     short_term_relations.sort(key=lambda x: int(x[0][1]))   # in place, like the reference
     video_relation_list = []
     last_modify_rel_list = []
+    launches = lookups = 0
     for i, (index, prediction) in enumerate(short_term_relations):
         vid, fstart, fend = index
         pred_list = prediction[0]
@@ -178,6 +264,21 @@ def greedy_relational_association(dataset, short_term_relations, max_traj_num_in
             traj.pstart, traj.pend = fstart, fend
             traj.vsig = "{}-{:04d}-{:04d}".format(vid, fstart, fend)
         cur_modify_rel_list = []
+        # the reference re-sorts the previous segment's relations before EVERY prediction (association.py:150); the
+        # keys of the relations still in that list cannot change inside a segment (an extended relation leaves it), and
+        # the sort is stable, so once per segment gives the same order; likewise the same-triplet scan, grouped once
+        by_triplet = {}
+        table = None
+        if i > 0 and sorted_pred_list:
+            last_modify_rel_list.sort(key=lambda r: r.mean_confs(), reverse=True)
+            for r in last_modify_rel_list:
+                by_triplet.setdefault(_triplet_key(r.triplet()), []).append(r)
+            if device is not None and last_modify_rel_list:
+                table = _SegmentIoUTable(device, trajs, fstart, fend)
+                wanted = {_triplet_key(p[1]) for p in sorted_pred_list}
+                for key in wanted:                                   # only relations a prediction can meet
+                    for r in by_triplet.get(key, ()):
+                        table.add((r.straj, r.otraj))
         for pred in sorted_pred_list:
             conf_score = pred[0]
             s_cid, pid, o_cid = pred[1]
@@ -188,13 +289,14 @@ def greedy_relational_association(dataset, short_term_relations, max_traj_num_in
                 video_relation_list.append(r)
                 cur_modify_rel_list.append(r)
                 continue
-            last_modify_rel_list.sort(key=lambda r: r.mean_confs(), reverse=True)
             merged = False
-            for r in last_modify_rel_list:
-                if bool(np.all(np.asarray(pred[1]) == np.asarray(r.triplet()))):
-                    if (straj.pstart < r.fend and otraj.pstart < r.fend) and r.both_overlap(straj, otraj):
+            candidates = by_triplet.get(_triplet_key(pred[1]), ())
+            for r in candidates:
+                if straj.pstart < r.fend and otraj.pstart < r.fend:
+                    lookups += 1
+                    if r.both_overlap(straj, otraj, table=table, s_idx=s_idx, o_idx=o_idx):
                         r.extend(straj, otraj, conf_score)
-                        last_modify_rel_list.remove(r)
+                        candidates.remove(r)
                         cur_modify_rel_list.append(r)
                         merged = True
                         break
@@ -202,5 +304,15 @@ def greedy_relational_association(dataset, short_term_relations, max_traj_num_in
                 r = VideoRelation(vid, s_cid, pid, o_cid, straj, otraj)   # confs = 1 (reference default)
                 video_relation_list.append(r)
                 cur_modify_rel_list.append(r)
+        if table is not None:
+            launches += table.launches
         last_modify_rel_list = cur_modify_rel_list
+    if stats is not None:
+        stats.update(iou_launches=launches, iou_lookups=lookups, segments=len(short_term_relations))
     return [rel.serialize(dataset) for rel in video_relation_list]
+
+
+def _triplet_key(triplet):
+    """Hashable form of a prediction's / relation's (s_cid, pid, o_cid): the reference compares them element-wise
+    with numpy (association.py:152), so 3, np.int64(3) and a 0-d array holding 3 are the same triplet."""
+    return tuple(np.asarray(triplet).tolist())

@@ -40,7 +40,108 @@ __global__ __launch_bounds__(256) void traj_iou_kernel(const float4* __restrict_
   out[bidx * N1 * N2 + ij] = inters / uni;
 }
 
+// ---- association-time IoU (f3): every live trajectory of the previous segment's relations against every
+// tracklet of the current segment, on their common frames, in ONE launch.
+//
+// Replaces the per-candidate calls `_traj_iou(r.straj, straj)` / `_traj_iou(r.otraj, otraj)` of
+// reference lib/modeling/association.py:35-48,101-106 (-> trajectory.py:144-158 traj_iou -> cubic_iou with
+// float64 boxes).  Rounding recipe of that call chain, kept to the bit:
+//   * max / min of the float64 coordinates are STORED as float32 (`out=` arrays of trajectory.py:91-94);
+//     (+1), the subtraction, the clip, w*h and the running sum over frames are float32, in frame order;
+//   * box areas are float64, summed over the common frames in numpy's pairwise order (np.sum of a contiguous
+//     run: eight interleaved partial sums per block of <= 128, halves split at a multiple of 8 above that);
+//   * union = (area1 + area2) - float64(inters); iou = float32(float64(inters) / union).
+// Row u of `a` holds trajectory u from the current segment's first frame on; its first len_a[u] frames are the
+// common ones (0: the trajectories do not overlap -> 0, association.py:36-37).
+template <class F>
+__device__ inline double np_block_sum(F&& f, int64_t lo, int64_t n) {
+  if (n < 8) {
+    double res = 0.;
+    for (int64_t i = 0; i < n; ++i) res += f(lo + i);
+    return res;
+  }
+  double r[8];
+  for (int k = 0; k < 8; ++k) r[k] = f(lo + k);
+  int64_t i = 8;
+  for (; i < n - (n % 8); i += 8)
+    for (int k = 0; k < 8; ++k) r[k] += f(lo + i + k);
+  double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+  for (; i < n; ++i) res += f(lo + i);
+  return res;
+}
+
+template <class F>
+__device__ inline double np_pairwise_sum(F&& f, int64_t n) {
+  if (n <= 128) return np_block_sum(f, 0, n);
+  struct Frame { int64_t lo, n; int stage; double left; };
+  Frame st[48];               // depth <= log2(n / 64): far below 48 for any int64 n
+  int sp = 0;
+  double ret = 0.;
+  st[sp++] = Frame{0, n, 0, 0.};
+  while (sp > 0) {
+    Frame& fr = st[sp - 1];
+    if (fr.stage == 0) {
+      if (fr.n <= 128) { ret = np_block_sum(f, fr.lo, fr.n); --sp; continue; }
+      int64_t n2 = fr.n / 2; n2 -= n2 % 8;
+      fr.stage = 1;
+      st[sp++] = Frame{fr.lo, n2, 0, 0.};
+    } else if (fr.stage == 1) {
+      int64_t n2 = fr.n / 2; n2 -= n2 % 8;
+      fr.left = ret;
+      fr.stage = 2;
+      st[sp++] = Frame{fr.lo + n2, fr.n - n2, 0, 0.};
+    } else {
+      ret = fr.left + ret;
+      --sp;
+    }
+  }
+  return ret;
+}
+
+__global__ __launch_bounds__(256) void traj_iou_tail_f64_kernel(const double* __restrict__ a,
+                                                                const int32_t* __restrict__ len_a,
+                                                                const double* __restrict__ b, int64_t U, int64_t N,
+                                                                int64_t L, float* __restrict__ out) {
+  const int64_t un = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (un >= U * N) return;
+  const int64_t u = un / N, n = un - u * N;
+  const int64_t len = len_a[u];
+  if (len <= 0) { out[un] = 0.f; return; }
+  const double* pa = a + u * L * 4;
+  const double* pb = b + n * L * 4;
+  float inters = 0.f;
+  for (int64_t t = 0; t < len; ++t) {
+    const double* p = pa + 4 * t;
+    const double* q = pb + 4 * t;
+    const float lo_x = (float)fmax(p[0], q[0]), hi_x = (float)fmin(p[2], q[2]);
+    float w = (hi_x + 1.f) - lo_x;
+    w = fmaxf(w, 0.f);
+    const float lo_y = (float)fmax(p[1], q[1]), hi_y = (float)fmin(p[3], q[3]);
+    float h = (hi_y + 1.f) - lo_y;
+    h = fmaxf(h, 0.f);
+    inters += w * h;
+  }
+  auto area_of = [](const double* r) {
+    return [r](int64_t t) { return (r[4 * t + 2] - r[4 * t] + 1.) * (r[4 * t + 3] - r[4 * t + 1] + 1.); };
+  };
+  const double a1 = np_pairwise_sum(area_of(pa), len);
+  const double a2 = np_pairwise_sum(area_of(pb), len);
+  const double uni = (a1 + a2) - (double)inters;
+  out[un] = (float)((double)inters / uni);
+}
+
 }  // namespace
+
+extern "C" int tspn_traj_iou_tail_f64(const double* a, const int32_t* len_a, const double* b, int64_t U,
+                                      int64_t N, int64_t L, float* out, void* stream) {
+  TSPN_REQUIRE(U >= 0 && N >= 0 && L >= 0, TSPN_EINVAL, "tspn_traj_iou_tail_f64: bad sizes");
+  if (U == 0 || N == 0) return TSPN_OK;
+  TSPN_REQUIRE(len_a && out && (L == 0 || (a && b)), TSPN_EINVAL, "tspn_traj_iou_tail_f64: null pointer");
+  TSPN_REQUIRE(U * N < ((int64_t)1 << 31) * 256, TSPN_EUNSUPPORTED, "tspn_traj_iou_tail_f64: too many pairs");
+  hipLaunchKernelGGL(traj_iou_tail_f64_kernel, dim3((unsigned)tspn::ceil_div(U * N, 256)), dim3(256), 0,
+                     TSPN_STREAM(stream), a, len_a, b, U, N, L, out);
+  return tspn::check_launch("tspn_traj_iou_tail_f64");
+}
 
 extern "C" int tspn_traj_iou_f32(const float* boxes1, int64_t N1, const float* boxes2, int64_t N2,
                                  int64_t B, int64_t T, float* out, void* stream) {

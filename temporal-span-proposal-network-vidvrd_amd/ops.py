@@ -12,7 +12,7 @@ import torch
 from . import _abi
 
 __all__ = [
-    "predicate_head", "feature_preprocess_", "ppn_pair_matrix_topk", "traj_iou", "pair_index",
+    "predicate_head", "feature_preprocess_", "ppn_pair_matrix_topk", "traj_iou", "traj_iou_tail", "pair_index",
     "pair_gather", "pack_conv3", "conv3", "conv3_tc", "pack_conv3_wino63", "conv3_tc_wino63", "heads", "heads_pairgrid", "temporal_mean", "pair_rows", "transpose_td",
     "forward_fused", "temporal_encoder_heads", "fused_workspace_bytes", "fused_bf16_workspace_bytes", "decode_topk", "decode_spans",
     "cast_bf16", "pack_conv3_bf16", "pack_heads_bf16", "conv3_tc_bf16", "heads_pairgrid_bf16",
@@ -229,6 +229,29 @@ def traj_iou(boxes1, boxes2=None):
     out = torch.empty((B, N1, N2), dtype=torch.float32, device=b1.device)
     _abi.check(_abi.lib().tspn_traj_iou_f32(_p(b1), N1, _p(b2), N2, B, T, _p(out), _stream()))
     return out[0] if squeeze else out
+
+
+@_on_tensor_device
+def traj_iou_tail(a, len_a, b, out=None):
+    """Association-time IoU, one launch per segment (replaces the per-candidate `_traj_iou` calls of reference
+    lib/modeling/association.py:35-48,101-106): a [U,L,4] float64 = trajectories from the segment's first frame on,
+    len_a [U] int32 = their number of common frames (<= L; 0 -> IoU 0), b [N,L,4] float64 = the segment's tracklets
+    -> [U,N] float32 with the reference chain's roundings (tspn_traj_iou_tail_f64)."""
+    _dev(a, "a", torch.float64), _dev(b, "b", torch.float64), _dev(len_a, "len_a", torch.int32)
+    if a.dim() != 3 or b.dim() != 3 or a.shape[2] != 4 or b.shape[2] != 4 or a.shape[1] != b.shape[1]:
+        raise ValueError(f"traj_iou_tail: a [U,L,4] and b [N,L,4] expected, got {tuple(a.shape)} and {tuple(b.shape)}")
+    U, L, _ = a.shape
+    N = b.shape[0]
+    if len_a.shape != (U,):
+        raise ValueError(f"traj_iou_tail: len_a must be [{U}], got {tuple(len_a.shape)}")
+    if not (a.is_contiguous() and b.is_contiguous() and len_a.is_contiguous()):
+        raise ValueError("traj_iou_tail: operands must be contiguous")
+    if out is None:
+        out = torch.empty((U, N), dtype=torch.float32, device=a.device)
+    elif out.shape != (U, N) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != a.device:
+        raise ValueError("traj_iou_tail: out must be a contiguous float32 [U,N] tensor on the operands' device")
+    _abi.check(_abi.lib().tspn_traj_iou_tail_f64(_p(a), _p(len_a), _p(b), U, N, L, _p(out), _stream()))
+    return out
 
 
 def pair_index(n, device, base=0):

@@ -94,3 +94,39 @@ def test_association_empty_and_capped_inputs(tspn):
                                           trajectories={("v", 0, 30): [box, box]})
     assert [round(r["score"], 2) for r in out] == [0.09, 0.08, 0.07, 0.06]
     assert A.load_trajectories("no-such-video", 0, 30, root="/nonexistent") == []
+
+
+def test_numpy_pairwise_summation_order_restated():
+    """The device kernel `traj_iou_tail_f64_kernel` sums the float64 box areas in numpy's pairwise order so that it
+    equals `np.sum` (trajectory.py:110-123) to the bit.  This pins that order on the CPU: the restatement below (the
+    algorithm csrc/tspn_iou.hip implements) equals np.sum exactly for every length 0..1300 on ill-conditioned data."""
+    def block(a):
+        n = len(a)
+        if n < 8:
+            r = 0.0
+            for v in a:
+                r += v
+            return r
+        r = [float(v) for v in a[:8]]
+        i = 8
+        while i < n - (n % 8):
+            for k in range(8):
+                r[k] += a[i + k]
+            i += 8
+        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]))
+        for v in a[i:]:
+            res += v
+        return res
+
+    def pairwise(a):
+        n = len(a)
+        if n <= 128:
+            return block(a)
+        n2 = n // 2
+        n2 -= n2 % 8
+        return pairwise(a[:n2]) + pairwise(a[n2:])
+
+    rs = np.random.RandomState(5)
+    for n in list(range(0, 140)) + [255, 256, 257, 300, 511, 777, 1024, 1100, 1300]:
+        a = (rs.uniform(1, 2, size=n) * 10.0 ** rs.randint(-3, 6, size=n)).astype(np.float64)
+        assert float(np.sum(a)) == pairwise([float(v) for v in a]), n
