@@ -105,6 +105,14 @@ def parse(argv=None):
     ap.add_argument("--ops-level", action="store_true",
                     help="time ops.forward_fused with pre-allocated workspace / outputs instead of BaseModel.forward + "
                          "BaseModel.decode on PairLists (the default)")
+    ap.add_argument("--host-inputs", choices=["off", "pageable", "pinned", "prefetch", "prefetch-pinned", "naive"], default="off",
+                    help="cfg2/cfg3/cfg4 through BaseModel: the PairLists hold HOST tensors, as the reference's predict.py:50-57 "
+                         "hands them (pageable = a plain DataLoader; pinned = DataLoader(pin_memory=True) / PairList."
+                         "pin_memory()); forward pipelines upload, encoder and download over chunks of videos and returns "
+                         "host results; prefetch[-pinned] = the same host batches through dataset.DevicePrefetcher (batch i+1 uploads "
+                         "under batch i, forward sees device tensors); naive = round 3's path, one blocking .to(device) per "
+                         "tensor.  The line then reports the PCIe-INCLUSIVE rate (never the headline value)")
+    ap.add_argument("--host-chunk", type=int, default=None, help="--host-inputs: videos per pipelined chunk (default 4)")
     ap.add_argument("--frames", type=int, default=None, help="cfg5: frames per video (default 900)")
     ap.add_argument("--tracklets", type=int, default=None, help="cfg5: tracklets per video (default 64)")
     ap.add_argument("--roi-streams", type=int, default=0,
@@ -530,6 +538,23 @@ class ScoringWorkload:
         for i, (a, b) in enumerate(self.events):  # create the HIP event handles
             a.record(); b.record(); self.ev_logits[i].record(); self.ev_side[i].record()
         self.geom = None
+        self.host = args.host_inputs != "off"
+        if self.host:
+            if not self.via_model:
+                raise SystemExit("bench.py: --host-inputs runs through BaseModel (drop --ops-level)")
+            place = (lambda x: x.cpu().pin_memory()) if args.host_inputs.endswith("pinned") else (lambda x: x.cpu())
+            self.feats_all = [place(x) for x in self.feats_all]
+            self.cls_all = [place(x) for x in self.cls_all]
+            self.boxes_all = [place(x) for x in self.boxes_all]
+            self.prefetch = None
+            if args.host_inputs.startswith("prefetch"):
+                def loader():          # what the reference's DataLoader yields (build.py:84-93): host batches, forever
+                    i = 0
+                    while True:
+                        f, c, bx = self.feats_all[i % nb], self.cls_all[i % nb], self.boxes_all[i % nb]
+                        yield [tspn.PairList.from_tracklets(f[b * N:(b + 1) * N], bx[b * N:(b + 1) * N], c[b]) for b in range(B)]
+                        i += 1
+                self.prefetch = iter(tspn.dataset.DevicePrefetcher(loader(), dev))
         if self.via_model:
             self._init_model()
         else:
@@ -543,7 +568,9 @@ class ScoringWorkload:
                                      "PREDICT.FEATURE_DIM": self.C, "RELPN.DPN.NUM_ANCHORS_PER_LOCATION": A_ANCH,
                                      "PREDICT.PREDICATE_NUM": K_PRED, "RELPN.PPN.NUM_PAIR_PROPOSALS": TOPK_PPN,
                                      "RELPN.DPN.PAIR_GEOMETRY": True, "RELPN.OVERLAP_TAIL": not self.args.serial_tail,
-                                     "RELPN.DPN.CONV_ALGO": "direct" if self.args.conv == "direct" else "auto"})
+                                     "RELPN.DPN.CONV_ALGO": "direct" if self.args.conv == "direct" else "auto",
+                                     **({"RELPN.DPN.HOST_CHUNK_VIDEOS": self.args.host_chunk} if self.args.host_chunk else {}),
+                                     **({"RELPN.DPN.HOST_CHUNK_VIDEOS": 0} if self.args.host_inputs == "naive" else {})})
         model = tspn.BaseModel(cfg)
         model.load_state_dict({k: torch.from_numpy(v) for k, v in self.sd.items()})
         self.model = model.to(self.dev).eval()
@@ -551,8 +578,11 @@ class ScoringWorkload:
     def _step_model(self, i):
         tspn, torch, N, B = self.tspn, self.torch, self.N, self.B
         feats, cls, boxes = self.feats_all[i % self.nb], self.cls_all[i % self.nb], self.boxes_all[i % self.nb]
-        plists = [tspn.PairList.from_tracklets(feats[b * N:(b + 1) * N], boxes[b * N:(b + 1) * N], cls[b])
-                  for b in range(B)]
+        if self.host and self.prefetch is not None:
+            plists = next(self.prefetch)
+        else:
+            plists = [tspn.PairList.from_tracklets(feats[b * N:(b + 1) * N], boxes[b * N:(b + 1) * N], cls[b])
+                      for b in range(B)]
         self.model.profile_conv_events(self.events[i])
         pair_props, dur_props, rel_logits = self.model(plists, None)
         dec = self.model.decode(plists, rel_logits, topk_per_pair=TOPK_PAIR, topk_per_seg=TOPK_SEG)
@@ -660,8 +690,11 @@ class ScoringWorkload:
             "dtype": "bf16" if bf16 else "f32",
             "config": {"workload": cfg_name,
                        "videos_per_gpu_per_step": B, "pairs_per_video": self.P_vid, "resident_input_batches": self.nb,
-                       "surface": ("BaseModel.forward(pair_list) + BaseModel.decode on device-resident PairLists"
+                       "surface": (("BaseModel.forward(pair_list) + BaseModel.decode on HOST-resident PairLists ("
+                                    + args.host_inputs + " memory), host results: PCIe inclusive") if self.host else
+                                   "BaseModel.forward(pair_list) + BaseModel.decode on device-resident PairLists"
                                    if self.via_model else "ops.forward_fused (pre-allocated workspace and outputs)"),
+                       "host_inputs": args.host_inputs,
                        "path": ("fused/factorised (tspn_forward_fused_bf16)" if bf16 else
                                 "fused/factorised (tspn_forward_fused_f32)")
                                + " + pair geometry + PPN top-k + top-k triplet decode" + gather_txt
@@ -846,6 +879,7 @@ def main():
 
     import tspn_mi355x as tspn
 
+    torch.set_num_threads(usable_cores())   # torch sizes its pool by the visible cores; the box grants a quota of them
     # stdout carries exactly ONE line, the JSON result: native libraries write there too (RCCL prints a
     # version banner to stdout when the first communicator is created), so fd 1 points at stderr until
     # the result is printed
@@ -935,7 +969,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": rep["dtype"], "data": "synthetic",
+            "dtype": rep["dtype"],
+            "data": "synthetic" if args.host_inputs == "off" else f"synthetic, {args.host_inputs} HOST memory (PCIe inclusive)",
             "config": rep["config"],
             "roofline": rep["roofline"],
         }

@@ -66,7 +66,10 @@ _DEFAULTS = {
                 # build extension: algorithm of the k=3 temporal conv on the GPU (both exact fp32 MFMA):
                 # "auto" = Winograd F(6,3) where the shape allows it (D % 32 == 0; 4/9 of the direct MFMA work,
                 # error bound in DESIGN.md §4), else the direct taps; "direct" = always the direct taps
-                "CONV_ALGO": "auto"},
+                "CONV_ALGO": "auto",
+                # build extension: tracklet features handed over in HOST memory (predict.py:50-57) go to the device in
+                # chunks of this many videos, pipelined under the encoder (model._HostPipeline)
+                "HOST_CHUNK_VIDEOS": 4},
     },
     "ETC": {"RANDOM_SEED": 0, "MODEL_DUMP_FILE": "baseline_weights_epoch_100.pt"},
 }

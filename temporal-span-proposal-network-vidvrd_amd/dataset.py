@@ -32,7 +32,7 @@ import torch
 from . import ops
 from .pair_list import PairList, TargetList
 
-__all__ = ["proposal_pair_list", "proposal_pair_lists", "select_proposal_pairs", "segment_signature", "feature_path",
+__all__ = ["DevicePrefetcher", "proposal_pair_list", "proposal_pair_lists", "select_proposal_pairs", "segment_signature", "feature_path",
            "write_traj_cls_json", "read_traj_cls_json", "tracklets_to_traj_cls", "write_relation_h5",
            "read_relation_h5"]
 
@@ -208,3 +208,111 @@ def read_relation_h5(path):
     h5py = _h5py()
     with h5py.File(path, "r") as fin:
         return fin["pairs"][:], fin["feats"][:], fin["iou"][:], fin["trackid"][:]
+
+
+# ---- host-resident batches (what the reference's loader yields) one step ahead on the device -------------------
+class DevicePrefetcher:
+    """Wraps the reference's test / train loader (an iterable of `(pair_list, target_list, indexs)` batches with HOST
+    tensors, lib/dataset/build.py:84-93, consumed at lib/modeling/predict.py:50-57):
+
+        for pair_list, target_list, indexs in DevicePrefetcher(data_loader, device):
+            pair_proposals, duration_proposals, rel_logits = model(pair_list, target_list)
+
+    yields the same batches with every tensor already in HBM, and uploads batch i+1 on a copy stream while the caller
+    works on batch i - the whole-batch upload (39 MB per cfg2 video) hides under the previous batch's encoder, and
+    `forward` runs its resident path (one launch over the whole batch; results stay on the device, where `decode`
+    wants them).  Pinned host tensors (`DataLoader(pin_memory=True)` -> `PairList.pin_memory()`) are DMA'd in place;
+    pageable ones are first copied into pinned memory by a few copy workers.  Ordinary stream semantics for the
+    consumer: the yielded tensors are ready on the CURRENT stream of `device` at the time of the `next()`."""
+
+    def __init__(self, loader, device=None):
+        self.loader = loader
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if self.device.type != "cuda":
+            raise RuntimeError("DevicePrefetcher needs a HIP device")
+        self._stream = None
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _pin(self, t):
+        from .model import _stage_pool
+        if t.is_pinned():
+            return t
+        out = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        src = t if t.is_contiguous() else t.contiguous()
+        if t.numel() * t.element_size() < (1 << 20) or t.dim() == 0:
+            out.copy_(src)
+            return out
+        pool, nt = _stage_pool()
+        rows = t.shape[0]
+        step = max(1, -(-rows // nt))
+        list(pool.map(lambda r: out[r:r + step].copy_(src[r:r + step]), range(0, rows, step)))
+        return out
+
+    def _upload(self, obj, keep):
+        """Mirror `obj` (tensor / PairList-like / list / tuple / dict) with host tensors replaced by device copies issued
+        on the copy stream; `keep` collects the pinned sources so that they outlive their DMA."""
+        if isinstance(obj, torch.Tensor):
+            if obj.is_cuda:
+                return obj
+            pinned = self._pin(obj)
+            keep.append(pinned)
+            return pinned.to(self.device, non_blocking=True)
+        if hasattr(obj, "extra_fields") and hasattr(obj, "_derive"):           # PairList / TargetList of this package
+            return obj._derive(self._upload(obj._primary_value(), keep), lambda v: self._upload(v, keep))
+        if hasattr(obj, "extra_fields") and hasattr(obj, "to"):                # the reference's own list types
+            out = obj.to(self.device)
+            return out
+        if isinstance(obj, (list, tuple)):
+            return type(obj)(self._upload(v, keep) for v in obj)
+        if isinstance(obj, dict):
+            return {k: self._upload(v, keep) for k, v in obj.items()}
+        return obj                                                               # numpy fields, ints, index triples
+
+    def _device_tensors(self, obj, out):
+        if isinstance(obj, torch.Tensor):
+            if obj.is_cuda:
+                out.append(obj)
+        elif hasattr(obj, "extra_fields"):
+            self._device_tensors(getattr(obj, obj._primary) if hasattr(obj, "_primary") else None, out)
+            self._device_tensors(list(obj.extra_fields.values()), out)
+        elif isinstance(obj, (list, tuple)):
+            for v in obj:
+                self._device_tensors(v, out)
+        elif isinstance(obj, dict):
+            self._device_tensors(list(obj.values()), out)
+
+    def _stage(self, batch):
+        keep = []
+        with torch.cuda.stream(self._stream):
+            dev_batch = self._upload(batch, keep)
+            ev = torch.cuda.Event()
+            ev.record(self._stream)
+        return dev_batch, ev, keep
+
+    def __iter__(self):
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=self.device)
+        it = iter(self.loader)
+        try:
+            nxt = self._stage(next(it))
+        except StopIteration:
+            return
+        held = None
+        while nxt is not None:
+            cur = nxt
+            try:
+                nxt = self._stage(next(it))        # batch i+1 starts uploading before batch i is handed out
+            except StopIteration:
+                nxt = None
+            dev_batch, ev, keep = cur
+            main = torch.cuda.current_stream(self.device)
+            main.wait_event(ev)
+            tensors = []
+            self._device_tensors(dev_batch, tensors)
+            for t in tensors:
+                t.record_stream(main)              # allocated under the copy stream, consumed on the caller's
+            held = keep                            # pinned sources of the batch in flight stay alive one more round
+            yield dev_batch
+        del held

@@ -552,6 +552,129 @@ def make_relpn(cfg):
     return RelPN(cfg)
 
 
+def _usable_cpus():
+    """Cores this process may really use: the affinity mask capped by the cgroup CPU quota (a container that shows 256
+    cores and grants 16 throttles a 128-thread copy to a crawl)."""
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+_STAGE_POOL = None
+
+
+def _stage_pool():
+    """A few single-threaded copy workers for the pageable -> pinned staging copies (torch's intra-op pool is sized by
+    the visible cores, not by the quota, and is shared with everything else the caller runs)."""
+    global _STAGE_POOL
+    if _STAGE_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        nt = max(1, min(8, _usable_cpus() - 1))
+        _STAGE_POOL = (ThreadPoolExecutor(nt, thread_name_prefix="tspn-stage", initializer=lambda: torch.set_num_threads(1)), nt)
+    return _STAGE_POOL
+
+
+class _HostPipeline:
+    """Transfers of one forward whose tracklet features live in HOST memory (what the reference's predict.py:50-57
+    hands over: CPU PairLists from a DataLoader): the videos of a group go to the device in chunks on a copy stream,
+    the fused pass runs chunk by chunk behind the chunks' copy events, and every chunk's results come back on a third
+    stream into pinned tensors - so chunk k+1 uploads, and chunk k-1 downloads, under the encoder of chunk k.
+    Pinned sources (`PairList.pin_memory()`, `DataLoader(pin_memory=True)`) are DMA'd as they are; pageable ones
+    are staged through a pinned buffer kept here (a multi-threaded host copy), one chunk ahead of the GPU."""
+
+    def __init__(self, dev):
+        self.dev = dev
+        self.h2d = torch.cuda.Stream(device=dev)
+        self.d2h = torch.cuda.Stream(device=dev)
+        self.dev_buf, self.pin_buf = {}, {}
+        self.compute_done = None        # event on the caller's stream: the last pass that read dev_buf
+        self.h2d_done = None            # event on the copy stream: the last DMA out of pin_buf
+
+    @staticmethod
+    def schedule(nm, chunk):
+        """[(lo, hi)) video ranges.  Only the first upload is exposed, and a fused pass over few videos is less efficient
+        than one over many (cfg2: 2.41 ms per video at 2 videos, 2.07 at 4, 1.72 at 16): start with half a chunk, then
+        `chunk`, then double while every upload still hides under the pass before it; the last range takes the rest
+        (16 videos, chunk 4: 2 + 4 + 10)."""
+        chunk = max(1, int(chunk))
+        out, lo, size = [], 0, max(1, chunk // 2)
+        while lo < nm:
+            rest = nm - lo
+            nxt = chunk if not out else 2 * size
+            hi = nm if (out and rest <= nxt + nxt // 4) else min(nm, lo + size)
+            out.append((lo, hi))
+            lo, size = hi, nxt
+        return out
+
+    def begin(self, src, dtype):
+        """Device buffer [nm*n, t, d] for the group + the staging state; nothing is copied yet."""
+        nm, (n, t, d) = len(src), tuple(src[0].shape)
+        key = (nm, n, t, d, dtype)
+        for cache in (self.dev_buf, self.pin_buf):
+            if key not in cache and len(cache) >= 4:
+                cache.clear()
+        if key not in self.dev_buf:
+            self.dev_buf[key] = torch.empty((nm * n, t, d), dtype=dtype, device=self.dev)
+        self.src, self.n, self.dst = src, n, self.dev_buf[key]
+        self.direct = all(x.dtype == dtype and x.is_contiguous() and x.is_pinned() for x in src)
+        self.pin = None
+        if not self.direct:
+            if key not in self.pin_buf:
+                self.pin_buf[key] = torch.empty((nm * n, t, d), dtype=dtype, pin_memory=True)
+            self.pin = self.pin_buf[key]
+            if self.h2d_done is not None:
+                self.h2d_done.synchronize()        # the previous forward's DMAs out of the staging buffer are done
+        if self.compute_done is not None:
+            self.h2d.wait_event(self.compute_done)  # ... and its passes no longer read the device buffer
+        return self.dst
+
+    def stage(self, lo, hi):
+        """Videos [lo, hi): (host copy into the pinned staging buffer,) async DMA on the copy stream; returns the event
+        the compute stream has to wait for."""
+        n = self.n
+        if not self.direct:
+            # host copies into the pinned staging buffer (cast included), row blocks spread over the copy workers
+            pool, nt = _stage_pool()
+            parts = max(1, min(n, -(-nt // (hi - lo))))
+            step = -(-n // parts)
+            jobs = [(v * n + r, min(v * n + r + step, (v + 1) * n), v, r) for v in range(lo, hi) for r in range(0, n, step)]
+            list(pool.map(lambda j: self.pin[j[0]:j[1]].copy_(self.src[j[2]][j[3]:j[3] + (j[1] - j[0])]), jobs))
+        for v in range(lo, hi):
+            x = self.src[v] if self.direct else self.pin[v * n:(v + 1) * n]
+            with torch.cuda.stream(self.h2d):
+                self.dst[v * n:(v + 1) * n].copy_(x, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(self.h2d)
+        if not self.direct:
+            self.h2d_done = ev
+        return ev
+
+    def download(self, main, pairs):
+        """`pairs` = [(pinned host tensor, device tensor), ...] of one chunk, complete on `main` now: copied back on the
+        download stream."""
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self.d2h.wait_event(ev)
+        with torch.cuda.stream(self.d2h):
+            for host, devt in pairs:
+                host.copy_(devt, non_blocking=True)
+
+    def finish(self, main):
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self.compute_done = ev
+        self.d2h.synchronize()             # the caller gets host tensors: they must be complete
+
+
 class BaseModel(_CachedWeightsMixin, nn.Module):
     """RelPN -> RelOIPool -> predicate classifier (reference lib/modeling/model.py:7-65)."""
 
@@ -579,7 +702,11 @@ class BaseModel(_CachedWeightsMixin, nn.Module):
         # stream before their results are handed out, so the caller sees ordinary stream semantics.
         self.overlap_tail = bool(getattr(cfg.RELPN, "OVERLAP_TAIL", True))
         self._side = {}              # device index -> (side stream, logits-ready event)
-        self._logits_token = None    # (device index, the last fused pass's batched logits tensor, caller stream)
+        self._logits_token = None    # (device index, the last fused pass's batched logits tensor, caller stream[, ids of
+        #                              the host tensors handed out for them])
+        # host-resident inputs (predict.py hands CPU PairLists): videos per pipelined chunk, see _HostPipeline
+        self.host_chunk_videos = int(getattr(cfg.RELPN.DPN, "HOST_CHUNK_VIDEOS", 4))
+        self._host_pipes = {}
         self.conv_algo = str(getattr(cfg.RELPN.DPN, "CONV_ALGO", "auto"))
         if self.conv_algo not in ("auto", "direct"):
             raise ValueError(f"RELPN.DPN.CONV_ALGO must be auto or direct (got {self.conv_algo})")
@@ -749,11 +876,18 @@ class BaseModel(_CachedWeightsMixin, nn.Module):
             # segments with an explicit pair table are scored on their own
             key = (tuple(f.shape), i + 1 if custom_pairs(plist) is not None else 0, f.dtype == torch.bfloat16)
             groups.setdefault(key, []).append(i)
-        for (shape, _, bf16), members in groups.items():
+        for (shape, custom_key, bf16), members in groups.items():
             n, t, d = shape
             nm = len(members)
             per = n * (n - 1)
             src = [pair_list[i].get_field("tracklet_feats") for i in members]
+            if (self.host_chunk_videos > 0 and custom_key == 0 and not self.pool_top_span and per > 0
+                    and (d % 16 == 0 if bf16 else True)
+                    and all(isinstance(x, torch.Tensor) and not x.is_cuda for x in src)):
+                # host-resident features, canonical pair table: chunked upload / compute / download pipeline
+                self._forward_host_group(pair_list, members, shape, bf16, dev, (hw, hb, cw, cb), durations, logits,
+                                         track_token=len(groups) == 1)
+                continue
             if bf16:
                 # bf16 tracklet features select the bf16-operand kernels (BASELINE config 3)
                 if any(custom_pairs(pair_list[i]) is not None for i in members):
@@ -835,6 +969,77 @@ class BaseModel(_CachedWeightsMixin, nn.Module):
             main.wait_stream(side)                 # PPN / geometry are complete for whatever the caller does next
         return pair_proposals, durations, logits
 
+    def _forward_host_group(self, pair_list, members, shape, bf16, dev, weights, durations, logits, track_token):
+        """One group of equal-shape segments whose `tracklet_feats` are HOST tensors (the reference's predict.py:50-57
+        hands CPU PairLists): upload, fused pass and download run as a three-stage pipeline over chunks of videos
+        (_HostPipeline); results are pinned host tensors, complete when this returns (same device as the inputs,
+        reference model.py:53-65).  Same kernels, same per-video results as the resident path."""
+        dpn = self.relpn.duration_proposal_network
+        cls = self.classifier.rel_predictor
+        hw, hb, cw, cb = weights
+        n, t, d = shape
+        nm, per = len(members), n * (n - 1)
+        src = [pair_list[i].get_field("tracklet_feats") for i in members]
+        pipe = self._host_pipes.get(dev.index)
+        if pipe is None:
+            pipe = self._host_pipes[dev.index] = _HostPipeline(dev)
+        main = torch.cuda.current_stream(dev)
+        if bf16:
+            packed, cbias, hpk, hb16 = dpn._bf16_weights(dev)
+            cw16, cb16 = self.classifier._cache.get(
+                "cls_bf16", (cls.weight, cls.bias), dev,
+                lambda ts: tuple(ops.cast_bf16(x.contiguous()).float() for x in ts))
+            a3, k_out = hb16.numel(), cw16.shape[0]
+        else:
+            packed, cbias = dpn._conv_split(dev, winograd=(self.conv_algo == "auto" and d % 32 == 0))
+            a3, k_out = hb.numel(), cw.shape[0]
+        chunks = pipe.schedule(nm, self.host_chunk_videos)
+        feats = pipe.begin(src, torch.bfloat16 if bf16 else torch.float32)
+        heads_dev = torch.empty((nm * per, a3, t), dtype=torch.float32, device=dev)
+        lg_dev = torch.empty((nm * per, k_out), dtype=torch.float32, device=dev)
+        heads_host = torch.empty((nm * per, a3, t), dtype=torch.float32, pin_memory=True)
+        lg_host = torch.empty((nm * per, k_out), dtype=torch.float32, pin_memory=True)
+        want_geom = self.pair_geometry_in_forward and all(
+            pair_list[i].has_field("tracklet_boxes") and pair_list[i].get_field("tracklet_boxes") is not None for i in members)
+        geom_host = torch.empty((nm * per, 8, t), dtype=torch.float32, pin_memory=True) if want_geom else None
+        cmax = max(hi - lo for lo, hi in chunks)
+        wsb = ops.fused_bf16_workspace_bytes if bf16 else ops.fused_workspace_bytes
+        ws = self._workspace(dev, wsb(cmax, n, t, d, a3 // 3, k_out, cmax * per))
+        # the small side inputs go up NOW, while the caller's stream is empty: a blocking .to(device) issued after a
+        # pass has been queued would wait for that pass and stall the pipeline
+        boxes_dev = _batch_rows([pair_list[i].get_field("tracklet_boxes") for i in members], dev) if want_geom else None
+        ready = pipe.stage(*chunks[0])
+        for k, (lo, hi) in enumerate(chunks):
+            c = hi - lo
+            main.wait_event(ready)
+            allp, _ = self._canonical_pairs(dev, c, n)
+            rows = slice(lo * per, hi * per)
+            if bf16:
+                ops.forward_fused_bf16(feats[lo * n:hi * n], allp, c, n, packed, cbias, hpk, hb16, cw16, cb16, workspace=ws,
+                                       conv_events=self._conv_events if k == len(chunks) - 1 else None,
+                                       out_heads=heads_dev[rows], out_logits=lg_dev[rows])
+            else:
+                ops.forward_fused(feats[lo * n:hi * n], allp, c, n, packed, cbias, hw, hb, cw, cb, workspace=ws,
+                                  check_pairs=False, canonical_pairs=True,
+                                  conv_events=self._conv_events if k == len(chunks) - 1 else None,
+                                  out_heads=heads_dev[rows], out_logits=lg_dev[rows])
+            back = [(heads_host[rows], heads_dev[rows]), (lg_host[rows], lg_dev[rows])]
+            if want_geom:
+                _, g = ops.pair_gather(None, boxes_dev[lo * n:hi * n], allp, want_feat=False, check_pairs=False)
+                back.append((geom_host[rows], g))
+            pipe.download(main, back)
+            if k + 1 < len(chunks):
+                ready = pipe.stage(*chunks[k + 1])         # host staging of chunk k+1 runs while the GPU works on chunk k
+        pipe.finish(main)
+        for k, i in enumerate(members):
+            sl = slice(k * per, (k + 1) * per)
+            durations[i] = dpn._wrap(heads_host[sl], None if geom_host is None else geom_host[sl])
+            logits[i] = lg_host[sl]
+        if track_token:
+            # `decode` on these very host tensors reads the device copy instead of uploading them again
+            self._logits_token = (dev.index, lg_dev, main.cuda_stream,
+                                  tuple((logits[i].data_ptr(), logits[i]._version) for i in members))
+
     @staticmethod
     def _pair_geometry_batch(pair_list, members, allp, dev):
         """The bbox half of the N^2 pair builder for one group of equal-shape segments, ONE launch: relative
@@ -879,14 +1084,21 @@ class BaseModel(_CachedWeightsMixin, nn.Module):
         for (n, lshape, quirk, _), members in groups.items():
             dev = _compute_device(*[rel_logits[i] for i in members])
             nm = len(members)
-            lg = _batch_rows([rel_logits[i] for i in members], dev).view(nm, lshape[0], lshape[1])
+            tok = self._logits_token
+            if (tok is not None and len(tok) == 4 and tok[0] == dev.index and tok[1].numel() == nm * lshape[0] * lshape[1]
+                    and tok[2] == torch.cuda.current_stream(dev).cuda_stream
+                    and tok[3] == tuple((rel_logits[i].data_ptr(), rel_logits[i]._version) for i in members)):
+                # the host tensors the last forward handed out, untouched: their device copy is still there
+                lg = tok[1].view(nm, lshape[0], lshape[1])
+            else:
+                lg = _batch_rows([rel_logits[i] for i in members], dev).view(nm, lshape[0], lshape[1])
             # these are the logits of the last fused forward, still on the stream that produced them: decode on the
             # side stream behind their ready-event, i.e. UNDER that forward's encoder, and join afterwards
             main = torch.cuda.current_stream(dev)
             custom = [pair_list[i].has_field("tracklet_pairs") and pair_list[i].get_field("tracklet_pairs") is not None
                       for i in members]
             side, tok = None, self._logits_token
-            if (overlap and self.overlap_tail and tok is not None and tok[0] == dev.index and tok[2] == main.cuda_stream
+            if (overlap and self.overlap_tail and tok is not None and len(tok) == 3 and tok[0] == dev.index and tok[2] == main.cuda_stream
                     and tok[1].data_ptr() == lg.data_ptr() and tok[1].numel() == lg.numel() and not quirk
                     and not any(custom) and all(pair_list[i].get_field("track_cls_logits").is_cuda for i in members)):
                 side, ev_logits = self._side_stream(dev)

@@ -732,7 +732,7 @@ def fused_bf16_workspace_bytes(B, N, T, D, A, K, P):
 
 
 def forward_fused_bf16(feats, pairs, B, N, conv_packed, conv_bias, head_packed, head_b, cls_w, cls_b,
-                       workspace=None, conv_events=None, logits_event=None):
+                       workspace=None, conv_events=None, logits_event=None, out_heads=None, out_logits=None):
     """Whole scoring pass, bf16 operands (tspn_forward_fused_bf16), canonical pair table only.
 
     feats bf16 [B*N,T,D]; conv_packed = pack_conv3_bf16(conv.weight, split=D); head_packed =
@@ -768,8 +768,15 @@ def forward_fused_bf16(feats, pairs, B, N, conv_packed, conv_bias, head_packed, 
         workspace = _ws(need, feats.device)
     elif workspace.numel() * workspace.element_size() < need:
         raise ValueError("forward_fused_bf16: workspace too small")
-    out_heads = torch.empty((P, 3 * A, T), dtype=torch.float32, device=feats.device)
-    out_logits = torch.empty((P, K), dtype=torch.float32, device=feats.device)
+    if out_heads is None:
+        out_heads = torch.empty((P, 3 * A, T), dtype=torch.float32, device=feats.device)
+    elif tuple(out_heads.shape) != (P, 3 * A, T):
+        raise ValueError("forward_fused_bf16: out_heads shape mismatch")
+    if out_logits is None:
+        out_logits = torch.empty((P, K), dtype=torch.float32, device=feats.device)
+    elif tuple(out_logits.shape) != (P, K):
+        raise ValueError("forward_fused_bf16: out_logits shape mismatch")
+    _dev(out_heads, "out_heads"); _dev(out_logits, "out_logits")
     d.out_heads, d.out_logits = out_heads.data_ptr(), out_logits.data_ptr()
     d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     if conv_events is not None:

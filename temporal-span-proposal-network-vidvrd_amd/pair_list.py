@@ -50,9 +50,22 @@ class _FieldList:
             out.add_field(name, field_fn(value))
         return out
 
-    def to(self, device):
-        return self._derive(self._primary_value().to(device),
-                            lambda v: v.to(device) if hasattr(v, "to") else v)
+    def to(self, device, non_blocking=False):
+        """Reference semantics (list_pair.py:28-31): the primary tensor and every field with a `.to` move, numpy
+        fields stay.  `non_blocking=True` (build extension) makes the copies of PINNED host tensors asynchronous on the
+        current stream, which is what a prefetching loader wants."""
+        if not non_blocking:
+            return self._derive(self._primary_value().to(device),
+                                lambda v: v.to(device) if hasattr(v, "to") else v)
+        mv = lambda v: v.to(device, non_blocking=True) if isinstance(v, torch.Tensor) else (v.to(device) if hasattr(v, "to") else v)  # noqa: E731
+        return self._derive(mv(self._primary_value()), mv)
+
+    def pin_memory(self):
+        """Page-locked copies of the host tensors (primary + tensor fields): `torch.utils.data.DataLoader(pin_memory=
+        True)` calls this on the batches its workers produce (it looks for a `pin_memory` method on custom types), in
+        its own thread.  `BaseModel.forward` DMAs pinned tracklet features straight from where they are."""
+        pin = lambda v: v.pin_memory() if isinstance(v, torch.Tensor) and not v.is_cuda else v  # noqa: E731
+        return self._derive(pin(self._primary_value()), pin)
 
     def __getitem__(self, item):
         return self._derive(self._primary_value()[item], lambda v: v[item])

@@ -681,3 +681,114 @@ def test_overlapped_geometry_equals_serial(tspn, device):
             assert torch.equal(res[0][0][b].geom, res[1][0][b].geom) and torch.equal(res[0][1][b], res[1][1][b])
             ref = oracle.pair_geometry(t(vids[b]["tracklet_boxes"]), oracle.pair_index(N))
             np.testing.assert_allclose(res[0][0][b].geom.cpu().numpy(), ref.numpy(), rtol=2e-6, atol=2e-6)
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("pinned", [False, True])
+def test_host_inputs_pipeline_equals_resident(tspn, device, bf16, pinned):
+    """predict.py:50-57 hands CPU PairLists.  The chunked upload / encoder / download pipeline (model._HostPipeline;
+    pageable sources staged through pinned memory, pinned ones DMA'd in place) gives the resident path's results bit
+    for bit, returns HOST tensors, survives buffer reuse over consecutive forwards with other data, and `decode` on the
+    returned host logits (device copy reused) equals decode on the resident logits -- also after an in-place edit of
+    the host logits, which must be seen."""
+    D, N, T, B = 64, 7, 30, 7
+    sd = tspn.synth.make_weights(12, c=2 * D, bias_std=0.05)
+    cfg = cases.baseline_cfg(**{"RELPN.USE_PPN": True, "RELPN.USE_DPN": True, "RELPN.DPN.IN_CHANNELS": 2 * D,
+                                "PREDICT.FEATURE_DIM": 2 * D, "RELPN.DPN.PAIR_GEOMETRY": True,
+                                "RELPN.DPN.HOST_CHUNK_VIDEOS": 2})
+    m = tspn.BaseModel(cfg)
+    load(m, sd)
+    m.eval()
+    assert m.host_chunk_videos == 2
+    for step in range(3):
+        vids = [tspn.synth.make_video(800 + 10 * step + b, N, T, D) for b in range(B)]
+        host, res = [], []
+        for v in vids:
+            f = t(v["tracklet_feats"])
+            if bf16:
+                f = f.to(torch.bfloat16)
+            c = 8.0 * t(v["track_cls_logits"])
+            pl = tspn.PairList.from_tracklets(f, t(v["tracklet_boxes"]), c)
+            host.append(pl.pin_memory() if pinned else pl)
+            res.append(tspn.PairList.from_tracklets(f.to(device), t(v["tracklet_boxes"]).to(device), c.to(device)))
+        assert host[0].get_field("tracklet_feats").is_pinned() is pinned
+        pp_h, dp_h, lg_h = m(host, None)
+        dec_h = m.decode(host, lg_h)
+        pp_r, dp_r, lg_r = m(res, None)
+        dec_r = m.decode(res, lg_r)
+        torch.cuda.synchronize()
+        for b in range(B):
+            assert lg_h[b].device.type == "cpu" and dp_h[b].heads.device.type == "cpu" and dp_h[b].geom.device.type == "cpu"
+            assert torch.equal(lg_h[b], lg_r[b].cpu()) and torch.equal(dp_h[b].heads, dp_r[b].heads.cpu())
+            assert torch.equal(dp_h[b].geom, dp_r[b].geom.cpu()) and torch.equal(pp_h[b].cpu(), pp_r[b].cpu())
+            assert all(torch.equal(x.cpu(), y.cpu()) for x, y in zip(dec_h[b], dec_r[b]))
+    # an edit of the returned host logits must reach decode (the cached device copy no longer applies)
+    pp_h, dp_h, lg_h = m(host, None)
+    lg_h[0].mul_(0.5)
+    dec_e = m.decode(host, lg_h)
+    lg_c = [x.clone() for x in lg_h]
+    dec_c = m.decode(host, lg_c)
+    for b in range(B):
+        assert all(torch.equal(x, y) for x, y in zip(dec_e[b], dec_c[b]))
+    assert not torch.equal(dec_e[0][0], dec_h[0][0])
+
+
+def test_pair_list_pin_memory_and_non_blocking_to(tspn, device):
+    """PairList.pin_memory() (what DataLoader(pin_memory=True) calls on custom batch types) and .to(device,
+    non_blocking=True): tensors move, numpy fields stay on the host as in the reference (list_pair.py:28-31)."""
+    pl = tspn.PairList(torch.arange(12.0).view(3, 4))
+    pl.add_field("track_cls_logits", torch.ones(2, 35))
+    pl.add_field("tracklet_pairs", np.array([[0, 1], [1, 0], [0, 1]]))
+    pl.add_field("num_tracklets", 2)
+    pin = pl.pin_memory()
+    assert pin.features.is_pinned() and pin.get_field("track_cls_logits").is_pinned()
+    assert isinstance(pin.get_field("tracklet_pairs"), np.ndarray) and pin.get_field("num_tracklets") == 2
+    dv = pin.to(device, non_blocking=True)
+    torch.cuda.synchronize()
+    assert dv.features.is_cuda and torch.equal(dv.features.cpu(), pl.features)
+    assert isinstance(dv.get_field("tracklet_pairs"), np.ndarray)
+    assert torch.equal(pl.to(device).features, dv.features)
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_device_prefetcher_yields_the_loaders_batches_on_the_device(tspn, device, pinned):
+    """dataset.DevicePrefetcher around a loader of host batches `(pair_list, target_list, indexs)` (the reference's
+    collate, lib/dataset/build.py:84-93): same batches, tensors in HBM, numpy / int fields untouched, model results
+    equal those on the host batches; works for an empty loader and for a single batch."""
+    D, N, T, B = 32, 5, 30, 3
+    sd = tspn.synth.make_weights(14, c=2 * D, bias_std=0.05)
+    cfg = cases.baseline_cfg(**{"RELPN.USE_PPN": True, "RELPN.USE_DPN": True, "RELPN.DPN.IN_CHANNELS": 2 * D,
+                                "PREDICT.FEATURE_DIM": 2 * D})
+    m = tspn.BaseModel(cfg)
+    load(m, sd)
+    m.eval()
+
+    def batches(count):
+        for step in range(count):
+            pls = []
+            for b in range(B):
+                v = tspn.synth.make_video(900 + 10 * step + b, N, T, D)
+                pl = tspn.PairList.from_tracklets(t(v["tracklet_feats"]).repeat(1, 40, 1)[:, :T * 40].contiguous()[:, :T],
+                                                  t(v["tracklet_boxes"]), 8.0 * t(v["track_cls_logits"]))
+                pl.add_field("ious", np.zeros((N, N), dtype=np.float32))
+                pls.append(pl.pin_memory() if pinned else pl)
+            yield pls, None, [("vid", 15 * step, 15 * step + 30)] * B
+
+    assert list(tspn.dataset.DevicePrefetcher(batches(0), device)) == []
+    for count in (1, 4):
+        host = list(batches(count))
+        got = list(tspn.dataset.DevicePrefetcher(batches(count), device))
+        assert len(got) == count
+        for (hp, _, hidx), (dp, dt, didx) in zip(host, got):
+            assert dt is None and didx == hidx
+            for a, b in zip(hp, dp):
+                f = b.get_field("tracklet_feats")
+                assert f.is_cuda and torch.equal(f.cpu(), a.get_field("tracklet_feats"))
+                assert isinstance(b.get_field("ious"), np.ndarray) and b.get_field("num_tracklets") == N
+            _, _, lg_h = m(hp, None)
+            _, _, lg_d = m(dp, None)
+            dec_h, dec_d = m.decode(hp, lg_h), m.decode(dp, lg_d)
+            torch.cuda.synchronize()
+            for b in range(B):
+                assert lg_d[b].is_cuda and torch.equal(lg_d[b].cpu(), lg_h[b])
+                assert all(torch.equal(x.cpu(), y.cpu()) for x, y in zip(dec_h[b], dec_d[b]))
