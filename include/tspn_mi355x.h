@@ -503,6 +503,18 @@ int tspn_bottleneck_tail_bf16(const uint16_t* h1, int64_t NB, int64_t H, int64_t
                               const uint16_t* frag2, const float* bias2, const uint16_t* frag3,
                               const float* bias3, const uint16_t* residual, uint16_t* out, void* stream);
 
+/* The same launch + conv1 of the FOLLOWING block on the tile it has just produced (round 4; CM = 256 = every res4
+ * block of an R-50 / R-101 C4 backbone): additionally
+ *     h1n = relu( W1n . out + b1n )        1x1, 4 CM -> CM channels, bf16 [NB,H,W,CM]
+ * with frag1n = tspn_pack_conv2d_frag_bf16(W1n [CM,4 CM,1,1]) of the next block's conv1 (stride 1).  The 4 CM-channel
+ * map is then read once per block (as the residual) instead of twice.  out and h1n are bit-identical to
+ * tspn_bottleneck_tail_bf16 followed by tspn_conv2d_nhwc_bf16(out, frag1n, relu) (same contraction order: channels
+ * 0..4 CM - 1 in k-steps of 16 on one accumulator chain). */
+int tspn_bottleneck_tail_next_bf16(const uint16_t* h1, int64_t NB, int64_t H, int64_t W, int64_t CM,
+                                   const uint16_t* frag2, const float* bias2, const uint16_t* frag3,
+                                   const float* bias3, const uint16_t* residual, uint16_t* out,
+                                   const uint16_t* frag1n, const float* bias1n, uint16_t* h1n, void* stream);
+
 /* ---- f4: bf16-operand stem of the C4 backbone (tspn_stem_bf16.hip) ----------------------------------------
  * detectron2 BasicStem conv (modeling/backbone/resnet.py: 7x7, stride 2, padding 3, RGB in, FrozenBN folded by the
  * caller into w / bias) + ReLU with bf16 operands: image and weights rounded to bf16, exact products, fp32

@@ -64,11 +64,24 @@ __device__ __forceinline__ void wait_w(f32x4& r0, f32x4& r1) {
   asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r0), "+v"(r1) : "n"(VM));
 #endif
 }
-template <int CM>
-__global__ __launch_bounds__(THREADS, (CM == 64 ? 3 : 2)) void bottleneck_bf16_kernel(
+// NEXT (CM = 256, round 4): the kernel also computes conv1 of the FOLLOWING block on its own output tile,
+//     h1n = relu(W1n . out + b1n)        1x1, K = 4 CM = 1024 -> CM rows,
+// so that the 4 CM-channel map is read once per block (as the next block's residual) instead of twice.  Phase 3 then
+// walks the output channels PASS-MAJOR (the four waves together finish channels [256 p, 256 p + 256) of all 128
+// pixels in pass p), writes the rounded bf16 results of a pass into a second LDS image [32 groups][132 slots][8] next to
+// the h2 image as well as to HBM, and after every pass the workgroup contracts that 256-channel chunk with W1n: the
+// inner loop of phase 2 again (wave = 64 rows x 128 pixels, eight accumulators, the registers phase 2 used; fragments
+// of W1n straight from L2 through a ring of four k-steps), k-steps in the natural channel order 0..1023 on one
+// accumulator chain = the contraction order of the stand-alone conv1 launch: bit-identical h1n.  The MFMAs of a
+// chunk run while the stores of the pass drain and the residual rows of the next pass land.  136 KB of LDS and
+// about 400 registers per lane: one workgroup per CU, which is what a launch of 8 frames (225 tiles) gives anyway.
+template <int CM, bool NEXT>
+__global__ __launch_bounds__(THREADS, (NEXT ? 1 : (CM == 64 ? 3 : 2))) void bottleneck_bf16_kernel(
     const __bf16* __restrict__ h1, const __bf16* __restrict__ Wf2, const float* __restrict__ bias2,
     const __bf16* __restrict__ Wf3, const float* __restrict__ bias3, const __bf16* __restrict__ residual,
-    __bf16* __restrict__ out, int H, int W, int64_t npix) {
+    __bf16* __restrict__ out, int H, int W, int64_t npix, const __bf16* __restrict__ Wf1n,
+    const float* __restrict__ bias1n, __bf16* __restrict__ h1n) {
+  static_assert(!NEXT || CM == 256, "the fused conv1 of the next block is built for CM = 256");
   constexpr int MI = 2;                                   // 32-row blocks per wave
   constexpr int WM = CM / 64, WN = 4 / WM, NI = 4 / WN;   // waves along rows / pixels, 32-pixel blocks per wave
   constexpr int CCH = CM / KC;                            // 64-channel chunks per tap = chunks of phase 3
@@ -80,6 +93,10 @@ __global__ __launch_bounds__(THREADS, (CM == 64 ? 3 : 2)) void bottleneck_bf16_k
   constexpr int NST = CM == 256 ? 4 : 3;
   constexpr int DIST = NST - 1;
   extern __shared__ __attribute__((aligned(16))) char Bs[];   // max(NST stages, h2 image) = max(NST, CCH) * B_ST
+  // NEXT: two chunk images [32 groups][SLPC slots][8 bf16] behind the stages / the h2 image, one per sub-pass parity
+  constexpr int CHUNK_OFF = (NST > CCH ? NST : CCH) * B_ST + 1024;
+  constexpr int SLPC = 68;                                  // 64 pixels + padding: conflict-free 16-byte reads like SLP
+  constexpr int CHUNK_BYTES = (CM / 8) * SLPC * 16;         // CM channels of 64 pixels: CM / 8 groups x SLPC slots x 16 B
 
   const int nwg = gridDim.x;
   const int bid = blockIdx.x;
@@ -467,7 +484,10 @@ __global__ __launch_bounds__(THREADS, (CM == 64 ? 3 : 2)) void bottleneck_bf16_k
   static_assert(UNROLLED || (KSTEPS % RING == 0 && NGRP % NRES == 0), "ring slots must not depend on a run-time sub-pass");
   const char* Hb = Bs + (kh * SLP + li) * 16;
   // sub-pass sp = 2 pass + part: rows (wm 4 + pass) MI + mi0 .., pixel blocks wn NI + ni0 ..
-  auto sub_rb = [&](int sp) { return (wm * 4 + (sp >> 1)) * MI + (NS < NI ? 0 : (sp & 1) * MS); };
+  // (NEXT: pass-major -- pass p of the four waves together covers row blocks 8 p .. 8 p + 7 = channels [256 p, 256 p + 256))
+  auto sub_rb = [&](int sp) {
+    return (NEXT ? (sp >> 1) * 4 + wm : wm * 4 + (sp >> 1)) * MI + (NS < NI ? 0 : (sp & 1) * MS);
+  };
   auto sub_nb = [&](int sp) { return wn * NI + (NS < NI ? (sp & 1) * NS : 0); };
   // a sub-pass index is either an int (run-time loop, CM >= 128) or an integral_constant (CM = 64, fully unrolled)
   auto cval = [](auto sp) constexpr {              // its compile-time value; 0 when the ring slots do not depend on it
@@ -572,6 +592,11 @@ __global__ __launch_bounds__(THREADS, (CM == 64 ? 3 : 2)) void bottleneck_bf16_k
     bf16x8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = (__bf16)fmaxf(v[j] + (float)rv[j], 0.f);
+    if constexpr (NEXT) {
+      // the sub-pass's chunk image (buffer e & 1): channel group (channel - 256 pass) / 8, slot = pixel of its 64
+      const int g8 = ((32 * (sub_rb(e) + ms)) & 255) / 8 + 2 * kh + h;
+      *reinterpret_cast<bf16x8*>(Bs + CHUNK_OFF + ((int)e & 1) * CHUNK_BYTES + (g8 * SLPC + nj * 32 + li) * 16) = o;
+    }
     if constexpr (h == 0) {
       ohold = o;
     } else {
@@ -599,6 +624,29 @@ __global__ __launch_bounds__(THREADS, (CM == 64 ? 3 : 2)) void bottleneck_bf16_k
   using M1 = std::integral_constant<int, -1>;
   // sub-pass sp into `cur` while the epilogue of sub-pass sp - 1 (in `prev`) drains: half g is finished after k-step
   // 2 g + 1
+  auto no_hook = [](auto) {};
+  // `hook(k)`: extra work issued after k-step k (NEXT: a k-step of the following block's conv1 on the previous chunk)
+  auto subpass_h = [&](f32x16 (&cur)[MS][NS], f32x16 (&prev)[MS][NS], auto sp, auto drain_tag, auto&& hook) {
+    constexpr bool DRAIN = decltype(drain_tag)::value;
+    zero(cur);
+    auto two = [&](auto g_tag) {
+      constexpr int g = decltype(g_tag)::value;
+      kstep(cur, sp, std::integral_constant<int, 2 * g>{});
+      hook(std::integral_constant<int, 2 * g>{});
+      __builtin_amdgcn_sched_barrier(0);
+      kstep(cur, sp, std::integral_constant<int, 2 * g + 1>{});
+      hook(std::integral_constant<int, 2 * g + 1>{});
+      if constexpr (DRAIN) group_finish(prev, plus(sp, M1{}), g_tag);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    two(std::integral_constant<int, 0>{});
+    two(std::integral_constant<int, 1>{});
+    if constexpr (G > 2) { two(std::integral_constant<int, 2>{}); two(std::integral_constant<int, 3>{}); }
+    if constexpr (G > 4) {
+      two(std::integral_constant<int, 4>{}); two(std::integral_constant<int, 5>{});
+      two(std::integral_constant<int, 6>{}); two(std::integral_constant<int, 7>{});
+    }
+  };
   auto subpass = [&](f32x16 (&cur)[MS][NS], f32x16 (&prev)[MS][NS], auto sp, auto drain_tag) {
     constexpr bool DRAIN = decltype(drain_tag)::value;
     zero(cur);
@@ -629,6 +677,133 @@ __global__ __launch_bounds__(THREADS, (CM == 64 ? 3 : 2)) void bottleneck_bf16_k
     };
     first(std::integral_constant<int, 0>{}); first(std::integral_constant<int, 1>{});
     first(std::integral_constant<int, 2>{}); first(std::integral_constant<int, 3>{});
+  }
+  if constexpr (NEXT) {
+    // ---- tail + conv1 of the next block.  A sub-pass finishes 256 channels (one pass) of 64 pixels; its rounded
+    // results are the chunk c = sub-pass index of conv1n's operand: K = 256 channels, N = 64 pixels.  Three things
+    // run in the MFMA stream of sub-pass s: its own k-steps, the epilogue of sub-pass s - 1 (-> chunk buffer
+    // (s - 1) & 1) and conv1n on chunk s - 2 (buffer s & 1), one k-step of each per k-step; a barrier between
+    // sub-passes publishes a chunk and frees the other buffer.  Output pixel half h sees chunks h, 2 + h, 4 + h, 6 + h
+    // = channels 0..1023 in natural order on one accumulator chain: the stand-alone conv1's contraction order.
+    (void)no_hook;
+    f32x16 acc1[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc1[mi][ni][e] = 0.f;
+    // W1n fragments, rows permuted like W3's (16 consecutive channels per accumulator lane): row block 2 wm + mi,
+    // 16 chunks of 4 KiB per row block, k-step s at s KiB.  The stream of (chunk, k-step) pairs runs through a ring
+    // of four; chunk c uses k-steps 16 (c / 2) + 0..15 (each k-step is fetched for both pixel halves: L2 hits)
+    const char* w1p[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+      w1p[mi] = reinterpret_cast<const char*>(Wf1n) + woff3 + (int64_t)(MI * wm + mi) * (4 * CCH * 4096);
+    f32x4 a1[4][MI];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) a1[j][mi] = *reinterpret_cast<const f32x4*>(w1p[mi] + j * 1024);
+    const char* Cb = Bs + CHUNK_OFF + (kh * SLPC + li) * 16;
+    // k-step ks of chunk c (parity PAR known at compile time; kbase = 16 (c / 2); `more`: a chunk follows)
+    auto c1step = [&](auto par_tag, int kbase, bool more, auto ks_tag) {
+      constexpr int PAR = decltype(par_tag)::value;
+      constexpr int ks = decltype(ks_tag)::value;
+      constexpr int slot = ks % 4;
+      bf16x8 b[2];
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj)
+        b[nj] = *reinterpret_cast<const bf16x8*>(Cb + PAR * CHUNK_BYTES + ((2 * ks) * SLPC + nj * 32) * 16);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const bf16x8 av = __builtin_bit_cast(bf16x8, a1[slot][mi]);
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj)
+          acc1[mi][2 * PAR + nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b[nj], acc1[mi][2 * PAR + nj], 0, 0, 0);
+      }
+      if constexpr (ks + 4 < 16) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) a1[slot][mi] = *reinterpret_cast<const f32x4*>(w1p[mi] + (int64_t)(kbase + ks + 4) * 1024);
+      } else if (more) {                                   // the first k-steps of the next chunk
+        const int nb = PAR ? kbase + 16 : kbase;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) a1[slot][mi] = *reinterpret_cast<const f32x4*>(w1p[mi] + (int64_t)(nb + ks + 4 - 16) * 1024);
+      }
+    };
+    auto publish = [&]() {                                 // chunk written / chunk read by every wave
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __syncthreads();
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    static_assert(G == 8 && KSTEPS == 16 && MS == 2 && NS == 2, "NEXT: CM = 256 schedule");
+    subpass(accA, accB, 0, std::false_type{});
+    subpass(accB, accA, 1, std::true_type{});              // epilogue of sub-pass 0 -> buffer 0
+    publish();
+#pragma unroll 1
+    for (int pass = 1; pass < 4; ++pass) {
+      const int kb = 16 * (pass - 1);
+      // sub-pass 2 pass: epilogue of 2 pass - 1 -> buffer 1, conv1n on chunk 2 pass - 2 (buffer 0)
+      subpass_h(accA, accB, 2 * pass, std::true_type{}, [&](auto k) { c1step(P0{}, kb, true, k); });
+      publish();
+      // sub-pass 2 pass + 1: epilogue of 2 pass -> buffer 0, conv1n on chunk 2 pass - 1 (buffer 1)
+      subpass_h(accB, accA, 2 * pass + 1, std::true_type{}, [&](auto k) { c1step(P1{}, kb, true, k); });
+      publish();
+    }
+    // drain: epilogue of sub-pass 7 -> buffer 1, interleaved with conv1n on chunk 6 (buffer 0)
+    {
+      auto fin2 = [&](auto g_tag) {
+        constexpr int g = decltype(g_tag)::value;
+        c1step(P0{}, 48, true, std::integral_constant<int, 2 * g>{});
+        __builtin_amdgcn_sched_barrier(0);
+        c1step(P0{}, 48, true, std::integral_constant<int, 2 * g + 1>{});
+        group_finish(accB, (int)(NSUB - 1), g_tag);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      fin2(std::integral_constant<int, 0>{}); fin2(std::integral_constant<int, 1>{});
+      fin2(std::integral_constant<int, 2>{}); fin2(std::integral_constant<int, 3>{});
+      fin2(std::integral_constant<int, 4>{}); fin2(std::integral_constant<int, 5>{});
+      fin2(std::integral_constant<int, 6>{}); fin2(std::integral_constant<int, 7>{});
+    }
+    publish();
+    {
+      auto last = [&](auto ks_tag) { c1step(P1{}, 48, false, ks_tag); __builtin_amdgcn_sched_barrier(0); };
+      last(std::integral_constant<int, 0>{});  last(std::integral_constant<int, 1>{});
+      last(std::integral_constant<int, 2>{});  last(std::integral_constant<int, 3>{});
+      last(std::integral_constant<int, 4>{});  last(std::integral_constant<int, 5>{});
+      last(std::integral_constant<int, 6>{});  last(std::integral_constant<int, 7>{});
+      last(std::integral_constant<int, 8>{});  last(std::integral_constant<int, 9>{});
+      last(std::integral_constant<int, 10>{}); last(std::integral_constant<int, 11>{});
+      last(std::integral_constant<int, 12>{}); last(std::integral_constant<int, 13>{});
+      last(std::integral_constant<int, 14>{}); last(std::integral_constant<int, 15>{});
+    }
+    // h1n = relu(acc1 + b1n), rounded once; a lane holds channels 32 (2 wm + mi) + 16 kh + 0..15 of pixel ni 32 + li
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int chb = 32 * (MI * wm + mi) + 16 * kh;
+      float bv[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 t4 = *reinterpret_cast<const float4*>(bias1n + chb + 4 * q);
+        bv[4 * q] = t4.x; bv[4 * q + 1] = t4.y; bv[4 * q + 2] = t4.z; bv[4 * q + 3] = t4.w;
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        bf16x8 o0, o1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          o0[j] = (__bf16)fmaxf(acc1[mi][ni][j] + bv[j], 0.f);
+          o1[j] = (__bf16)fmaxf(acc1[mi][ni][8 + j] + bv[8 + j], 0.f);
+        }
+        if ((okmask >> ni) & 1u) {
+          char* hp = reinterpret_cast<char*>(h1n + (n0 + ni * 32 + li) * CM + chb);
+          *reinterpret_cast<bf16x8*>(hp) = o0;
+          *reinterpret_cast<bf16x8*>(hp + 16) = o1;
+        }
+      }
+    }
+    return;
   }
   if constexpr (UNROLLED) {
     subpass(accA, accB, std::integral_constant<int, 0>{}, std::false_type{});
@@ -663,21 +838,26 @@ __global__ __launch_bounds__(THREADS, (CM == 64 ? 3 : 2)) void bottleneck_bf16_k
   }
 }
 
-template <int CM>
+template <int CM, bool NEXT>
 int launch(const uint16_t* h1, int64_t NB, int64_t H, int64_t W, const uint16_t* frag2, const float* bias2,
-           const uint16_t* frag3, const float* bias3, const uint16_t* residual, uint16_t* out, void* stream) {
+           const uint16_t* frag3, const float* bias3, const uint16_t* residual, uint16_t* out, void* stream,
+           const uint16_t* frag1n = nullptr, const float* bias1n = nullptr, uint16_t* h1n = nullptr) {
   const int64_t npix = NB * H * W;
   const int64_t tiles = tspn::ceil_div(npix, BN);
   TSPN_REQUIRE(tiles < (1LL << 31), TSPN_EUNSUPPORTED, "tspn_bottleneck_tail_bf16: grid too large");
   constexpr int nst = CM == 256 ? 4 : 3;
-  constexpr size_t smem = (size_t)(CM / KC > nst ? CM / KC : nst) * B_ST + 1024;   // + slots 128, 129 (once-staged form)
+  constexpr int cch = CM / KC;
+  // + slots 128, 129 (once-staged form / range ring); NEXT: + the chunk image of a pass
+  constexpr size_t smem = (size_t)(cch > nst ? cch : nst) * B_ST + 1024 + (NEXT ? (size_t)2 * (CM / 8) * 68 * 16 : 0);
+  static_assert(smem <= 160 * 1024, "LDS budget");
   static tspn::LdsLimit lds;
-  if (int rc = lds.ensure(reinterpret_cast<const void*>(bottleneck_bf16_kernel<CM>), smem, "tspn_bottleneck_tail_bf16"))
+  if (int rc = lds.ensure(reinterpret_cast<const void*>(bottleneck_bf16_kernel<CM, NEXT>), smem, "tspn_bottleneck_tail_bf16"))
     return rc;
-  hipLaunchKernelGGL(bottleneck_bf16_kernel<CM>, dim3((unsigned)tiles), dim3(THREADS), smem, TSPN_STREAM(stream),
+  hipLaunchKernelGGL((bottleneck_bf16_kernel<CM, NEXT>), dim3((unsigned)tiles), dim3(THREADS), smem, TSPN_STREAM(stream),
                      reinterpret_cast<const __bf16*>(h1), reinterpret_cast<const __bf16*>(frag2), bias2,
                      reinterpret_cast<const __bf16*>(frag3), bias3, reinterpret_cast<const __bf16*>(residual),
-                     reinterpret_cast<__bf16*>(out), (int)H, (int)W, npix);
+                     reinterpret_cast<__bf16*>(out), (int)H, (int)W, npix, reinterpret_cast<const __bf16*>(frag1n), bias1n,
+                     reinterpret_cast<__bf16*>(h1n));
   return tspn::check_launch("tspn_bottleneck_tail_bf16");
 }
 
@@ -696,7 +876,25 @@ extern "C" int tspn_bottleneck_tail_bf16(const uint16_t* h1, int64_t NB, int64_t
   TSPN_REQUIRE(al16(h1) && al16(frag2) && al16(bias2) && al16(frag3) && al16(bias3) && al16(residual) && al16(out),
                TSPN_EUNSUPPORTED, "tspn_bottleneck_tail_bf16: operands must be 16-byte aligned");
   TSPN_REQUIRE(H < (1 << 20) && W < (1 << 20), TSPN_EUNSUPPORTED, "tspn_bottleneck_tail_bf16: dimension too large");
-  if (CM == 256) return launch<256>(h1, NB, H, W, frag2, bias2, frag3, bias3, residual, out, stream);
-  if (CM == 128) return launch<128>(h1, NB, H, W, frag2, bias2, frag3, bias3, residual, out, stream);
-  return launch<64>(h1, NB, H, W, frag2, bias2, frag3, bias3, residual, out, stream);
+  if (CM == 256) return launch<256, false>(h1, NB, H, W, frag2, bias2, frag3, bias3, residual, out, stream);
+  if (CM == 128) return launch<128, false>(h1, NB, H, W, frag2, bias2, frag3, bias3, residual, out, stream);
+  return launch<64, false>(h1, NB, H, W, frag2, bias2, frag3, bias3, residual, out, stream);
+}
+
+extern "C" int tspn_bottleneck_tail_next_bf16(const uint16_t* h1, int64_t NB, int64_t H, int64_t W, int64_t CM,
+                                              const uint16_t* frag2, const float* bias2, const uint16_t* frag3,
+                                              const float* bias3, const uint16_t* residual, uint16_t* out,
+                                              const uint16_t* frag1n, const float* bias1n, uint16_t* h1n, void* stream) {
+  TSPN_REQUIRE(NB >= 0 && H > 0 && W > 0, TSPN_EINVAL, "tspn_bottleneck_tail_next_bf16: bad sizes");
+  TSPN_REQUIRE(CM == 256, TSPN_EUNSUPPORTED,
+               "tspn_bottleneck_tail_next_bf16: built for 256 bottleneck channels (got %lld)", (long long)CM);
+  if (NB == 0) return TSPN_OK;
+  TSPN_REQUIRE(h1 && frag2 && bias2 && frag3 && bias3 && residual && out && frag1n && bias1n && h1n, TSPN_EINVAL,
+               "tspn_bottleneck_tail_next_bf16: null pointer");
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  TSPN_REQUIRE(al16(h1) && al16(frag2) && al16(bias2) && al16(frag3) && al16(bias3) && al16(residual) && al16(out) &&
+                   al16(frag1n) && al16(bias1n) && al16(h1n),
+               TSPN_EUNSUPPORTED, "tspn_bottleneck_tail_next_bf16: operands must be 16-byte aligned");
+  TSPN_REQUIRE(H < (1 << 20) && W < (1 << 20), TSPN_EUNSUPPORTED, "tspn_bottleneck_tail_next_bf16: dimension too large");
+  return launch<256, true>(h1, NB, H, W, frag2, bias2, frag3, bias3, residual, out, stream, frag1n, bias1n, h1n);
 }

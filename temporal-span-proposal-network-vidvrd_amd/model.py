@@ -129,19 +129,28 @@ def _segment_pairs(plist, n, device):
     return ops.pair_index(n, device)
 
 
+_VERIFY_WEIGHTS = __import__("os").environ.get("TSPN_VERIFY_WEIGHTS", "0") not in ("", "0")
+
+
 class _DeviceCache:
     """Device-resident (and packed) copies of parameters, refreshed when a parameter changes.
 
     Contract: a change is seen through the parameter's storage pointer, its autograd version counter and
     its device — optimiser steps, `load_state_dict`, `.to()` / `.cuda()` and `train()` all refresh the
     cache (the last three through `invalidate_caches`).  In-place edits through `.data` (`p.data.copy_`,
-    EMA updates, legacy loaders) bump none of these: call `model.invalidate_caches()` after them."""
+    EMA updates, legacy loaders) bump none of these: call `model.invalidate_caches()` after them, or run with
+    TSPN_VERIFY_WEIGHTS=1 (a content fingerprint per parameter and forward: safe with any training loop, slower)."""
 
     def __init__(self):
         self._store = {}
 
     def get(self, key, params, device, build):
         sig = tuple((p.data_ptr(), p._version, str(p.device)) for p in params) + (str(device),)
+        if _VERIFY_WEIGHTS:
+            # TSPN_VERIFY_WEIGHTS=1: a content fingerprint joins the signature, so in-place `.data` edits (EMA, legacy
+            # loaders) refresh the cache too -- at the price of a device reduction and a host sync per parameter and call
+            with torch.no_grad():
+                sig += tuple((float(p.detach().double().sum()), float(p.detach().double().abs().sum())) for p in params)
         hit = self._store.get(key)
         if hit is not None and hit[0] == sig:
             return hit[1]

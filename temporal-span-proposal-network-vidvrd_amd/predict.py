@@ -16,7 +16,8 @@ def _host(x):
     return np.array(x)
 
 
-def predict_short_term_relations(model, data_loader, topk_per_pair=20, topk_per_seg=200, on_segment=None):
+def predict_short_term_relations(model, data_loader, topk_per_pair=20, topk_per_seg=200, on_segment=None,
+                                 prefetch_device=None):
     """`data_loader` yields `(pair_list, target_list, indexs)` like the reference's test loader
     (lib/dataset/build.py collate): `pair_list` a list of PairList with the fields set in
     vrdataset.py:75-81 ('tracklet_pairs', 'track_cls_logits', 'num_tracklets', 'ious', 'track_ids'),
@@ -26,7 +27,12 @@ def predict_short_term_relations(model, data_loader, topk_per_pair=20, topk_per_
     [(score, triplet[3], pair_tid[2]), ...] as numpy values, top `topk_per_seg` per segment in
     descending score order — the structure `greedy_relational_association` consumes
     (predict.py:106-116).  Segments with fewer than two tracklets are skipped (predict.py:61-64).
-    `on_segment(index)` is called after every segment (progress hook)."""
+    `on_segment(index)` is called after every segment (progress hook).
+    `prefetch_device`: a HIP device -> the loader's host batches go through `dataset.DevicePrefetcher` (batch i+1
+    uploads under batch i; 0.94-0.97 of the device-resident rate at cfg2 against 0.48-0.70 without)."""
+    if prefetch_device is not None:
+        from .dataset import DevicePrefetcher
+        data_loader = DevicePrefetcher(data_loader, prefetch_device)
     short_term_relations = {}
     was_training = model.training
     model.eval()

@@ -100,6 +100,9 @@ class BottleneckBlock(nn.Module):
         # LDS, results bit-identical to the two separate launches).  Needs 64 / 128 / 256 bottleneck channels and
         # the 4x expansion of the standard block; switched off by ResNetC4 / Res5RoIHead `fuse_bottlenecks = False`.
         self.fuse_tail = True
+        # ... and let that launch compute the NEXT block's conv1 too where it can (CM = 256: the res4 chain), so that
+        # the 1024-channel map is read once per block; switched by ResNetC4 `fuse_next_conv1`
+        self.fuse_next = True
 
     def _can_fuse(self, x):
         c2, c3 = self.conv2, self.conv3
@@ -107,28 +110,43 @@ class BottleneckBlock(nn.Module):
         return (self.fuse_tail and x.dtype == torch.bfloat16 and cm in (64, 128, 256) and c2.weight.shape[1] == cm
                 and c3.weight.shape[0] == 4 * cm and c2.kernel_size == 3 and c2.stride == 1 and c2.padding == 1)
 
-    def forward(self, x, presampled=False, out=None):
+    def _can_take_h1(self, x):
+        """This block's conv1 can be computed by the PREVIOUS block's tail launch (ops.bottleneck_tail_bf16 with
+        next_frag1): identity shortcut, stride 1, 256 bottleneck channels, 1x1 conv1 on 4 x 256 channels."""
+        c1 = self.conv1
+        return (self.fuse_next and self.shortcut is None and self.stride == 1 and c1.kernel_size == 1 and c1.padding == 0
+                and c1.weight.shape[0] == 256 and c1.weight.shape[1] == 1024 and x.dtype == torch.bfloat16)
+
+    def forward(self, x, presampled=False, out=None, h1=None, next_block=None):
         """`presampled`: x already holds only the pixels the strided 1x1 convs (conv1, shortcut) read -- every
         `stride`-th row and column -- so they run with stride 1 (Res5RoIHead lets ROIAlign produce just those bins).
         `out`: where to write the block's result (a contiguous tensor of its shape; the fused bf16 tail writes into it
-        directly, the other paths copy)."""
+        directly, the other paths copy).
+        `h1`: this block's conv1 output, already computed by the previous block's tail launch.
+        `next_block`: the block that follows; when it qualifies (`_can_take_h1`) this block's fused tail computes its
+        conv1 as well and the call returns (y, h1 of the next block) instead of y."""
         st = 1 if presampled else None
-        h = self.conv1(x, relu=True, stride=st)
+        h = h1 if h1 is not None else self.conv1(x, relu=True, stride=st)
         if self.shortcut is not None:
             sc = self.shortcut(x, stride=st)
         elif self.stride == 1:
             sc = x
         else:
             raise ValueError("identity shortcut needs stride 1")
+        hand_over = next_block is not None and next_block._can_take_h1(x) and self.conv2.weight.shape[0] == 256
         if self._can_fuse(x):
             f2, b2 = self.conv2.folded_bf16(x.device)
             f3, b3 = self.conv3.folded_bf16(x.device)
-            return ops.bottleneck_tail_bf16(h, f2, b2, f3, b3, sc.contiguous(), out=out)
+            if hand_over:
+                f1n, b1n = next_block.conv1.folded_bf16(x.device)
+                return ops.bottleneck_tail_bf16(h, f2, b2, f3, b3, sc.contiguous(), out=out, next_frag1=f1n, next_bias1=b1n)
+            y = ops.bottleneck_tail_bf16(h, f2, b2, f3, b3, sc.contiguous(), out=out)
+            return (y, None) if next_block is not None else y
         y = self.conv3(self.conv2(h, relu=True), residual=sc, relu=True)
-        if out is None:
-            return y
-        out.copy_(y)
-        return out
+        if out is not None:
+            out.copy_(y)
+            y = out
+        return (y, None) if next_block is not None else y
 
 
 def _warm_conv_weights(module, dev, bf16):
@@ -302,6 +320,20 @@ class BasicStem(nn.Module):
         return ops.max_pool_nhwc(y, 3, 2, 1, out_bf16=out_bf16)
 
 
+def _run_blocks(blocks, x, last_out=None):
+    """A stage's bottleneck blocks in a row.  Each block is told which block follows: where both qualify (bf16 map, 256
+    bottleneck channels: the res4 chain) its fused tail launch also computes the follower's conv1 on the tile it has
+    just produced, and the follower starts from that h1.  `last_out`: where the last block writes its result."""
+    blocks = list(blocks)
+    h1 = None
+    for i, blk in enumerate(blocks):
+        if i + 1 < len(blocks):
+            x, h1 = blk(x, h1=h1, next_block=blocks[i + 1])
+        else:
+            x = blk(x, h1=h1, out=last_out)
+    return x
+
+
 class ResNetC4(_CachedWeightsMixin, nn.Module):
     """The C4 backbone of detectron2's R-50/101-C4 models (build_resnet_backbone with OUT_FEATURES = res4):
     stem -> res2 -> res3 -> res4, bottleneck blocks with stride_in_1x1 and FrozenBN, parameter names as in a
@@ -314,7 +346,7 @@ class ResNetC4(_CachedWeightsMixin, nn.Module):
 
     BLOCKS = {50: (3, 4, 6), 101: (3, 4, 23)}
 
-    def __init__(self, depth=101, stem_out=64, res2_out=256, blocks=None, frame_chunk=4):
+    def __init__(self, depth=101, stem_out=64, res2_out=256, blocks=None, frame_chunk=9):
         super().__init__()
         blocks = tuple(blocks) if blocks is not None else self.BLOCKS[depth]
         self.stem = BasicStem(3, stem_out)
@@ -329,6 +361,12 @@ class ResNetC4(_CachedWeightsMixin, nn.Module):
         self.out_channels = cin
         self.frame_chunk = int(frame_chunk)
         self.fuse_bottlenecks = True     # bf16 maps: conv2 + conv3 + residual of every block in one launch
+        # ... which at res4 can also compute conv1 of the block that follows (round 4, tspn_bottleneck_tail_next_bf16): the
+        # 1024-channel map is then read once per block (-0.16 GB of fabric traffic per 720p frame) and the pair of launches
+        # takes 5 % less time on its own (109 against 115 us per 8 frames) -- but that launch needs 136 KB of LDS, one
+        # workgroup per CU, so the chunks of the other HIP stream no longer share CUs with it: 27.5 against 26.0 ms per 64
+        # frames with two streams (equal, 31.9 / 32.0, with one).  Off by default for that reason.
+        self.fuse_next_conv1 = False
         # frame chunks alternate between this many HIP streams: a launch's workgroups run in lockstep (all in their MFMA
         # phase, then all in their memory phase), two chunks in flight put the memory phase of one under the MFMA phase
         # of the other (tools/probe_tail_stagger.py: -10 % on the res4 tails; backbone -5 %)
@@ -343,13 +381,14 @@ class ResNetC4(_CachedWeightsMixin, nn.Module):
             for m in self.modules():
                 if isinstance(m, BottleneckBlock):
                     m.fuse_tail = bool(self.fuse_bottlenecks)
+                    m.fuse_next = bool(self.fuse_bottlenecks and self.fuse_next_conv1)
             out = []
             nchunks = -(-images.shape[0] // self.frame_chunk)
             ns = min(int(self.streams), nchunks) if images.is_cuda else 1
             if ns <= 1:
                 for lo in range(0, images.shape[0], self.frame_chunk):
                     x = self.stem(_f32(images[lo:lo + self.frame_chunk], dev), out_bf16=bf16)
-                    out.append(self.res4(self.res3(self.res2(x))))
+                    out.append(_run_blocks(self.res4, _run_blocks(self.res3, _run_blocks(self.res2, x))))
                 return torch.cat(out)
             main = torch.cuda.current_stream(dev)
             side = self._side_streams.setdefault((dev.index, ns), [torch.cuda.Stream(device=dev) for _ in range(ns)])
@@ -359,22 +398,22 @@ class ResNetC4(_CachedWeightsMixin, nn.Module):
                 st.wait_stream(main)
             res4 = list(self.res4)
             last = res4[-1]
-            direct = last.stride == 1          # its output has the shape of its input: the chunk's last block writes
+            direct = all(b.stride == 1 for b in res4[1:])   # the last block's output has the shape of its input: it writes
             res = None                         # its frames of the result directly (no torch.cat of the chunks)
             for k, lo in enumerate(range(0, images.shape[0], self.frame_chunk)):
                 with torch.cuda.stream(side[k % ns]):
                     x = self.stem(imgs[lo:lo + self.frame_chunk], out_bf16=bf16)
-                    x = self.res3(self.res2(x))
+                    x = _run_blocks(self.res3, _run_blocks(self.res2, x))
                     if not direct:
-                        out.append(self.res4(x))
+                        out.append(_run_blocks(res4, x))
                         continue
-                    for blk in res4[:-1]:
-                        x = blk(x)
                     if res is None:
+                        s4 = res4[0].stride
+                        hw = ((x.shape[1] - 1) // s4 + 1, (x.shape[2] - 1) // s4 + 1)
                         with torch.cuda.stream(main):      # the caller's stream owns the result
-                            res = torch.empty((images.shape[0],) + tuple(x.shape[1:3]) + (last.conv3.weight.shape[0],),
+                            res = torch.empty((images.shape[0],) + hw + (last.conv3.weight.shape[0],),
                                               dtype=x.dtype, device=dev)
-                    last(x, out=res[lo:lo + x.shape[0]])
+                    _run_blocks(res4, x, last_out=res[lo:lo + x.shape[0]])
             for st in side:
                 main.wait_stream(st)
             return res if direct else torch.cat(out)

@@ -62,12 +62,14 @@ def cfg5(tspn, device):
     model.load_state_dict({k: t(v) for k, v in sc_sd.items()})
     model.eval()
     img = tspn.hashrng.uniform(95, "img", (FRAMES, H5, W5, 3), -0.5, 0.5)
-    # hooks: input / output of selected bottleneck blocks (first, an inner and the last block of every stage)
-    watch = {"res2.0": net.res2[0], "res2.2": net.res2[2], "res3.0": net.res3[0], "res3.3": net.res3[3],
-             "res4.0": net.res4[0], "res4.11": net.res4[11], "res4.22": net.res4[22]}
+    # hooks: input / output of EVERY bottleneck block of the backbone's 30 (round 4; round 3 watched seven; the three
+    # res5 blocks run inside the RoI head, checked below).  A block that is told its follower returns (y, h1 of the
+    # follower or None)
+    watch = {f"{stage}.{b}": blk for stage in ("res2", "res3", "res4") for b, blk in enumerate(getattr(net, stage))}
+    assert len(watch) == 30
     taps = {}
-    hooks = [m.register_forward_hook(lambda mod, inp, out, name=name: taps.__setitem__(name, (inp[0], out)))
-             for name, m in watch.items()]
+    hooks = [m.register_forward_hook(lambda mod, inp, out, name=name: taps.__setitem__(
+                 name, (inp[0], out[0] if isinstance(out, tuple) else out))) for name, m in watch.items()]
     maps4 = net(t(img).to(device), bf16=True)
     for h in hooks:
         h.remove()
@@ -113,8 +115,11 @@ def test_cfg5_stem_on_720p_frames(tspn, cfg5):
     close_bf16(got, ref, "stem + pool, bottom-right", max_ulps=2.0, frac=0.995)
 
 
-@pytest.mark.parametrize("name,stride", [("res2.0", 1), ("res2.2", 1), ("res3.0", 2), ("res3.3", 1), ("res4.0", 2),
-                                         ("res4.11", 1), ("res4.22", 1)])
+ALL_BLOCKS = [(f"{stage}.{b}", 2 if (b == 0 and stage != "res2") else 1)
+              for stage, nb in (("res2", 3), ("res3", 4), ("res4", 23)) for b in range(nb)]
+
+
+@pytest.mark.parametrize("name,stride", ALL_BLOCKS)
 def test_cfg5_backbone_blocks_teacher_forced(cfg5, name, stride):
     """A bottleneck block of the full-size R-101 backbone (bf16 operands, fp32 accumulation, one rounding per conv)
     == the float64 restatement with the same rounding points, on a corner crop (true zero padding on two sides) and
@@ -136,7 +141,7 @@ def test_cfg5_roi_head_sampled_rois(cfg5):
     """ROIAlign (14 x 14, aligned, adaptive grid) on the 45 x 80 bf16 map + res5 + mean for sampled (tracklet, frame)
     RoIs of the 57 600 == the restatement on the same map."""
     p = {k: t(v) for k, v in cfg5["r5_sd"].items()}
-    for n, f in ((0, 0), (17, 449), (63, 899), (40, 2)):
+    for n, f in ((0, 0), (17, 449), (63, 899), (40, 2), (5, 123), (31, 700), (62, 1), (9, 898)):
         fm = cfg5["maps"][f:f + 1].cpu().float()
         ref = ro.res5_roi_head_bf16(fm, cfg5["boxes"][n:n + 1, f:f + 1], p)[0, 0]
         close_bf16(cfg5["feats"][n, f].cpu(), ref, f"RoI ({n},{f})", max_ulps=8.0, frac=0.95)

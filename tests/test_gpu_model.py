@@ -792,3 +792,26 @@ def test_device_prefetcher_yields_the_loaders_batches_on_the_device(tspn, device
             for b in range(B):
                 assert lg_d[b].is_cuda and torch.equal(lg_d[b].cpu(), lg_h[b])
                 assert all(torch.equal(x.cpu(), y.cpu()) for x, y in zip(dec_h[b], dec_d[b]))
+
+
+def test_in_place_data_edits_need_invalidate_or_verify_weights(tspn, device, monkeypatch):
+    """`_DeviceCache` sees optimiser steps, load_state_dict and .to(); an in-place edit through `.data` bumps no version
+    counter: the documented contract is `invalidate_caches()` -- or TSPN_VERIFY_WEIGHTS=1, which adds a content
+    fingerprint to the cache signature (checked here by switching the module flag the environment variable sets)."""
+    model_mod = __import__("importlib").import_module(tspn.BaseModel.__module__)
+    c = cases.g1_inputs()
+    m = tspn.BaseModel(cases.baseline_cfg())
+    load(m, c["state_dict"])
+    m.eval()
+    plist = tspn.PairList(oracle.feature_preprocess(t(c["raw"])).to(device))
+    base = m([plist], None)[2][0].clone()
+    m.classifier.rel_predictor.weight.data.mul_(0.5)              # no version bump, same storage
+    stale = m([plist], None)[2][0]
+    assert torch.equal(stale, base)                                 # the cached packed copy is still in use (documented)
+    m.invalidate_caches()
+    fresh = m([plist], None)[2][0]
+    assert not torch.equal(fresh, base)
+    monkeypatch.setattr(model_mod, "_VERIFY_WEIGHTS", True)
+    m.classifier.rel_predictor.weight.data.mul_(2.0)              # back to the original values, again in place
+    again = m([plist], None)[2][0]
+    assert torch.equal(again, base)                                 # seen without invalidate_caches()

@@ -399,6 +399,74 @@ def test_bottleneck_tail_fused_bit_identical_to_two_convs(tspn, device, CM, NB, 
     assert float(err.max()) <= 4 * 2.0 ** -8 * scale and float((err <= 2.0 ** -8 * ref.abs() + 1e-6).double().mean()) > 0.97
 
 
+@pytest.mark.parametrize("NB,H,W", [(3, 7, 11), (1, 45, 80), (1, 1, 1), (2, 16, 8), (1, 13, 129)])
+def test_bottleneck_tail_with_next_conv1_bit_identical(tspn, device, NB, H, W):
+    """tspn_bottleneck_tail_next_bf16 (round 4): the tail launch that also computes conv1 of the FOLLOWING block on the
+    tile it has just produced.  Its `out` equals tspn_bottleneck_tail_bf16's and its `h1_next` equals
+    tspn_conv2d_nhwc_bf16(out, W1n, relu) BIT FOR BIT (same contraction order: channels 0..1023 in k-steps of 16 on
+    one accumulator chain), on pixel counts that are not multiples of the 128-pixel tile; repeated launches agree."""
+    CM = 256
+    h1 = tspn.hashrng.uniform(93, "h1", (NB, H, W, CM), 0, 1)
+    res = tspn.hashrng.uniform(93, "res", (NB, H, W, 4 * CM), -1, 1)
+    w2 = tspn.hashrng.normal(93, "w2", (CM, CM, 3, 3), std=float(np.sqrt(2.0 / (9 * CM))))
+    w3 = tspn.hashrng.normal(93, "w3", (4 * CM, CM, 1, 1), std=float(np.sqrt(2.0 / CM)))
+    w1n = tspn.hashrng.normal(93, "w1n", (CM, 4 * CM, 1, 1), std=float(np.sqrt(2.0 / (4 * CM))))
+    b2 = tspn.hashrng.normal(93, "b2", (CM,), std=0.1)
+    b3 = tspn.hashrng.normal(93, "b3", (4 * CM,), std=0.1)
+    b1n = tspn.hashrng.normal(93, "b1n", (CM,), std=0.1)
+    d = lambda a, dt=None: (t(a).to(device) if dt is None else t(a).to(device).to(dt))   # noqa: E731
+    f2, f3, f1n = (tspn.ops.pack_conv2d_frag_bf16(d(w)) for w in (w2, w3, w1n))
+    h1d, resd = d(h1, torch.bfloat16), d(res, torch.bfloat16)
+    want = tspn.ops.bottleneck_tail_bf16(h1d, f2, d(b2), f3, d(b3), resd)
+    want_h = tspn.ops.conv2d_nhwc_bf16(want, f1n, (1, 1), 1, 0, bias=d(b1n), relu=True)
+    got, got_h = tspn.ops.bottleneck_tail_bf16(h1d, f2, d(b2), f3, d(b3), resd, next_frag1=f1n, next_bias1=d(b1n))
+    assert tuple(got_h.shape) == (NB, H, W, CM) and got_h.dtype == torch.bfloat16
+    assert torch.equal(got, want), f"out: max diff {float((got.float() - want.float()).abs().max())}"
+    assert torch.equal(got_h, want_h), f"h1_next: max diff {float((got_h.float() - want_h.float()).abs().max())}"
+    assert float(got_h.float().abs().max()) > 0.1                 # not a vacuous comparison
+    for _ in range(3):
+        g2, h2 = tspn.ops.bottleneck_tail_bf16(h1d, f2, d(b2), f3, d(b3), resd, next_frag1=f1n, next_bias1=d(b1n))
+        assert torch.equal(g2, got) and torch.equal(h2, got_h)
+    with pytest.raises(ValueError):
+        tspn.ops.bottleneck_tail_bf16(h1d, f2, d(b2), f3, d(b3), resd, next_frag1=f3, next_bias1=d(b1n))
+
+
+def test_backbone_chain_with_next_conv1_equals_separate_launches(tspn, device):
+    """ResNetC4 with res4 blocks of 256 bottleneck channels: `fuse_next_conv1` (every tail launch computes the follower's
+    conv1) on and off give the same maps bit for bit, on one stream and on two, with frame chunks whose pixel count
+    is not a multiple of the tile."""
+    net, _ = _backbone_and_weights(tspn, device, 64, 256, (1, 1, 4))
+    assert net.res4[1].conv1.weight.shape[:2] == (256, 1024)
+    img = t(tspn.hashrng.uniform(98, "img", (5, 80, 112, 3), -1, 1)).to(device)
+    net.frame_chunk = 2
+    outs = []
+    calls = []
+    real = tspn.ops.bottleneck_tail_bf16
+    try:
+        def spy(*a, **k):
+            calls.append(k.get("next_frag1") is not None)
+            return real(*a, **k)
+        tspn.ops.bottleneck_tail_bf16 = spy
+        tspn.roi_head.ops.bottleneck_tail_bf16 = spy
+        for nxt, ns in ((False, 1), (True, 1), (True, 2), (False, 2)):
+            net.fuse_next_conv1, net.streams = nxt, ns
+            calls.clear()
+            outs.append(net(img, bf16=True))
+            torch.cuda.synchronize()
+            # three frame chunks x (res2 + res3 + four res4 blocks); with the hand-over on, res4 blocks 0..2 of every chunk
+            # compute their follower's conv1 (block 0 has a projection shortcut itself, its FOLLOWER qualifies)
+            assert len(calls) == 3 * 6 and sum(calls) == (9 if nxt else 0)
+    finally:
+        tspn.ops.bottleneck_tail_bf16 = real
+        tspn.roi_head.ops.bottleneck_tail_bf16 = real
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    assert net.res4[2]._can_take_h1(outs[0]) is False            # switched off by the last configuration
+    net.fuse_next_conv1 = True
+    net(img, bf16=True)
+    assert net.res4[2]._can_take_h1(outs[0]) and not net.res4[0]._can_take_h1(outs[0])
+
+
 def test_backbone_and_roi_head_fused_equal_unfused(tspn, device):
     """ResNetC4 / Res5RoIHead with fuse_bottlenecks on and off: the same bf16 maps and features, bit for bit (every
     block incl. the stride-2 ones with a projection shortcut goes through the fused tail)."""
