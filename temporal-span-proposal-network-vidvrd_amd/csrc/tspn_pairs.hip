@@ -138,6 +138,35 @@ __global__ void temporal_mean_td_kernel(const float* __restrict__ x, int64_t R, 
   }
 }
 
+// The same for D % 4 == 0 and 16-byte aligned rows: a thread owns four channels (16-byte loads, whole 1-KiB row
+// segments per wave) and keeps TEN frames in flight; every channel is still summed frame by frame in order, so the
+// result is bit for bit the scalar kernel's (round 4: 0.236 -> 0.128 ms per 629 MB at cfg2 = 4.9 TB/s; the scalar form left the loop
+// latency-bound at 2.7 TB/s).
+__global__ __launch_bounds__(256) void temporal_mean_td4_kernel(const float4* __restrict__ x, int64_t R, int64_t T,
+                                                                int64_t D4, float4* __restrict__ out) {
+  const int64_t total = R * D4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / D4, d = i - r * D4;
+    const float4* s = x + r * T * D4 + d;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int64_t t = 0;
+    for (; t + 10 <= T; t += 10) {
+      float4 v[10];
+#pragma unroll
+      for (int k = 0; k < 10; ++k) v[k] = s[(t + k) * D4];
+#pragma unroll
+      for (int k = 0; k < 10; ++k) { acc.x += v[k].x; acc.y += v[k].y; acc.z += v[k].z; acc.w += v[k].w; }
+    }
+    for (; t < T; ++t) {
+      const float4 v = s[t * D4];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    const float ft = (float)T;
+    out[i] = make_float4(acc.x / ft, acc.y / ft, acc.z / ft, acc.w / ft);
+  }
+}
+
 // x[R,C,T] -> out[R,C]: one wave per (r,c) row, lanes stride over t, shuffle tree.
 __global__ __launch_bounds__(256) void temporal_mean_ct_kernel(const float* __restrict__ x,
                                                                int64_t rows, int64_t T,
@@ -239,7 +268,10 @@ extern "C" int tspn_temporal_mean_f32(const float* x, int64_t R, int64_t T, int6
   if (R == 0) return TSPN_OK;
   TSPN_REQUIRE(x && out, TSPN_EINVAL, "tspn_temporal_mean_f32: null pointer");
   hipStream_t s = TSPN_STREAM(stream);
-  if (layout_tc) {
+  if (layout_tc && Cdim % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+    hipLaunchKernelGGL(temporal_mean_td4_kernel, dim3(grid_for(R * (Cdim / 4))), dim3(256), 0, s,
+                       reinterpret_cast<const float4*>(x), R, T, Cdim / 4, reinterpret_cast<float4*>(out));
+  } else if (layout_tc) {
     hipLaunchKernelGGL(temporal_mean_td_kernel, dim3(grid_for(R * Cdim)), dim3(256), 0, s, x, R, T,
                        Cdim, out);
   } else {

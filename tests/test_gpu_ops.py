@@ -546,3 +546,19 @@ def test_cfg4_batch_independence(tspn, device):
     # determinism: two runs of the same launch are bitwise identical (no atomics anywhere)
     hb2, lb2 = run_fused(tspn, device, feats, pairs, B, N, w, canonical=True)
     assert torch.equal(hb, hb2) and torch.equal(lb, lb2)
+
+
+@pytest.mark.parametrize("R,T,D", [(5, 150, 64), (3, 7, 8), (2, 31, 2048), (4, 10, 4), (1, 900, 128)])
+def test_temporal_mean_vector_form_bit_identical_to_scalar(tspn, device, R, T, D):
+    """Round 4: x [R,T,D] with D % 4 == 0 on 16-byte aligned rows takes the four-channels-per-thread kernel (ten frames
+    in flight); a copy of the same values at a 4-byte offset takes the scalar kernel.  Same frame order per channel:
+    the two results are equal bit for bit, and equal the float64 mean within fp32 rounding."""
+    x = tspn.hashrng.uniform(61, "tm", (R, T, D), -1, 3)
+    xa = t(x).to(device)
+    buf = torch.zeros(R * T * D + 1, dtype=torch.float32, device=device)
+    buf[1:] = xa.flatten()
+    xb = buf[1:].view(R, T, D)                       # same values, rows at a 4-byte offset: not 16-byte aligned
+    assert xa.data_ptr() % 16 == 0 and xb.data_ptr() % 16 == 4
+    a, b = tspn.ops.temporal_mean(xa, layout_tc=True), tspn.ops.temporal_mean(xb, layout_tc=True)
+    assert torch.equal(a, b)
+    np.testing.assert_allclose(a.cpu().numpy(), x.astype(np.float64).mean(axis=1), rtol=0, atol=2e-6)
