@@ -515,6 +515,16 @@ int tspn_bottleneck_tail_next_bf16(const uint16_t* h1, int64_t NB, int64_t H, in
                                    const float* bias3, const uint16_t* residual, uint16_t* out,
                                    const uint16_t* frag1n, const float* bias1n, uint16_t* h1n, void* stream);
 
+/* tspn_bottleneck_tail_bf16 as a PERSISTENT kernel pipelined across tiles (round 4, tspn_bottleneck_pipe_bf16.hip; CM =
+ * 256): one workgroup of eight waves per CU walks the 128-pixel tiles; four waves run the 3x3 phase of tile t while the
+ * other four run the expand + residual + store of tile t - 1 (x ring and one h2 image side by side in 136 KB of LDS, 14
+ * workgroup barriers per tile on both sides).  Same arithmetic, bit-identical results.  max_workgroups: 0 = one per CU
+ * (what it is built for); a smaller positive number makes every workgroup walk more tiles (tests). */
+int tspn_bottleneck_tail_pipe_bf16(const uint16_t* h1, int64_t NB, int64_t H, int64_t W, int64_t CM,
+                                   const uint16_t* frag2, const float* bias2, const uint16_t* frag3,
+                                   const float* bias3, const uint16_t* residual, uint16_t* out,
+                                   int64_t max_workgroups, void* stream);
+
 /* ---- f4: bf16-operand stem of the C4 backbone (tspn_stem_bf16.hip) ----------------------------------------
  * detectron2 BasicStem conv (modeling/backbone/resnet.py: 7x7, stride 2, padding 3, RGB in, FrozenBN folded by the
  * caller into w / bias) + ReLU with bf16 operands: image and weights rounded to bf16, exact products, fp32

@@ -35,7 +35,7 @@ RES_PATH = os.path.join(HERE, "kernel_resources.json")   # next to the .so (git-
 # stale data.  The build FAILS when one of them spills or uses scratch.
 NO_SPILL_KERNELS = ("conv3_wino63_kernel", "heads_pairgrid4_kernel", "heads_pairgrid3_kernel",
                     "conv2d_nhwc_frag_kernel", "conv2d_nhwc_bf16_kernel", "conv2d_nhwc_cin4_kernel",
-                    "bottleneck_bf16_kernel", "conv3_bf16_big_kernel", "heads_pairgrid_bf16_kernel")
+                    "bottleneck_bf16_kernel", "bottleneck_pipe_bf16_kernel", "conv3_bf16_big_kernel", "heads_pairgrid_bf16_kernel")
 
 
 def sources():

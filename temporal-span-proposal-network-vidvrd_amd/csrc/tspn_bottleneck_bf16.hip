@@ -94,7 +94,12 @@ __global__ __launch_bounds__(THREADS, (NEXT ? 1 : (CM == 64 ? 3 : 2))) void bott
   constexpr int DIST = NST - 1;
   extern __shared__ __attribute__((aligned(16))) char Bs[];   // max(NST stages, h2 image) = max(NST, CCH) * B_ST
   // NEXT: two chunk images [32 groups][SLPC slots][8 bf16] behind the stages / the h2 image, one per sub-pass parity
-  constexpr int CHUNK_OFF = (NST > CCH ? NST : CCH) * B_ST + 1024;
+  // a 16-byte slot of zeros behind the side regions: fragment reads of taps that fall off the image are redirected to
+  // it BY ADDRESS (round 4; round 3 zeroed the loaded registers with four v_cndmask per fragment, which made the
+  // compiler wait for every LDS read right behind its issue: three or four exposed LDS latencies per k-step with one
+  // wave per SIMD -- the "issue structure" that kept phase 2 at half the MFMA rate with all memory traffic removed)
+  constexpr int ZERO_OFF = (NST > CCH ? NST : CCH) * B_ST + 1024;
+  constexpr int CHUNK_OFF = ZERO_OFF + 256;
   constexpr int SLPC = 68;                                  // 64 pixels + padding: conflict-free 16-byte reads like SLP
   constexpr int CHUNK_BYTES = (CM / 8) * SLPC * 16;         // CM channels of 64 pixels: CM / 8 groups x SLPC slots x 16 B
 
@@ -110,6 +115,8 @@ __global__ __launch_bounds__(THREADS, (NEXT ? 1 : (CM == 64 ? 3 : 2))) void bott
   const int wm = wave % WM, wn = wave / WM;
   const int li = lane & 31, kh = lane >> 5;
   const unsigned woff = lane * 16;
+  if (tid < 4) reinterpret_cast<float*>(Bs + ZERO_OFF)[tid] = 0.f;   // published by the first barrier of phase 2
+  const char* const zslot = Bs + ZERO_OFF;
 
   // ---------------------------------------------------------------- phase 2: 3x3 conv, K = 9 taps x CM
   const char* wbase[MI];
@@ -256,9 +263,8 @@ __global__ __launch_bounds__(THREADS, (NEXT ? 1 : (CM == 64 ? 3 : 2))) void bott
       for (int ni = 0; ni < NI; ++ni) {
         const char* bp = Bb + ni * 32 * 16;
         if (ni == 3) bp = (li + rb >= 32) ? extra + buf * 256 + ((g2 + kh) * 2 + (li + rb - 32)) * 16 : bp;
-        f32x4 bv = *reinterpret_cast<const f32x4*>(bp);
-        if (!((rmask[ni] >> tap) & 1u)) bv = f32x4{0.f, 0.f, 0.f, 0.f};
-        b[ni] = __builtin_bit_cast(bf16x8, bv);
+        if (!((rmask[ni] >> tap) & 1u)) bp = zslot;          // the tap falls off the image: read zeros
+        b[ni] = *reinterpret_cast<const bf16x8*>(bp);
       }
 #endif
     };
@@ -380,9 +386,14 @@ __global__ __launch_bounds__(THREADS, (NEXT ? 1 : (CM == 64 ? 3 : 2))) void bott
         const int sl = (wn * NI + ni) * 32 + li + rb;
         const char* bp = Bs + ra * B_ST + (g * SLP + sl) * 16;
         if ((wn * NI + ni) == 3 && sl >= 128) bp = extra + ((ra * 8 + g) * 2 + (sl - 128)) * 16;
-        f32x4 bv = *reinterpret_cast<const f32x4*>(bp);
-        if (!((rmask[ni] >> tap) & 1u)) bv = f32x4{0.f, 0.f, 0.f, 0.f};
-        b[ni] = __builtin_bit_cast(bf16x8, bv);
+        if constexpr (CM >= 128) {
+          if (!((rmask[ni] >> tap) & 1u)) bp = zslot;        // the tap falls off the image: read zeros
+          b[ni] = *reinterpret_cast<const bf16x8*>(bp);
+        } else {     // CM = 64 (three waves per SIMD, 168 registers): the address select spills; zero the registers
+          f32x4 bv = *reinterpret_cast<const f32x4*>(bp);
+          if (!((rmask[ni] >> tap) & 1u)) bv = f32x4{0.f, 0.f, 0.f, 0.f};
+          b[ni] = __builtin_bit_cast(bf16x8, bv);
+        }
       }
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
@@ -848,7 +859,8 @@ int launch(const uint16_t* h1, int64_t NB, int64_t H, int64_t W, const uint16_t*
   constexpr int nst = CM == 256 ? 4 : 3;
   constexpr int cch = CM / KC;
   // + slots 128, 129 (once-staged form / range ring); NEXT: + the chunk image of a pass
-  constexpr size_t smem = (size_t)(cch > nst ? cch : nst) * B_ST + 1024 + (NEXT ? (size_t)2 * (CM / 8) * 68 * 16 : 0);
+  // stages / h2 image + slots 128, 129 (side regions) + the zero slot (+ NEXT: two chunk images)
+  constexpr size_t smem = (size_t)(cch > nst ? cch : nst) * B_ST + 1024 + 256 + (NEXT ? (size_t)2 * (CM / 8) * 68 * 16 : 0);
   static_assert(smem <= 160 * 1024, "LDS budget");
   static tspn::LdsLimit lds;
   if (int rc = lds.ensure(reinterpret_cast<const void*>(bottleneck_bf16_kernel<CM, NEXT>), smem, "tspn_bottleneck_tail_bf16"))

@@ -89,7 +89,8 @@ __global__ __launch_bounds__(THREADS, (MI == 1 ? TSPN_ROI_BF16_MI1_WAVES : 2)) v
     int KW, int stride, int pad, int OH, int OW, int64_t npix, int tiles_m, int tiles_n, int relu) {
   constexpr int BM = 128 * MI;
   constexpr int EPI_BYTES = 4 * 32 * (32 * MI + 4) * 4;   // epilogue transpose: 4 waves x 32 pixels x padded row
-  __shared__ __attribute__((aligned(16))) char Bs[2 * B_ST + 512 > EPI_BYTES ? 2 * B_ST + 512 : EPI_BYTES];
+  constexpr int ZERO_OFF = 2 * B_ST + 512;                // RNG: 16 bytes of zeros, the target of taps that fall off the image
+  __shared__ __attribute__((aligned(16))) char Bs[ZERO_OFF + 16 > EPI_BYTES ? ZERO_OFF + 16 : EPI_BYTES];
 
   const int nwg = gridDim.x;
   const int bid = blockIdx.x;
@@ -193,6 +194,8 @@ __global__ __launch_bounds__(THREADS, (MI == 1 ? TSPN_ROI_BF16_MI1_WAVES : 2)) v
 
   if constexpr (RNG) {
     char* const extra = Bs + 2 * B_ST;                       // [stage][8 groups][2 slots] x 16 B
+    if (tid < 4) reinterpret_cast<float*>(Bs + ZERO_OFF)[tid] = 0.f;   // published by the barrier below
+    const char* const zslot = Bs + ZERO_OFF;
     unsigned rmask[4];                                       // tap masks of the pixels this lane reads as its B columns
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
@@ -229,9 +232,10 @@ __global__ __launch_bounds__(THREADS, (MI == 1 ? TSPN_ROI_BF16_MI1_WAVES : 2)) v
       for (int ni = 0; ni < 4; ++ni) {
         const char* bp = Bb + ni * 32 * 16;
         if (ni == 3) bp = (li + rb >= 32) ? extra + buf * 256 + ((2 * ks + kh) * 2 + (li + rb - 32)) * 16 : bp;
-        f32x4 bv = *reinterpret_cast<const f32x4*>(bp);
-        if (!((rmask[ni] >> tap) & 1u)) bv = f32x4{0.f, 0.f, 0.f, 0.f};
-        b[ni] = __builtin_bit_cast(bf16x8, bv);
+        // a tap off the image reads the zero slot: masking by ADDRESS leaves the loaded registers untouched, so the
+        // compiler no longer waits for every read right behind its issue (round 4; four v_cndmask per fragment before)
+        if (!((rmask[ni] >> tap) & 1u)) bp = zslot;
+        b[ni] = *reinterpret_cast<const bf16x8*>(bp);
       }
     };
     const int nrng = 3 * cchunks;

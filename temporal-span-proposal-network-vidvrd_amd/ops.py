@@ -949,14 +949,18 @@ def max_pool_nhwc(x, kernel_size=3, stride=2, padding=1, out_bf16=False):
     return out
 
 
-def bottleneck_tail_bf16(h1, frag2, bias2, frag3, bias3, residual, out=None, next_frag1=None, next_bias1=None):
+def bottleneck_tail_bf16(h1, frag2, bias2, frag3, bias3, residual, out=None, next_frag1=None, next_bias1=None,
+                         persistent=False, max_workgroups=0):
     """relu(conv1x1(relu(conv3x3(h1) + b2)) + b3 + residual) in one launch (tspn_bottleneck_tail_bf16): h1 bf16
     [NB,H,W,CM], CM in (64, 128, 256); frag2 / frag3 = pack_conv2d_frag_bf16 of the folded conv2 / conv3 weights;
     residual bf16 [NB,H,W,4 CM] -> bf16 [NB,H,W,4 CM] (written into `out` when given: a contiguous tensor of that
     shape, e.g. a slice of the caller's result along the first dimension).
     `next_frag1`, `next_bias1` (CM = 256): pack_conv2d_frag_bf16 of the FOLLOWING block's conv1 [CM,4 CM,1,1] and its
     bias: the launch also computes that conv1 on its own output (tspn_bottleneck_tail_next_bf16) and the call returns
-    (out, h1_next [NB,H,W,CM]) -- both bit-identical to the separate launches."""
+    (out, h1_next [NB,H,W,CM]) -- both bit-identical to the separate launches.
+    `persistent` (CM = 256): the persistent kernel pipelined across tiles (tspn_bottleneck_tail_pipe_bf16: one
+    workgroup per CU, the 3x3 phase of tile t beside the expand / store phase of tile t - 1), same results;
+    `max_workgroups` > 0 limits its grid (tests)."""
     _dev(h1, "h1", torch.bfloat16); _dev(frag2, "frag2", torch.bfloat16); _dev(frag3, "frag3", torch.bfloat16)
     _dev(bias2, "bias2"); _dev(bias3, "bias3"); _dev(residual, "residual", torch.bfloat16)
     NB, H, W, CM = h1.shape
@@ -972,6 +976,12 @@ def bottleneck_tail_bf16(h1, frag2, bias2, frag3, bias3, residual, out=None, nex
         _dev(out, "out", torch.bfloat16)
         if tuple(out.shape) != (NB, H, W, 4 * CM):
             raise ValueError(f"bottleneck_tail_bf16: out must be {(NB, H, W, 4 * CM)}, got {tuple(out.shape)}")
+    if persistent:
+        if CM != 256 or next_frag1 is not None:
+            raise ValueError("bottleneck_tail_bf16: the persistent form is built for 256 bottleneck channels, without next_frag1")
+        _abi.check(_abi.lib().tspn_bottleneck_tail_pipe_bf16(_p(h1), NB, H, W, CM, _p(frag2), _p(bias2), _p(frag3), _p(bias3),
+                                                             _p(residual), _p(out), int(max_workgroups), _stream()))
+        return out
     if next_frag1 is not None:
         _dev(next_frag1, "next_frag1", torch.bfloat16); _dev(next_bias1, "next_bias1")
         if CM != 256:

@@ -431,6 +431,32 @@ def test_bottleneck_tail_with_next_conv1_bit_identical(tspn, device, NB, H, W):
         tspn.ops.bottleneck_tail_bf16(h1d, f2, d(b2), f3, d(b3), resd, next_frag1=f3, next_bias1=d(b1n))
 
 
+@pytest.mark.parametrize("NB,H,W,wgs", [(3, 7, 11, 0), (1, 45, 80, 0), (1, 1, 1, 0), (2, 16, 8, 1), (1, 13, 129, 3),
+                                         (9, 45, 80, 0), (40, 45, 80, 0), (5, 31, 33, 7)])
+def test_bottleneck_tail_persistent_pipelined_bit_identical(tspn, device, NB, H, W, wgs):
+    """tspn_bottleneck_tail_pipe_bf16 (round 4): the persistent eight-wave kernel -- phase 2 of tile t on four waves
+    beside phase 3 of tile t - 1 on the other four, 14 workgroup barriers per tile on both sides -- equals
+    tspn_bottleneck_tail_bf16 BIT FOR BIT: fewer tiles than CUs, one tile, several tiles per workgroup (a grid limited
+    to 1 / 3 / 7 workgroups, and 40 frames of the res4 shape = 1125 tiles on 256 CUs), pixel counts that are not a
+    multiple of the tile; repeated launches agree."""
+    CM = 256
+    h1 = tspn.hashrng.uniform(94, "h1", (NB, H, W, CM), 0, 1)
+    res = tspn.hashrng.uniform(94, "res", (NB, H, W, 4 * CM), -1, 1)
+    w2 = tspn.hashrng.normal(94, "w2", (CM, CM, 3, 3), std=float(np.sqrt(2.0 / (9 * CM))))
+    w3 = tspn.hashrng.normal(94, "w3", (4 * CM, CM, 1, 1), std=float(np.sqrt(2.0 / CM)))
+    b2 = tspn.hashrng.normal(94, "b2", (CM,), std=0.1)
+    b3 = tspn.hashrng.normal(94, "b3", (4 * CM,), std=0.1)
+    d = lambda a, dt=None: (t(a).to(device) if dt is None else t(a).to(device).to(dt))   # noqa: E731
+    f2, f3 = tspn.ops.pack_conv2d_frag_bf16(d(w2)), tspn.ops.pack_conv2d_frag_bf16(d(w3))
+    h1d, resd = d(h1, torch.bfloat16), d(res, torch.bfloat16)
+    want = tspn.ops.bottleneck_tail_bf16(h1d, f2, d(b2), f3, d(b3), resd)
+    for rep in range(3):
+        got = tspn.ops.bottleneck_tail_bf16(h1d, f2, d(b2), f3, d(b3), resd, persistent=True, max_workgroups=wgs)
+        assert torch.equal(got, want), f"rep {rep}: max diff {float((got.float() - want.float()).abs().max())}"
+    with pytest.raises(ValueError):
+        tspn.ops.bottleneck_tail_bf16(h1d[..., :128].contiguous(), f2, d(b2), f3, d(b3), resd, persistent=True)
+
+
 def test_backbone_chain_with_next_conv1_equals_separate_launches(tspn, device):
     """ResNetC4 with res4 blocks of 256 bottleneck channels: `fuse_next_conv1` (every tail launch computes the follower's
     conv1) on and off give the same maps bit for bit, on one stream and on two, with frame chunks whose pixel count

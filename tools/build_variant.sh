@@ -7,7 +7,8 @@ set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 CSRC=$ROOT/temporal-span-proposal-network-vidvrd_amd/csrc
 NAME=$1; VFILE=$2; shift 2
-OBJ=/tmp/tspn_objs; mkdir -p $OBJ $ROOT/variants
+VDIR=${TSPN_VARIANT_DIR:-$ROOT/variants}
+OBJ=/tmp/tspn_objs; mkdir -p $OBJ $VDIR
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-gpu-rdc -Wno-unused-function -Wno-pass-failed -I$ROOT/include -I$CSRC"
 objs=""
 for f in $CSRC/*.hip; do
@@ -22,5 +23,5 @@ for f in $CSRC/*.hip; do
     objs="$objs $OBJ/$b.o"
   fi
 done
-hipcc --offload-arch=gfx950 -shared -fPIC $objs -o $ROOT/variants/libtspn_$NAME.so
-echo $ROOT/variants/libtspn_$NAME.so
+hipcc --offload-arch=gfx950 -shared -fPIC $objs -o $VDIR/libtspn_$NAME.so
+echo $VDIR/libtspn_$NAME.so
