@@ -673,6 +673,11 @@ class ScoringWorkload:
         # F(6,3) issues 8 channel-GEMMs on a sixth of the columns (ceil(T/6) sextets per tracklet): 4/9 of the direct work
         frac = {"direct": 1.0, "winograd6": (4.0 / 9.0) * (6 * -(-T // 6)) / T}[args.conv]
         conv_flop = conv_flop_direct * (1.0 if bf16 else frac)
+        if self.host and self.prefetch is None and getattr(self.model, "host_chunk_videos", 0) > 0:
+            # host-resident inputs are scored chunk by chunk (model._HostPipeline): the events bracket the LAST chunk's launch
+            chunks = type(self.model)._host_chunk_schedule(B, self.model.host_chunk_videos)
+            share = (chunks[-1][1] - chunks[-1][0]) / float(B)
+            conv_flop_direct, conv_flop = conv_flop_direct * share, conv_flop * share
         achieved = conv_flop / conv_avg_s / 1e12
         peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
         cfg_name = {"cfg2": "BASELINE cfg2: synthetic VidVRD shape N=32 T=150 D=2048 (C=4096, A=4, K=132), fp32, "

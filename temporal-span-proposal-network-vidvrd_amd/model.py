@@ -978,6 +978,11 @@ class BaseModel(_CachedWeightsMixin, nn.Module):
             main.wait_stream(side)                 # PPN / geometry are complete for whatever the caller does next
         return pair_proposals, durations, logits
 
+    @staticmethod
+    def _host_chunk_schedule(nm, chunk):
+        """Video ranges the host-input pipeline scores one after the other (bench.py reads the last one)."""
+        return _HostPipeline.schedule(nm, chunk)
+
     def _forward_host_group(self, pair_list, members, shape, bf16, dev, weights, durations, logits, track_token):
         """One group of equal-shape segments whose `tracklet_feats` are HOST tensors (the reference's predict.py:50-57
         hands CPU PairLists): upload, fused pass and download run as a three-stage pipeline over chunks of videos

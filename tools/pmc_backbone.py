@@ -30,6 +30,9 @@ def main():
     ap.add_argument("dst")
     ap.add_argument("--frames", type=int, default=64)
     ap.add_argument("--passes", type=int, default=4, help="forward passes the tool ran (1 warm-up + --iters)")
+    ap.add_argument("--name", default="pmc_hbm_traffic_backbone.csv", help="output file name under DST")
+    ap.add_argument("--no-json", action="store_true", help="do not touch profiles/pmc_traffic.json")
+    ap.add_argument("--note", default="--chunk 8")
     args = ap.parse_args()
     tot = collections.defaultdict(lambda: {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "n": 0})
     for sub, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
@@ -52,15 +55,18 @@ def main():
         rows.append((k, d["n"] / args.passes, 2.0 * d["FETCH_SIZE"] / per, d["WRITE_SIZE"] / per, by))
         total += by
     os.makedirs(args.dst, exist_ok=True)
-    name = os.path.join(args.dst, "pmc_hbm_traffic_backbone.csv")
+    name = os.path.join(args.dst, args.name)
     with open(name, "w") as fh:
         fh.write(f"# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of tools/bench_backbone.py --frames "
-                 f"{args.frames} --chunk 8 --bf16; bytes per 720p frame = sum over the dispatches of {args.passes} forward "
+                 f"{args.frames} {args.note} --bf16; bytes per 720p frame = sum over the dispatches of {args.passes} forward "
                  "passes / (passes x frames); reads x2 (gfx950, tools/pmc_summary.py)\n")
         fh.write("kernel,launches_per_pass,read_bytes_per_frame,write_bytes_per_frame,bytes_per_frame\n")
         for r in rows:
             fh.write("%s,%.1f,%.0f,%.0f,%.0f\n" % r)
         fh.write("total,,,,%.0f\n" % total)
+    if args.no_json:
+        print(open(name).read())
+        return
     path = os.path.join(os.path.dirname(args.dst.rstrip("/")), "pmc_traffic.json")
     allsets = json.load(open(path))
     allsets["sets"]["cfg5:1"] = {"workload": "cfg5", "videos_per_launch": 1, "source": name,
