@@ -250,6 +250,9 @@ int tspn_heads_pairgrid_f32(const float* y, int64_t B, int64_t N, int64_t C, int
  * mean over t of x[R, C, T] -> out[R, C]   (layout_tc = 0, channels-first)  */
 int tspn_temporal_mean_f32(const float* x, int64_t R, int64_t T, int64_t Cdim,
                            int layout_tc, float* out, void* stream);
+/* sum over t of x[R, T, D] -> out[R, D], frames added in order (with R = 1: the column sums of a matrix -- the bias
+ * gradients of the training step, lib/modeling/train.py:74-78; round 4)                                          */
+int tspn_temporal_sum_f32(const float* x, int64_t R, int64_t T, int64_t Cdim, float* out, void* stream);
 
 /* gather rows: out[P, 2D] = cat(src[pairs[p,0]], src[pairs[p,1]])           */
 int tspn_pair_rows_f32(const float* src, int64_t NT, int64_t D, const int64_t* pairs,

@@ -91,6 +91,7 @@ PROTOTYPES = {
                               _i64, _vp, _vp]),
     "tspn_heads_pairgrid_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp]),
     "tspn_temporal_mean_f32": (_int, [_vp, _i64, _i64, _i64, _int, _vp, _vp]),
+    "tspn_temporal_sum_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "tspn_pair_rows_f32": (_int, [_vp, _i64, _i64, _vp, _i64, _vp, _vp]),
     "tspn_transpose_td_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "tspn_decode_topk_workspace_bytes": (_sz, [_i64, _i64, _i64]),

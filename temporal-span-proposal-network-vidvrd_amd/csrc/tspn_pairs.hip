@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void pair_geometry_kernel(
 // ----------------------------------------------------------- RelOIPool (mean)
 // x[R,T,D] -> out[R,D]: thread per (r,d), coalesced along d, frames in order.
 __global__ void temporal_mean_td_kernel(const float* __restrict__ x, int64_t R, int64_t T,
-                                        int64_t D, float* __restrict__ out) {
+                                        int64_t D, float* __restrict__ out, int mean = 1) {
   const int64_t total = R * D;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
@@ -134,7 +134,7 @@ __global__ void temporal_mean_td_kernel(const float* __restrict__ x, int64_t R, 
     const float* s = x + r * T * D + d;
     float acc = 0.f;
     for (int64_t t = 0; t < T; ++t) acc += s[t * D];
-    out[i] = acc / (float)T;
+    out[i] = mean ? acc / (float)T : acc;
   }
 }
 
@@ -282,6 +282,15 @@ extern "C" int tspn_temporal_mean_f32(const float* x, int64_t R, int64_t T, int6
                        out);
   }
   return tspn::check_launch("tspn_temporal_mean_f32");
+}
+
+extern "C" int tspn_temporal_sum_f32(const float* x, int64_t R, int64_t T, int64_t Cdim, float* out, void* stream) {
+  TSPN_REQUIRE(R >= 0 && T > 0 && Cdim > 0, TSPN_EINVAL, "tspn_temporal_sum_f32: bad sizes");
+  if (R == 0) return TSPN_OK;
+  TSPN_REQUIRE(x && out, TSPN_EINVAL, "tspn_temporal_sum_f32: null pointer");
+  hipLaunchKernelGGL(temporal_mean_td_kernel, dim3(grid_for(R * Cdim)), dim3(256), 0, TSPN_STREAM(stream), x, R, T,
+                     Cdim, out, 0);
+  return tspn::check_launch("tspn_temporal_sum_f32");
 }
 
 extern "C" int tspn_pair_rows_f32(const float* src, int64_t NT, int64_t D, const int64_t* pairs,

@@ -163,8 +163,55 @@ class _DeviceCache:
         self._store.clear()
 
 
+def _nt(a, b, bias=None, sigmoid=False):
+    """a [M,K] . b [N,K]^T (+ bias [N]) on the HIP split-K MFMA GEMM of the predicate head (tspn_predicate_head_f32): the
+    one GEMM form the library has, so every product of the training step is brought to it with HIP transposes."""
+    return ops.predicate_head(a.contiguous(), b.contiguous(), None if bias is None else bias.contiguous(), apply_sigmoid=sigmoid)
+
+
+def _tr(a):
+    """[M,N] -> [N,M] contiguous (tspn_transpose_td_f32)."""
+    return ops.transpose_td(a.contiguous().unsqueeze(0))[0]
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T + b with HIP forward AND backward (round 4; the backward was torch / rocBLAS GEMMs before):
+        dx = g W = nt(g, W^T),   dW = g^T x = nt(g^T, x^T),   db = column sums of g  (tspn_temporal_sum_f32)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return _nt(x, w, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = g.contiguous()
+        gx = _nt(g, _tr(w)) if ctx.needs_input_grad[0] else None
+        gw = _nt(_tr(g), _tr(x)) if ctx.needs_input_grad[1] else None
+        gb = ops.temporal_sum(g.unsqueeze(0))[0] if ctx.needs_input_grad[2] else None
+        return gx, gw, gb
+
+
+class _MatmulNTFn(torch.autograd.Function):
+    """a b^T with HIP forward and backward: da = g b = nt(g, b^T), db = g^T a = nt(g^T, a^T)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return _nt(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g.contiguous()
+        ga = _nt(g, _tr(b)) if ctx.needs_input_grad[0] else None
+        gb = _nt(_tr(g), _tr(a)) if ctx.needs_input_grad[1] else None
+        return ga, gb
+
+
 class _PredicateHeadFn(torch.autograd.Function):
-    """HIP forward; backward with plain torch GEMMs (training is outside the measured path)."""
+    """sigmoid(x W^T + b): HIP forward (sigmoid inside the GEMM's reduce kernel) and HIP backward (see _LinearFn)."""
 
     @staticmethod
     def forward(ctx, x, w, b):
@@ -175,22 +222,42 @@ class _PredicateHeadFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, w, out = ctx.saved_tensors
-        gz = g * out * (1.0 - out)
-        return gz @ w, gz.t() @ x, gz.sum(0)
+        gz = (g * out * (1.0 - out)).contiguous()
+        gx = _nt(gz, _tr(w)) if ctx.needs_input_grad[0] else None
+        gw = _nt(_tr(gz), _tr(x)) if ctx.needs_input_grad[1] else None
+        gb = ops.temporal_sum(gz.unsqueeze(0))[0] if ctx.needs_input_grad[2] else None
+        return gx, gw, gb
+
+
+def _rows_of(x):
+    """[R, C, T] -> [C, R*T] contiguous (a torch permute + copy: byte movement, no arithmetic)."""
+    return x.permute(1, 0, 2).reshape(x.shape[1], -1).contiguous()
 
 
 def _conv3_weight_grad(x_cf, dz):
-    """dL/dW of y = Conv1d(k=3, padding=1)(x): W[m, c, k] += sum_{n,t} dz[n, m, t] x[n, c, t + k - 1]
-    (three plain GEMMs on shifted views; x_cf [R, Cin, T], dz [R, M, T])."""
+    """dL/dW of y = Conv1d(k=3, padding=1)(x): W[m, c, k] = sum_{n,t} dz[n, m, t] x[n, c, t + k - 1]: per tap one product
+    dZ [M, R T] . X_k [C, R T]^T on the library's HIP GEMM (round 4; three torch einsums before); x_cf [R, Cin, T], dz [R, M, T]."""
     xp = F.pad(x_cf, (1, 1))
     t = x_cf.shape[2]
-    return torch.stack([torch.einsum("nmt,nct->mc", dz, xp[:, :, k:k + t]) for k in range(3)], dim=2)
+    dzr = _rows_of(dz)
+    return torch.stack([_nt(dzr, _rows_of(xp[:, :, k:k + t])) for k in range(3)], dim=2)
+
+
+def _heads_backward(head_w, g, act):
+    """Backward of heads = head_w . act (+ b) for g [P,H,T], act [P,C,T] = relu(...):
+    dZ [P,C,T] = (head_w^T g) . [act > 0]  and  d_head_w [H,C] = sum_{p,t} g act -- two products on the HIP GEMM."""
+    p, h, t = g.shape
+    c = act.shape[1]
+    gt = g.permute(0, 2, 1).reshape(p * t, h).contiguous()              # [(p,t), H]
+    dz = _nt(gt, _tr(head_w)).view(p, t, c).permute(0, 2, 1) * (act > 0)  # [(p,t), C] -> [P,C,T]
+    d_head_w = _nt(_rows_of(g), _rows_of(act))                          # [H, P T] . [C, P T]^T
+    return dz.contiguous(), d_head_w
 
 
 class _TemporalHeadsDenseFn(torch.autograd.Function):
     """DPNHead on a materialised x [P,C,T] (reference relpn/dpn.py:69-73) for training: HIP forward
-    (tspn_temporal_encoder_heads_f32); backward recomputes the encoder activation with the HIP conv and
-    uses plain torch GEMMs (training is outside the measured path, like _PredicateHeadFn)."""
+    (tspn_temporal_encoder_heads_f32); backward recomputes the encoder activation with the HIP conv and forms every
+    product on the library's HIP GEMM / conv kernels (round 4; torch einsums before)."""
 
     @staticmethod
     def forward(ctx, x, conv_w, conv_b, head_w, head_b):
@@ -203,16 +270,18 @@ class _TemporalHeadsDenseFn(torch.autograd.Function):
         x, conv_w, conv_b, head_w = ctx.saved_tensors
         g = g.contiguous()
         act = ops.conv3(x, ops.pack_conv3(conv_w), conv_b, relu=True)          # relu(conv(x) + b) [P,C,T]
-        dz = torch.einsum("hc,pht->pct", head_w, g) * (act > 0)
-        d_head_w = torch.einsum("pht,pct->hc", g, act)
-        dx = torch.nn.grad.conv1d_input(x.shape, conv_w, dz, padding=1) if ctx.needs_input_grad[0] else None
+        dz, d_head_w = _heads_backward(head_w, g, act)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            # conv1d_input = the k=3 conv of dZ with the taps reversed and the channel roles swapped
+            dx = ops.conv3(dz, ops.pack_conv3(conv_w.flip(2).transpose(0, 1).contiguous()), None, relu=False)
         return dx, _conv3_weight_grad(x, dz), dz.sum((0, 2)), d_head_w, g.sum((0, 2))
 
 
 class _TemporalHeadsTrackletFn(torch.autograd.Function):
     """Factorised pair encoder + heads on tracklet tensors for training.  Forward: the HIP
     projections U‖V (tspn_conv3_tc_f32 on the split-packed weight) and the indexed pair stage
-    (tspn_heads_f32).  Backward: dZ_p = (head_w^T g_p) . [relu(U[s]+V[o]) > 0] per block of pairs,
+    (tspn_heads_f32).  Backward: dZ_p = (head_w^T g_p) . [relu(U[s]+V[o]) > 0] per block of pairs (HIP GEMM),
     scattered back onto dU[s], dV[o]; the conv weight gradient is then a per-TRACKLET contraction (the
     same N-1 saving as the forward)."""
 
@@ -242,10 +311,10 @@ class _TemporalHeadsTrackletFn(torch.autograd.Function):
         d_head_w = torch.zeros_like(head_w)
         for lo in range(0, pairs.shape[0], _TemporalHeadsTrackletFn.PAIR_BLOCK):
             blk = slice(lo, lo + _TemporalHeadsTrackletFn.PAIR_BLOCK)
-            s, o, gb = pairs[blk, 0], pairs[blk, 1], g[blk]
+            s, o, gb = pairs[blk, 0], pairs[blk, 1], g[blk].contiguous()
             act = torch.relu(u[s] + v[o])
-            dz = torch.einsum("hc,pht->pct", head_w, gb) * (act > 0)
-            d_head_w += torch.einsum("pht,pct->hc", gb, act)
+            dz, dhw = _heads_backward(head_w, gb, act)
+            d_head_w += dhw
             du.index_add_(0, s, dz)
             dv.index_add_(0, o, dz)
         x_cf = feats.transpose(1, 2)
@@ -315,10 +384,17 @@ class PPNHead(nn.Module):
         return names, [sd[n] for n in names]
 
     def forward(self, sub_logits, obj_logits):
-        """Autograd (training) form with torch ops on the device; eval goes through PPN.propose."""
-        s = self.sub_emb(sub_logits)
-        o = self.obj_emb(obj_logits)
-        return torch.sigmoid(torch.mm(s, o.t()))
+        """Autograd (training) form: every GEMM of the two MLPs and of the pair matrix, forward and backward, on the
+        library's HIP GEMM (round 4; torch.mm before); ReLU / sigmoid are elementwise torch ops.  Eval goes through
+        PPN.propose (one fused launch)."""
+        def mlp(seq, x):
+            h = torch.relu(_LinearFn.apply(x.contiguous(), seq[0].weight, seq[0].bias))
+            return _LinearFn.apply(h, seq[2].weight, seq[2].bias)
+        if not sub_logits.is_cuda:
+            raise RuntimeError("training needs the inputs on the HIP device")
+        s = mlp(self.sub_emb, sub_logits.float())
+        o = mlp(self.obj_emb, obj_logits.float())
+        return torch.sigmoid(_MatmulNTFn.apply(s, o))
 
 
 class PPN(nn.Module):

@@ -13,7 +13,7 @@ from . import _abi
 
 __all__ = [
     "predicate_head", "feature_preprocess_", "ppn_pair_matrix_topk", "traj_iou", "traj_iou_tail", "pair_index",
-    "pair_gather", "pack_conv3", "conv3", "conv3_tc", "pack_conv3_wino63", "conv3_tc_wino63", "heads", "heads_pairgrid", "temporal_mean", "pair_rows", "transpose_td",
+    "pair_gather", "pack_conv3", "conv3", "conv3_tc", "pack_conv3_wino63", "conv3_tc_wino63", "heads", "heads_pairgrid", "temporal_mean", "temporal_sum", "pair_rows", "transpose_td",
     "forward_fused", "temporal_encoder_heads", "fused_workspace_bytes", "fused_bf16_workspace_bytes", "decode_topk", "decode_spans",
     "cast_bf16", "pack_conv3_bf16", "pack_heads_bf16", "conv3_tc_bf16", "heads_pairgrid_bf16",
     "transpose_cast_bf16", "temporal_encoder_heads_bf16",
@@ -435,6 +435,16 @@ def temporal_mean(x, layout_tc):
         R, Cd, T = x.shape
     out = torch.empty((R, Cd), dtype=torch.float32, device=x.device)
     _abi.check(_abi.lib().tspn_temporal_mean_f32(_p(x), R, T, Cd, 1 if layout_tc else 0, _p(out), _stream()))
+    return out
+
+
+def temporal_sum(x):
+    """Sum over the middle axis: x[R,T,D] -> [R,D], frames added in order (tspn_temporal_sum_f32); with R = 1 the
+    column sums of a matrix (bias gradients of the training step)."""
+    _dev(x, "x")
+    R, T, Cd = x.shape
+    out = torch.empty((R, Cd), dtype=torch.float32, device=x.device)
+    _abi.check(_abi.lib().tspn_temporal_sum_f32(_p(x), R, T, Cd, _p(out), _stream()))
     return out
 
 

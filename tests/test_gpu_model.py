@@ -91,7 +91,27 @@ def test_use_ppn_eval_and_train(tspn, device):
     np.testing.assert_allclose(loss["loss_pair"].item(), g["loss_pair"], rtol=2e-5)
     np.testing.assert_allclose(loss["loss_rel"].item(), g["loss_rel"], rtol=2e-5)
     sum(loss.values()).backward()
-    assert model.relpn.pair_proposal_network.ppn_head.sub_emb[0].weight.grad is not None
+    head = model.relpn.pair_proposal_network.ppn_head
+    assert head.sub_emb[0].weight.grad is not None
+    # round 4: every GEMM of the PPN training step (two MLPs + the pair matrix), forward and backward, runs on the
+    # library's HIP GEMM -- gradients against float64 autograd of the same formula (ppn.py:92-112, 57-71)
+    sd = {k: t(v).double().requires_grad_(True) for k, v in c["state_dict"].items() if k.startswith("relpn.pair_proposal_network.")}
+    pre = "relpn.pair_proposal_network.ppn_head."
+    x = t(c["cls"]).double()
+
+    def mlp(name):
+        h = torch.relu(x @ sd[pre + name + ".0.weight"].t() + sd[pre + name + ".0.bias"])
+        return h @ sd[pre + name + ".2.weight"].t() + sd[pre + name + ".2.bias"]
+    pm = torch.sigmoid(mlp("sub_emb") @ mlp("obj_emb").t())
+    gt = tspn.PPN._gt_matrices([sample()], [tspn.TargetList(t(c["targets"]))])[0].double()
+    ref_loss = torch.nn.functional.binary_cross_entropy(pm, gt)
+    ref_loss.backward()
+    assert abs(float(loss["loss_pair"]) - float(ref_loss)) <= 1e-6 * max(1.0, float(ref_loss))   # fp32 loss vs float64
+    for name in ("sub_emb.0.weight", "sub_emb.0.bias", "sub_emb.2.weight", "sub_emb.2.bias",
+                 "obj_emb.0.weight", "obj_emb.0.bias", "obj_emb.2.weight", "obj_emb.2.bias"):
+        got = dict(head.named_parameters())[name].grad.cpu().double()
+        want = sd[pre + name].grad
+        assert float((got - want).abs().max()) <= 2e-7 + 1e-5 * float(want.abs().max()), name
 
 
 def temporal_cfg(D, use_ppn=True):
@@ -436,6 +456,29 @@ def _oracle_train_reference(v, pairs, sd, gt_dur, gt_rel, targets):
     losses["loss_rel"] = torch.nn.functional.binary_cross_entropy(logit, targets.double())
     sum(losses.values()).backward()
     return {k: float(x) for k, x in losses.items()}, {k: x.grad for k, x in w.items()}
+
+
+def test_dense_temporal_heads_input_gradient(tspn, device):
+    """Round 4: the backward of the dense DPNHead runs on the library's HIP GEMM / conv kernels; the gradient with
+    respect to the INPUT features (conv1d_input = the k=3 conv of dZ with reversed taps and swapped channel roles)
+    and every parameter gradient against float64 autograd of relpn/dpn.py:69-73."""
+    model_mod = __import__("importlib").import_module(tspn.BaseModel.__module__)
+    P, C, T, H = 5, 24, 11, 12
+    rs = np.random.RandomState(3)
+    mk = lambda *shape: torch.from_numpy(rs.randn(*shape).astype(np.float32))   # noqa: E731
+    x, cw, cb, hw, hb = mk(P, C, T), 0.3 * mk(C, C, 3), 0.1 * mk(C), 0.3 * mk(H, C), 0.1 * mk(H)
+    gout = mk(P, H, T)
+    dev_in = [v.clone().to(device).requires_grad_(True) for v in (x, cw, cb, hw, hb)]
+    out = model_mod._TemporalHeadsDenseFn.apply(*dev_in)
+    out.backward(gout.to(device))
+    ref_in = [v.clone().double().requires_grad_(True) for v in (x, cw, cb, hw, hb)]
+    act = torch.relu(torch.nn.functional.conv1d(ref_in[0], ref_in[1], ref_in[2], padding=1))
+    ref = torch.nn.functional.conv1d(act, ref_in[3].unsqueeze(2), ref_in[4])
+    ref.backward(gout.double())
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=0, atol=2e-5)
+    for name, a, b in zip(("x", "conv_w", "conv_b", "head_w", "head_b"), dev_in, ref_in):
+        scale = max(1.0, float(b.grad.abs().max()))
+        np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.numpy(), rtol=0, atol=2e-5 * scale, err_msg=name)
 
 
 @pytest.mark.parametrize("form,with_relness", [("tracklets", True), ("tracklets", False), ("dense", True)])
