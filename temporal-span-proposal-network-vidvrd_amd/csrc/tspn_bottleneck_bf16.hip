@@ -99,7 +99,11 @@ __global__ __launch_bounds__(THREADS, (NEXT ? 1 : (CM == 64 ? 3 : 2))) void bott
   // compiler wait for every LDS read right behind its issue: three or four exposed LDS latencies per k-step with one
   // wave per SIMD -- the "issue structure" that kept phase 2 at half the MFMA rate with all memory traffic removed)
   constexpr int ZERO_OFF = (NST > CCH ? NST : CCH) * B_ST + 1024;
-  constexpr int CHUNK_OFF = ZERO_OFF + 256;
+  // b3 (4 CM floats) lives in LDS (round 4): read from global memory inside the epilogue of phase 3, the two float4 of
+  // every half group sat on the wave's one in-order vector-memory counter -- the compiler's wait for them was
+  // `s_waitcnt vmcnt(0)`, i.e. a full drain of the W3 ring, the residual ring and the output stores 64 times per tile
+  constexpr int BIAS_OFF = ZERO_OFF + 256;
+  constexpr int CHUNK_OFF = BIAS_OFF + 4 * CM * 4;
   constexpr int SLPC = 68;                                  // 64 pixels + padding: conflict-free 16-byte reads like SLP
   constexpr int CHUNK_BYTES = (CM / 8) * SLPC * 16;         // CM channels of 64 pixels: CM / 8 groups x SLPC slots x 16 B
 
@@ -116,6 +120,8 @@ __global__ __launch_bounds__(THREADS, (NEXT ? 1 : (CM == 64 ? 3 : 2))) void bott
   const int li = lane & 31, kh = lane >> 5;
   const unsigned woff = lane * 16;
   if (tid < 4) reinterpret_cast<float*>(Bs + ZERO_OFF)[tid] = 0.f;   // published by the first barrier of phase 2
+  for (int i = tid; i < CM; i += THREADS)                              // b3 -> LDS, published by the same barrier
+    *reinterpret_cast<float4*>(Bs + BIAS_OFF + 16 * i) = *reinterpret_cast<const float4*>(bias3 + 4 * i);
   const char* const zslot = Bs + ZERO_OFF;
 
   // ---------------------------------------------------------------- phase 2: 3x3 conv, K = 9 taps x CM
@@ -594,8 +600,16 @@ __global__ __launch_bounds__(THREADS, (NEXT ? 1 : (CM == 64 ? 3 : 2))) void bott
     constexpr int grp = g >> 1, h = g & 1, ms = grp % MS, nj = grp / MS;
     constexpr int slot = (cval(decltype(e){}) * NGRP + grp) % NRES;
     const int chm = 32 * (sub_rb(e) + ms) + 16 * kh + 8 * h;
-    const float4 bv0 = *reinterpret_cast<const float4*>(bias3 + chm);
-    const float4 bv1 = *reinterpret_cast<const float4*>(bias3 + chm + 4);
+    // (NEXT is at 510 of 512 registers: the two LDS addresses spill it; it keeps the loads from global memory)
+#if defined(TSPN_BT_BIAS_GLOBAL)    // probe build: b3 from global memory inside the epilogue (round 3)
+    constexpr bool BIAS_GLOBAL = true;
+#else
+    constexpr bool BIAS_GLOBAL = NEXT;
+#endif
+    const float4 bv0 = BIAS_GLOBAL ? *reinterpret_cast<const float4*>(bias3 + chm)
+                            : *reinterpret_cast<const float4*>(Bs + BIAS_OFF + 4 * chm);
+    const float4 bv1 = BIAS_GLOBAL ? *reinterpret_cast<const float4*>(bias3 + chm + 4)
+                            : *reinterpret_cast<const float4*>(Bs + BIAS_OFF + 4 * chm + 16);
     const float v[8] = {c[ms][nj][8 * h] + bv0.x,     c[ms][nj][8 * h + 1] + bv0.y, c[ms][nj][8 * h + 2] + bv0.z,
                         c[ms][nj][8 * h + 3] + bv0.w, c[ms][nj][8 * h + 4] + bv1.x, c[ms][nj][8 * h + 5] + bv1.y,
                         c[ms][nj][8 * h + 6] + bv1.z, c[ms][nj][8 * h + 7] + bv1.w};
@@ -860,7 +874,8 @@ int launch(const uint16_t* h1, int64_t NB, int64_t H, int64_t W, const uint16_t*
   constexpr int cch = CM / KC;
   // + slots 128, 129 (once-staged form / range ring); NEXT: + the chunk image of a pass
   // stages / h2 image + slots 128, 129 (side regions) + the zero slot (+ NEXT: two chunk images)
-  constexpr size_t smem = (size_t)(cch > nst ? cch : nst) * B_ST + 1024 + 256 + (NEXT ? (size_t)2 * (CM / 8) * 68 * 16 : 0);
+  constexpr size_t smem = (size_t)(cch > nst ? cch : nst) * B_ST + 1024 + 256 + (size_t)4 * CM * 4 +
+                          (NEXT ? (size_t)2 * (CM / 8) * 68 * 16 : 0);      // ... + b3
   static_assert(smem <= 160 * 1024, "LDS budget");
   static tspn::LdsLimit lds;
   if (int rc = lds.ensure(reinterpret_cast<const void*>(bottleneck_bf16_kernel<CM, NEXT>), smem, "tspn_bottleneck_tail_bf16"))

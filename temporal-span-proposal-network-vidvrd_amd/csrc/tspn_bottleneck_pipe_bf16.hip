@@ -50,7 +50,8 @@ constexpr int EXTRA_OFF = NST * B_ST;   // slots 128, 129 of the stages: [stage]
 constexpr int ZERO_OFF = EXTRA_OFF + 1024;
 constexpr int SYNC_OFF = ZERO_OFF + 64;  // three counters: +0 team A's ring barrier, +4 h2 written, +8 h2 read
 constexpr int H2_OFF = ZERO_OFF + 256;  // h2 image [32 groups][132 slots][8 bf16]
-constexpr int SMEM = H2_OFF + CCH * B_ST;
+constexpr int BIAS_OFF = H2_OFF + CCH * B_ST;   // b3 (4 CM floats): read in phase 3's epilogue without touching vmcnt
+constexpr int SMEM = BIAS_OFF + 4 * CM * 4;
 static_assert(SMEM <= 160 * 1024, "LDS budget");
 
 __device__ __bf16 g_zero_page_bp[128];  // source of padding taps (never written)
@@ -374,8 +375,8 @@ __device__ __forceinline__ void team_b(const __bf16* __restrict__ Wf3, const flo
       constexpr int grp = g >> 1, h = g & 1, ms = grp % MS, nj = grp / MS;
       constexpr int slot = grp % NRES;
       const int chm = 32 * (sub_rb(e) + ms) + 16 * kh + 8 * h;
-      const float4 bv0 = *reinterpret_cast<const float4*>(bias3 + chm);
-      const float4 bv1 = *reinterpret_cast<const float4*>(bias3 + chm + 4);
+      const float4 bv0 = *reinterpret_cast<const float4*>(Bs + BIAS_OFF + 4 * chm);
+      const float4 bv1 = *reinterpret_cast<const float4*>(Bs + BIAS_OFF + 4 * chm + 16);
       const float v[8] = {c[ms][nj][8 * h] + bv0.x,     c[ms][nj][8 * h + 1] + bv0.y, c[ms][nj][8 * h + 2] + bv0.z,
                           c[ms][nj][8 * h + 3] + bv0.w, c[ms][nj][8 * h + 4] + bv1.x, c[ms][nj][8 * h + 5] + bv1.y,
                           c[ms][nj][8 * h + 6] + bv1.z, c[ms][nj][8 * h + 7] + bv1.w};
@@ -459,6 +460,7 @@ __global__ __launch_bounds__(THREADS, 2) void bottleneck_pipe_bf16_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (tid < 4) reinterpret_cast<float*>(Bs + ZERO_OFF)[tid] = 0.f;     // the zero slot ...
   if (tid >= 16 && tid < 19) reinterpret_cast<unsigned*>(Bs + SYNC_OFF)[tid - 16] = 0u;   // ... and the three counters
+  if (tid < CM) *reinterpret_cast<float4*>(Bs + BIAS_OFF + 16 * tid) = *reinterpret_cast<const float4*>(bias3 + 4 * tid);
   __syncthreads();                                                       // the only workgroup barrier of the kernel
   if (wave < 4) team_a(h1, Wf2, bias2, H, W, npix, ntiles, Bs, wave, lane);
   else team_b(Wf3, bias3, residual, out, npix, ntiles, Bs, wave - 4, lane);

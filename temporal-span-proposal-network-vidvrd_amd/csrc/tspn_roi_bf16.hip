@@ -396,6 +396,21 @@ __global__ __launch_bounds__(THREADS, (MI == 1 ? TSPN_ROI_BF16_MI1_WAVES : 2)) v
       }
     const int pl = lane / CPL, cg = lane - pl * CPL;
     const int mc = mw + 8 * cg;                 // this lane's 8 channels in the read phase
+    // residual rows of the whole tile are requested UP FRONT (round 4): with the load inside the pass loop every pass
+    // was one exposed HBM round trip (load, s_waitcnt vmcnt(0), use, store: 16 of them in a row per wave at MI = 2) and
+    // the 1x1 expand convs with a residual ran at 2.2 - 2.5 TB/s.  Lanes outside the tensor read row 0 (not used).
+    constexpr int NPASS = 32 / PPP;
+    bf16x8 rres[4][NPASS];
+    if (residual) {
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+          const int64_t n = n0 + ni * 32 + pass * PPP + pl;
+          const bool ok = n < npix && mc < Cout;
+          rres[ni][pass] = *reinterpret_cast<const bf16x8*>(residual + (ok ? n * Cout + mc : 0));
+        }
+    }
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
 #pragma unroll
@@ -416,7 +431,7 @@ __global__ __launch_bounds__(THREADS, (MI == 1 ? TSPN_ROI_BF16_MI1_WAVES : 2)) v
         if (n < npix && mc < Cout) {
           float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
           if (residual) {
-            const bf16x8 rv = *reinterpret_cast<const bf16x8*>(residual + n * Cout + mc);
+            const bf16x8 rv = rres[ni][pass];
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] += (float)rv[k];
           }
