@@ -149,7 +149,7 @@ constexpr size_t G_SMEM = (size_t)R_NST * G_ST;
 
 __global__ __launch_bounds__(G_THREADS, 1) void conv3_bf16_big_kernel(
     const __bf16* __restrict__ x, const __bf16* __restrict__ Wp, const float* __restrict__ bias,
-    float* __restrict__ y, int Cin, int T, int M, int64_t ncols, int tiles_m, int tiles_n, int ldm) {
+    float* __restrict__ y, int Cin, int T, int M, int64_t ncols, int tiles_m, int tiles_n, int ldm, int w_bytes) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   // workgroup -> tile: bijective XCD remap, then groups of 2 weight panels x all column tiles
@@ -174,19 +174,28 @@ __global__ __launch_bounds__(G_THREADS, 1) void conv3_bf16_big_kernel(
   const int wm = wave >> 2, wn = wave & 3;
   const int li = lane & 31, kh = lane >> 5;
 
-  // weight pieces: pa = ((tap*2 + group)*4 + quarter), 64 rows each; wave w stages pa = 3w .. 3w+2
-  const __bf16* asrc[3];
+  // weight pieces: pa = ((tap*2 + group)*4 + quarter), 64 rows each; wave w stages pa = 3w .. 3w+2.
+  // The pieces are BUFFER loads (buffer_load_dwordx4 ... offen lds: an SGPR descriptor, a fixed 32-bit lane offset and a
+  // scalar offset that advances per chunk) rather than global_load_lds_dwordx4 with a 64-bit pointer per lane: beside MFMAs
+  // the buffer form costs its wave 110 - 140 cycles of issue per piece against 175 - 195 (tools/probes/lds_dma_issue_probe.hip,
+  // profiles/r4/lds_dma_issue_probe.txt), and the per-chunk pointer arithmetic moves from the vector to the scalar unit.
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Wp), 0, w_bytes, 0x00020000);
+  unsigned aoff[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int pa = wave * 3 + i;
     const int tap = pa >> 3, kg = (pa >> 2) & 1, quarter = pa & 3;
     int m = m0 + 64 * quarter + lane;
     m = m < M ? m : 0;
-    asrc[i] = Wp + (((int64_t)tap * (Cin >> 3) + kg) * M + m) * 8;
+    aoff[i] = (unsigned)((((int64_t)tap * (Cin >> 3) + kg) * M + m) * 16);
   }
-  const int64_t a_step = (int64_t)R_KG * M * 8;
-  // x pieces: wave w stages units [64w, 64w+64); wave 0 also the 8 units of piece 8
-  const __bf16* bsrc[2];
+  const int a_step = R_KG * M * 16;                        // bytes per chunk
+  // x pieces: wave w stages units [64w, 64w+64); wave 0 also the 8 units of piece 8.  Descriptor based at the first
+  // column this tile reads (any clip count: the lane offsets stay below 260 columns)
+  const int64_t nbase = n0 > 0 ? n0 - 1 : 0;
+  const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<__bf16*>(x) + nbase * Cin, 0, (int)min((int64_t)(G_BN + 4) * Cin * 2, (ncols - nbase) * (int64_t)Cin * 2), 0x00020000);
+  unsigned boff[2];
   bool bval[2];
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
@@ -195,24 +204,25 @@ __global__ __launch_bounds__(G_THREADS, 1) void conv3_bf16_big_kernel(
     bval[q] = u < G_X_UNITS && slot < G_BN + 2 && (q == 0 || wave == 0);
     int64_t n = n0 + slot - 1;
     n = n < 0 ? 0 : (n < ncols ? n : ncols - 1);
-    bsrc[q] = x + n * Cin + 8 * (g < R_KG ? g : 0);
+    boff[q] = (unsigned)((n - nbase) * Cin * 2 + 16 * (g < R_KG ? g : 0));
   }
+  int a_soff = 0, x_soff = 0;                              // scalar offsets of the next chunk to stage
+  auto bglds16 = [&](const __amdgpu_buffer_rsrc_t& r, unsigned voff, int soff, char* l) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)l, 16, (int)voff, soff, 0, 0);
+  };
   auto stage_chunk = [&](int st) {
 #if defined(TSPN_BF16_ABL_NODMA)
     return;
 #endif
     char* sa = smem + st * G_ST;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      glds16(asrc[i], sa + (wave * 3 + i) * 1024);
-      asrc[i] += a_step;
-    }
-    if (bval[0]) glds16(bsrc[0], sa + G_A_ST + 64 * wave * 16);
-    bsrc[0] += R_KC;
+    for (int i = 0; i < 3; ++i) bglds16(rsrc_a, aoff[i], a_soff, sa + (wave * 3 + i) * 1024);
+    a_soff += a_step;
+    if (bval[0]) bglds16(rsrc_x, boff[0], x_soff, sa + G_A_ST + 64 * wave * 16);
     if (wave == 0) {
-      if (bval[1]) glds16(bsrc[1], sa + G_A_ST + 64 * 8 * 16);
-      bsrc[1] += R_KC;
+      if (bval[1]) bglds16(rsrc_x, boff[1], x_soff, sa + G_A_ST + 64 * 8 * 16);
     }
+    x_soff += R_KC * 2;
   };
   auto wait_keep = [&](auto chunks_tag) {   // pieces in flight per chunk: 4 (waves 1-7) or 5 (wave 0)
     constexpr int CH = decltype(chunks_tag)::value;
@@ -439,7 +449,12 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void heads_pairgrid_bf16_
   // so that (a) one DMA piece fetches 8 complete 128-byte lines of y (8 frames x 32 channels) and
   // (b) the fragment read of lane (f, kg) for quad 2 kg + r sits at slot (f & 7) + 8 (kg & 1): the
   // four 16-lane groups of a ds_read_b128 each cover all 16 slots -- conflict-free.
-  const float* src[8];
+  // (buffer loads: descriptor = this video's rows of y, a fixed 32-bit lane offset per piece, one scalar offset that
+  // advances 128 bytes per k-step -- cheaper to issue beside MFMAs than global_load_lds with eight 64-bit pointers per
+  // lane, and eight registers and sixteen vector adds per k-step less; tools/probes/lds_dma_issue_probe.hip)
+  const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(y) + (int64_t)b * N * T * ldm, 0, (int)(unsigned)((int64_t)N * T * ldm * 4), 0x00020000);
+  unsigned voff[8];
   {
     const int fq = lane & 7;
     const int q = (lane >> 5) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 4) & 1);
@@ -449,26 +464,28 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void heads_pairgrid_bf16_
       int trk = r < SBLK ? sb * SBLK + r : ob * OB + r - SBLK;
       trk = min(trk, N - 1);
       const int t = min(t0 + 8 * j + fq, T - 1);
-      src[i] = y + (((int64_t)b * N + trk) * T + t) * ldm + (r < SBLK ? 0 : C) + 4 * q;
+      voff[i] = (unsigned)((((int64_t)trk * T + t) * ldm + (r < SBLK ? 0 : C) + 4 * q) * 4);
     }
   }
-  const bf16x8* wsrc = reinterpret_cast<const bf16x8*>(Whp) + lane;          // + 64 per k-step
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Whp), 0, C * 32, 0x00020000);
+  int y_soff = 0, w_soff = 0;
   auto stage = [&](int buf) {
 #if defined(TSPN_HPB_ABL_NODMA)
     return;
 #endif
     char* dst = smem + buf * ST + wave * 4 * HP_ROW;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      glds16(src[i], dst + i * 1024);
-      src[i] += HP_KC;
-    }
+    for (int i = 0; i < 8; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, (__attribute__((address_space(3))) void*)(dst + i * 1024), 16,
+                                               (int)voff[i], y_soff, 0, 0);
+    y_soff += HP_KC * 4;
     // head weights of the k-step, [4 kg][16 h][8 ch] bf16 = the packed layout itself; staged through
     // LDS as well so that no register-returning global load (whose wait the compiler would place at the
     // top of the loop, serialising the whole DMA queue with the compute) is left in the loop
     if (wave == 0) {
-      glds16(wsrc, smem + buf * ST + ROWS * HP_ROW);
-      wsrc += 64;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(smem + buf * ST + ROWS * HP_ROW),
+                                               16, lane * 16, w_soff, 0, 0);
+      w_soff += 1024;
     }
   };
 
@@ -712,8 +729,8 @@ extern "C" int tspn_conv3_tc_bf16(const uint16_t* x, int64_t B, int64_t T, int64
                (long long)Cin, (long long)M, (long long)ldm);
   TSPN_REQUIRE(aligned16(x) && aligned16(packed) && aligned16(y) && (bias == nullptr || aligned16(bias)),
                TSPN_EUNSUPPORTED, "tspn_conv3_tc_bf16: pointers must be 16-byte aligned");
-  TSPN_REQUIRE(Cin < (1 << 24) && T < (1 << 24) && M < (1 << 24) && ldm < (1 << 24), TSPN_EUNSUPPORTED,
-               "tspn_conv3_tc_bf16: dimension too large");
+  TSPN_REQUIRE(Cin < (1 << 24) && T < (1 << 24) && M < (1 << 24) && ldm < (1 << 24) && 3 * Cin * M * 2 < (1LL << 31),
+               TSPN_EUNSUPPORTED, "tspn_conv3_tc_bf16: dimension too large");
   const int64_t ncols = B * T;
   const int64_t tiles_m = tspn::ceil_div(M, BM), tiles_n = tspn::ceil_div(ncols, BN);
   TSPN_REQUIRE(tiles_m * tiles_n < (1LL << 31), TSPN_EUNSUPPORTED, "tspn_conv3_tc_bf16: grid too large");
@@ -725,7 +742,7 @@ extern "C" int tspn_conv3_tc_bf16(const uint16_t* x, int64_t B, int64_t T, int64
     hipLaunchKernelGGL(conv3_bf16_big_kernel, dim3((unsigned)(tm * tn)), dim3(G_THREADS), G_SMEM,
                        TSPN_STREAM(stream), reinterpret_cast<const __bf16*>(x),
                        reinterpret_cast<const __bf16*>(packed), bias, y, (int)Cin, (int)T, (int)M, ncols,
-                       (int)tm, (int)tn, (int)ldm);
+                       (int)tm, (int)tn, (int)ldm, (int)(3 * Cin * M * 2));
     return tspn::check_launch("tspn_conv3_tc_bf16");
   }
 }
@@ -744,8 +761,8 @@ extern "C" int tspn_heads_pairgrid_bf16(const float* y, int64_t ldm, int64_t B, 
   const int64_t sblk = big ? 16 : 8;
   const int64_t nsb = tspn::ceil_div(N, sblk), nfb = tspn::ceil_div(T, HP_FB);
   const int64_t grid = B * nsb * nsb * nfb;
-  TSPN_REQUIRE(grid < (1LL << 31) && N < (1 << 20) && T < (1 << 24) && C < (1 << 24), TSPN_EUNSUPPORTED,
-               "tspn_heads_pairgrid_bf16: problem too large");
+  TSPN_REQUIRE(grid < (1LL << 31) && N < (1 << 20) && T < (1 << 24) && C < (1 << 24) && N * T * ldm * 4 < (1LL << 32),
+               TSPN_EUNSUPPORTED, "tspn_heads_pairgrid_bf16: problem too large (a video's projections must stay below 4 GB)");
   const size_t smem = 2 * ((size_t)(2 * sblk) * HP_ROW + 1024);
   static tspn::LdsLimit lds[2];
   if (int rc = big ? lds[1].ensure(reinterpret_cast<const void*>(heads_pairgrid_bf16_kernel<8, 16, TSPN_HPB_SW>), smem,

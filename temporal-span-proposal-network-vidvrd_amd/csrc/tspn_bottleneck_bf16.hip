@@ -46,12 +46,6 @@ constexpr int KC = 64;                  // channels per chunk
 constexpr int SLP = 132;                // padded pixel slots per channel group
 constexpr int B_ST = 8 * SLP * 16;      // bytes per x stage = per 64 channels of the h2 image
 
-__device__ __bf16 g_zero_page_bt[128];  // source of padding taps (never written)
-
-__device__ __forceinline__ void glds16(const void* g, void* l) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-}
 template <int OFF>
 __device__ __forceinline__ void load_wfrag(f32x4& dst, unsigned lane_off, const char* base) {
   asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(lane_off), "s"(base), "n"(OFF) : "memory");
@@ -132,28 +126,16 @@ __global__ __launch_bounds__(THREADS, (NEXT ? 1 : (CM == 64 ? 3 : 2))) void bott
   // x pieces: the four pieces of a lane belong to ONE pixel (slot), channel groups bg, bg + 2, bg + 4, bg + 6
   const int slot = 64 * (wave & 1) + lane;
   const int bg = wave >> 1;
-  int64_t pbase;
-  unsigned tapmask = 0;
-  {
-    const int64_t n = n0 + slot;
-    const bool okn = n < npix;
-    const int64_t nc = okn ? n : 0;
-    const int64_t nb = nc / ((int64_t)H * W);
-    const int r = (int)(nc - nb * H * W);
-    const int oh = r / W, ow = r - oh * W;
-    pbase = ((nb * H + oh - 1) * (int64_t)W + ow - 1) * CM;
-    for (int a = 0; a < 3; ++a)
-      for (int b = 0; b < 3; ++b)
-        if (okn && oh - 1 + a >= 0 && oh - 1 + a < H && ow - 1 + b >= 0 && ow - 1 + b < W) tapmask |= 1u << (a * 3 + b);
-  }
-  auto stage_x = [&](int buf, int i) {             // exactly four pieces per wave
-    const int c = i / 9, tap = i - c * 9;          // chunk order of conv2d_nhwc_bf16: channel chunk by chunk, its taps in a row
-    const int ta = tap / 3, tb = tap - ta * 3;
-    const bool valid = (tapmask >> tap) & 1u;
-    const __bf16* xs = valid ? h1 + pbase + ((int64_t)ta * W + tb) * CM + c * KC + 8 * bg : g_zero_page_bt + 8 * bg;
-    char* dst = Bs + buf * B_ST + (bg * SLP + 64 * (wave & 1)) * 16;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) glds16(xs + 16 * p, dst + 2 * p * SLP * 16);
+  // The h1 ranges are staged by BUFFER loads (buffer_load_dwordx4 ... offen lds; round 4): one SGPR descriptor based at the
+  // first pixel a range of this tile can start at, a 32-bit lane offset, the 64-channel part as the scalar offset; a range
+  // pixel outside the tensor is an offset beyond the descriptor's range and arrives as ZEROS (tools/probes/
+  // buffer_lds_oob_probe.hip): no zero page, no choice between two 64-bit pointers per lane, and the buffer form is the
+  // cheaper one to issue beside MFMAs (tools/probes/lds_dma_issue_probe.hip)
+  constexpr unsigned OOB = 0x80000000u;
+  const int64_t rbase = n0 - W - 1 > 0 ? n0 - W - 1 : 0;
+  const __amdgpu_buffer_rsrc_t rsrc_h1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(h1) + rbase * CM, 0, 0x7fffffff, 0x00020000);
+  auto bglds16 = [&](unsigned voff, int soff, char* l) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_h1, (__attribute__((address_space(3))) void*)l, 16, (int)voff, soff, 0, 0);
   };
 
   f32x16 acc[MI][NI];
@@ -237,16 +219,17 @@ __global__ __launch_bounds__(THREADS, (NEXT ? 1 : (CM == 64 ? 3 : 2))) void bott
       if (i >= DIST) return;
 #endif
       const int c = i / 3, ra = i - 3 * c;
+      const int soff = c * KC * 2;
       const int64_t q = n0 + (int64_t)(ra - 1) * W - 1 + slot;
-      const __bf16* xs = (q >= 0 && q < npix) ? h1 + q * CM + c * KC + 8 * bg : g_zero_page_bt + 8 * bg;
+      const unsigned voff = (q >= 0 && q < npix) ? (unsigned)((q - rbase) * CM * 2 + 16 * bg) : OOB;
       char* dst = Bs + buf * B_ST + (bg * SLP + 64 * (wave & 1)) * 16;
 #pragma unroll
-      for (int p = 0; p < 4; ++p) glds16(xs + 16 * p, dst + 2 * p * SLP * 16);
+      for (int p = 0; p < 4; ++p) bglds16(voff + 32 * p, soff, dst + 2 * p * SLP * 16);
       if (wave == 0 && lane < 16) {                          // slots 128, 129: [group][2]
         const int g = lane >> 1, e = lane & 1;
         const int64_t q2 = n0 + (int64_t)(ra - 1) * W - 1 + 128 + e;
-        const __bf16* xs2 = (q2 >= 0 && q2 < npix) ? h1 + q2 * CM + c * KC + 8 * g : g_zero_page_bt + 8 * g;
-        glds16(xs2, extra + buf * 256);                      // the DMA adds lane * 16
+        const unsigned voff2 = (q2 >= 0 && q2 < npix) ? (unsigned)((q2 - rbase) * CM * 2 + 16 * g) : OOB;
+        bglds16(voff2, soff, extra + buf * 256);             // the DMA adds lane * 16
       }
     };
 #pragma unroll
@@ -427,16 +410,16 @@ __global__ __launch_bounds__(THREADS, (NEXT ? 1 : (CM == 64 ? 3 : 2))) void bott
 #pragma unroll
       for (int ra = 0; ra < 3; ++ra) {
         const int64_t q = n0 + (int64_t)(ra - 1) * W - 1 + slot;
-        const __bf16* xs = (q >= 0 && q < npix) ? h1 + q * CM + half * KC + 8 * bg : g_zero_page_bt + 8 * bg;
+        const unsigned voff = (q >= 0 && q < npix) ? (unsigned)((q - rbase) * CM * 2 + 16 * bg) : OOB;
         char* dst = Bs + ra * B_ST + (bg * SLP + 64 * (wave & 1)) * 16;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) glds16(xs + 16 * p, dst + 2 * p * SLP * 16);
+        for (int p = 0; p < 4; ++p) bglds16(voff + 32 * p, half * KC * 2, dst + 2 * p * SLP * 16);
       }
       if (wave == 0 && lane < 48) {                          // slots 128, 129 of the three ranges: [range][group][2]
         const int ra = lane >> 4, g = (lane >> 1) & 7, e = lane & 1;
         const int64_t q = n0 + (int64_t)(ra - 1) * W - 1 + 128 + e;
-        const __bf16* xs = (q >= 0 && q < npix) ? h1 + q * CM + half * KC + 8 * g : g_zero_page_bt + 8 * g;
-        glds16(xs, extra);                                   // the DMA adds lane * 16
+        const unsigned voff = (q >= 0 && q < npix) ? (unsigned)((q - rbase) * CM * 2 + 16 * g) : OOB;
+        bglds16(voff, half * KC * 2, extra);                 // the DMA adds lane * 16
       }
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) wl[mi] = wbase[mi] + half * (9 * 4096);

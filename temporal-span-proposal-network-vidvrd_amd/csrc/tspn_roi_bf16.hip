@@ -39,12 +39,6 @@ constexpr int KC = 64;                  // channels per chunk
 constexpr int SLP = 132;                // padded pixel slots per channel group
 constexpr int B_ST = 8 * SLP * 16;      // bytes per x stage: [8 groups][132 slots][8 bf16]
 
-__device__ __bf16 g_zero_page_bf16[128];   // source of padding taps (never written)
-
-__device__ __forceinline__ void glds16(const void* g, void* l) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-}
 template <int OFF>
 __device__ __forceinline__ void load_wfrag(f32x4& dst, unsigned lane_off, const char* base) {
   asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(lane_off), "s"(base), "n"(OFF) : "memory");
@@ -123,32 +117,50 @@ __global__ __launch_bounds__(THREADS, (MI == 1 ? TSPN_ROI_BF16_MI1_WAVES : 2)) v
     wbase[mi] = reinterpret_cast<const char*>(Wf) + (int64_t)mb * nchunks * 4096;
   }
   // x pieces: the four pieces of a lane belong to ONE output pixel (slot), channel groups bg, bg + 2, bg + 4, bg + 6
+  // The pieces are BUFFER loads (buffer_load_dwordx4 ... offen lds; round 4): an SGPR descriptor based at the image the
+  // tile starts in, a 32-bit lane offset, and a lane whose tap falls off the image simply gets an offset beyond
+  // the descriptor's range -- the hardware then writes ZEROS into LDS (tools/probes/buffer_lds_oob_probe.hip), so there is
+  // no zero page and no per-lane choice between two 64-bit pointers; beside MFMAs the buffer form is also the cheaper one
+  // to issue (tools/probes/lds_dma_issue_probe.hip: 110 - 140 against 175 - 195 cycles per piece).
   const int slot = 64 * (wave & 1) + lane;
   const int bg = wave >> 1;
-  int64_t pbase;
+  constexpr unsigned OOB = 0x80000000u;            // beyond num_records = 2^31 - 1: the piece arrives as zeros
+  auto in_pixel = [&](int64_t n, int& ih0, int& iw0) {      // first tap's input pixel index of output pixel n (may be < 0)
+    const int64_t nb = n / ((int64_t)OH * OW);
+    const int r = (int)(n - nb * OH * OW);
+    const int oh = r / OW, ow = r - oh * OW;
+    ih0 = oh * stride - pad; iw0 = ow * stride - pad;
+    return (nb * H + ih0) * (int64_t)W + iw0;
+  };
+  // base = the first pixel of the image the tile starts in: every valid tap of the tile lies at or behind it
+  const int64_t base_pix = ((n0 < npix ? n0 : 0) / ((int64_t)OH * OW)) * H * W;
+  const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(x) + base_pix * Cin, 0, 0x7fffffff, 0x00020000);
+  unsigned pboff;                                  // byte offset of this lane's pixel (first tap, channel group bg) from the base
   unsigned long long tapmask = 0;
   {
     const int64_t n = n0 + slot;
     const bool okn = n < npix;
     const int64_t nc = okn ? n : 0;
-    const int64_t nb = nc / ((int64_t)OH * OW);
-    const int r = (int)(nc - nb * OH * OW);
-    const int oh = r / OW, ow = r - oh * OW;
-    const int ih0 = oh * stride - pad, iw0 = ow * stride - pad;
-    pbase = ((nb * H + ih0) * (int64_t)W + iw0) * Cin;
+    int ih0, iw0;
+    const int64_t ip = in_pixel(nc, ih0, iw0);
+    pboff = (unsigned)((ip - base_pix) * Cin * 2 + 16 * bg);
     for (int a = 0; a < KH; ++a)
       for (int b = 0; b < KW; ++b)
         if (okn && ih0 + a >= 0 && ih0 + a < H && iw0 + b >= 0 && iw0 + b < W) tapmask |= 1ull << (a * KW + b);
   }
+  auto bglds16 = [&](unsigned voff, int soff, char* l) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)l, 16, (int)voff, soff, 0, 0);
+  };
   auto stage_x = [&](int buf, int i) {             // exactly four pieces per wave
     const int ntaps = KH * KW;
     const int c = i / ntaps, tap = i - c * ntaps;
     const int ta = tap / KW, tb = tap - ta * KW;
     const bool valid = (tapmask >> tap) & 1ull;
-    const __bf16* xs = valid ? x + pbase + ((int64_t)ta * W + tb) * Cin + c * KC + 8 * bg : g_zero_page_bf16 + 8 * bg;
+    const unsigned voff = valid ? pboff + (unsigned)((ta * W + tb) * Cin * 2) : OOB;
+    const int soff = c * KC * 2;
     char* dst = Bs + buf * B_ST + (bg * SLP + 64 * (wave & 1)) * 16;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) glds16(xs + 16 * p, dst + 2 * p * SLP * 16);
+    for (int p = 0; p < 4; ++p) bglds16(voff + 32 * p, soff, dst + 2 * p * SLP * 16);
   };
 
   f32x16 acc[MI][4];
@@ -212,18 +224,25 @@ __global__ __launch_bounds__(THREADS, (MI == 1 ? TSPN_ROI_BF16_MI1_WAVES : 2)) v
       rmask[ni] = m;
     }
     const int64_t npin = npix;                               // stride 1, pad 1: input pixels = output pixels
+    // ranges: descriptor based at pixel max(n0 - W - 1, 0); a range pixel outside the tensor is an out-of-range offset
+    const int64_t rbase = n0 - W - 1 > 0 ? n0 - W - 1 : 0;
+    const __amdgpu_buffer_rsrc_t rsrc_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(x) + rbase * Cin, 0, 0x7fffffff, 0x00020000);
     auto stage_r = [&](int buf, int i) {                     // range i = 3 c + ra
       const int c = i / 3, ra = i - 3 * c;
+      const int soff = c * KC * 2;
       const int64_t q = n0 + (int64_t)(ra - 1) * W - 1 + slot;
-      const __bf16* xs = (q >= 0 && q < npin) ? x + q * Cin + c * KC + 8 * bg : g_zero_page_bf16 + 8 * bg;
+      const unsigned voff = (q >= 0 && q < npin) ? (unsigned)((q - rbase) * Cin * 2 + 16 * bg) : OOB;
       char* dst = Bs + buf * B_ST + (bg * SLP + 64 * (wave & 1)) * 16;
 #pragma unroll
-      for (int p = 0; p < 4; ++p) glds16(xs + 16 * p, dst + 2 * p * SLP * 16);
+      for (int p = 0; p < 4; ++p)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_r, (__attribute__((address_space(3))) void*)(dst + 2 * p * SLP * 16), 16,
+                                                 (int)(voff + 32 * p), soff, 0, 0);
       if (wave == 0 && lane < 16) {                          // slots 128, 129: [group][2]
         const int g = lane >> 1, e = lane & 1;
         const int64_t q2 = n0 + (int64_t)(ra - 1) * W - 1 + 128 + e;
-        const __bf16* xs2 = (q2 >= 0 && q2 < npin) ? x + q2 * Cin + c * KC + 8 * g : g_zero_page_bf16 + 8 * g;
-        glds16(xs2, extra + buf * 256);                      // the DMA adds lane * 16
+        const unsigned voff2 = (q2 >= 0 && q2 < npin) ? (unsigned)((q2 - rbase) * Cin * 2 + 16 * g) : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_r, (__attribute__((address_space(3))) void*)(extra + buf * 256), 16,
+                                                 (int)voff2, soff, 0, 0);      // the DMA adds lane * 16
       }
     };
     auto read_r = [&](int buf, int tap, int rb, int ks, bf16x8 (&b)[4]) {

@@ -165,6 +165,11 @@ __device__ __forceinline__ void load_frag(f32x4& dst, unsigned lane_off, const c
   asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(lane_off), "s"(base), "n"(OFF) : "memory");
 }
 
+// BUFV: the V pieces are buffer loads (buffer_load_dwordx4 ... offen lds: one SGPR descriptor of the workspace, a fixed
+// 32-bit lane offset per piece, a scalar offset per super-stage) instead of global_load_lds_dwordx4 with sixteen 64-bit
+// pointers per lane that are bumped by vector adds every super-stage: cheaper to issue in the MFMA shadows
+// (tools/probes/lds_dma_issue_probe.hip) and 16 registers less.  Needs a workspace below 4 GB (the launcher chooses).
+template <bool BUFV>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3_wino63_kernel(
     const float* __restrict__ Vg, const float* __restrict__ Wf, const float* __restrict__ bias,
     float* __restrict__ y, int Cin, int T, int M, int nq, int64_t nsext, int64_t nsp, int tiles_m,
@@ -202,22 +207,36 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
   }
 
   // V super-stage DMA: piece pp = 16 wave + k, same LDS image as the 8-wave form
-  const float* vsrc[NPIECE];
+  const float* vsrc[BUFV ? 1 : NPIECE];
+  unsigned voff[BUFV ? NPIECE : 1];
 #pragma unroll
   for (int k = 0; k < NPIECE; ++k) {
     const int pp = NPIECE * wave + k;
     const int rr = 2 * (pp & 31) + kh;
     const int cl = rr >> 4, rem = rr & 15;
     const int g = rem >> 3, j = rem & 7;
-    vsrc[k] = Vg + (((int64_t)(2 * cl + g) * NJ + j) * nsp + S0 + ST * (pp >> 5) + li) * 4;
+    const int64_t e = (((int64_t)(2 * cl + g) * NJ + j) * nsp + S0 + ST * (pp >> 5) + li) * 4;
+    if constexpr (BUFV) voff[k] = (unsigned)(e * 4); else vsrc[k] = Vg + e;
   }
   const int64_t super_step = (int64_t)8 * NJ * nsp * 4;
+  const __amdgpu_buffer_rsrc_t rsrc_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Vg), 0, (int)0xffffffffu, 0x00020000);
+  const unsigned super_bytes = (unsigned)(super_step * 4);
   auto stage_piece = [&](int S, int k) {          // piece k of this wave, super-stage S -> ring buffer S & 1
 #if !defined(TSPN_W63_ABL_NODMA)
-    glds16(vsrc[k], Vs + (S & 1) * VSS + (NPIECE * wave + k) * 256);
+    if constexpr (BUFV) {
+#if defined(TSPN_W63_PROBE_HOTV)
+      const int soff = 0;
+#else
+      const int soff = (int)((unsigned)S * super_bytes);
+#endif
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_v, (__attribute__((address_space(3))) void*)(Vs + (S & 1) * VSS + (NPIECE * wave + k) * 256),
+                                               16, (int)voff[k], soff, 0, 0);
+    } else {
+      glds16(vsrc[k], Vs + (S & 1) * VSS + (NPIECE * wave + k) * 256);
+    }
 #endif
 #if !defined(TSPN_W63_PROBE_HOTV)
-    vsrc[k] += super_step;
+    if constexpr (!BUFV) vsrc[k] += super_step;
 #endif
   };
 
@@ -480,12 +499,20 @@ int tspn::wino63_contract(const void* workspace, int64_t B, int64_t T, int64_t C
   const int64_t tiles_m = tspn::ceil_div(M, BM), tiles_n = nsp / SWG;
   TSPN_REQUIRE(tiles_m * tiles_n < (1LL << 31), TSPN_EUNSUPPORTED, "%s: grid too large", what);
   const int vec2 = (ldy % 2 == 0) && (ldy >= 6 * nq) && ((reinterpret_cast<uintptr_t>(y) & 7) == 0);
-  static tspn::LdsLimit lds;   // 128 KB of dynamic LDS: above the 64 KB default limit
-  if (int rc = lds.ensure(reinterpret_cast<const void*>(conv3_wino63_kernel), SMEM_BYTES, what)) return rc;
-  hipLaunchKernelGGL(conv3_wino63_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(THREADS), SMEM_BYTES,
-                     TSPN_STREAM(stream), static_cast<const float*>(workspace), frag, bias, y, (int)Cin, (int)T, (int)M,
-                     (int)nq, nsext, nsp, (int)tiles_m, (int)tiles_n, relu, (int)ldy, TSPN_WINO63_GM, vec2);
-  return tspn::check_launch(what);
+  // buffer-load form of the V pieces where every byte offset into the workspace fits 32 bits
+#ifndef TSPN_WINO63_BUFV
+#define TSPN_WINO63_BUFV 1
+#endif
+  const bool bufv = TSPN_WINO63_BUFV && tspn::wino63_workspace_bytes(B, T, Cin) < (1ull << 32);
+  static tspn::LdsLimit lds[2];   // 128 KB of dynamic LDS: above the 64 KB default limit
+  auto launch = [&](auto kern, tspn::LdsLimit& lim) {
+    if (int rc = lim.ensure(reinterpret_cast<const void*>(kern), SMEM_BYTES, what)) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n)), dim3(THREADS), SMEM_BYTES, TSPN_STREAM(stream),
+                       static_cast<const float*>(workspace), frag, bias, y, (int)Cin, (int)T, (int)M, (int)nq, nsext, nsp,
+                       (int)tiles_m, (int)tiles_n, relu, (int)ldy, TSPN_WINO63_GM, vec2);
+    return tspn::check_launch(what);
+  };
+  return bufv ? launch(conv3_wino63_kernel<true>, lds[1]) : launch(conv3_wino63_kernel<false>, lds[0]);
 }
 
 int tspn::conv3_tc_wino63(const float* x, int64_t B, int64_t T, int64_t Cin, const float* frag, int64_t M,
