@@ -34,6 +34,8 @@ __global__ __launch_bounds__(512, 1) void probe(const char* __restrict__ src, si
   bf16x8 a = {}, b = {};
   a[0] = (__bf16)(float)lane; b[0] = (__bf16)1.f;
   unsigned long long t_issue = 0, t_all0 = 0;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  f32x4 regs[PIECES] = {};
   auto issue = [&](int it) {
     char* dst = smem + ((it % DEPTH) * 8 + wave) * PIECES * 1024;
 #pragma unroll
@@ -43,14 +45,19 @@ __global__ __launch_bounds__(512, 1) void probe(const char* __restrict__ src, si
       if (MODE == 0)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + o),
                                          (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
-      else
+      else if (MODE == 1)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + p * 1024), 16,
                                                  (int)o, 0, 0, 0);
+      else if (MODE == 2)          // register-returning loads (the weight path of the conv kernels): SGPR base + 32-bit lane offset
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(regs[p]) : "v"((unsigned)o), "s"(src) : "memory");
+      else
+        regs[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)o, 0, 0));
     }
     off += stride_it;
     if (off >= src_bytes) off -= src_bytes;
   };
-  for (int it = 0; it < DEPTH - 1; ++it) issue(it);
+  if (MODE < 2)        // (register-returning loads have no ring: every load is waited for in its own iteration)
+    for (int it = 0; it < DEPTH - 1; ++it) issue(it);
   __syncthreads();
   t_all0 = now();
   for (int it = DEPTH - 1; it < iters; ++it) {
@@ -65,7 +72,12 @@ __global__ __launch_bounds__(512, 1) void probe(const char* __restrict__ src, si
 #pragma unroll
     for (int m = 0; m < MFMAS; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    wait_vm<PIECES * (DEPTH - 1)>();
+    if (MODE >= 2) {     // register-returning loads: the destination registers stay reserved until this tied wait
+#pragma unroll
+      for (int p = 0; p < PIECES; ++p) asm volatile("s_waitcnt vmcnt(0)" : "+v"(regs[p]));
+    } else {
+      wait_vm<PIECES * (DEPTH - 1)>();
+    }
     __builtin_amdgcn_s_barrier();
   }
   const unsigned long long t_all1 = now();
@@ -74,7 +86,8 @@ __global__ __launch_bounds__(512, 1) void probe(const char* __restrict__ src, si
     out[(blockIdx.x * 8 + wave) * 2] = t_issue;
     out[(blockIdx.x * 8 + wave) * 2 + 1] = t_all1 - t_all0;
   }
-  if (acc[0] == 12345.f) sink[threadIdx.x] = acc[0] + smem[threadIdx.x];
+  asm volatile("" : "+v"(regs[0]), "+v"(regs[PIECES - 1]));
+  if (acc[0] == 12345.f) sink[threadIdx.x] = acc[0] + smem[threadIdx.x] + regs[0][0] + regs[PIECES - 1][1];
 }
 
 template <int MODE, int PIECES, int DEPTH, int MFMAS>
@@ -117,6 +130,8 @@ int main() {
     run<1, 4, 4, 16>("buffer_load_dwordx4 offen lds + 16 MFMA", src, bytes, iters, dout, sink);
     run<0, 2, 4, 16>("global_load_lds_dwordx4 + 16 MFMA", src, bytes, iters, dout, sink);
     run<1, 2, 4, 16>("buffer_load_dwordx4 offen lds + 16 MFMA", src, bytes, iters, dout, sink);
+    run<2, 4, 2, 16>("global_load_dwordx4 saddr -> VGPR + 16 MFMA", src, bytes, iters, dout, sink);
+    run<3, 4, 2, 16>("buffer_load_dwordx4 offen -> VGPR + 16 MFMA", src, bytes, iters, dout, sink);
     run<0, 4, 2, 16>("global_load_lds_dwordx4 + 16 MFMA", src, bytes, iters, dout, sink);
     run<0, 2, 8, 16>("global_load_lds_dwordx4 + 16 MFMA", src, bytes, iters, dout, sink);
     CHECK(hipFree(src));
