@@ -360,10 +360,12 @@ int tspn_pack_conv3_bf16(const float* W, int64_t M, int64_t Cin, int64_t split, 
 /* 1x1 head weights [H <= 16, C] fp32 -> [C/8][16][8] bf16 (rows H..15 zero) */
 int tspn_pack_heads_bf16(const float* W, int64_t H, int64_t C, uint16_t* packed, void* stream);
 /* k=3, pad=1 conv over time; x bf16 channels-last [B, T, Cin]; y fp32 channels-last [B*T, ldm]
- * (y[n][m], n = b*T + t), + bias[m] if given.  Needs Cin % 16 == 0, M % 4 == 0, ldm % 4 == 0. */
+ * (y[n][m], n = b*T + t), + bias[m] if given.  Needs Cin % 16 == 0, M % 4 == 0, ldm % 4 == 0 and packed weights below
+ * 2 GB (the operand pieces are buffer loads with 32-bit offsets; x may have any size). */
 int tspn_conv3_tc_bf16(const uint16_t* x, int64_t B, int64_t T, int64_t Cin, const uint16_t* packed,
                        int64_t M, const float* bias, float* y, int64_t ldm, void* stream);
-/* pair stage on the canonical pair table: y fp32 [B*N*T, ldm] with U = channels [0,C), V = [C,2C);
+/* pair stage on the canonical pair table: y fp32 [B*N*T, ldm] with U = channels [0,C), V = [C,2C) (ONE video's rows,
+ * N*T*ldm*4 bytes, must stay below 4 GB: buffer loads with 32-bit offsets from the video's base);
  * out[p][h][t] = head_b[h] + sum_c Wh[h][c] * bf16(relu(U[s][t][c] + V[o][t][c])), out [B*N*(N-1), H, T] */
 int tspn_heads_pairgrid_bf16(const float* y, int64_t ldm, int64_t B, int64_t N, int64_t C, int64_t T,
                              const uint16_t* head_packed, const float* head_b, int64_t H, float* out,
