@@ -33,6 +33,7 @@
 // V registers from S + 1, and the pieces of S + 2 go into the buffer S left during the first chunk of S + 1.
 // Needs Cin % 32 == 0 and M % 32 == 0.
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "tspn_common.h"
@@ -503,7 +504,10 @@ int tspn::wino63_contract(const void* workspace, int64_t B, int64_t T, int64_t C
 #ifndef TSPN_WINO63_BUFV
 #define TSPN_WINO63_BUFV 1
 #endif
-  const bool bufv = TSPN_WINO63_BUFV && tspn::wino63_workspace_bytes(B, T, Cin) < (1ull << 32);
+  // (TSPN_WINO63_PTRV=1 in the environment forces the pointer form: tests compare the two)
+  const char* const ptrv_env = getenv("TSPN_WINO63_PTRV");
+  const bool bufv = TSPN_WINO63_BUFV && tspn::wino63_workspace_bytes(B, T, Cin) < (1ull << 32) &&
+                    !(ptrv_env && ptrv_env[0] == '1');
   static tspn::LdsLimit lds[2];   // 128 KB of dynamic LDS: above the 64 KB default limit
   auto launch = [&](auto kern, tspn::LdsLimit& lim) {
     if (int rc = lim.ensure(reinterpret_cast<const void*>(kern), SMEM_BYTES, what)) return rc;
