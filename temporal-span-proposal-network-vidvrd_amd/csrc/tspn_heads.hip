@@ -579,25 +579,32 @@ __global__ __launch_bounds__(256, 2) void heads_pairgrid4_kernel(
   const int t0 = tb * PG_T;
   const int64_t rowlen = 2 * (int64_t)C * ldt;
 
-  // ---- DMA sources (as in heads_pairgrid3_kernel): wave w stages tile rows 4w..4w+3
-  const float* srow[4];
+  // ---- DMA sources (as in heads_pairgrid3_kernel): wave w stages tile rows 4w..4w+3.  Buffer loads (round 4): one SGPR
+  // descriptor of this video's projections (the launcher checks they stay below 4 GB), a 32-bit lane offset per row, the
+  // channel chunk / half as the scalar offset -- cheaper to issue than global_load_lds (tools/probes/lds_dma_issue_probe.hip)
+  const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(y) + b * N * rowlen, 0, (int)(unsigned)((int64_t)N * rowlen * 4), 0x00020000);
+  unsigned voff[4];
+  const unsigned loff = (unsigned)((lane >> 3) * ldt + min((int64_t)t0 + (lane & 7) * 4, ldt - 4));
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = 4 * wave + r;
     const int local = row < PG_S ? sb * PG_S + row : ob * PG_O + (row - PG_S);
-    const int64_t trk = b * N + min(local, N - 1);
-    srow[r] = y + trk * rowlen + (row < PG_S ? 0 : (int64_t)C * ldt);
+    const int64_t trk = min(local, N - 1);
+    voff[r] = (unsigned)((trk * rowlen + (row < PG_S ? 0 : (int64_t)C * ldt) + loff) * 4);
   }
-  const unsigned loff = (unsigned)((lane >> 3) * ldt + min((int64_t)t0 + (lane & 7) * 4, ldt - 4));
-  const int64_t half_step = 8 * ldt, chunk_step = 16 * ldt;
+  const int half_bytes = (int)(8 * ldt * 4);
+  int y_soff = 0;                                    // byte offset of the next chunk's channels
   auto stage_chunk = [&](int buf) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh)
-        hglds16(srow[r] + hh * half_step + loff, S + buf * PG_STAGE + ((4 * wave + r) * PG_CK + 8 * hh) * PG_T);
-      srow[r] += chunk_step;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            rsrc_y, (__attribute__((address_space(3))) void*)(S + buf * PG_STAGE + ((4 * wave + r) * PG_CK + 8 * hh) * PG_T), 16,
+            (int)voff[r], y_soff + hh * half_bytes, 0, 0);
     }
+    y_soff += 2 * half_bytes;
   };
 
   f32x2 acc[PG_O / 2][H];     // (object 2 op, object 2 op + 1) x head
@@ -776,7 +783,9 @@ int tspn::heads_pairgrid(const float* y, int64_t ldt, int64_t B, int64_t N, int6
                     ((reinterpret_cast<uintptr_t>(out) & 7) == 0);
   TSPN_REQUIRE(v3 || ldt == T, TSPN_EUNSUPPORTED,
                "tspn_heads_pairgrid_f32: padded rows (ldt != T) need the DMA kernel's preconditions");
-  if (v3 && H == 12 && Wp12 != nullptr) {   // scalar-weight VALU form (no 12 -> 16 row padding, no MFMA / VALU serialisation)
+  // (its operand pieces are buffer loads with 32-bit offsets from the video's first row: a video's projections below 4 GB)
+  const bool fits32 = N * 2 * C * ldt * 4 < (1LL << 32);
+  if (v3 && H == 12 && Wp12 != nullptr && fits32) {   // scalar-weight VALU form (no 12 -> 16 row padding, no MFMA / VALU serialisation)
     hipLaunchKernelGGL(pack_heads12_kernel, dim3((unsigned)tspn::ceil_div(C * 12, 256)), dim3(256), 0,
                        TSPN_STREAM(stream), Wh, (int)C, Wp12);
     static tspn::LdsLimit lds4;
