@@ -77,7 +77,7 @@ template <bool RES>
 __global__ __launch_bounds__(Q_THREADS, 1) void conv1x1_big_bf16_kernel(
     const __bf16* __restrict__ x, const __bf16* __restrict__ Wr, const float* __restrict__ bias,
     const __bf16* __restrict__ residual, __bf16* __restrict__ out, int Cin, int M, int Mp, int64_t npix, int H, int W,
-    int OH, int OW, int stride, int tiles_m, int tiles_n, int GM, int relu) {
+    int OH, int OW, int stride, int tiles_m, int tiles_n, int GM, int relu, int w_bytes) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   // workgroup -> tile: every XCD takes a contiguous range of tile indices; inside it groups of GM weight panels x all
@@ -129,56 +129,60 @@ __global__ __launch_bounds__(Q_THREADS, 1) void conv1x1_big_bf16_kernel(
   // weight pieces 2 w, 2 w + 1 (channel group w >> 1, row quarters 2 (w & 1) + {0, 1}) and the x pieces of the same
   // group and pixel quarters.
   const int pg = wave >> 1;
-  const __bf16* asrc[2];
-  const __bf16* xsrc[2];
+  // buffer loads (buffer_load_dwordx4 ... offen lds): one descriptor per operand, a fixed 32-bit lane offset per piece and
+  // the chunk as the scalar offset -- 110 - 140 issue cycles per piece beside MFMAs instead of the 175 - 235 of
+  // global_load_lds with a 64-bit address per lane (tools/probes/lds_dma_issue_probe.hip)
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Wr), 0, w_bytes, 0x00020000);
+  const int64_t img = (int64_t)OH * OW;
+  const int64_t base_pix = ((n0 < npix ? n0 : 0) / img) * H * W;       // first pixel of the image the tile starts in
+  const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(x) + base_pix * Cin, 0, 0x7fffffff, 0x00020000);
+  unsigned aoff[2], xoff[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int quarter = 2 * (wave & 1) + i;
     int r = m0 + 64 * quarter + lane;
     r = r < Mp ? r : 0;
-    asrc[i] = Wr + ((int64_t)pg * Mp + r) * 8;
+    aoff[i] = (unsigned)(((int64_t)pg * Mp + r) * 16);
     int64_t n = n0 + 64 * quarter + lane;
     n = n < npix ? n : npix - 1;
     int64_t ip = n;
     if (stride != 1 || H != OH || W != OW) {
-      const int64_t nb = n / ((int64_t)OH * OW);
-      const int rr = (int)(n - nb * OH * OW);
+      const int64_t nb = n / img;
+      const int rr = (int)(n - nb * img);
       const int oh = rr / OW, ow = rr - oh * OW;
       ip = (nb * H + (int64_t)oh * stride) * W + (int64_t)ow * stride;
     }
-    xsrc[i] = x + ip * Cin + 8 * pg;
+    xoff[i] = (unsigned)((ip - base_pix) * Cin * 2 + 16 * pg);
   }
-  const int64_t a_step = (int64_t)Q_KG * Mp * 8;
+  const int a_step = Q_KG * Mp * 16;                         // bytes per chunk
+  int a_soff = 0, x_soff = 0;
 #if defined(TSPN_Q_ABL_ROT)          // probe build: every pixel tile walks the K chunks from its own starting point (wrong sums)
   int rot_c = (tile_n * TSPN_Q_ABL_ROT) % (Cin / Q_KC);
-  const __bf16* const abase[2] = {asrc[0], asrc[1]};
-  const __bf16* const xbase[2] = {xsrc[0], xsrc[1]};
 #endif
+  auto bglds16 = [&](const __amdgpu_buffer_rsrc_t& r, unsigned voff, int soff, char* l) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)l, 16, (int)voff, soff, 0, 0);
+  };
   auto stage_chunk = [&](int st) {
     char* sa = smem + st * Q_ST + (2 * wave) * 1024;
     char* sx = smem + st * Q_ST + Q_A_ST + (pg * Q_SLP + 128 * (wave & 1)) * 16;
 #if defined(TSPN_Q_ABL_ROT)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      asrc[i] = abase[i] + rot_c * a_step;
-      xsrc[i] = xbase[i] + rot_c * Q_KC;
-    }
+    a_soff = rot_c * a_step; x_soff = rot_c * Q_KC * 2;
     rot_c = rot_c + 1 == Cin / Q_KC ? 0 : rot_c + 1;
 #endif
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #if !defined(TSPN_Q_ABL_NOW)         // probe build: no weight pieces
-      glds16(asrc[i], sa + i * 1024);
+      bglds16(rsrc_w, aoff[i], a_soff, sa + i * 1024);
 #endif
-      asrc[i] += a_step;
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #if !defined(TSPN_Q_ABL_NOX)         // probe build: no x pieces
-      glds16(xsrc[i], sx + i * 1024);
+      bglds16(rsrc_x, xoff[i], x_soff, sx + i * 1024);
 #endif
-      xsrc[i] += Q_KC;
     }
+    a_soff += a_step;
+    x_soff += Q_KC * 2;
   };
   auto wait_keep = [&](auto chunks_tag) {                  // four pieces in flight per chunk and wave
     constexpr int CH = decltype(chunks_tag)::value;
@@ -342,8 +346,9 @@ extern "C" int tspn_conv1x1_big_bf16(const uint16_t* x, int64_t NB, int64_t H, i
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   TSPN_REQUIRE(al16(x) && al16(rows) && al16(out) && (!bias || al16(bias)) && (!residual || al16(residual)),
                TSPN_EUNSUPPORTED, "tspn_conv1x1_big_bf16: operands must be 16-byte aligned");
-  TSPN_REQUIRE(H < (1 << 20) && W < (1 << 20) && Cin < (1 << 24) && Cout < (1 << 24), TSPN_EUNSUPPORTED,
-               "tspn_conv1x1_big_bf16: dimension too large");
+  TSPN_REQUIRE(H < (1 << 20) && W < (1 << 20) && Cin < (1 << 24) && Cout < (1 << 24) && Cin * Cout * 2 < (1LL << 31) &&
+                   H * W * Cin * 2 < (1LL << 30),
+               TSPN_EUNSUPPORTED, "tspn_conv1x1_big_bf16: dimension too large");
   const int64_t OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
   const int64_t npix = NB * OH * OW;
   const int64_t tiles_m = tspn::ceil_div(Cout, Q_BM), tiles_n = tspn::ceil_div(npix, Q_BN);
@@ -357,7 +362,8 @@ extern "C" int tspn_conv1x1_big_bf16(const uint16_t* x, int64_t NB, int64_t H, i
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n)), dim3(Q_THREADS), Q_SMEM, TSPN_STREAM(stream),
                        reinterpret_cast<const __bf16*>(x), reinterpret_cast<const __bf16*>(rows), bias,
                        reinterpret_cast<const __bf16*>(residual), reinterpret_cast<__bf16*>(out), (int)Cin, (int)Cout,
-                       (int)Cout, npix, (int)H, (int)W, (int)OH, (int)OW, (int)stride, (int)tiles_m, (int)tiles_n, gm, relu);
+                       (int)Cout, npix, (int)H, (int)W, (int)OH, (int)OW, (int)stride, (int)tiles_m, (int)tiles_n, gm, relu,
+                       (int)(Cin * Cout * 2));
   };
   if (residual) launch(conv1x1_big_bf16_kernel<true>); else launch(conv1x1_big_bf16_kernel<false>);
   return tspn::check_launch("tspn_conv1x1_big_bf16");
