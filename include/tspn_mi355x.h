@@ -365,7 +365,7 @@ int tspn_pack_heads_bf16(const float* W, int64_t H, int64_t C, uint16_t* packed,
 int tspn_conv3_tc_bf16(const uint16_t* x, int64_t B, int64_t T, int64_t Cin, const uint16_t* packed,
                        int64_t M, const float* bias, float* y, int64_t ldm, void* stream);
 /* pair stage on the canonical pair table: y fp32 [B*N*T, ldm] with U = channels [0,C), V = [C,2C) (ONE video's rows,
- * N*T*ldm*4 bytes, must stay below 4 GB: buffer loads with 32-bit offsets from the video's base);
+ * N*T*ldm*4 bytes, must stay below 2 GB: buffer loads with 32-bit offsets from the video's base);
  * out[p][h][t] = head_b[h] + sum_c Wh[h][c] * bf16(relu(U[s][t][c] + V[o][t][c])), out [B*N*(N-1), H, T] */
 int tspn_heads_pairgrid_bf16(const float* y, int64_t ldm, int64_t B, int64_t N, int64_t C, int64_t T,
                              const uint16_t* head_packed, const float* head_b, int64_t H, float* out,

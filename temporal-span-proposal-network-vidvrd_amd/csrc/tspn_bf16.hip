@@ -761,8 +761,8 @@ extern "C" int tspn_heads_pairgrid_bf16(const float* y, int64_t ldm, int64_t B, 
   const int64_t sblk = big ? 16 : 8;
   const int64_t nsb = tspn::ceil_div(N, sblk), nfb = tspn::ceil_div(T, HP_FB);
   const int64_t grid = B * nsb * nsb * nfb;
-  TSPN_REQUIRE(grid < (1LL << 31) && N < (1 << 20) && T < (1 << 24) && C < (1 << 24) && N * T * ldm * 4 < (1LL << 32),
-               TSPN_EUNSUPPORTED, "tspn_heads_pairgrid_bf16: problem too large (a video's projections must stay below 4 GB)");
+  TSPN_REQUIRE(grid < (1LL << 31) && N < (1 << 20) && T < (1 << 24) && C < (1 << 24) && N * T * ldm * 4 < (1LL << 31),
+               TSPN_EUNSUPPORTED, "tspn_heads_pairgrid_bf16: problem too large (a video's projections must stay below 2 GB)");
   const size_t smem = 2 * ((size_t)(2 * sblk) * HP_ROW + 1024);
   static tspn::LdsLimit lds[2];
   if (int rc = big ? lds[1].ensure(reinterpret_cast<const void*>(heads_pairgrid_bf16_kernel<8, 16, TSPN_HPB_SW>), smem,

@@ -580,7 +580,7 @@ __global__ __launch_bounds__(256, 2) void heads_pairgrid4_kernel(
   const int64_t rowlen = 2 * (int64_t)C * ldt;
 
   // ---- DMA sources (as in heads_pairgrid3_kernel): wave w stages tile rows 4w..4w+3.  Buffer loads (round 4): one SGPR
-  // descriptor of this video's projections (the launcher checks they stay below 4 GB), a 32-bit lane offset per row, the
+  // descriptor of this video's projections (the launcher checks they stay below 2 GB), a 32-bit lane offset per row, the
   // channel chunk / half as the scalar offset -- cheaper to issue than global_load_lds (tools/probes/lds_dma_issue_probe.hip)
   const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(y) + b * N * rowlen, 0, (int)(unsigned)((int64_t)N * rowlen * 4), 0x00020000);
@@ -783,8 +783,8 @@ int tspn::heads_pairgrid(const float* y, int64_t ldt, int64_t B, int64_t N, int6
                     ((reinterpret_cast<uintptr_t>(out) & 7) == 0);
   TSPN_REQUIRE(v3 || ldt == T, TSPN_EUNSUPPORTED,
                "tspn_heads_pairgrid_f32: padded rows (ldt != T) need the DMA kernel's preconditions");
-  // (its operand pieces are buffer loads with 32-bit offsets from the video's first row: a video's projections below 4 GB)
-  const bool fits32 = N * 2 * C * ldt * 4 < (1LL << 32);
+  // (its operand pieces are buffer loads with 32-bit offsets from the video's first row: a video's projections below 2 GB)
+  const bool fits32 = N * 2 * C * ldt * 4 < (1LL << 31);
   if (v3 && H == 12 && Wp12 != nullptr && fits32) {   // scalar-weight VALU form (no 12 -> 16 row padding, no MFMA / VALU serialisation)
     hipLaunchKernelGGL(pack_heads12_kernel, dim3((unsigned)tspn::ceil_div(C * 12, 256)), dim3(256), 0,
                        TSPN_STREAM(stream), Wh, (int)C, Wp12);

@@ -506,7 +506,7 @@ int tspn::wino63_contract(const void* workspace, int64_t B, int64_t T, int64_t C
 #endif
   // (TSPN_WINO63_PTRV=1 in the environment forces the pointer form: tests compare the two)
   const char* const ptrv_env = getenv("TSPN_WINO63_PTRV");
-  const bool bufv = TSPN_WINO63_BUFV && tspn::wino63_workspace_bytes(B, T, Cin) < (1ull << 32) &&
+  const bool bufv = TSPN_WINO63_BUFV && tspn::wino63_workspace_bytes(B, T, Cin) < (1ull << 32) &&   /* offsets are unsigned 32-bit */
                     !(ptrv_env && ptrv_env[0] == '1');
   static tspn::LdsLimit lds[2];   // 128 KB of dynamic LDS: above the 64 KB default limit
   auto launch = [&](auto kern, tspn::LdsLimit& lim) {

@@ -440,18 +440,16 @@ def test_dense_bf16_pieces_ragged_and_errors(tspn, device):
 
 def test_bf16_buffer_offset_limits_are_refused_not_wrapped(tspn, device):
     """The operand pieces of the bf16 conv and pair stage are buffer loads with 32-bit offsets: a video whose projections
-    reach 4 GB, or packed conv weights of 2 GB, are refused with TSPN_EUNSUPPORTED before any launch (the sizes are only
+    reach 2 GB, or packed conv weights of 2 GB, are refused with TSPN_EUNSUPPORTED before any launch (the sizes are only
     declared here: nothing that large is allocated)."""
     lib = tspn._abi.lib()
     small = torch.zeros(4096, dtype=torch.float32, device=device)
     s16 = torch.zeros(4096, dtype=torch.bfloat16, device=device)
     p = lambda z: z.data_ptr()
-    # pair stage: N * T * ldm * 4 = 64 * 8200 * 2048 * 4 = 4.3 GB per video
-    rc = lib.tspn_heads_pairgrid_bf16(p(small), 2048, 1, 64, 1024, 8200, p(s16), p(small), 12, p(small), 0)
-    assert rc == tspn._abi.TSPN_EUNSUPPORTED and "4 GB" in tspn._abi.lib().tspn_last_error().decode()
+    # pair stage: N * T * ldm * 4 = 64 * 4200 * 2048 * 4 = 2.2 GB per video
+    rc = lib.tspn_heads_pairgrid_bf16(p(small), 2048, 1, 64, 1024, 4200, p(s16), p(small), 12, p(small), 0)
+    assert rc == tspn._abi.TSPN_EUNSUPPORTED and "2 GB" in tspn._abi.lib().tspn_last_error().decode()
     # conv: 3 * Cin * M * 2 = 3 * 16384 * 32768 * 2 = 3.2 GB of packed weights
     rc = lib.tspn_conv3_tc_bf16(p(s16), 1, 8, 16384, p(s16), 32768, None, p(small), 32768, 0)
     assert rc == tspn._abi.TSPN_EUNSUPPORTED
-    # just below the pair-stage limit nothing is refused on account of the size (T = 8000: 4.19 GB > 2^32?  no: 64 * 8000 *
-    # 2048 * 4 = 4 194 304 000 < 4 294 967 296), but then the pointers would have to be real: only the check is exercised
-    assert 64 * 8000 * 2048 * 4 < 2 ** 32 <= 64 * 8200 * 2048 * 4
+    assert 64 * 4000 * 2048 * 4 < 2 ** 31 <= 64 * 4200 * 2048 * 4
