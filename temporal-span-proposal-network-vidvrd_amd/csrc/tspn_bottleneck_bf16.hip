@@ -39,6 +39,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int THREADS = 256;
 constexpr int BN = 128;                 // pixels per workgroup
@@ -503,15 +504,25 @@ __global__ __launch_bounds__(THREADS, (NEXT ? 1 : (CM == 64 ? 3 : 2))) void bott
   // channels 16 kh + 0..15 of the block: 32 contiguous bytes per lane, 64 per pixel and lane pair, with no cross-lane
   // movement at all (round 3 first used v_permlane32_swap pairs for 8 consecutive channels per lane)
   const unsigned woff3 = (unsigned)((kh << 5) | (((li >> 2) & 1) << 4) | ((li >> 3) << 2) | (li & 3)) * 16;
+  // Every vector-memory access of this phase is a BUFFER instruction (round 4): an SGPR descriptor, the lane's fixed 32-bit
+  // offset in one VGPR and the wave-uniform part (row block, k-step, pixel block) as the scalar offset.  The pointer form
+  // made hipcc build a 64-bit address per lane for each of the 48 accesses of a sub-pass (119 v_lshl_add_u64 and
+  // `global_load_dwordx4 v[..], v[a:a+1], off` in the ISA) in a phase whose instruction stream, not its bytes, is what
+  // bounds it (profiles/r4/bottleneck_pipeline_study.md §8).  Pixels beyond the end get an out-of-range offset: their loads
+  // return zeros, their stores are dropped -- no branch around the stores.
+  const __amdgpu_buffer_rsrc_t rsrc_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Wf3), 0, C4 * CM * 2, 0x00020000);
+  // (NEXT sits at 510 of 512 registers and spills with the descriptors: it keeps the pointer form)
   const char* const w3base = reinterpret_cast<const char*>(Wf3) + woff3;
-  auto a_ptr = [&](int sp, int k, int ms) {         // fragment of k-step k, row block ms of sub-pass sp
-    return w3base + (int64_t)(sub_rb(sp) + ms) * (CCH * 4096) + k * 1024;
+  auto w3_load = [&](int sp, int k, int ms) {       // fragment of k-step k, row block ms of sub-pass sp
+    const int so = (sub_rb(sp) + ms) * (CCH * 4096) + k * 1024;
+    if constexpr (NEXT) return *reinterpret_cast<const f32x4*>(w3base + so);
+    else return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w3, (int)woff3, so, 0));
   };
   f32x4 ar[RING][MS];
 #pragma unroll
   for (int j = 0; j < RING; ++j)
 #pragma unroll
-    for (int ms = 0; ms < MS; ++ms) ar[j][ms] = *reinterpret_cast<const f32x4*>(a_ptr(j / KSTEPS, j % KSTEPS, ms));
+    for (int ms = 0; ms < MS; ++ms) ar[j][ms] = w3_load(j / KSTEPS, j % KSTEPS, ms);
   f32x16 accA[MS][NS], accB[MS][NS];
 
   // one k-step of sub-pass sp into `c`; refills the ring slot with the fragment RING k-steps ahead in the stream
@@ -532,7 +543,7 @@ __global__ __launch_bounds__(THREADS, (NEXT ? 1 : (CM == 64 ? 3 : 2))) void bott
     constexpr int dsp = (k + RING) / KSTEPS, kn = (k + RING) % KSTEPS;   // the fragment that takes this slot
     if ((int)sp + dsp < NSUB) {
 #pragma unroll
-      for (int ms = 0; ms < MS; ++ms) ar[slot][ms] = *reinterpret_cast<const f32x4*>(a_ptr((int)sp + dsp, kn, ms));
+      for (int ms = 0; ms < MS; ++ms) ar[slot][ms] = w3_load((int)sp + dsp, kn, ms);
     }
   };
   // epilogue: group grp = (nj, ms), ms fastest = one 32-row x 32-pixel accumulator block = 16 consecutive channels
@@ -551,8 +562,16 @@ __global__ __launch_bounds__(THREADS, (NEXT ? 1 : (CM == 64 ? 3 : 2))) void bott
   unsigned okmask = 0;                               // bit b: pixel li of pixel block b of this tile exists
 #pragma unroll
   for (int b = 0; b < 4; ++b) okmask |= (n0 + b * 32 + li < npix ? 1u : 0u) << b;
-  const unsigned voff_in = (unsigned)(li * C4 + 16 * kh) * 2, voff_out = (unsigned)(16 * kh) * 2;
-  auto row_base = [&](int sp, int grp) {             // uniform element offset of the group's rows
+  const unsigned voff_in = (unsigned)(li * C4 + 16 * kh) * 2;
+  constexpr unsigned OOB3 = 0x80000000u;
+  // descriptors based at the tile's first pixel; uniform byte offset of a group's rows inside the tile
+  const __amdgpu_buffer_rsrc_t rsrc_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(residual) + n0 * C4, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc(out + n0 * C4, 0, 0x7fffffff, 0x00020000);
+  auto row_soff = [&](int sp, int grp) {
+    const int ms = grp % MS, nj = grp / MS;
+    return ((sub_nb(sp) + nj) * 32 * C4 + 32 * (sub_rb(sp) + ms)) * 2;
+  };
+  auto row_base = [&](int sp, int grp) {             // (pointer form, NEXT) uniform element offset of the group's rows
     const int ms = grp % MS, nj = grp / MS;
     const int64_t pb = n0 + (sub_nb(sp) + nj) * 32;
     return (pb < npix ? pb : 0) * C4 + 32 * (sub_rb(sp) + ms);
@@ -567,9 +586,15 @@ __global__ __launch_bounds__(THREADS, (NEXT ? 1 : (CM == 64 ? 3 : 2))) void bott
     for (int j = 0; j < 8; ++j) rres[slot][0][j] = rres[slot][1][j] = (__bf16)0.f;
 #else
     const bool okp = (okmask >> (sub_nb(e) + grp / MS)) & 1u;
-    const char* rp = reinterpret_cast<const char*>(residual + row_base(e, grp)) + (okp ? voff_in : voff_out);
-    rres[slot][0] = *reinterpret_cast<const bf16x8*>(rp);
-    rres[slot][1] = *reinterpret_cast<const bf16x8*>(rp + 16);
+    if constexpr (NEXT) {
+      const char* rp = reinterpret_cast<const char*>(residual + row_base(e, grp)) + (okp ? voff_in : (unsigned)(16 * kh) * 2);
+      rres[slot][0] = *reinterpret_cast<const bf16x8*>(rp);
+      rres[slot][1] = *reinterpret_cast<const bf16x8*>(rp + 16);
+    } else {
+      const int vo = (int)(okp ? voff_in : OOB3), so = row_soff(e, grp);
+      rres[slot][0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_res, vo, so, 0));
+      rres[slot][1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_res, vo + 16, so, 0));
+    }
 #endif
   };
   // the group NRES after (e, grp) in the stream, if there is one
@@ -608,15 +633,20 @@ __global__ __launch_bounds__(THREADS, (NEXT ? 1 : (CM == 64 ? 3 : 2))) void bott
     if constexpr (h == 0) {
       ohold = o;
     } else {
-      const bool okp = (okmask >> (sub_nb(e) + nj)) & 1u;
-      char* op = reinterpret_cast<char*>(out + row_base(e, grp)) + voff_in;
+      bool okp = (okmask >> (sub_nb(e) + nj)) & 1u;
 #if defined(TSPN_BT_ABL_NOSTORE)    // probe build: results are computed but (almost) never stored
-      if (okp && o[0] == (__bf16)12345.f) {
-#else
-      if (okp) {
+      okp = okp && o[0] == (__bf16)12345.f;
 #endif
-        *reinterpret_cast<bf16x8*>(op) = ohold;
-        *reinterpret_cast<bf16x8*>(op + 16) = o;
+      if constexpr (NEXT) {
+        char* op = reinterpret_cast<char*>(out + row_base(e, grp)) + voff_in;
+        if (okp) {
+          *reinterpret_cast<bf16x8*>(op) = ohold;
+          *reinterpret_cast<bf16x8*>(op + 16) = o;
+        }
+      } else {
+        const int vo = (int)(okp ? voff_in : OOB3), so = row_soff(e, grp);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ohold), rsrc_out, vo, so, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rsrc_out, vo + 16, so, 0);
       }
       res_issue_ahead(e, std::integral_constant<int, grp>{});   // its ring slot is free now
     }
