@@ -1,10 +1,12 @@
 #!/bin/bash
 # Turn gpurun_out/prof4 (tools/profile_round4.sh) into the tracked summaries under profiles/r4/ (run in the build container).
+# gpurun merges a run's files into gpurun_out/ next to those of earlier runs: delete gpurun_out/prof4 before a new profile run (or
+# its files older than the run) -- the PMC summaries read every csv they find.
 set -e
 cd "$(dirname "$0")/.."
 O=gpurun_out/prof4
 for w in cfg2 cfg3 cfg5 backbone; do
-  f=$(find $O/stats_$w -name "*kernel_stats.csv" | head -1)
+  f=$(ls -t $(find $O/stats_$w -name "*kernel_stats.csv") | head -1)    # newest: gpurun MERGES into gpurun_out/, older runs' files stay
   n=bench_kernel_stats.csv; [ $w = cfg3 ] && n=bench_cfg3_kernel_stats.csv; [ $w = cfg5 ] && n=bench_cfg5_kernel_stats.csv; [ $w = backbone ] && n=backbone_kernel_stats.csv
   python tools/kernel_stats.py $f profiles/r4/$n > /dev/null
 done
