@@ -631,3 +631,28 @@ def test_bottleneck_tail_and_stem_random_shapes(tspn, device, seed):
     frag = tspn.ops.pack_stem_bf16(t(w).to(device))
     assert torch.equal(tspn.ops.stem_pool_bf16(t(x).to(device), frag, t(b).to(device)),
                        tspn.ops.max_pool_nhwc_bf16(y, 3, 2, 1)), (IH, IW, Cout)
+
+
+def test_bf16_convs_on_maps_beyond_two_gigabytes(tspn, device):
+    """The operand pieces, residual reads and stores of the bf16 conv kernels are buffer instructions with 32-bit offsets
+    from a per-tile base: a map of more than 2^31 bytes (76 res2 maps of 720p) must give, image by image, what the same
+    image gives alone -- first, middle and last image, the generic 1x1 conv and the fused tail."""
+    NB, H, W, C4, CM = 76, 180, 320, 256, 64
+    assert NB * H * W * C4 * 2 > 2 ** 31
+    g = torch.Generator(device=device).manual_seed(5)
+    one = lambda shape, s=1.0: ((torch.rand(shape, device=device, generator=g) - 0.5) * s).to(torch.bfloat16)
+    x = torch.empty((NB, H, W, C4), dtype=torch.bfloat16, device=device)
+    for lo in range(0, NB, 19):                                   # filled in slices: no 9-GB fp32 temporary
+        x[lo:lo + 19] = one((min(19, NB - lo), H, W, C4))
+    w1 = (torch.rand((CM, C4, 1, 1), device=device, generator=g) - 0.5) * 0.1
+    w2 = (torch.rand((CM, CM, 3, 3), device=device, generator=g) - 0.5) * 0.1
+    w3 = (torch.rand((C4, CM, 1, 1), device=device, generator=g) - 0.5) * 0.1
+    b1, b2, b3 = (torch.rand(n, device=device, generator=g) - 0.5 for n in (CM, CM, C4))
+    f1, f2, f3 = (tspn.ops.pack_conv2d_frag_bf16(w) for w in (w1, w2, w3))
+    h1 = tspn.ops.conv2d_nhwc_bf16(x, f1, (1, 1), 1, 0, bias=b1, relu=True)
+    y = tspn.ops.bottleneck_tail_bf16(h1, f2, b2, f3, b3, x)
+    for i in (0, NB // 2, NB - 1):
+        h1_i = tspn.ops.conv2d_nhwc_bf16(x[i:i + 1].contiguous(), f1, (1, 1), 1, 0, bias=b1, relu=True)
+        assert torch.equal(h1[i:i + 1], h1_i), i
+        y_i = tspn.ops.bottleneck_tail_bf16(h1_i, f2, b2, f3, b3, x[i:i + 1].contiguous())
+        assert torch.equal(y[i:i + 1], y_i), i
