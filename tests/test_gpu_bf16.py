@@ -453,3 +453,21 @@ def test_bf16_buffer_offset_limits_are_refused_not_wrapped(tspn, device):
     rc = lib.tspn_conv3_tc_bf16(p(s16), 1, 8, 16384, p(s16), 32768, None, p(small), 32768, 0)
     assert rc == tspn._abi.TSPN_EUNSUPPORTED
     assert 64 * 4000 * 2048 * 4 < 2 ** 31 <= 64 * 4200 * 2048 * 4
+
+
+def test_conv3_bf16_on_features_beyond_two_gigabytes(tspn, device):
+    """x pieces of conv3_bf16_big_kernel are buffer loads based at the tile's first column: on 2.2 GB of features every
+    tracklet still gives what it gives alone (first, middle, last)."""
+    B, T, Cin, M = 1200, 900, 1024, 256
+    assert B * T * Cin * 2 > 2 ** 31
+    g = torch.Generator(device=device).manual_seed(6)
+    x = torch.empty((B, T, Cin), dtype=torch.bfloat16, device=device)
+    for lo in range(0, B, 200):
+        x[lo:lo + 200] = (torch.rand((200, T, Cin), device=device, generator=g) - 0.5).to(torch.bfloat16)
+    w = (torch.rand((M, Cin, 3), device=device, generator=g) - 0.5) * 0.05
+    b = torch.rand(M, device=device, generator=g) - 0.5
+    packed = tspn.ops.pack_conv3_bf16(w)
+    y = tspn.ops.conv3_tc_bf16(x, packed, b)
+    assert tuple(y.shape) == (B, T, M)
+    for i in (0, B // 2, B - 1):
+        assert torch.equal(y[i:i + 1], tspn.ops.conv3_tc_bf16(x[i:i + 1].contiguous(), packed, b)), i
