@@ -586,9 +586,14 @@ class ScoringWorkload:
         self.model.profile_conv_events(self.events[i])
         pair_props, dur_props, rel_logits = self.model(plists, None)
         dec = self.model.decode(plists, rel_logits, topk_per_pair=TOPK_PAIR, topk_per_seg=TOPK_SEG)
-        sc, trip, tid = (torch.stack([d[k] for d in dec]) for k in range(3))
+        # the per-video results are slices of the batched tensors the decode / PPN launches wrote: batch them back as a
+        # view (torch.stack when they are not laid out that way) -- no copy kernels between the step's last launch and the gather
+        def batched(ts):
+            v = tspn.model._consecutive_view(ts)
+            return torch.stack(ts) if v is None else v.view((len(ts),) + tuple(ts[0].shape))
+        sc, trip, tid = (batched([d[k] for d in dec]) for k in range(3))
         self.geom = dur_props[0].geom
-        self.gather(sc, trip, tid, torch.stack(pair_props),
+        self.gather(sc, trip, tid, batched(list(pair_props)),
                     logits=torch.stack(rel_logits) if self.args.gather == "logits" else None)
 
     # -- ops level: caller-held packed weights, workspace and outputs
