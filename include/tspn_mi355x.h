@@ -217,6 +217,10 @@ size_t tspn_conv3_tc_wino63_workspace_bytes(int64_t B, int64_t T, int64_t Cin);
 int tspn_conv3_tc_wino63_f32(const float* x, int64_t B, int64_t T, int64_t Cin, const float* frag,
                              int64_t M, const float* bias, int relu, float* y,
                              void* workspace, size_t workspace_bytes, void* stream);
+/* How the MFMA kernel addresses the transformed input: 0 (default) = buffer loads with 32-bit offsets where the
+ * workspace is below 4 GB, 64-bit pointers above; 1 = pointers everywhere.  Both forms land the same bytes in LDS
+ * (tests compare them bit for bit).  Process-wide; returns the previous value, TSPN_EINVAL for any other `form`. */
+int tspn_conv3_tc_wino63_set_piece_form(int form);
 
 
 

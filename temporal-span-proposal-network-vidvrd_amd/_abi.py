@@ -132,6 +132,7 @@ PROTOTYPES = {
     "tspn_pack_conv3_wino63_frag_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "tspn_conv3_tc_wino63_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "tspn_conv3_tc_wino63_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _int, _vp, _vp, _sz, _vp]),
+    "tspn_conv3_tc_wino63_set_piece_form": (_int, [_int]),
     "tspn_span_predicate_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "tspn_span_predicate_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _sz, _vp]),
     "tspn_cast_bf16": (_int, [_vp, _i64, _vp, _vp]),

@@ -211,9 +211,6 @@ __global__ __launch_bounds__(G_THREADS, 1) void conv3_bf16_big_kernel(
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)l, 16, (int)voff, soff, 0, 0);
   };
   auto stage_chunk = [&](int st) {
-#if defined(TSPN_BF16_ABL_NODMA)
-    return;
-#endif
     char* sa = smem + st * G_ST;
 #pragma unroll
     for (int i = 0; i < 3; ++i) bglds16(rsrc_a, aoff[i], a_soff, sa + (wave * 3 + i) * 1024);
@@ -262,16 +259,6 @@ __global__ __launch_bounds__(G_THREADS, 1) void conv3_bf16_big_kernel(
   auto load_tap = [&](int st, int tap) {
     const char* Ab = smem + st * G_ST + (kh * G_BM + wm * 128 + li) * 16;
     const char* Xb = smem + st * G_ST + G_A_ST + (kh * G_SLP + wn * 64 + li) * 16;
-#if defined(TSPN_BF16_ABL_NOLDS)
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-      a[tap][mi] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)st, (unsigned)tap, (unsigned)mi, (unsigned)lane});
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-      b[tap][ni] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)lane, (unsigned)ni, (unsigned)tap, (unsigned)st});
-    (void)Ab; (void)Xb;
-    return;
-#endif
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
       a[tap][mi] = *reinterpret_cast<const bf16x8*>(Ab + (tap * R_KG * G_BM + mi * 32) * 16);
@@ -371,11 +358,7 @@ __global__ __launch_bounds__(G_THREADS, 1) void conv3_bf16_big_kernel(
         const int row = 2 * r + rsel;
         const f32x4 v = *reinterpret_cast<const f32x4*>(tw + row * 512 + ((unit ^ row) << 4)) + bv;
         const int64_t n = n0 + wn * 64 + ni * 32 + row;
-#if defined(TSPN_BF16_ABL_NOSTORE)
-        if (n < ncols && mcol < M && v[0] == 12345.678f)
-#else
         if (n < ncols && mcol < M)
-#endif
           *reinterpret_cast<f32x4*>(y + n * (int64_t)ldm + mcol) = v;
       }
     }
@@ -470,9 +453,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void heads_pairgrid_bf16_
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Whp), 0, C * 32, 0x00020000);
   int y_soff = 0, w_soff = 0;
   auto stage = [&](int buf) {
-#if defined(TSPN_HPB_ABL_NODMA)
-    return;
-#endif
     char* dst = smem + buf * ST + wave * 4 * HP_ROW;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -538,25 +518,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void heads_pairgrid_bf16_
       const f32x4 v0 = vq[o % 3][0], v1 = vq[o % 3][1];
 #pragma unroll
       for (int s = 0; s < SW; ++s) {
-#if defined(TSPN_HPB_ABL_NOVALU)
-        u32x4 pk = {__builtin_bit_cast(unsigned, u[s][0][0]) ^ __builtin_bit_cast(unsigned, v0[0]),
-                    __builtin_bit_cast(unsigned, u[s][0][1]) ^ __builtin_bit_cast(unsigned, v0[2]),
-                    __builtin_bit_cast(unsigned, u[s][1][0]) ^ __builtin_bit_cast(unsigned, v1[1]),
-                    __builtin_bit_cast(unsigned, u[s][1][1]) ^ __builtin_bit_cast(unsigned, v1[3])};
-#else
-#if defined(TSPN_HPB_SCALAR_ADD)   // probe: eight v_add_f32 instead of four v_pk_add_f32
-        f32x4 a0, a1;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          asm("v_add_f32 %0, %1, %2" : "=v"(a0[e]) : "v"(u[s][0][e]), "v"(v0[e]));
-          asm("v_add_f32 %0, %1, %2" : "=v"(a1[e]) : "v"(u[s][1][e]), "v"(v1[e]));
-        }
-#else
         const f32x4 a0 = u[s][0] + v0, a1 = u[s][1] + v1;
-#endif
         u32x4 pk = {relu_pack(a0[0], a0[1]), relu_pack(a0[2], a0[3]), relu_pack(a1[0], a1[1]),
                     relu_pack(a1[2], a1[3])};
-#endif
         acc[s][o] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag, __builtin_bit_cast(bf16x8, pk),
                                                              acc[s][o], 0, 0, 0);
       }

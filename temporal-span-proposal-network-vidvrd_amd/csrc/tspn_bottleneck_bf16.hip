@@ -53,11 +53,7 @@ __device__ __forceinline__ void load_wfrag(f32x4& dst, unsigned lane_off, const 
 }
 template <int VM>
 __device__ __forceinline__ void wait_w(f32x4& r0, f32x4& r1) {
-#if defined(TSPN_BT_ABL_NOWAIT)     // probe build: no counted waits in phase 2
-  asm volatile("" : "+v"(r0), "+v"(r1));
-#else
   asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r0), "+v"(r1) : "n"(VM));
-#endif
 }
 // NEXT (CM = 256, round 4): the kernel also computes conv1 of the FOLLOWING block on its own output tile,
 //     h1n = relu(W1n . out + b1n)        1x1, K = 4 CM = 1024 -> CM rows,
@@ -149,13 +145,8 @@ __global__ __launch_bounds__(THREADS, (NEXT ? 1 : (CM == 64 ? 3 : 2))) void bott
 
   f32x4 a[4][MI];      // weight fragments of the four k-steps of a chunk
   auto read_b = [&](const char* Bb, int g2, bf16x8 (&b)[NI]) {   // fragments of channel groups g2 + kh of NI pixel blocks
-#if defined(TSPN_BT_ABL_NOB)        // probe build: no LDS fragment reads in phase 2 (registers keep whatever they hold)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) asm volatile("" : "+v"(b[ni]));
-#else
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const bf16x8*>(Bb + (g2 * SLP + ni * 32) * 16);
-#endif
   };
   auto mfma_step = [&](f32x16 (&c)[MI][NI], const f32x4 (&aw)[MI], const bf16x8 (&b)[NI]) {
 #pragma unroll
@@ -167,22 +158,16 @@ __global__ __launch_bounds__(THREADS, (NEXT ? 1 : (CM == 64 ? 3 : 2))) void bott
   };
   auto load_step = [&](auto ks_tag) {
     constexpr int KS = decltype(ks_tag)::value;
-#if defined(TSPN_BT_ABL_NOLOAD)     // probe build: the weight registers keep what the prologue loaded
-    (void)KS;
-#else
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) load_wfrag<1024 * KS>(a[KS][mi], woff, wbase[mi]);
-#endif
   };
   using K0 = std::integral_constant<int, 0>;
   using K1 = std::integral_constant<int, 1>;
   using K2 = std::integral_constant<int, 2>;
   using K3 = std::integral_constant<int, 3>;
   auto bump = [&]() {
-#if !defined(TSPN_BT_ABL_NOBUMP)    // probe build: every chunk loads the first chunk's weights (L1-hot)
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) wbase[mi] += 4096;
-#endif
   };
 
 #ifndef TSPN_BT_ONCE_MAX
@@ -216,9 +201,6 @@ __global__ __launch_bounds__(THREADS, (NEXT ? 1 : (CM == 64 ? 3 : 2))) void bott
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) rmask[ni] = tap_mask(n0 + ni * 32 + li);
     auto stage_r = [&](int buf, int i) {                     // range i = 3 c + ra: four pieces per wave (+ one: wave 0)
-#if defined(TSPN_BT_ABL_NODMA)      // probe build: no x DMA in the loop at all
-      if (i >= DIST) return;
-#endif
       const int c = i / 3, ra = i - 3 * c;
       const int soff = c * KC * 2;
       const int64_t q = n0 + (int64_t)(ra - 1) * W - 1 + slot;
@@ -243,11 +225,6 @@ __global__ __launch_bounds__(THREADS, (NEXT ? 1 : (CM == 64 ? 3 : 2))) void bott
 
     // fragment of channel groups g2 + kh of the NI pixel blocks at slot offset rb of a stage, masked by tap 3 ra + rb
     auto read_r = [&](int buf, int tap, int rb, int g2, bf16x8 (&b)[NI]) {
-#if defined(TSPN_BT_ABL_NOB)        // probe build: no LDS fragment reads in phase 2
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) asm volatile("" : "+v"(b[ni]));
-      (void)buf; (void)tap; (void)rb; (void)g2;
-#else
       const char* Bb = Bs + buf * B_ST + ((g2 + kh) * SLP + li + rb) * 16;
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
@@ -256,7 +233,6 @@ __global__ __launch_bounds__(THREADS, (NEXT ? 1 : (CM == 64 ? 3 : 2))) void bott
         if (!((rmask[ni] >> tap) & 1u)) bp = zslot;          // the tap falls off the image: read zeros
         b[ni] = *reinterpret_cast<const bf16x8*>(bp);
       }
-#endif
     };
     // one round = the four k-steps of tap (ra, rb) of range i.  VMEM issue order as in the tap ring: [range i + DIST:
     // 4 pieces, first round only] a0' | a1' | a2' | a3' (MI loads each, the weights four k-steps ahead); counts =
@@ -458,9 +434,6 @@ __global__ __launch_bounds__(THREADS, (NEXT ? 1 : (CM == 64 ? 3 : 2))) void bott
       }
     }
   __syncthreads();
-#if defined(TSPN_BT_ABL_NOP3)       // probe build: phase 2 + h2 only
-  if (npix >= 0) return;
-#endif
 
   // ---------------------------------------------------------------- phase 3: 1x1 expand, K = CM, software-pipelined
   // Eight sub-passes per wave, each a [32 MS rows x 32 NS pixels] accumulator set (half of what the wave owns in a pass
@@ -580,11 +553,6 @@ __global__ __launch_bounds__(THREADS, (NEXT ? 1 : (CM == 64 ? 3 : 2))) void bott
   auto res_issue = [&](auto e, auto grp_tag) {
     constexpr int grp = decltype(grp_tag)::value;
     constexpr int slot = (cval(decltype(e){}) * NGRP + grp) % NRES;
-#if defined(TSPN_BT_ABL_NORES)      // probe build: no residual traffic
-    (void)e;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) rres[slot][0][j] = rres[slot][1][j] = (__bf16)0.f;
-#else
     const bool okp = (okmask >> (sub_nb(e) + grp / MS)) & 1u;
     if constexpr (NEXT) {
       const char* rp = reinterpret_cast<const char*>(residual + row_base(e, grp)) + (okp ? voff_in : (unsigned)(16 * kh) * 2);
@@ -595,7 +563,6 @@ __global__ __launch_bounds__(THREADS, (NEXT ? 1 : (CM == 64 ? 3 : 2))) void bott
       rres[slot][0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_res, vo, so, 0));
       rres[slot][1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_res, vo + 16, so, 0));
     }
-#endif
   };
   // the group NRES after (e, grp) in the stream, if there is one
   auto res_issue_ahead = [&](auto e, auto grp_tag) {
@@ -609,11 +576,7 @@ __global__ __launch_bounds__(THREADS, (NEXT ? 1 : (CM == 64 ? 3 : 2))) void bott
     constexpr int slot = (cval(decltype(e){}) * NGRP + grp) % NRES;
     const int chm = 32 * (sub_rb(e) + ms) + 16 * kh + 8 * h;
     // (NEXT is at 510 of 512 registers: the two LDS addresses spill it; it keeps the loads from global memory)
-#if defined(TSPN_BT_BIAS_GLOBAL)    // probe build: b3 from global memory inside the epilogue (round 3)
-    constexpr bool BIAS_GLOBAL = true;
-#else
     constexpr bool BIAS_GLOBAL = NEXT;
-#endif
     const float4 bv0 = BIAS_GLOBAL ? *reinterpret_cast<const float4*>(bias3 + chm)
                             : *reinterpret_cast<const float4*>(Bs + BIAS_OFF + 4 * chm);
     const float4 bv1 = BIAS_GLOBAL ? *reinterpret_cast<const float4*>(bias3 + chm + 4)
@@ -634,9 +597,6 @@ __global__ __launch_bounds__(THREADS, (NEXT ? 1 : (CM == 64 ? 3 : 2))) void bott
       ohold = o;
     } else {
       bool okp = (okmask >> (sub_nb(e) + nj)) & 1u;
-#if defined(TSPN_BT_ABL_NOSTORE)    // probe build: results are computed but (almost) never stored
-      okp = okp && o[0] == (__bf16)12345.f;
-#endif
       if constexpr (NEXT) {
         char* op = reinterpret_cast<char*>(out + row_base(e, grp)) + voff_in;
         if (okp) {

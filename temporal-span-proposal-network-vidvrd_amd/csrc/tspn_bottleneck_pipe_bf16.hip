@@ -110,11 +110,6 @@ __device__ __forceinline__ void team_a(const __bf16* __restrict__ h1, const __bf
   const int iters = (ntiles - (int)blockIdx.x + G - 1) / G;      // tiles of this workgroup
   unsigned epoch = 0;                                      // 4 x (ring barriers passed)
   for (int it = 0; it < iters; ++it) {
-#if defined(TSPN_BP_ONLY_B)         // probe build: phase 3 alone (on whatever the h2 image holds)
-    lds_wait_ge(Bs, SYNC_OFF + 8, 4u * it);
-    lds_add1(Bs, SYNC_OFF + 4, lane_in);
-    continue;
-#endif
     // everything derived from the lane / wave number is recomputed per tile from an opaque copy: hoisted out of the
     // tile loop these values stay live across the whole tile and the 254-register body spills (140 registers)
     int lane = lane_in, w4 = w4_in;
@@ -302,11 +297,6 @@ __device__ __forceinline__ void team_b(const __bf16* __restrict__ Wf3, const flo
   const int G = gridDim.x;
   const int iters = (ntiles - (int)blockIdx.x + G - 1) / G;
   for (int it = 0; it < iters; ++it) {
-#if defined(TSPN_BP_ONLY_A)         // probe build: phase 2 alone
-    lds_wait_ge(Bs, SYNC_OFF + 4, 4u * (it + 1));
-    lds_add1(Bs, SYNC_OFF + 8, lane_in);
-    continue;
-#endif
     int lane = lane_in, w4 = w4_in;                        // opaque per tile: see team_a
     asm volatile("" : "+v"(lane));
     asm volatile("" : "+s"(w4));

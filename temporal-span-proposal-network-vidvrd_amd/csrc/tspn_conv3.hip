@@ -130,12 +130,6 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_mfma_kernel(
   // ds_write two chunks later: any use here would make the wave wait for the load at once.
   auto load_chunk = [&](auto set_tag, int c0) {
     constexpr int S = decltype(set_tag)::value;
-#if defined(TSPN_ABLATE_NOLOAD)
-    if (c0 > 0) return;  // diagnostic build
-#endif
-#if defined(TSPN_ABLATE_HOTLOAD)
-    c0 = c0 & 16;  // diagnostic build: always re-read chunks 0/1 (cache-hot), same instruction stream
-#endif
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
       const int row = (tid >> 5) + r * 8;  // 0..47 = tap*KC + ci
@@ -166,14 +160,6 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_mfma_kernel(
   // (a zero A row kills the product); columns past the tensor are zeroed on the x side.
   auto store_chunk = [&](auto set_tag, int c0) {  // set S -> LDS buffer S
     constexpr int S = decltype(set_tag)::value;
-#if defined(TSPN_ABLATE_NOSTORE)
-    if (c0 > 0) {  // diagnostic build: consume the registers, write nothing
-      for (int r = 0; r < 6; ++r) asm volatile("" ::"v"(a_reg[S][r].x), "v"(a_reg[S][r].y), "v"(a_reg[S][r].z), "v"(a_reg[S][r].w));
-      for (int r = 0; r < 8; ++r) asm volatile("" ::"v"(b_reg[S][r]));
-      asm volatile("" ::"v"(h_reg[S]));
-      return;
-    }
-#endif
     float* Ab = As + S * A_STAGE;
     float* Bb = Bs + S * B_STAGE;
 #pragma unroll
@@ -223,12 +209,6 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_mfma_kernel(
   };
   auto read_frag = [&](const float* Ab, const float* Bb, int kk) {
     Frag f;
-#if defined(TSPN_ABLATE_NOLDS)
-    for (int tap = 0; tap < 3; ++tap) { f.a[tap][0] = 1.f + kk; f.a[tap][1] = 2.f; }
-    for (int ni = 0; ni < 2; ++ni) for (int j = 0; j < 3; ++j) f.b[ni][j] = 0.5f * kh;
-    asm volatile("" : "+v"(f.a[0][0]), "+v"(f.b[0][0]));
-    return f;
-#endif
     const int k = 2 * kk + kh;
 #pragma unroll
     for (int tap = 0; tap < 3; ++tap) {
@@ -284,17 +264,13 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_mfma_kernel(
       }
       __builtin_amdgcn_sched_barrier(0);
       if (kk == STORE_AT) {
-#if !defined(TSPN_ABLATE_NOGLOBAL)
         // LDS buffer NEXT has been free since the barrier that ended chunk c-1.
         if (c + 1 < nchunks) store_chunk(next_tag, (c + 1) * KC);
         if (c + 3 < nchunks) load_chunk(next_tag, (c + 3) * KC);
-#endif
       }
       cur = nxt;
     }
-#if !defined(TSPN_ABLATE_NOBARRIER)
     __syncthreads();
-#endif
   };
   for (int c = 0; c < nchunks; c += 2) {
     chunk_body(Set1{}, c);
@@ -426,28 +402,15 @@ __global__ __launch_bounds__(THREADS, (KCD == 8 ? 4 : 2)) void conv3_mfma_dma_ke
   constexpr int NDMA = RA / 2 + 2 * RB;
   auto stage_one = [&](int buf, auto d_tag) {
     constexpr int d = decltype(d_tag)::value;
-#if defined(TSPN_ABLATE_NODMA)
-    return;
-#endif
-#if defined(TSPN_ABLATE_NODMA_A)
-    if (d < RA / 2) return;
-#endif
-#if defined(TSPN_ABLATE_NODMA_B)
-    if (d >= RA / 2) return;
-#endif
     if constexpr (d < RA / 2) {
       glds16(asrc[d], As + buf * A_ST + (wave * RA + 2 * d) * BM);
-#if !defined(TSPN_ABLATE_HOTDMA)
       asrc[d] += a_step;
-#endif
     } else if constexpr (d < NDMA) {
       constexpr int r = (d - RA / 2) >> 1, h = (d - RA / 2) & 1;
       glds4(bsrc[h] + (int64_t)r * T, Bs + buf * B_ST + (wave * RB + r) * BNP + 1 + 64 * h);
       if constexpr (d == NDMA - 1) {
-#if !defined(TSPN_ABLATE_HOTDMA)
         bsrc[0] += b_step;
         bsrc[1] += b_step;
-#endif
       }
     }
   };
@@ -491,12 +454,6 @@ __global__ __launch_bounds__(THREADS, (KCD == 8 ? 4 : 2)) void conv3_mfma_dma_ke
   };
   auto read_frag = [&](const float* Ab, const float* Bb, int kk) {
     Frag f;
-#if defined(TSPN_ABLATE_NOLDS)
-    for (int tap = 0; tap < 3; ++tap) { f.a[tap][0] = 1.f + kk; f.a[tap][1] = 2.f; }
-    for (int ni = 0; ni < 2; ++ni) for (int j = 0; j < 3; ++j) f.b[ni][j] = 0.5f * kh;
-    asm volatile("" : "+v"(f.a[0][0]), "+v"(f.b[0][0]));
-    return f;
-#endif
     const int k = 2 * kk + kh;
 #pragma unroll
     for (int tap = 0; tap < 3; ++tap) {
@@ -535,10 +492,6 @@ __global__ __launch_bounds__(THREADS, (KCD == 8 ? 4 : 2)) void conv3_mfma_dma_ke
     for (int kk = 0; kk < KSTEPS; ++kk) {
       Frag nxt = cur;
       if (kk + 1 < KSTEPS) nxt = read_frag(Ab, Bb, kk + 1);
-#if defined(TSPN_SCHED_PINNED)
-      // next k-step's LDS reads are issued before this step's 12 MFMAs (768 cycles of cover)
-      __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
       for (int tap = 0; tap < 3; ++tap) {
         float b0 = cur.b[0][tap], b1 = cur.b[1][tap];
@@ -554,9 +507,6 @@ __global__ __launch_bounds__(THREADS, (KCD == 8 ? 4 : 2)) void conv3_mfma_dma_ke
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[tap][1], b0, acc[1][0], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[tap][1], b1, acc[1][1], 0, 0, 0);
         if (MORE) {
-#if defined(TSPN_SCHED_PINNED)
-          __builtin_amdgcn_sched_barrier(0);
-#endif
           if (kk == 0 && tap == 0) stage_one(buf ^ 1, std::integral_constant<int, 0>{});
           if (kk == 0 && tap == 1) stage_one(buf ^ 1, std::integral_constant<int, 1>{});
           if (kk == 0 && tap == 2) stage_one(buf ^ 1, std::integral_constant<int, 2>{});
@@ -573,7 +523,6 @@ __global__ __launch_bounds__(THREADS, (KCD == 8 ? 4 : 2)) void conv3_mfma_dma_ke
           if (KSTEPS > 4 && kk == 4 && tap == 1) stage_one(buf ^ 1, std::integral_constant<int, 13>{});
         }
       }
-#if !defined(TSPN_SCHED_PINNED)
       // Issue pattern for the k-step (measured +2.5 % over issuing the reads as one burst ahead of
       // the MFMAs): after each MFMA one LDS read of the NEXT k-step, one VALU (mask / address)
       // and, every fourth group, one LDS-DMA piece issue in the shadow of that MFMA's 64 cycles.
@@ -586,15 +535,12 @@ __global__ __launch_bounds__(THREADS, (KCD == 8 ? 4 : 2)) void conv3_mfma_dma_ke
       TSPN_G(1, 0) TSPN_G(1, 0) TSPN_G(1, 0) TSPN_G(1, 1)
       TSPN_G(1, 0) TSPN_G(1, 0) TSPN_G(1, 0) TSPN_G(1, 1)
 #undef TSPN_G
-#endif
       __builtin_amdgcn_sched_barrier(0);
       cur = nxt;
     }
     if (MORE && tid < 2 * KCD) Bs[(buf ^ 1) * B_ST + hrow * BNP + hslot] = hvalid ? h_reg : 0.f;
-#if !defined(TSPN_ABLATE_NOBARRIER)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed before the barrier publishes them
     __syncthreads();
-#endif
   };
   for (int c = 0; c + 1 < nchunks; ++c) chunk_body(c & 1, std::true_type{});
   chunk_body((nchunks - 1) & 1, std::false_type{});

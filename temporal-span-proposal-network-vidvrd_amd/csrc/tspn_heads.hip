@@ -249,9 +249,7 @@ __global__ __launch_bounds__(256, 2) void heads_pairgrid_kernel(
   for (int c = 0; c < nchunks; ++c) {
     const int buf = c & 1;
     const int c0 = c * PG_CK;
-#if !defined(TSPN_ABLATE_NOSTAGE)
     if (c + 1 < nchunks) load_chunk(c0 + PG_CK);
-#endif
     const float* Sb = S + buf * PG_STAGE + 2 * j;
 #pragma unroll
     for (int ks = 0; ks < PG_CK / 4; ++ks) {
@@ -269,23 +267,17 @@ __global__ __launch_bounds__(256, 2) void heads_pairgrid_kernel(
       for (int si = 0; si < 2; ++si)
 #pragma unroll
         for (int oj = 0; oj < PG_O; ++oj) {
-#if defined(TSPN_ABLATE_NOVALU)
-          const float h0 = v[oj].x, h1 = u[si].y;
-#else
           const float h0 = fmaxf(u[si].x + v[oj].x, 0.f);
           const float h1 = fmaxf(u[si].y + v[oj].y, 0.f);
-#endif
           acc[si][oj][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, h0, acc[si][oj][0], 0, 0, 0);
           acc[si][oj][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, h1, acc[si][oj][1], 0, 0, 0);
         }
     }
-#if !defined(TSPN_ABLATE_NOSTAGE)
     if (c + 1 < nchunks) {
       store_chunk(buf ^ 1);
 #pragma unroll
       for (int ks = 0; ks < PG_CK / 4; ++ks) wa[ks] = wreg[ks];
     }
-#endif
     __syncthreads();
   }
 

@@ -177,7 +177,6 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_nhwc_kernel(
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[1][e], b0, acc[1][0], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[1][e], b1, acc[1][1], 0, 0, 0);
       }
-#if !defined(TSPN_CONV2D_NOINTERLEAVE)
 #define TSPN_G(NVM)                                     \
   __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    \
   __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    \
@@ -187,7 +186,6 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_nhwc_kernel(
       else { TSPN_G(0) TSPN_G(0) TSPN_G(0) TSPN_G(0) TSPN_G(0) TSPN_G(0) TSPN_G(0) TSPN_G(0) }
 #undef TSPN_G
       __builtin_amdgcn_sched_barrier(0);
-#endif
       cur = nxt;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed before the barrier publishes them

@@ -369,35 +369,6 @@ __global__ __launch_bounds__(THREADS, (MI == 1 ? TSPN_ROI_BF16_MI1_WAVES : 2)) v
   // through the now idle stage memory -- fp32 (acc + bias), rows padded by 16 bytes: conflict-free 16-byte
   // writes -- and every lane then handles 8 consecutive channels of a pixel: residual read, ReLU, the single
   // rounding to bf16 and the store are 16 bytes per lane, whole 64 MI-byte row segments per pixel.
-#if defined(TSPN_CONV2D_BF16_DIRECT_EPILOGUE)
-#pragma unroll
-  for (int ni = 0; ni < 4; ++ni) {
-    const int64_t n = n0 + ni * 32 + li;
-    if (n >= npix) continue;
-    __bf16* orow = out + n * Cout;
-    const __bf16* rrow = residual ? residual + n * Cout : nullptr;
-#pragma unroll
-    for (int mq = 0; mq < 4 * MI; ++mq) {
-      const int mi = mq >> 2, q = mq & 3;
-      const int m = m0 + (MI * wave + mi) * 32 + 8 * q + 4 * kh;
-      if (m >= Cout) continue;
-      float v[4] = {acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
-      if (bias) {
-        const float4 bv = *reinterpret_cast<const float4*>(bias + m);
-        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-      }
-      if (rrow) {
-        const bf16x4 rv = *reinterpret_cast<const bf16x4*>(rrow + m);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] += (float)rv[k];
-      }
-      bf16x4 o;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) o[k] = (__bf16)(relu ? fmaxf(v[k], 0.f) : v[k]);
-      *reinterpret_cast<bf16x4*>(orow + m) = o;
-    }
-  }
-#else
   {
     constexpr int CW = 32 * MI;                 // channels of this wave
     constexpr int PITCH = CW + 4;               // floats per pixel row in LDS (16 bytes of padding)
@@ -462,7 +433,6 @@ __global__ __launch_bounds__(THREADS, (MI == 1 ? TSPN_ROI_BF16_MI1_WAVES : 2)) v
       }
     }
   }
-#endif
 }
 
 }  // namespace
@@ -502,6 +472,12 @@ extern "C" int tspn_conv2d_nhwc_bf16(const uint16_t* x, int64_t NB, int64_t H, i
   TSPN_REQUIRE(H < (1 << 20) && W < (1 << 20) && Cin < (1 << 24) && Cout < (1 << 24), TSPN_EUNSUPPORTED,
                "tspn_conv2d_nhwc_bf16: dimension too large");
   const int64_t npix = NB * OH * OW;
+  // x goes out as buffer loads: 32-bit byte offsets from the first pixel of the image the tile starts in, num_records
+  // 2^31 - 1 (an offset beyond it would read as padding zeros: silently wrong).  A 128-pixel tile spans at most
+  // 127 / (OH OW) + 2 images, a tap reaches KH rows further.
+  TSPN_REQUIRE(((int64_t)(BN - 1) / (OH * OW) + 2) * H * W * Cin * 2 + KH * W * Cin * 2 < (1LL << 31), TSPN_EUNSUPPORTED,
+               "tspn_conv2d_nhwc_bf16: the images one 128-pixel tile spans must stay below 2 GB (H=%lld W=%lld Cin=%lld)",
+               (long long)H, (long long)W, (long long)Cin);
   // 64 rows per wave where Cout allows — except the 1x1 layers with K <= 256 (res2 - res4 expand convs): four K
   // chunks of MFMAs between a 64 KB operand prologue and a residual + store epilogue are latency-bound, and
   // the 32-row form at three workgroups per CU hides more of it (backbone conv time 8.59 -> 8.12 ms per 16

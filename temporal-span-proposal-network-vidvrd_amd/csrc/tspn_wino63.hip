@@ -33,7 +33,7 @@
 // V registers from S + 1, and the pieces of S + 2 go into the buffer S left during the first chunk of S + 1.
 // Needs Cin % 32 == 0 and M % 32 == 0.
 #include <algorithm>
-#include <cstdlib>
+#include <atomic>
 #include <type_traits>
 
 #include "tspn_common.h"
@@ -223,22 +223,14 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
   const __amdgpu_buffer_rsrc_t rsrc_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Vg), 0, (int)0xffffffffu, 0x00020000);
   const unsigned super_bytes = (unsigned)(super_step * 4);
   auto stage_piece = [&](int S, int k) {          // piece k of this wave, super-stage S -> ring buffer S & 1
-#if !defined(TSPN_W63_ABL_NODMA)
     if constexpr (BUFV) {
-#if defined(TSPN_W63_PROBE_HOTV)
-      const int soff = 0;
-#else
       const int soff = (int)((unsigned)S * super_bytes);
-#endif
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_v, (__attribute__((address_space(3))) void*)(Vs + (S & 1) * VSS + (NPIECE * wave + k) * 256),
                                                16, (int)voff[k], soff, 0, 0);
     } else {
       glds16(vsrc[k], Vs + (S & 1) * VSS + (NPIECE * wave + k) * 256);
     }
-#endif
-#if !defined(TSPN_W63_PROBE_HOTV)
     if constexpr (!BUFV) vsrc[k] += super_step;
-#endif
   };
 
   f32x16 acc[2][NJ];
@@ -335,9 +327,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
     mfma_pair(ap, 6, 7, S1, 3);
     if (HAS2) {
       load_a_pair(ap, P3{}, abase);
-#if !defined(TSPN_W63_PROBE_HOTA)
       abase += NJ * 1024;
-#endif
     }
     if (HAS1) { load_v(vn, NCL, 6); load_v(vn, NCL, 7); }
     __builtin_amdgcn_sched_barrier(0);
@@ -346,9 +336,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
       // S + 1 (in-order VMEM return): this wave's pieces have landed; the reads above (V of chunk 4 S + 3) were the last
       // ones of buffer S & 1; the next chunk refills v from buffer S + 1
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#if !defined(TSPN_W63_ABL_NOBAR)
       __builtin_amdgcn_s_barrier();
-#endif
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -486,6 +474,9 @@ int tspn::wino63_input_transform(const float* x, int64_t B, int64_t T, int64_t C
   return tspn::check_launch(what);
 }
 
+// 0 = buffer-load V pieces where the workspace allows (default), 1 = 64-bit pointer pieces everywhere
+static std::atomic<int> g_piece_form{0};
+
 // step 2: the MFMA kernel on the transformed input
 int tspn::wino63_contract(const void* workspace, int64_t B, int64_t T, int64_t Cin, const float* frag, int64_t M,
                           const float* bias, int relu, float* y, int64_t ldy, void* stream) {
@@ -504,10 +495,9 @@ int tspn::wino63_contract(const void* workspace, int64_t B, int64_t T, int64_t C
 #ifndef TSPN_WINO63_BUFV
 #define TSPN_WINO63_BUFV 1
 #endif
-  // (TSPN_WINO63_PTRV=1 in the environment forces the pointer form: tests compare the two)
-  const char* const ptrv_env = getenv("TSPN_WINO63_PTRV");
+  // (tspn_conv3_tc_wino63_set_piece_form(1) forces the pointer form: tests compare the two)
   const bool bufv = TSPN_WINO63_BUFV && tspn::wino63_workspace_bytes(B, T, Cin) < (1ull << 32) &&   /* offsets are unsigned 32-bit */
-                    !(ptrv_env && ptrv_env[0] == '1');
+                    g_piece_form.load(std::memory_order_relaxed) == 0;
   static tspn::LdsLimit lds[2];   // 128 KB of dynamic LDS: above the 64 KB default limit
   auto launch = [&](auto kern, tspn::LdsLimit& lim) {
     if (int rc = lim.ensure(reinterpret_cast<const void*>(kern), SMEM_BYTES, what)) return rc;
@@ -525,6 +515,11 @@ int tspn::conv3_tc_wino63(const float* x, int64_t B, int64_t T, int64_t Cin, con
   if (int rc = check_common("tspn_conv3_tc_wino63_f32", B, T, Cin, M, ldy)) return rc;
   if (int rc = tspn::wino63_input_transform(x, B, T, Cin, workspace, workspace_bytes, stream)) return rc;
   return tspn::wino63_contract(workspace, B, T, Cin, frag, M, bias, relu, y, ldy, stream);
+}
+
+extern "C" int tspn_conv3_tc_wino63_set_piece_form(int form) {
+  TSPN_REQUIRE(form == 0 || form == 1, TSPN_EINVAL, "tspn_conv3_tc_wino63_set_piece_form: form must be 0 or 1");
+  return g_piece_form.exchange(form, std::memory_order_relaxed);
 }
 
 extern "C" int tspn_conv3_tc_wino63_f32(const float* x, int64_t B, int64_t T, int64_t Cin, const float* frag,

@@ -275,8 +275,13 @@ class DevicePrefetcher:
             if obj.is_cuda:
                 out.append(obj)
         elif hasattr(obj, "extra_fields"):
-            self._device_tensors(getattr(obj, obj._primary) if hasattr(obj, "_primary") else None, out)
-            self._device_tensors(list(obj.extra_fields.values()), out)
+            if hasattr(obj, "_primary"):
+                self._device_tensors(getattr(obj, obj._primary), out)
+                self._device_tensors(list(obj.extra_fields.values()), out)
+            else:
+                # the reference's own list types (lib/dataset/list_pair.py:3-31): the primary tensor sits under an
+                # attribute name this package does not know -- take every attribute (extra_fields included)
+                self._device_tensors(list(vars(obj).values()), out)
         elif isinstance(obj, (list, tuple)):
             for v in obj:
                 self._device_tensors(v, out)

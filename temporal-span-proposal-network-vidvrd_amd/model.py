@@ -166,6 +166,15 @@ class _DeviceCache:
 def _nt(a, b, bias=None, sigmoid=False):
     """a [M,K] . b [N,K]^T (+ bias [N]) on the HIP split-K MFMA GEMM of the predicate head (tspn_predicate_head_f32): the
     one GEMM form the library has, so every product of the training step is brought to it with HIP transposes."""
+    m, k = a.shape
+    n = b.shape[0]
+    if m == 0 or n == 0 or k == 0:
+        # an empty product (no sampled pairs / an empty batch): the sum over nothing is zero -- the C entry refuses
+        # zero-length contractions, the reference's torch.mm / einsum return zeros (and zero gradients) here
+        out = torch.zeros((m, n), dtype=torch.float32, device=a.device)
+        if bias is not None:
+            out = out + bias
+        return torch.sigmoid(out) if sigmoid else out
     return ops.predicate_head(a.contiguous(), b.contiguous(), None if bias is None else bias.contiguous(), apply_sigmoid=sigmoid)
 
 
@@ -720,6 +729,10 @@ class _HostPipeline:
                 self.h2d_done.synchronize()        # the previous forward's DMAs out of the staging buffer are done
         if self.compute_done is not None:
             self.h2d.wait_event(self.compute_done)  # ... and its passes no longer read the device buffer
+        # dev_buf comes out of the CALLER stream's pool: a freshly handed-out block may still be in use by kernels
+        # queued on that stream (the allocator only orders reuse within one stream), and the first write into it is a
+        # DMA on h2d -- so the copy stream starts behind everything the caller has queued so far
+        self.h2d.wait_stream(torch.cuda.current_stream(self.dev))
         return self.dst
 
     def stage(self, lo, hi):
@@ -1092,6 +1105,9 @@ class BaseModel(_CachedWeightsMixin, nn.Module):
         want_geom = self.pair_geometry_in_forward and all(
             pair_list[i].has_field("tracklet_boxes") and pair_list[i].get_field("tracklet_boxes") is not None for i in members)
         geom_host = torch.empty((nm * per, 8, t), dtype=torch.float32, pin_memory=True) if want_geom else None
+        # like heads_dev / lg_dev: lives until finish() has synchronised the download stream (a per-chunk temporary
+        # would go back to the caller stream's pool while d2h still reads it)
+        geom_dev = torch.empty((nm * per, 8, t), dtype=torch.float32, device=dev) if want_geom else None
         cmax = max(hi - lo for lo, hi in chunks)
         wsb = ops.fused_bf16_workspace_bytes if bf16 else ops.fused_workspace_bytes
         ws = self._workspace(dev, wsb(cmax, n, t, d, a3 // 3, k_out, cmax * per))
@@ -1115,8 +1131,9 @@ class BaseModel(_CachedWeightsMixin, nn.Module):
                                   out_heads=heads_dev[rows], out_logits=lg_dev[rows])
             back = [(heads_host[rows], heads_dev[rows]), (lg_host[rows], lg_dev[rows])]
             if want_geom:
-                _, g = ops.pair_gather(None, boxes_dev[lo * n:hi * n], allp, want_feat=False, check_pairs=False)
-                back.append((geom_host[rows], g))
+                ops.pair_gather(None, boxes_dev[lo * n:hi * n], allp, want_feat=False, check_pairs=False,
+                                out_geom=geom_dev[rows])
+                back.append((geom_host[rows], geom_dev[rows]))
             pipe.download(main, back)
             if k + 1 < len(chunks):
                 ready = pipe.stage(*chunks[k + 1])         # host staging of chunk k+1 runs while the GPU works on chunk k

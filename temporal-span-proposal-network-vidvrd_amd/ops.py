@@ -267,8 +267,9 @@ def pair_index(n, device, base=0):
     return out
 
 
-def pair_gather(tracklet_feats, tracklet_boxes, pairs, want_feat=True, want_geom=True, check_pairs=True):
-    """N^2 pair builder: -> (pair_feats [P,2D,T] | None, pair_geom [P,8,T] | None)."""
+def pair_gather(tracklet_feats, tracklet_boxes, pairs, want_feat=True, want_geom=True, check_pairs=True, out_geom=None):
+    """N^2 pair builder: -> (pair_feats [P,2D,T] | None, pair_geom [P,8,T] | None).  `out_geom`: caller-held
+    contiguous fp32 [P,8,T] the geometry is written into (e.g. a slice of a buffer another stream reads later)."""
     _dev(pairs, "pairs", torch.int64)
     P = pairs.shape[0]
     if pairs.dim() != 2 or pairs.shape[1] != 2:
@@ -286,7 +287,13 @@ def pair_gather(tracklet_feats, tracklet_boxes, pairs, want_feat=True, want_geom
         if NT is not None and tuple(tracklet_boxes.shape[:2]) != (NT, T):
             raise ValueError("pair_gather: feats / boxes shape mismatch")
         NT, T = tracklet_boxes.shape[:2]
-        geom = torch.empty((P, _abi.GEOM_CHANNELS, T), dtype=torch.float32, device=pairs.device)
+        if out_geom is None:
+            geom = torch.empty((P, _abi.GEOM_CHANNELS, T), dtype=torch.float32, device=pairs.device)
+        else:
+            _dev(out_geom, "out_geom")
+            if tuple(out_geom.shape) != (P, _abi.GEOM_CHANNELS, T):
+                raise ValueError(f"pair_gather: out_geom must be [{P},{_abi.GEOM_CHANNELS},{T}], got {tuple(out_geom.shape)}")
+            geom = out_geom
         D = D or 1
     if NT is None:
         return None, None
@@ -387,6 +394,15 @@ def conv3_tc_wino63(x, frag, bias=None, relu=False, workspace=None):
     _abi.check(l.tspn_conv3_tc_wino63_f32(_p(x), B, T, Cin, _p(frag), M, _p(bias), 1 if relu else 0, _p(y),
                                           _p(workspace), workspace.numel() * workspace.element_size(), _stream()))
     return y
+
+
+def wino63_set_piece_form(form):
+    """0 = buffer-load pieces where the workspace is below 4 GB (default), 1 = 64-bit pointer pieces everywhere
+    (tspn_conv3_tc_wino63_set_piece_form).  Returns the previous setting."""
+    prev = _abi.lib().tspn_conv3_tc_wino63_set_piece_form(int(form))
+    if prev < 0:
+        _abi.check(prev)
+    return prev
 
 
 def heads(a, head_w, head_b, b=None, ia=None, ib=None, bias=None, channels=None, num_pairs=None):

@@ -453,6 +453,9 @@ def test_bf16_buffer_offset_limits_are_refused_not_wrapped(tspn, device):
     rc = lib.tspn_conv3_tc_bf16(p(s16), 1, 8, 16384, p(s16), 32768, None, p(small), 32768, 0)
     assert rc == tspn._abi.TSPN_EUNSUPPORTED
     assert 64 * 4000 * 2048 * 4 < 2 ** 31 <= 64 * 4200 * 2048 * 4
+    # 2-D conv: one 32768 x 32768 x 64 bf16 image is 128 GB -- every tap past 2 GB would read as padding
+    rc = lib.tspn_conv2d_nhwc_bf16(p(s16), 1, 32768, 32768, 64, p(s16), 64, 1, 1, 1, 0, None, None, 0, p(s16), 0)
+    assert rc == tspn._abi.TSPN_EUNSUPPORTED and "2 GB" in tspn._abi.lib().tspn_last_error().decode()
 
 
 def test_conv3_bf16_on_features_beyond_two_gigabytes(tspn, device):

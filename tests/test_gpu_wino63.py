@@ -188,16 +188,19 @@ def test_basemodel_conv_algo_config(tspn, device):
 
 
 @pytest.mark.parametrize("B,Cin,T,M", [(5, 96, 33, 160), (9, 256, 150, 256), (70, 32, 6, 32)])
-def test_conv3_winograd63_buffer_and_pointer_pieces_are_bit_identical(tspn, device, monkeypatch, B, Cin, T, M):
+def test_conv3_winograd63_buffer_and_pointer_pieces_are_bit_identical(tspn, device, B, Cin, T, M):
     """The V pieces of conv3_wino63_kernel go out as buffer loads (one descriptor, 32-bit offsets) where the workspace is
-    below 4 GB and as global_load_lds with 64-bit pointers otherwise (TSPN_WINO63_PTRV=1 forces that form): the same bytes
+    below 4 GB and as global_load_lds with 64-bit pointers otherwise (ops.wino63_set_piece_form(1) forces that form): the same bytes
     land in LDS, so the results are the same bits."""
     x = t(tspn.hashrng.uniform(62, "x", (B, T, Cin), -1, 1)).to(device)
     w = t(tspn.hashrng.normal(62, "w", (M, Cin, 3), std=0.1)).to(device)
     b = t(tspn.hashrng.normal(62, "b", (M,), std=0.1)).to(device)
     fr = tspn.ops.pack_conv3_wino63(w)
-    monkeypatch.delenv("TSPN_WINO63_PTRV", raising=False)
+    assert tspn.ops.wino63_set_piece_form(0) == 0
     y_buf = tspn.ops.conv3_tc_wino63(x, fr, bias=b, relu=True)
-    monkeypatch.setenv("TSPN_WINO63_PTRV", "1")
-    y_ptr = tspn.ops.conv3_tc_wino63(x, fr, bias=b, relu=True)
+    try:
+        tspn.ops.wino63_set_piece_form(1)
+        y_ptr = tspn.ops.conv3_tc_wino63(x, fr, bias=b, relu=True)
+    finally:
+        assert tspn.ops.wino63_set_piece_form(0) == 1
     assert torch.equal(y_buf, y_ptr)
