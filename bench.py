@@ -970,6 +970,8 @@ def main():
                     "note": "gather_ms = the all-gather of the decoded rows alone (HIP events on the issuing stream; wall "
                             "clock under gloo), inside ms_per_step; a rank that waits for a slower one shows it here"}
         gather.check(rank)
+        per_rank["gathered_equals_local"] = True     # Gatherer.check raised otherwise: every rank holds every video's rows
+        per_rank["backend"] = dist.get_backend()
 
     if rank == 0:
         rep = wl.report(elapsed, clock_mhz)

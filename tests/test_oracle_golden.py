@@ -176,6 +176,30 @@ def test_factorised_equals_dense(n, tt, d):
         np.testing.assert_allclose(a[k].numpy(), b[k].numpy(), rtol=0, atol=2e-6)
 
 
+@pytest.mark.parametrize("n,tt,d", [(6, 9, 8), (5, 30, 32)])
+def test_bf16_factorised_oracle_equals_dense_bf16_oracle(n, tt, d):
+    """forward_bf16_factorised (the whole-video yardstick of the full-size cfg3 GPU test) lands every bf16 rounding where
+    forward_bf16 (pinned by g8 / g11) does: identical activations, so identical outputs up to float64 summation order;
+    the float64 / chunked form of forward_factorised equals its fp32 form within fp32 rounding."""
+    import tspn_mi355x as tspn
+    v = tspn_video(12, n, tt, d)
+    sd = sd_t(tspn.synth.make_weights(0, c=2 * d, k=17, bias_std=0.05))
+    w = {"conv_w": sd[DPN_PRE + "conv.weight"], "conv_b": sd[DPN_PRE + "conv.bias"],
+         "dur_w": sd[DPN_PRE + "duration_pred.weight"], "dur_b": sd[DPN_PRE + "duration_pred.bias"],
+         "rel_w": sd[DPN_PRE + "relness_pred.weight"], "rel_b": sd[DPN_PRE + "relness_pred.bias"],
+         "cls_w": sd["classifier.rel_predictor.weight"], "cls_b": sd["classifier.rel_predictor.bias"]}
+    pairs = oracle.pair_index(n)
+    a = oracle.forward_bf16(t(v["tracklet_feats"]), pairs, w)
+    b = oracle.forward_bf16_factorised(t(v["tracklet_feats"]), pairs, w, pair_chunk=7)
+    for k in ("relness", "duration", "rel_logits"):
+        np.testing.assert_allclose(a[k].numpy(), b[k].numpy(), rtol=0, atol=1e-6)
+    f32 = oracle.forward_factorised(t(v["tracklet_feats"]), t(v["tracklet_boxes"]), pairs, w)
+    f64 = oracle.forward_factorised(t(v["tracklet_feats"]), t(v["tracklet_boxes"]), pairs, w, dtype=torch.float64, pair_chunk=5)
+    for k in ("relness", "duration", "rel_logits"):
+        assert f64[k].dtype == torch.float64
+        np.testing.assert_allclose(f32[k].numpy(), f64[k].numpy(), rtol=0, atol=2e-6)
+
+
 def test_rel_oi_pool_spans():
     x = torch.arange(2 * 3 * 5, dtype=torch.float32).reshape(2, 3, 5)
     np.testing.assert_allclose(oracle.rel_oi_pool(x).numpy(), x.mean(2).numpy())
