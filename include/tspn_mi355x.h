@@ -512,6 +512,17 @@ int tspn_bottleneck_tail_bf16(const uint16_t* h1, int64_t NB, int64_t H, int64_t
                               const uint16_t* frag2, const float* bias2, const uint16_t* frag3,
                               const float* bias3, const uint16_t* residual, uint16_t* out, void* stream);
 
+/* A whole identity-shortcut bottleneck block in ONE launch (tspn_block_bf16.hip; detectron2 BottleneckBlock.forward,
+ * modeling/backbone/resnet.py, with stride 1 and no projection shortcut -- every block of a stage but its first):
+ *   out = relu(W3 . relu(W2 (*) relu(W1 . x + b1) + b2) + b3 + x)
+ * x, out bf16 channels-last [NB, H, W, 4 CM]; frag1 / frag2 / frag3 = tspn_pack_conv2d_frag_bf16 of the folded
+ * 1x1 (4 CM -> CM), 3x3 (CM -> CM) and 1x1 (CM -> 4 CM) weights; fp32 biases.  CM = 64 or 128 (the memory-bound stages
+ * res2 / res3): the 4 CM-channel map is read once and h1 / h2 stay on the CU.  Bit-identical to tspn_conv2d_nhwc_bf16
+ * (conv1) followed by tspn_bottleneck_tail_bf16.  out must not alias x; one image's map below 2 GB. */
+int tspn_bottleneck_block_bf16(const uint16_t* x, int64_t NB, int64_t H, int64_t W, int64_t CM,
+                               const uint16_t* frag1, const float* bias1, const uint16_t* frag2, const float* bias2,
+                               const uint16_t* frag3, const float* bias3, uint16_t* out, void* stream);
+
 /* The same launch + conv1 of the FOLLOWING block on the tile it has just produced (round 4; CM = 256 = every res4
  * block of an R-50 / R-101 C4 backbone): additionally
  *     h1n = relu( W1n . out + b1n )        1x1, 4 CM -> CM channels, bf16 [NB,H,W,CM]

@@ -1,0 +1,343 @@
+// A whole identity-shortcut ResNet bottleneck block on bf16 operands in ONE launch (BASELINE cfg5
+// backbone; detectron2 BottleneckBlock.forward, modeling/backbone/resnet.py, FrozenBN folded into W / b by the caller):
+//     h1  = relu(W1 . x + b1)                         1x1, 4 CM -> CM
+//     h2  = relu(W2 (*) h1 + b2)                      3x3 / pad 1 / stride 1
+//     out = relu(W3 . h2 + b3 + x)                    1x1, CM -> 4 CM, the block's input as the residual
+// for the memory-bound stages res2 / res3 (CM = 64 / 128).  The three-launch chain moves 28 CM bytes of HBM traffic per
+// pixel (conv1: 8 in + 2 out; tail: 2 h1 + 8 residual + 8 out), this kernel 16 CM plus the halo of its tile: the
+// 4 CM-channel map is read once (as conv1's operand; the residual re-read of the tile's own pixels hits L2) and
+// h1 / h2 never leave the CU.
+//
+// Tile = TR x TW = 6 x 30 output pixels of one image.  conv1 runs on the tile with its one-pixel halo, 8 x 32
+// pixels = eight 32-pixel MFMA column blocks, straight from global memory (the channels-last map IS the B-operand
+// layout: a lane's eight channels of a pixel are 16 contiguous bytes); pixels outside the image give h1 = 0 (the 3x3's
+// zero padding).  h1 sits in LDS as the B-operand image [CM / 8 groups][260 slots][8 bf16] with slot = 32 r + c, so
+// tap (a, b) of output column n = 32 r + c is slot n + 32 a + b -- the linear-range form of the fused tail
+// (tspn_bottleneck_bf16.hip) with the LDS row pitch in place of the image width and no tap masks: the halo is in the
+// tile.  Output columns with c >= 30 (12 of 192) are computed on whatever their slots hold and never stored.
+// Contraction order and rounding points are those of conv2d_nhwc_bf16_kernel / bottleneck_bf16_kernel (64-channel part
+// by part, its taps in a row, k-steps in order, one fp32 accumulator chain; relu(acc + b) rounded to bf16 once per
+// layer; (acc + b3) + residual): the results are bit-identical to the three launches (tests/test_gpu_roi_head.py).
+//
+// What bounds these stages is the operand traffic between L2 and the CUs, not HBM and not the MFMA pipe (probe builds
+// of the first form of this kernel -- 4 x 30 tiles, every phase on 2 x 2 waves: 326 / 223 us per 9 frames of 720p at
+// CM = 64 / 128; with every weight fragment read from one L1-hot line 262 / 123, with conv1's x operand from one hot
+// line 232 / 214, with both 162 / 79; profiles/r5/bottleneck_block_study.md).  So every phase tiles its waves to read
+// each operand byte as few times as it can: the phases whose B operand lives in LDS (3x3, expand) split the waves along
+// the ROWS of the weights only -- every weight fragment enters the CU once per tile --, conv1 (B operand from global
+// memory) reads x once at CM = 64 (four waves along the pixels) and twice at CM = 128 (2 x 2: its weights are four
+// times larger).  Weight fragments go from L2 straight into MFMA operand registers (fragment-major packing of
+// tspn_pack_conv2d_frag_bf16) through rings several k-steps deep, W3 with its rows permuted at load time so that an
+// accumulator lane holds 16 consecutive channels (32 contiguous bytes of residual / output per lane, no LDS transpose).
+#include <algorithm>
+
+#include "tspn_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int THREADS = 256;
+constexpr int TR = 6, TW = 30;          // output pixels of a tile
+constexpr int RP = TW + 2;              // LDS row pitch in slots = one 32-pixel column block per halo row
+constexpr int NPB1 = TR + 2;            // column blocks of conv1 (halo rows)
+constexpr int SL1 = NPB1 * 32 + 4;      // slots of the h1 image: + the two a garbage column may touch; = 4 mod 16
+constexpr int SL2 = TR * 32 + 4;        // slots of the h2 image
+static_assert(SL1 % 16 == 4 && SL2 % 16 == 4, "conflict-free 16-byte fragment reads");
+
+template <int CM>
+__global__ __launch_bounds__(THREADS, 2) void bottleneck_block_bf16_kernel(
+    const __bf16* __restrict__ x, const __bf16* __restrict__ Wf1, const float* __restrict__ bias1,
+    const __bf16* __restrict__ Wf2, const float* __restrict__ bias2, const __bf16* __restrict__ Wf3,
+    const float* __restrict__ bias3, __bf16* __restrict__ out, int H, int W, int tiles_x, int tiles_y, int ntiles) {
+  constexpr int C4 = 4 * CM;
+  constexpr int C1 = C4 / 64, C2 = CM / 64;         // 64-channel parts of conv1's / the 3x3's and expand's K
+  extern __shared__ __attribute__((aligned(16))) char Bs[];   // h1 image, then (same memory) the h2 image
+
+  // consecutive tiles stay on one XCD (shared halo rows in its L2)
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  if (wg >= ntiles) return;
+  const int per_img = tiles_x * tiles_y;
+  const int img = wg / per_img, tin = wg - img * per_img;
+  const int ty = tin / tiles_x, tx = tin - ty * tiles_x;
+  const int y0 = ty * TR, x0 = tx * TW;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kh = lane >> 5;
+  const unsigned woff = lane * 16;
+
+  // one descriptor per tensor, based at this image: every offset below is a 32-bit byte offset inside the image
+  const int64_t img_off = (int64_t)img * H * W * C4;
+  const unsigned img_bytes = (unsigned)((int64_t)H * W * C4 * 2);
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(x) + img_off, 0, (int)img_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(out + img_off, 0, (int)img_bytes, 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;             // beyond every descriptor: loads give zeros, stores are dropped
+  auto ldw = [&](const __bf16* base, int64_t byte_off) {           // a weight fragment: 16 bytes per lane
+    return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + byte_off + woff);
+  };
+
+  // ---------------------------------------------------------------- conv1 on the 8 x 32 halo tile
+  {
+    constexpr int WM = CM == 64 ? 1 : 2, WN = 4 / WM;      // waves along rows / column blocks
+    constexpr int MI = (CM / 32) / WM, PB = NPB1 / WN;     // 2 row blocks x 2 (CM = 64) / 4 (CM = 128) column blocks per wave
+    const int wm = wave % WM, wn = wave / WM;
+    f32x16 acc[MI][PB];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int pj = 0; pj < PB; ++pj)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[mi][pj][e] = 0.f;
+    unsigned xo[PB];                                 // byte offset of this lane's pixel of each column block (channel 8 kh)
+    bool inimg[PB];
+#pragma unroll
+    for (int pj = 0; pj < PB; ++pj) {
+      const int yy = y0 - 1 + PB * wn + pj, xx = x0 - 1 + li;
+      inimg[pj] = yy >= 0 && yy < H && xx >= 0 && xx < W;
+      xo[pj] = inimg[pj] ? (unsigned)(((yy * W + xx) * C4 + 8 * kh) * 2) : OOB;
+    }
+    const int64_t w1row = (int64_t)C1 * 4096;        // bytes per 32-row block of Wf1
+    // operands D1 k-steps ahead (first form: one k-step ahead, every k-step waited a full round trip)
+    constexpr int D1 = CM == 64 ? 4 : 3;
+    f32x4 a[D1][MI];
+    bf16x8 b[D1][PB];
+    auto load_ks = [&](int slot, int k) {            // k = 4 c + ks: channels 16 k ..
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) a[slot][mi] = ldw(Wf1, (MI * wm + mi) * w1row + (int64_t)k * 1024);
+#pragma unroll
+      for (int pj = 0; pj < PB; ++pj)
+        b[slot][pj] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)xo[pj], k * 32, 0));
+    };
+    constexpr int KS1 = C4 / 16;
+#pragma unroll
+    for (int d = 0; d < D1; ++d) load_ks(d, d);
+#pragma unroll
+    for (int k = 0; k < KS1; ++k) {
+      const int slot = k % D1;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const bf16x8 av = __builtin_bit_cast(bf16x8, a[slot][mi]);
+#pragma unroll
+        for (int pj = 0; pj < PB; ++pj) acc[mi][pj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b[slot][pj], acc[mi][pj], 0, 0, 0);
+      }
+      if (k + D1 < KS1) load_ks(slot, k + D1);
+      __builtin_amdgcn_sched_barrier(0);             // keep the ring D1 deep: the scheduler would hoist every load of the unrolled loop
+    }
+    // h1 = relu(acc + b1) -> bf16 -> LDS; exactly 0 outside the image.  Accumulator registers 4 q + j of lane (li, kh)
+    // are rows 8 q + 4 kh + j of the block.
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int ch = 32 * (MI * wm + mi) + 8 * q + 4 * kh;
+        const float4 bv = *reinterpret_cast<const float4*>(bias1 + ch);
+#pragma unroll
+        for (int pj = 0; pj < PB; ++pj) {
+          bf16x4 v;
+          v[0] = (__bf16)fmaxf(acc[mi][pj][4 * q] + bv.x, 0.f);
+          v[1] = (__bf16)fmaxf(acc[mi][pj][4 * q + 1] + bv.y, 0.f);
+          v[2] = (__bf16)fmaxf(acc[mi][pj][4 * q + 2] + bv.z, 0.f);
+          v[3] = (__bf16)fmaxf(acc[mi][pj][4 * q + 3] + bv.w, 0.f);
+          if (!inimg[pj]) v = bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+          *reinterpret_cast<bf16x4*>(Bs + ((ch >> 3) * SL1 + (PB * wn + pj) * 32 + li) * 16 + 8 * kh) = v;
+        }
+      }
+    if (tid < 4 * (CM / 8)) {                        // the four slots behind the tile: only garbage columns read them; keep them finite
+      const int g = tid >> 2, sl = NPB1 * 32 + (tid & 3);
+      *reinterpret_cast<f32x4*>(Bs + (g * SL1 + sl) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  __syncthreads();
+
+  // ---------------------------------------------------------------- 3x3 on the h1 image: K = C2 parts x 9 taps x 64
+  {
+    constexpr int WM = CM / 32, WN = 4 / WM;         // one 32-row block per wave: every W2 fragment enters the CU once
+    constexpr int PB = TR / WN;                      // (CM = 64: two waves along the rows x two along the pixels)
+    const int wm = wave % WM, wn = wave / WM;
+    f32x16 acc[PB];
+#pragma unroll
+    for (int pj = 0; pj < PB; ++pj)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[pj][e] = 0.f;
+    const int64_t w2row = (int64_t)C2 * 9 * 4096;
+    const char* hb = Bs + (kh * SL1 + PB * wn * 32 + li) * 16;   // + (group pair, tap offset, column block)
+    constexpr int D2 = 8;                            // weight fragments (L2) eight k-steps ahead
+    f32x4 a[D2];
+    auto load_w = [&](int slot, int j) {             // j = (c 9 + tap) 4 + ks: fragments are stored in this order
+      a[slot] = ldw(Wf2, wm * w2row + (int64_t)j * 1024);
+    };
+    constexpr int KS2 = C2 * 36;
+#pragma unroll
+    for (int d = 0; d < D2; ++d) load_w(d, d);
+#pragma unroll
+    for (int j = 0; j < KS2; ++j) {
+      const int slot = j % D2;
+      const int ks = j & 3, ct = j >> 2, c = ct / 9, tap = ct - 9 * c, ta = tap / 3, tb = tap - 3 * ta;
+      const char* bp = hb + ((8 * c + 2 * ks) * SL1 + ta * RP + tb) * 16;
+      const bf16x8 av = __builtin_bit_cast(bf16x8, a[slot]);
+#pragma unroll
+      for (int pj = 0; pj < PB; ++pj)
+        acc[pj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, *reinterpret_cast<const bf16x8*>(bp + pj * 32 * 16), acc[pj], 0, 0, 0);
+      if (j + D2 < KS2) load_w(slot, j + D2);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();                                 // every wave has read what it needs of h1: h2 takes its memory
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ch = 32 * wm + 8 * q + 4 * kh;
+      const float4 bv = *reinterpret_cast<const float4*>(bias2 + ch);
+#pragma unroll
+      for (int pj = 0; pj < PB; ++pj) {
+        bf16x4 v;
+        v[0] = (__bf16)fmaxf(acc[pj][4 * q] + bv.x, 0.f);
+        v[1] = (__bf16)fmaxf(acc[pj][4 * q + 1] + bv.y, 0.f);
+        v[2] = (__bf16)fmaxf(acc[pj][4 * q + 2] + bv.z, 0.f);
+        v[3] = (__bf16)fmaxf(acc[pj][4 * q + 3] + bv.w, 0.f);
+        *reinterpret_cast<bf16x4*>(Bs + ((ch >> 3) * SL2 + (PB * wn + pj) * 32 + li) * 16 + 8 * kh) = v;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---------------------------------------------------------------- expand + residual + ReLU: M = 4 CM, K = CM
+  {
+    // four waves along the rows: wave w owns row blocks [NPASS w, NPASS w + NPASS), one per pass, all TR column blocks --
+    // every W3 fragment enters the CU once.  W3 rows permuted at load time (as in bottleneck_bf16_kernel): the lane that
+    // feeds MFMA row 8 q + 4 h + j fetches the fragment slot of channel 16 h + 4 q + j, so accumulator lane (li, kh)
+    // holds channels 16 kh + 0..15 of the block
+    const unsigned woff3 = (unsigned)((kh << 5) | (((li >> 2) & 1) << 4) | ((li >> 3) << 2) | (li & 3)) * 16;
+    constexpr int KS3 = CM / 16;
+    constexpr int NPASS = CM / 32;
+    const int64_t w3row = (int64_t)C2 * 4096;
+    const char* hb = Bs + (kh * SL2 + li) * 16;
+    // the TR output pixels of this lane (column block = tile row): valid if c < TW and inside the image
+    unsigned po[TR];
+#pragma unroll
+    for (int pj = 0; pj < TR; ++pj) {
+      const int yy = y0 + pj, xx = x0 + li;
+      const bool ok = li < TW && yy < H && xx < W;
+      po[pj] = ok ? (unsigned)(((yy * W + xx) * C4 + 16 * kh) * 2) : OOB;
+    }
+    u32x4_t keep[2] = {};                            // store data of the previous group (see the epilogue)
+    constexpr int NA = CM == 64 ? 2 : 1;             // CM = 64: the next pass's W3 fragments are requested a pass ahead
+    f32x4 a[NA][KS3];
+    auto w3_issue = [&](int slot, int p) {
+      const int mb = NPASS * wave + p;
+#pragma unroll
+      for (int k = 0; k < KS3; ++k)
+        a[slot][k] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(Wf3) + mb * w3row + k * 1024 + woff3);
+    };
+    w3_issue(0, 0);
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+      const int mb = NPASS * wave + p;               // channels 32 mb .. + 31
+      // residual rows: 32 contiguous bytes per lane and pixel, requested in front of the pass's MFMAs
+      bf16x8 res[TR][2];
+#pragma unroll
+      for (int pj = 0; pj < TR; ++pj)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          res[pj][h] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+              rs_x, (int)(po[pj] == OOB ? OOB : po[pj] + 16 * h), mb * 64, 0));
+      if (NA == 2 && p + 1 < NPASS) w3_issue((p + 1) & 1, p + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      f32x16 acc[TR];
+#pragma unroll
+      for (int pj = 0; pj < TR; ++pj)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[pj][e] = 0.f;
+#pragma unroll
+      for (int k = 0; k < KS3; ++k) {
+        const bf16x8 av = __builtin_bit_cast(bf16x8, a[NA == 2 ? (p & 1) : 0][k]);
+#pragma unroll
+        for (int pj = 0; pj < TR; ++pj)
+          acc[pj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, *reinterpret_cast<const bf16x8*>(hb + (2 * k * SL2 + pj * 32) * 16),
+                                                            acc[pj], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (NA == 1 && p + 1 < NPASS) w3_issue(0, p + 1);   // CM = 128: the next pass's fragments fly under this pass's epilogue
+      const int chm = 32 * mb + 16 * kh;
+      float bv[16];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 t = *reinterpret_cast<const float4*>(bias3 + chm + 4 * i);
+        bv[4 * i] = t.x; bv[4 * i + 1] = t.y; bv[4 * i + 2] = t.z; bv[4 * i + 3] = t.w;
+      }
+#pragma unroll
+      for (int pj = 0; pj < TR; ++pj) {
+        u32x4_t o2[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          bf16x8 o;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = (__bf16)fmaxf((acc[pj][8 * h + j] + bv[8 * h + j]) + (float)res[pj][h][j], 0.f);
+          o2[h] = __builtin_bit_cast(u32x4_t, o);
+        }
+        // both 16-byte stores of the lane's 32 bytes back to back: the lane pair of a pixel completes a 64-byte sector
+        __builtin_amdgcn_raw_buffer_store_b128(o2[0], rs_o, (int)(po[pj] == OOB ? OOB : po[pj]), mb * 64, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(o2[1], rs_o, (int)(po[pj] == OOB ? OOB : po[pj] + 16), mb * 64, 0);
+        // STORE-DATA HAZARD (found the hard way, round 5): a 128-bit buffer store reads its data registers AFTER it has
+        // issued, and hipcc does not separate it from a following VALU write of those registers when the store has an
+        // SGPR soffset (GCNHazardRecognizer::createsVALUHazard assumes that form is safe).  With several waves per
+        // SIMD the next group's `v_add_f32 v32, ...` landed in the data of the store before it, in the lanes the store
+        // reads last (pixels 12..15 / 28..29 of a block; wrong bits in ~0.02 % of the outputs, different ones every
+        // launch; none with one workgroup per CU).  The data registers of a group therefore stay LIVE until the stores
+        // of the NEXT group have been issued (an empty asm that names them), i.e. for ~50 vector instructions.
+        asm volatile("" ::"v"(keep[0]), "v"(keep[1]));
+        keep[0] = o2[0];
+        keep[1] = o2[1];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // ... and the last group's until well after its stores (the wave ends here)
+    asm volatile("s_nop 15\n s_nop 15" ::"v"(keep[0]), "v"(keep[1]));
+  }
+}
+
+template <int CM>
+int launch(const uint16_t* x, int64_t NB, int64_t H, int64_t W, const uint16_t* f1, const float* b1, const uint16_t* f2,
+           const float* b2, const uint16_t* f3, const float* b3, uint16_t* out, void* stream) {
+  const char* what = "tspn_bottleneck_block_bf16";
+  const int64_t tiles_x = tspn::ceil_div(W, TW), tiles_y = tspn::ceil_div(H, TR);
+  const int64_t ntiles = NB * tiles_x * tiles_y;
+  TSPN_REQUIRE(ntiles < (1LL << 30), TSPN_EUNSUPPORTED, "%s: grid too large", what);
+  const int64_t grid = tspn::ceil_div(ntiles, 8) * 8;            // whole rounds over the eight XCDs
+  constexpr size_t smem = (size_t)(CM / 8) * SL1 * 16;           // the h1 image (the h2 image is smaller and takes its place)
+  static tspn::LdsLimit lds;
+  if (int rc = lds.ensure(reinterpret_cast<const void*>(bottleneck_block_bf16_kernel<CM>), smem, what)) return rc;
+  hipLaunchKernelGGL((bottleneck_block_bf16_kernel<CM>), dim3((unsigned)grid), dim3(THREADS), smem, TSPN_STREAM(stream),
+                     reinterpret_cast<const __bf16*>(x), reinterpret_cast<const __bf16*>(f1), b1,
+                     reinterpret_cast<const __bf16*>(f2), b2, reinterpret_cast<const __bf16*>(f3), b3,
+                     reinterpret_cast<__bf16*>(out), (int)H, (int)W, (int)tiles_x, (int)tiles_y, (int)ntiles);
+  return tspn::check_launch(what);
+}
+
+}  // namespace
+
+extern "C" int tspn_bottleneck_block_bf16(const uint16_t* x, int64_t NB, int64_t H, int64_t W, int64_t CM,
+                                          const uint16_t* frag1, const float* bias1, const uint16_t* frag2,
+                                          const float* bias2, const uint16_t* frag3, const float* bias3, uint16_t* out,
+                                          void* stream) {
+  const char* what = "tspn_bottleneck_block_bf16";
+  TSPN_REQUIRE(NB >= 0 && H > 0 && W > 0, TSPN_EINVAL, "%s: bad sizes", what);
+  TSPN_REQUIRE(CM == 64 || CM == 128, TSPN_EUNSUPPORTED, "%s: bottleneck channels must be 64 or 128 (got %lld)", what,
+               (long long)CM);
+  if (NB == 0) return TSPN_OK;
+  TSPN_REQUIRE(x && frag1 && bias1 && frag2 && bias2 && frag3 && bias3 && out, TSPN_EINVAL, "%s: null pointer", what);
+  TSPN_REQUIRE(x != out, TSPN_EINVAL, "%s: the block cannot run in place (tiles read their neighbours' pixels)", what);
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  TSPN_REQUIRE(al16(x) && al16(frag1) && al16(bias1) && al16(frag2) && al16(bias2) && al16(frag3) && al16(bias3) && al16(out),
+               TSPN_EUNSUPPORTED, "%s: operands must be 16-byte aligned", what);
+  // 32-bit byte offsets inside one image
+  TSPN_REQUIRE(H * W * 4 * CM * 2 < (1LL << 31), TSPN_EUNSUPPORTED, "%s: one image's map must stay below 2 GB", what);
+  if (CM == 128) return launch<128>(x, NB, H, W, frag1, bias1, frag2, bias2, frag3, bias3, out, stream);
+  return launch<64>(x, NB, H, W, frag1, bias1, frag2, bias2, frag3, bias3, out, stream);
+}

@@ -17,7 +17,7 @@ __all__ = [
     "forward_fused", "temporal_encoder_heads", "fused_workspace_bytes", "fused_bf16_workspace_bytes", "decode_topk", "decode_spans",
     "cast_bf16", "pack_conv3_bf16", "pack_heads_bf16", "conv3_tc_bf16", "heads_pairgrid_bf16",
     "transpose_cast_bf16", "temporal_encoder_heads_bf16",
-    "temporal_mean_bf16", "forward_fused_bf16", "span_predicate",
+    "temporal_mean_bf16", "forward_fused_bf16", "span_predicate", "bottleneck_block_bf16",
     "proposal_pair_filter", "gather_rows",
     "pack_conv2d", "pack_conv2d_frag", "conv2d_nhwc", "roi_align_nhwc", "pack_conv2d_frag_bf16", "conv2d_nhwc_bf16", "max_pool_nhwc", "pack_conv2d_frag_cin4", "conv2d_nhwc_cin4", "max_pool_nhwc_bf16", "pack_stem_bf16", "stem_conv_bf16", "stem_pool_bf16", "bottleneck_tail_bf16",
 ]
@@ -972,6 +972,36 @@ def max_pool_nhwc(x, kernel_size=3, stride=2, padding=1, out_bf16=False):
     out = torch.empty((NB, OH, OW, C), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
     _abi.check(_abi.lib().tspn_max_pool_nhwc_f32(_p(x), NB, H, W, C, kernel_size, stride, padding, _p(out),
                                                  1 if out_bf16 else 0, _stream()))
+    return out
+
+
+def bottleneck_block_bf16(x, frag1, bias1, frag2, bias2, frag3, bias3, out=None):
+    """A whole identity-shortcut bottleneck block in one launch (tspn_bottleneck_block_bf16):
+    relu(conv1x1(relu(conv3x3(relu(conv1x1(x) + b1)) + b2)) + b3 + x) for x bf16 [NB,H,W,4 CM], CM in (64, 128);
+    frag1 / frag2 / frag3 = pack_conv2d_frag_bf16 of the folded conv1 [CM,4CM,1,1], conv2 [CM,CM,3,3], conv3 [4CM,CM,1,1].
+    Bit-identical to conv2d_nhwc_bf16 (conv1) + bottleneck_tail_bf16; the 4 CM-channel map is read once."""
+    _dev(x, "x", torch.bfloat16)
+    for nm, t in (("frag1", frag1), ("frag2", frag2), ("frag3", frag3)):
+        _dev(t, nm, torch.bfloat16)
+    _dev(bias1, "bias1"); _dev(bias2, "bias2"); _dev(bias3, "bias3")
+    NB, H, W, C4 = x.shape
+    CM = C4 // 4
+    if CM not in (64, 128) or C4 != 4 * CM:
+        raise ValueError(f"bottleneck_block_bf16: needs 4 x 64 or 4 x 128 channels (got {C4})")
+    if (tuple(frag1.shape) != (CM // 32, C4 // 64, 1, 4, 64, 8) or tuple(frag2.shape) != (CM // 32, CM // 64, 9, 4, 64, 8)
+            or tuple(frag3.shape) != (CM // 8, CM // 64, 1, 4, 64, 8)):
+        raise ValueError("bottleneck_block_bf16: frag1 / frag2 / frag3 must be pack_conv2d_frag_bf16 of [CM,4CM,1,1] / "
+                         "[CM,CM,3,3] / [4CM,CM,1,1]")
+    if bias1.shape != (CM,) or bias2.shape != (CM,) or bias3.shape != (C4,):
+        raise ValueError("bottleneck_block_bf16: bias shape mismatch")
+    if out is None:
+        out = torch.empty_like(x)
+    else:
+        _dev(out, "out", torch.bfloat16)
+        if tuple(out.shape) != tuple(x.shape):
+            raise ValueError(f"bottleneck_block_bf16: out must be {tuple(x.shape)}, got {tuple(out.shape)}")
+    _abi.check(_abi.lib().tspn_bottleneck_block_bf16(_p(x), NB, H, W, CM, _p(frag1), _p(bias1), _p(frag2), _p(bias2),
+                                                     _p(frag3), _p(bias3), _p(out), _stream()))
     return out
 
 

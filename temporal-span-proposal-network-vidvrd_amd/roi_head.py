@@ -103,6 +103,17 @@ class BottleneckBlock(nn.Module):
         # ... and let that launch compute the NEXT block's conv1 too where it can (CM = 256: the res4 chain), so that
         # the 1024-channel map is read once per block; switched by ResNetC4 `fuse_next_conv1`
         self.fuse_next = True
+        # ... and whole identity blocks of the memory-bound stages (64 / 128 bottleneck channels, stride 1, no projection)
+        # as ONE launch that reads the 4 CM-channel map once (csrc/tspn_block_bf16.hip, round 5); same bits
+        self.fuse_block = True
+
+    def _can_fuse_block(self, x, h1):
+        c1, c2, c3 = self.conv1, self.conv2, self.conv3
+        cm = c2.weight.shape[0]
+        return (self.fuse_tail and self.fuse_block and h1 is None and x.dtype == torch.bfloat16 and cm in (64, 128)
+                and self.shortcut is None and self.stride == 1 and c1.kernel_size == 1 and c1.padding == 0
+                and tuple(c1.weight.shape[:2]) == (cm, 4 * cm) and c2.weight.shape[1] == cm and c2.kernel_size == 3
+                and c2.stride == 1 and c2.padding == 1 and tuple(c3.weight.shape[:2]) == (4 * cm, cm) and c3.kernel_size == 1)
 
     def _can_fuse(self, x):
         c2, c3 = self.conv2, self.conv3
@@ -126,6 +137,12 @@ class BottleneckBlock(nn.Module):
         `next_block`: the block that follows; when it qualifies (`_can_take_h1`) this block's fused tail computes its
         conv1 as well and the call returns (y, h1 of the next block) instead of y."""
         st = 1 if presampled else None
+        if self._can_fuse_block(x, h1):
+            f1, b1 = self.conv1.folded_bf16(x.device)
+            f2, b2 = self.conv2.folded_bf16(x.device)
+            f3, b3 = self.conv3.folded_bf16(x.device)
+            y = ops.bottleneck_block_bf16(x.contiguous(), f1, b1, f2, b2, f3, b3, out=out)
+            return (y, None) if next_block is not None else y
         h = h1 if h1 is not None else self.conv1(x, relu=True, stride=st)
         if self.shortcut is not None:
             sc = self.shortcut(x, stride=st)

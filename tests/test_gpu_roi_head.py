@@ -399,6 +399,84 @@ def test_bottleneck_tail_fused_bit_identical_to_two_convs(tspn, device, CM, NB, 
     assert float(err.max()) <= 4 * 2.0 ** -8 * scale and float((err <= 2.0 ** -8 * ref.abs() + 1e-6).double().mean()) > 0.97
 
 
+@pytest.mark.parametrize("CM,NB,H,W", [(64, 2, 9, 13), (128, 1, 16, 16), (64, 1, 1, 1), (128, 2, 30, 17), (64, 3, 4, 30),
+                                      (64, 1, 5, 31), (128, 1, 3, 61), (64, 1, 45, 80), (128, 2, 23, 40)])
+def test_bottleneck_block_one_launch_bit_identical_to_conv1_plus_fused_tail(tspn, device, CM, NB, H, W):
+    """tspn_bottleneck_block_bf16 (round 5): a whole identity-shortcut bottleneck block -- conv1, 3x3, expand, residual,
+    ReLU -- in ONE launch on 4 x 30 pixel tiles with the halo recomputed, h1 / h2 in LDS, the 4 CM-channel map read once.
+    BIT FOR BIT the chain it replaces (tspn_conv2d_nhwc_bf16 for conv1, then tspn_bottleneck_tail_bf16): same contraction
+    order and rounding points; images smaller than a tile, exactly a tile, one pixel more than a tile in either direction,
+    several images; and == the float64 restatement within bf16 rounding.  Repeated launches agree."""
+    x = tspn.hashrng.uniform(95, "x", (NB, H, W, 4 * CM), -1, 1)
+    w1 = tspn.hashrng.normal(95, "w1", (CM, 4 * CM, 1, 1), std=float(np.sqrt(2.0 / (4 * CM))))
+    w2 = tspn.hashrng.normal(95, "w2", (CM, CM, 3, 3), std=float(np.sqrt(2.0 / (9 * CM))))
+    w3 = tspn.hashrng.normal(95, "w3", (4 * CM, CM, 1, 1), std=float(np.sqrt(2.0 / CM)))
+    b1 = tspn.hashrng.normal(95, "b1", (CM,), std=0.1)
+    b2 = tspn.hashrng.normal(95, "b2", (CM,), std=0.1)
+    b3 = tspn.hashrng.normal(95, "b3", (4 * CM,), std=0.1)
+    d = lambda a, dt=None: (t(a).to(device) if dt is None else t(a).to(device).to(dt))   # noqa: E731
+    f1, f2, f3 = (tspn.ops.pack_conv2d_frag_bf16(d(w)) for w in (w1, w2, w3))
+    xd = d(x, torch.bfloat16)
+    h1 = tspn.ops.conv2d_nhwc_bf16(xd, f1, (1, 1), 1, 0, bias=d(b1), relu=True)
+    want = tspn.ops.bottleneck_tail_bf16(h1, f2, d(b2), f3, d(b3), xd)
+    got = tspn.ops.bottleneck_block_bf16(xd, f1, d(b1), f2, d(b2), f3, d(b3))
+    assert got.dtype == torch.bfloat16 and tuple(got.shape) == (NB, H, W, 4 * CM)
+    assert torch.equal(got, want), f"max diff {float((got.float() - want.float()).abs().max())}"
+    assert float(got.float().abs().max()) > 0.1
+    big = torch.zeros((NB + 2, H, W, 4 * CM), dtype=torch.bfloat16, device=device)      # `out`: a slice of a larger result
+    ret = tspn.ops.bottleneck_block_bf16(xd, f1, d(b1), f2, d(b2), f3, d(b3), out=big[1:NB + 1])
+    assert ret.data_ptr() == big[1:].data_ptr() and torch.equal(big[1:NB + 1], want)
+    assert not bool(big[0].any()) and not bool(big[NB + 1].any())
+    for _ in range(2):
+        assert torch.equal(tspn.ops.bottleneck_block_bf16(xd, f1, d(b1), f2, d(b2), f3, d(b3)), want)
+    with pytest.raises(ValueError):
+        tspn.ops.bottleneck_block_bf16(xd, f2, d(b1), f2, d(b2), f3, d(b3))
+    with pytest.raises(RuntimeError):                                                    # in place: refused by the entry
+        tspn.ops.bottleneck_block_bf16(xd, f1, d(b1), f2, d(b2), f3, d(b3), out=xd)
+    xf = xd.cpu().float().permute(0, 3, 1, 2)
+    r1 = ro.conv2d_bf16(xf, t(w1), t(b1), relu=True)
+    r2 = ro.conv2d_bf16(r1, t(w2), t(b2), padding=1, relu=True)
+    ref = ro.conv2d_bf16(r2, t(w3), t(b3), residual=xf, relu=True).permute(0, 2, 3, 1)
+    err = (got.cpu().double() - ref).abs()
+    scale = float(ref.abs().max())
+    assert float(err.max()) <= 4 * 2.0 ** -8 * scale
+    if err.numel() >= 4096:      # three bf16 roundings in a row: most values within one ulp (a statistic: not for tiny maps)
+        assert float((err <= 2.0 ** -8 * ref.abs() + 1e-6).double().mean()) > 0.95
+
+
+def test_backbone_with_one_launch_blocks_equals_the_chain(tspn, device):
+    """ResNetC4 on bf16 maps: `fuse_block` on (identity blocks of res2 / res3 as one launch each) and off (conv1 + fused
+    tail) give the same res4 maps bit for bit, on one stream and on two; the one-launch form really ran."""
+    net, _ = _backbone_and_weights(tspn, device, 64, 256, (3, 4, 2))
+    img = t(tspn.hashrng.uniform(99, "img", (5, 96, 128, 3), -1, 1)).to(device)
+    net.frame_chunk = 2
+    calls = []
+    real = tspn.ops.bottleneck_block_bf16
+    outs = []
+    try:
+        def spy(*a, **k):
+            calls.append(a[0].shape[3])
+            return real(*a, **k)
+        tspn.ops.bottleneck_block_bf16 = spy
+        tspn.roi_head.ops.bottleneck_block_bf16 = spy
+        for streams in (1, 2):
+            for on in (True, False):
+                net.streams = streams
+                for m in net.modules():
+                    if isinstance(m, tspn.roi_head.BottleneckBlock):
+                        m.fuse_block = on
+                n0 = len(calls)
+                outs.append(net(img, bf16=True))
+                torch.cuda.synchronize(device)
+                assert (len(calls) - n0) == (3 * (2 + 3) if on else 0)        # 3 frame chunks x (2 res2 + 3 res3 blocks)
+    finally:
+        tspn.ops.bottleneck_block_bf16 = real
+        tspn.roi_head.ops.bottleneck_block_bf16 = real
+    assert set(calls) == {256, 512}
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+
+
 @pytest.mark.parametrize("NB,H,W", [(3, 7, 11), (1, 45, 80), (1, 1, 1), (2, 16, 8), (1, 13, 129)])
 def test_bottleneck_tail_with_next_conv1_bit_identical(tspn, device, NB, H, W):
     """tspn_bottleneck_tail_next_bf16 (round 4): the tail launch that also computes conv1 of the FOLLOWING block on the
