@@ -384,6 +384,9 @@ class ResNetC4(_CachedWeightsMixin, nn.Module):
         # workgroup per CU, so the chunks of the other HIP stream no longer share CUs with it: 27.5 against 26.0 ms per 64
         # frames with two streams (equal, 31.9 / 32.0, with one).  Off by default for that reason.
         self.fuse_next_conv1 = False
+        # identity blocks of res2 / res3 (64 / 128 bottleneck channels) as ONE launch each (round 5, tspn_bottleneck_block_bf16:
+        # the 4 CM-channel map read once, h1 / h2 on the CU; same bits as conv1 + fused tail)
+        self.fuse_blocks = True
         # frame chunks alternate between this many HIP streams: a launch's workgroups run in lockstep (all in their MFMA
         # phase, then all in their memory phase), two chunks in flight put the memory phase of one under the MFMA phase
         # of the other (tools/probe_tail_stagger.py: -10 % on the res4 tails; backbone -5 %)
@@ -399,6 +402,7 @@ class ResNetC4(_CachedWeightsMixin, nn.Module):
                 if isinstance(m, BottleneckBlock):
                     m.fuse_tail = bool(self.fuse_bottlenecks)
                     m.fuse_next = bool(self.fuse_bottlenecks and self.fuse_next_conv1)
+                    m.fuse_block = bool(self.fuse_bottlenecks and self.fuse_blocks)
             out = []
             nchunks = -(-images.shape[0] // self.frame_chunk)
             ns = min(int(self.streams), nchunks) if images.is_cuda else 1

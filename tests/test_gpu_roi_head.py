@@ -462,9 +462,7 @@ def test_backbone_with_one_launch_blocks_equals_the_chain(tspn, device):
         for streams in (1, 2):
             for on in (True, False):
                 net.streams = streams
-                for m in net.modules():
-                    if isinstance(m, tspn.roi_head.BottleneckBlock):
-                        m.fuse_block = on
+                net.fuse_blocks = on
                 n0 = len(calls)
                 outs.append(net(img, bf16=True))
                 torch.cuda.synchronize(device)

@@ -20,11 +20,13 @@ ap.add_argument("--bf16", action="store_true")
 ap.add_argument("--streams", type=int, default=2)
 ap.add_argument("--no-next", action="store_true", help="(default) fuse_next_conv1 = False: every conv1 as its own launch")
 ap.add_argument("--next", action="store_true", help="fuse_next_conv1 = True: res4 tails also compute the follower's conv1")
+ap.add_argument("--no-block", action="store_true", help="identity blocks of res2 / res3 as conv1 + fused tail (round 4) instead of one launch")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 net = tspn.ResNetC4(depth=args.depth, frame_chunk=args.chunk).to(dev)
 net.streams = args.streams
 net.fuse_next_conv1 = bool(args.next) and not args.no_next
+net.fuse_blocks = not args.no_block
 g = torch.Generator(device=dev).manual_seed(0)
 img = torch.rand((args.frames, args.h, args.w, 3), device=dev, generator=g) - 0.5
 
