@@ -8,13 +8,13 @@
 // 4 CM-channel map is read once (as conv1's operand; the residual re-read of the tile's own pixels hits L2) and
 // h1 / h2 never leave the CU.
 //
-// Tile = TR x TW = 6 x 30 output pixels of one image.  conv1 runs on the tile with its one-pixel halo, 8 x 32
-// pixels = eight 32-pixel MFMA column blocks, straight from global memory (the channels-last map IS the B-operand
+// Tile = TR x TW output pixels of one image, TR = 10 (CM = 64) / 6 (CM = 128), TW = 30.  conv1 runs on the tile with
+// its one-pixel halo, (TR + 2) x 32 pixels = TR + 2 32-pixel MFMA column blocks, straight from global memory (the channels-last map IS the B-operand
 // layout: a lane's eight channels of a pixel are 16 contiguous bytes); pixels outside the image give h1 = 0 (the 3x3's
-// zero padding).  h1 sits in LDS as the B-operand image [CM / 8 groups][260 slots][8 bf16] with slot = 32 r + c, so
+// zero padding).  h1 sits in LDS as the B-operand image [CM / 8 groups][32 (TR + 2) + 4 slots][8 bf16] with slot = 32 r + c, so
 // tap (a, b) of output column n = 32 r + c is slot n + 32 a + b -- the linear-range form of the fused tail
 // (tspn_bottleneck_bf16.hip) with the LDS row pitch in place of the image width and no tap masks: the halo is in the
-// tile.  Output columns with c >= 30 (12 of 192) are computed on whatever their slots hold and never stored.
+// tile.  Output columns with c >= 30 (two per row) are computed on whatever their slots hold and never stored.
 // Contraction order and rounding points are those of conv2d_nhwc_bf16_kernel / bottleneck_bf16_kernel (64-channel part
 // by part, its taps in a row, k-steps in order, one fp32 accumulator chain; relu(acc + b) rounded to bf16 once per
 // layer; (acc + b3) + residual): the results are bit-identical to the three launches (tests/test_gpu_roi_head.py).
@@ -42,12 +42,10 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int THREADS = 256;
-constexpr int TR = 6, TW = 30;          // output pixels of a tile
+constexpr int TW = 30;                  // output pixels of a tile row
 constexpr int RP = TW + 2;              // LDS row pitch in slots = one 32-pixel column block per halo row
-constexpr int NPB1 = TR + 2;            // column blocks of conv1 (halo rows)
-constexpr int SL1 = NPB1 * 32 + 4;      // slots of the h1 image: + the two a garbage column may touch; = 4 mod 16
-constexpr int SL2 = TR * 32 + 4;        // slots of the h2 image
-static_assert(SL1 % 16 == 4 && SL2 % 16 == 4, "conflict-free 16-byte fragment reads");
+// rows of a tile: the weights are re-streamed from L2 per tile, so CM = 64 (small accumulators) takes ten rows
+constexpr int tile_rows(int cm) { return cm == 64 ? 10 : 6; }
 
 template <int CM>
 __global__ __launch_bounds__(THREADS, 2) void bottleneck_block_bf16_kernel(
@@ -56,6 +54,12 @@ __global__ __launch_bounds__(THREADS, 2) void bottleneck_block_bf16_kernel(
     const float* __restrict__ bias3, __bf16* __restrict__ out, int H, int W, int tiles_x, int tiles_y, int ntiles) {
   constexpr int C4 = 4 * CM;
   constexpr int C1 = C4 / 64, C2 = CM / 64;         // 64-channel parts of conv1's / the 3x3's and expand's K
+  constexpr int TR = tile_rows(CM);
+  constexpr int NPB1 = TR + 2;                      // column blocks of conv1 (halo rows)
+  constexpr int SL1 = NPB1 * 32 + 4;                // slots of the h1 image: + the two a garbage column may touch; = 4 mod 16
+  constexpr int SL2 = TR * 32 + 4;                  // slots of the h2 image
+  static_assert(SL1 % 16 == 4 && SL2 % 16 == 4, "conflict-free 16-byte fragment reads");
+  constexpr int B3_OFF = (CM / 8) * SL1 * 16;       // b3 (4 CM floats) behind the h1 image
   extern __shared__ __attribute__((aligned(16))) char Bs[];   // h1 image, then (same memory) the h2 image
 
   // consecutive tiles stay on one XCD (shared halo rows in its L2)
@@ -84,7 +88,10 @@ __global__ __launch_bounds__(THREADS, 2) void bottleneck_block_bf16_kernel(
     return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + byte_off + woff);
   };
 
-  // ---------------------------------------------------------------- conv1 on the 8 x 32 halo tile
+  for (int i = tid; i < CM; i += THREADS)            // b3 -> LDS (read in the epilogue of the expand; published by the first barrier)
+    *reinterpret_cast<float4*>(Bs + B3_OFF + 16 * i) = *reinterpret_cast<const float4*>(bias3 + 4 * i);
+
+  // ---------------------------------------------------------------- conv1 on the (TR + 2) x 32 halo tile
   {
     constexpr int WM = CM == 64 ? 1 : 2, WN = 4 / WM;      // waves along rows / column blocks
     constexpr int MI = (CM / 32) / WM, PB = NPB1 / WN;     // 2 row blocks x 2 (CM = 64) / 4 (CM = 128) column blocks per wave
@@ -227,74 +234,94 @@ __global__ __launch_bounds__(THREADS, 2) void bottleneck_block_bf16_kernel(
       po[pj] = ok ? (unsigned)(((yy * W + xx) * C4 + 16 * kh) * 2) : OOB;
     }
     u32x4_t keep[2] = {};                            // store data of the previous group (see the epilogue)
-    constexpr int NA = CM == 64 ? 2 : 1;             // CM = 64: the next pass's W3 fragments are requested a pass ahead
-    f32x4 a[NA][KS3];
-    auto w3_issue = [&](int slot, int p) {
-      const int mb = NPASS * wave + p;
+    // The wave's row blocks go in PAIRS (two 32-channel blocks = one 128-byte line of a pixel) and the tile's column blocks
+    // in groups of two: the four 16-byte stores that complete a pixel's line are issued back to back.  (First form: one
+    // row block per pass, the two halves of a line a whole pass apart -- L2 hands part-written lines to the fabric as
+    // they are, profiles/r3: the expand phase took 150 of the kernel's 247 us at CM = 64, 1.8 TB/s of stores.)
+    constexpr int NPP = NPASS / 2, NG = TR / 2;
+    static_assert(NPASS % 2 == 0 && TR % 2 == 0, "pairs of row blocks, pairs of column blocks");
+    const char* const b3s = Bs + B3_OFF + 64 * kh;   // bias3 in LDS (staged below): 16 floats per (row block, lane half)
+    f32x4 a[2][KS3];                                 // W3 fragments of the pair: [row block][k-step]
+    bf16x8 res[2][2][2][2];                          // residual rows two groups deep: [buffer][row block][column block][half]
+    auto res_issue = [&](int buf, int mbA, int g) {
 #pragma unroll
-      for (int k = 0; k < KS3; ++k)
-        a[slot][k] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(Wf3) + mb * w3row + k * 1024 + woff3);
+      for (int pj = 0; pj < 2; ++pj)
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+            res[buf][ms][pj][h] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                rs_x, (int)(po[2 * g + pj] == OOB ? OOB : po[2 * g + pj] + 16 * h), (mbA + ms) * 64, 0));
     };
-    w3_issue(0, 0);
 #pragma unroll
-    for (int p = 0; p < NPASS; ++p) {
-      const int mb = NPASS * wave + p;               // channels 32 mb .. + 31
-      // residual rows: 32 contiguous bytes per lane and pixel, requested in front of the pass's MFMAs
-      bf16x8 res[TR][2];
+    for (int pp = 0; pp < NPP; ++pp) {
+      const int mbA = NPASS * wave + 2 * pp;         // channels 32 mbA .. + 63
 #pragma unroll
-      for (int pj = 0; pj < TR; ++pj)
+      for (int ms = 0; ms < 2; ++ms)
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-          res[pj][h] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
-              rs_x, (int)(po[pj] == OOB ? OOB : po[pj] + 16 * h), mb * 64, 0));
-      if (NA == 2 && p + 1 < NPASS) w3_issue((p + 1) & 1, p + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      f32x16 acc[TR];
+        for (int k = 0; k < KS3; ++k)
+          a[ms][k] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(Wf3) + (mbA + ms) * w3row + k * 1024 + woff3);
+      res_issue(0, mbA, 0);
 #pragma unroll
-      for (int pj = 0; pj < TR; ++pj)
+      for (int g = 0; g < NG; ++g) {
+        f32x16 acc[2][2];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[pj][e] = 0.f;
+        for (int ms = 0; ms < 2; ++ms)
 #pragma unroll
-      for (int k = 0; k < KS3; ++k) {
-        const bf16x8 av = __builtin_bit_cast(bf16x8, a[NA == 2 ? (p & 1) : 0][k]);
+          for (int pj = 0; pj < 2; ++pj)
 #pragma unroll
-        for (int pj = 0; pj < TR; ++pj)
-          acc[pj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, *reinterpret_cast<const bf16x8*>(hb + (2 * k * SL2 + pj * 32) * 16),
-                                                            acc[pj], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (NA == 1 && p + 1 < NPASS) w3_issue(0, p + 1);   // CM = 128: the next pass's fragments fly under this pass's epilogue
-      const int chm = 32 * mb + 16 * kh;
-      float bv[16];
+            for (int e = 0; e < 16; ++e) acc[ms][pj][e] = 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float4 t = *reinterpret_cast<const float4*>(bias3 + chm + 4 * i);
-        bv[4 * i] = t.x; bv[4 * i + 1] = t.y; bv[4 * i + 2] = t.z; bv[4 * i + 3] = t.w;
-      }
+        for (int k = 0; k < KS3; ++k) {
+          bf16x8 b[2];
 #pragma unroll
-      for (int pj = 0; pj < TR; ++pj) {
-        u32x4_t o2[2];
+          for (int pj = 0; pj < 2; ++pj) b[pj] = *reinterpret_cast<const bf16x8*>(hb + (2 * k * SL2 + (2 * g + pj) * 32) * 16);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          bf16x8 o;
+          for (int ms = 0; ms < 2; ++ms) {
+            const bf16x8 av = __builtin_bit_cast(bf16x8, a[ms][k]);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) o[j] = (__bf16)fmaxf((acc[pj][8 * h + j] + bv[8 * h + j]) + (float)res[pj][h][j], 0.f);
-          o2[h] = __builtin_bit_cast(u32x4_t, o);
+            for (int pj = 0; pj < 2; ++pj) acc[ms][pj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b[pj], acc[ms][pj], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
-        // both 16-byte stores of the lane's 32 bytes back to back: the lane pair of a pixel completes a 64-byte sector
-        __builtin_amdgcn_raw_buffer_store_b128(o2[0], rs_o, (int)(po[pj] == OOB ? OOB : po[pj]), mb * 64, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(o2[1], rs_o, (int)(po[pj] == OOB ? OOB : po[pj] + 16), mb * 64, 0);
-        // STORE-DATA HAZARD (found the hard way, round 5): a 128-bit buffer store reads its data registers AFTER it has
-        // issued, and hipcc does not separate it from a following VALU write of those registers when the store has an
-        // SGPR soffset (GCNHazardRecognizer::createsVALUHazard assumes that form is safe).  With several waves per
-        // SIMD the next group's `v_add_f32 v32, ...` landed in the data of the store before it, in the lanes the store
-        // reads last (pixels 12..15 / 28..29 of a block; wrong bits in ~0.02 % of the outputs, different ones every
-        // launch; none with one workgroup per CU).  The data registers of a group therefore stay LIVE until the stores
-        // of the NEXT group have been issued (an empty asm that names them), i.e. for ~50 vector instructions.
-        asm volatile("" ::"v"(keep[0]), "v"(keep[1]));
-        keep[0] = o2[0];
-        keep[1] = o2[1];
+        if (g + 1 < NG) res_issue((g + 1) & 1, mbA, g + 1);   // the next group's rows fly under this group's epilogue
         __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int pj = 0; pj < 2; ++pj) {
+          const unsigned pofs = po[2 * g + pj];
+#pragma unroll
+          for (int ms = 0; ms < 2; ++ms) {
+            float bv[16];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float4 t = *reinterpret_cast<const float4*>(b3s + (mbA + ms) * 128 + 16 * i);
+              bv[4 * i] = t.x; bv[4 * i + 1] = t.y; bv[4 * i + 2] = t.z; bv[4 * i + 3] = t.w;
+            }
+            u32x4_t o2[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              bf16x8 o;
+#pragma unroll
+              for (int j = 0; j < 8; ++j)
+                o[j] = (__bf16)fmaxf((acc[ms][pj][8 * h + j] + bv[8 * h + j]) + (float)res[g & 1][ms][pj][h][j], 0.f);
+              o2[h] = __builtin_bit_cast(u32x4_t, o);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(o2[0], rs_o, (int)(pofs == OOB ? OOB : pofs), (mbA + ms) * 64, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(o2[1], rs_o, (int)(pofs == OOB ? OOB : pofs + 16), (mbA + ms) * 64, 0);
+            // STORE-DATA HAZARD (found the hard way, round 5): a 128-bit buffer store reads its data registers AFTER it
+            // has issued, and hipcc does not separate it from a following VALU write of those registers when the store
+            // has an SGPR soffset (GCNHazardRecognizer::createsVALUHazard assumes that form is safe).  With several waves
+            // per SIMD the next group's `v_add_f32 v32, ...` landed in the data of the store before it, in the lanes the
+            // store reads last (pixels 12..15 / 28..29 of a block; wrong bits in ~0.02 % of the outputs, different ones
+            // every launch; none with one workgroup per CU).  The data registers of a group therefore stay LIVE until the
+            // stores of the NEXT group have been issued (an empty asm that names them), i.e. for ~50 vector instructions
+            // (tools/lint_store_hazard.py checks the ISA of every kernel for the pattern).
+            asm volatile("" ::"v"(keep[0]), "v"(keep[1]));
+            keep[0] = o2[0];
+            keep[1] = o2[1];
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
       }
     }
     // ... and the last group's until well after its stores (the wave ends here)
@@ -306,11 +333,12 @@ template <int CM>
 int launch(const uint16_t* x, int64_t NB, int64_t H, int64_t W, const uint16_t* f1, const float* b1, const uint16_t* f2,
            const float* b2, const uint16_t* f3, const float* b3, uint16_t* out, void* stream) {
   const char* what = "tspn_bottleneck_block_bf16";
+  constexpr int TR = tile_rows(CM);
   const int64_t tiles_x = tspn::ceil_div(W, TW), tiles_y = tspn::ceil_div(H, TR);
   const int64_t ntiles = NB * tiles_x * tiles_y;
   TSPN_REQUIRE(ntiles < (1LL << 30), TSPN_EUNSUPPORTED, "%s: grid too large", what);
   const int64_t grid = tspn::ceil_div(ntiles, 8) * 8;            // whole rounds over the eight XCDs
-  constexpr size_t smem = (size_t)(CM / 8) * SL1 * 16;           // the h1 image (the h2 image is smaller and takes its place)
+  constexpr size_t smem = (size_t)(CM / 8) * ((TR + 2) * 32 + 4) * 16 + 4 * CM * 4;   // the h1 image (h2 takes its place) + b3
   static tspn::LdsLimit lds;
   if (int rc = lds.ensure(reinterpret_cast<const void*>(bottleneck_block_bf16_kernel<CM>), smem, what)) return rc;
   hipLaunchKernelGGL((bottleneck_block_bf16_kernel<CM>), dim3((unsigned)grid), dim3(THREADS), smem, TSPN_STREAM(stream),
