@@ -92,7 +92,92 @@ __global__ __launch_bounds__(THREADS, 2) void bottleneck_block_bf16_kernel(
     *reinterpret_cast<float4*>(Bs + B3_OFF + 16 * i) = *reinterpret_cast<const float4*>(bias3 + 4 * i);
 
   // ---------------------------------------------------------------- conv1 on the (TR + 2) x 32 halo tile
-  {
+  if constexpr (CM == 128) {
+    // Four waves along the ROWS (one 32-row block each, all NPB1 column blocks): every W1 fragment enters the CU once.
+    // x then has to be shared: its 64-channel chunks go through LDS by DMA -- a ring of two stages [8 groups][SL1 slots]
+    // [8 bf16] that lives in the memory of the h1 image (which is only written after the last chunk has been read).
+    // With x from global memory on 2 x 2 waves this phase took 83 of the kernel's 159 us per 9 frames: both operands
+    // read twice, 622 MB through L2 (profiles/r5/bottleneck_block_study.md).
+    constexpr int XST = 8 * SL1 * 16;                // bytes per stage; 2 XST = the h1 image
+    static_assert(2 * XST == (CM / 8) * SL1 * 16 && NPB1 == 8, "x ring = h1 image");
+    f32x16 acc[NPB1];
+#pragma unroll
+    for (int pj = 0; pj < NPB1; ++pj)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[pj][e] = 0.f;
+    // DMA pieces: wave w stages channel groups 2 w, 2 w + 1 of all 256 slots: piece (gg, sq) = group 2 w + gg, slots
+    // 64 sq .. + 63, lane = slot (the DMA writes lane * 16 behind the piece's base)
+    unsigned xv[4];
+#pragma unroll
+    for (int sq = 0; sq < 4; ++sq) {
+      const int yy = y0 - 1 + 2 * sq + (lane >> 5), xx = x0 - 1 + li;
+      xv[sq] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? (unsigned)((yy * W + xx) * C4 * 2) : OOB;   // outside: zeros
+    }
+    auto stage = [&](int buf, int c) {
+#pragma unroll
+      for (int gg = 0; gg < 2; ++gg)
+#pragma unroll
+        for (int sq = 0; sq < 4; ++sq)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(
+              rs_x, (__attribute__((address_space(3))) void*)(Bs + buf * XST + ((2 * wave + gg) * SL1 + 64 * sq) * 16), 16,
+              (int)xv[sq], c * 128 + (2 * wave + gg) * 16, 0, 0);
+    };
+    const int64_t w1row = (int64_t)C1 * 4096;
+    f32x4 a[2][4];                                   // W1 fragments of a chunk's four k-steps, this chunk's and the next's
+    auto load_a = [&](int buf, int c) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) a[buf][ks] = ldw(Wf1, wave * w1row + (int64_t)(4 * c + ks) * 1024);
+    };
+    stage(0, 0);
+    load_a(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const char* xb = Bs + (kh * SL1 + li) * 16;
+#pragma unroll
+    for (int c = 0; c < C1; ++c) {
+      // stage (c + 1) & 1 was last read in chunk c - 1; the barrier at its end lies behind every wave
+      if (c + 1 < C1) { stage((c + 1) & 1, c + 1); load_a((c + 1) & 1, c + 1); }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 av = __builtin_bit_cast(bf16x8, a[c & 1][ks]);
+#pragma unroll
+        for (int pj = 0; pj < NPB1; ++pj)
+          acc[pj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              av, *reinterpret_cast<const bf16x8*>(xb + (c & 1) * XST + (2 * ks * SL1 + pj * 32) * 16), acc[pj], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of chunk c + 1 have landed ...
+      __syncthreads();                                     // ... everybody's have, and nobody reads stage c & 1 any more
+    }
+    // h1 = relu(acc + b1) -> bf16 -> LDS (over the x ring); exactly 0 outside the image
+    unsigned inmask = 0;
+#pragma unroll
+    for (int pj = 0; pj < NPB1; ++pj) {
+      const int yy = y0 - 1 + pj, xx = x0 - 1 + li;
+      inmask |= (yy >= 0 && yy < H && xx >= 0 && xx < W ? 1u : 0u) << pj;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ch = 32 * wave + 8 * q + 4 * kh;
+      const float4 bv = *reinterpret_cast<const float4*>(bias1 + ch);
+#pragma unroll
+      for (int pj = 0; pj < NPB1; ++pj) {
+        bf16x4 v;
+        v[0] = (__bf16)fmaxf(acc[pj][4 * q] + bv.x, 0.f);
+        v[1] = (__bf16)fmaxf(acc[pj][4 * q + 1] + bv.y, 0.f);
+        v[2] = (__bf16)fmaxf(acc[pj][4 * q + 2] + bv.z, 0.f);
+        v[3] = (__bf16)fmaxf(acc[pj][4 * q + 3] + bv.w, 0.f);
+        if (!((inmask >> pj) & 1u)) v = bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+        *reinterpret_cast<bf16x4*>(Bs + ((ch >> 3) * SL1 + pj * 32 + li) * 16 + 8 * kh) = v;
+      }
+    }
+    if (tid < 4 * (CM / 8)) {                        // the four slots behind the tile: only garbage columns read them; keep them finite
+      const int g = tid >> 2, sl = NPB1 * 32 + (tid & 3);
+      *reinterpret_cast<f32x4*>(Bs + (g * SL1 + sl) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  if constexpr (CM == 64) {
+    // x straight from global memory into B-operand registers: four waves along the pixels read it exactly once
     constexpr int WM = CM == 64 ? 1 : 2, WN = 4 / WM;      // waves along rows / column blocks
     constexpr int MI = (CM / 32) / WM, PB = NPB1 / WN;     // 2 row blocks x 2 (CM = 64) / 4 (CM = 128) column blocks per wave
     const int wm = wave % WM, wn = wave / WM;
