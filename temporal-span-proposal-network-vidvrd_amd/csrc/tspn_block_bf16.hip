@@ -47,13 +47,20 @@ constexpr int RP = TW + 2;              // LDS row pitch in slots = one 32-pixel
 // rows of a tile: the weights are re-streamed from L2 per tile, so CM = 64 (small accumulators) takes ten rows
 constexpr int tile_rows(int cm) { return cm == 64 ? 10 : 6; }
 
-template <int CM>
+// PROJ: the first block of a stage -- its input has CIN channels at ST times the output resolution, conv1 is a 1x1 of
+// stride ST and the residual is the PROJECTION shortcut  sc = bf16(Ws . x + bs)  (1x1, stride ST, CIN -> 4 CM, rounded
+// to bf16 like the separate launch's output), computed in the expand phase from the tile's own input pixels instead of
+// being written to and read back from HBM (res2.0: 265 + 265 MB per 9 frames of 720p).  Identity blocks: CIN = 4 CM,
+// ST = 1, the input itself is the residual.
+template <int CM, int CIN, int ST, bool PROJ>
 __global__ __launch_bounds__(THREADS, 2) void bottleneck_block_bf16_kernel(
     const __bf16* __restrict__ x, const __bf16* __restrict__ Wf1, const float* __restrict__ bias1,
     const __bf16* __restrict__ Wf2, const float* __restrict__ bias2, const __bf16* __restrict__ Wf3,
-    const float* __restrict__ bias3, __bf16* __restrict__ out, int H, int W, int tiles_x, int tiles_y, int ntiles) {
+    const float* __restrict__ bias3, const __bf16* __restrict__ Wfs, const float* __restrict__ biass,
+    __bf16* __restrict__ out, int H, int W, int Hin, int Win, int tiles_x, int tiles_y, int ntiles) {
+  static_assert(PROJ || (CIN == 4 * CM && ST == 1), "identity blocks take their input as the residual");
   constexpr int C4 = 4 * CM;
-  constexpr int C1 = C4 / 64, C2 = CM / 64;         // 64-channel parts of conv1's / the 3x3's and expand's K
+  constexpr int C1 = CIN / 64, C2 = CM / 64;        // 64-channel parts of conv1's / the 3x3's and expand's K
   constexpr int TR = tile_rows(CM);
   constexpr int NPB1 = TR + 2;                      // column blocks of conv1 (halo rows)
   constexpr int SL1 = NPB1 * 32 + 4;                // slots of the h1 image: + the two a garbage column may touch; = 4 mod 16
@@ -79,17 +86,21 @@ __global__ __launch_bounds__(THREADS, 2) void bottleneck_block_bf16_kernel(
   const unsigned woff = lane * 16;
 
   // one descriptor per tensor, based at this image: every offset below is a 32-bit byte offset inside the image
-  const int64_t img_off = (int64_t)img * H * W * C4;
-  const unsigned img_bytes = (unsigned)((int64_t)H * W * C4 * 2);
-  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(x) + img_off, 0, (int)img_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(out + img_off, 0, (int)img_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<__bf16*>(x) + (int64_t)img * Hin * Win * CIN, 0, (int)(unsigned)((int64_t)Hin * Win * CIN * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(
+      out + (int64_t)img * H * W * C4, 0, (int)(unsigned)((int64_t)H * W * C4 * 2), 0x00020000);
+  // byte offset of the input pixel under output pixel (yy, xx): a 1x1 conv of stride ST reads pixel (ST yy, ST xx)
+  auto xpix = [&](int yy, int xx) { return (unsigned)(((yy * ST) * Win + xx * ST) * CIN * 2); };
   constexpr unsigned OOB = 0x80000000u;             // beyond every descriptor: loads give zeros, stores are dropped
   auto ldw = [&](const __bf16* base, int64_t byte_off) {           // a weight fragment: 16 bytes per lane
     return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + byte_off + woff);
   };
 
-  for (int i = tid; i < CM; i += THREADS)            // b3 -> LDS (read in the epilogue of the expand; published by the first barrier)
+  for (int i = tid; i < CM; i += THREADS) {          // b3 (and bs) -> LDS (read in the epilogue of the expand; published by the first barrier)
     *reinterpret_cast<float4*>(Bs + B3_OFF + 16 * i) = *reinterpret_cast<const float4*>(bias3 + 4 * i);
+    if constexpr (PROJ) *reinterpret_cast<float4*>(Bs + B3_OFF + 16 * CM + 16 * i) = *reinterpret_cast<const float4*>(biass + 4 * i);
+  }
 
   // ---------------------------------------------------------------- conv1 on the (TR + 2) x 32 halo tile
   if constexpr (CM == 128) {
@@ -111,7 +122,7 @@ __global__ __launch_bounds__(THREADS, 2) void bottleneck_block_bf16_kernel(
 #pragma unroll
     for (int sq = 0; sq < 4; ++sq) {
       const int yy = y0 - 1 + 2 * sq + (lane >> 5), xx = x0 - 1 + li;
-      xv[sq] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? (unsigned)((yy * W + xx) * C4 * 2) : OOB;   // outside: zeros
+      xv[sq] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? xpix(yy, xx) : OOB;   // outside: zeros
     }
     auto stage = [&](int buf, int c) {
 #pragma unroll
@@ -194,11 +205,12 @@ __global__ __launch_bounds__(THREADS, 2) void bottleneck_block_bf16_kernel(
     for (int pj = 0; pj < PB; ++pj) {
       const int yy = y0 - 1 + PB * wn + pj, xx = x0 - 1 + li;
       inimg[pj] = yy >= 0 && yy < H && xx >= 0 && xx < W;
-      xo[pj] = inimg[pj] ? (unsigned)(((yy * W + xx) * C4 + 8 * kh) * 2) : OOB;
+      xo[pj] = inimg[pj] ? xpix(yy, xx) + 16 * kh : OOB;
     }
     const int64_t w1row = (int64_t)C1 * 4096;        // bytes per 32-row block of Wf1
     // operands D1 k-steps ahead (first form: one k-step ahead, every k-step waited a full round trip)
     constexpr int D1 = CM == 64 ? 4 : 3;
+    static_assert(D1 <= CIN / 16, "conv1 ring");
     f32x4 a[D1][MI];
     bf16x8 b[D1][PB];
     auto load_ks = [&](int slot, int k) {            // k = 4 c + ks: channels 16 k ..
@@ -208,7 +220,7 @@ __global__ __launch_bounds__(THREADS, 2) void bottleneck_block_bf16_kernel(
       for (int pj = 0; pj < PB; ++pj)
         b[slot][pj] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)xo[pj], k * 32, 0));
     };
-    constexpr int KS1 = C4 / 16;
+    constexpr int KS1 = CIN / 16;
 #pragma unroll
     for (int d = 0; d < D1; ++d) load_ks(d, d);
 #pragma unroll
@@ -328,15 +340,85 @@ __global__ __launch_bounds__(THREADS, 2) void bottleneck_block_bf16_kernel(
     const char* const b3s = Bs + B3_OFF + 64 * kh;   // bias3 in LDS (staged below): 16 floats per (row block, lane half)
     f32x4 a[2][KS3];                                 // W3 fragments of the pair: [row block][k-step]
     bf16x8 res[2][2][2][2];                          // residual rows two groups deep: [buffer][row block][column block][half]
-    auto res_issue = [&](int buf, int mbA, int g) {
+    // PROJ: the residual of a group = bf16(Ws . x + bs) on the group's own input pixels: K = CIN in KSX k-steps, B operand
+    // straight from global memory (lane = pixel, 16 bytes per k-step), Ws rows permuted like W3's.  The result goes into
+    // `res` in the layout the loaded rows have.
+    constexpr int KSX = CIN / 16;
+    constexpr bool WS_RESIDENT = PROJ && KSX <= 4;   // the pair's Ws fragments stay in registers across the groups
+    const int64_t wsrow = (int64_t)C1 * 4096;
+    const char* const bss = Bs + B3_OFF + 16 * CM + 64 * kh;
+    unsigned xc[TR];                                 // PROJ: byte offset of the input pixel under each output pixel (channel 8 kh)
+    if constexpr (PROJ) {
 #pragma unroll
-      for (int pj = 0; pj < 2; ++pj)
+      for (int pj = 0; pj < TR; ++pj) {
+        const int yy = y0 + pj, xx = x0 + li;
+        xc[pj] = (li < TW && yy < H && xx < W) ? xpix(yy, xx) + 16 * kh : OOB;
+      }
+    }
+    f32x4 asr[WS_RESIDENT ? 2 : 1][WS_RESIDENT ? KSX : 1];
+    auto res_issue = [&](int buf, int mbA, int g) {
+      if constexpr (!PROJ) {
+#pragma unroll
+        for (int pj = 0; pj < 2; ++pj)
+#pragma unroll
+          for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+              res[buf][ms][pj][h] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                  rs_x, (int)(po[2 * g + pj] == OOB ? OOB : po[2 * g + pj] + 16 * h), (mbA + ms) * 64, 0));
+      } else {
+        f32x16 sc[2][2];
 #pragma unroll
         for (int ms = 0; ms < 2; ++ms)
 #pragma unroll
-          for (int h = 0; h < 2; ++h)
-            res[buf][ms][pj][h] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
-                rs_x, (int)(po[2 * g + pj] == OOB ? OOB : po[2 * g + pj] + 16 * h), (mbA + ms) * 64, 0));
+          for (int pj = 0; pj < 2; ++pj)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sc[ms][pj][e] = 0.f;
+        constexpr int DX = 4;                        // operands four k-steps ahead
+        bf16x8 xf[DX][2];
+        f32x4 aw[DX][2];
+        auto load_k = [&](int slot, int k) {
+#pragma unroll
+          for (int pj = 0; pj < 2; ++pj)
+            xf[slot][pj] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)xc[2 * g + pj], k * 32, 0));
+          if constexpr (!WS_RESIDENT) {
+#pragma unroll
+            for (int ms = 0; ms < 2; ++ms)
+              aw[slot][ms] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(Wfs) + (mbA + ms) * wsrow + k * 1024 + woff3);
+          }
+        };
+#pragma unroll
+        for (int d = 0; d < DX && d < KSX; ++d) load_k(d, d);
+#pragma unroll
+        for (int k = 0; k < KSX; ++k) {
+#pragma unroll
+          for (int ms = 0; ms < 2; ++ms) {
+            const bf16x8 av = __builtin_bit_cast(bf16x8, WS_RESIDENT ? asr[WS_RESIDENT ? ms : 0][WS_RESIDENT ? k : 0] : aw[k % DX][ms]);
+#pragma unroll
+            for (int pj = 0; pj < 2; ++pj) sc[ms][pj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, xf[k % DX][pj], sc[ms][pj], 0, 0, 0);
+          }
+          if (k + DX < KSX) load_k(k % DX, k + DX);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms) {
+          float bs16[16];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float4 t = *reinterpret_cast<const float4*>(bss + (mbA + ms) * 128 + 16 * i);
+            bs16[4 * i] = t.x; bs16[4 * i + 1] = t.y; bs16[4 * i + 2] = t.z; bs16[4 * i + 3] = t.w;
+          }
+#pragma unroll
+          for (int pj = 0; pj < 2; ++pj)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              bf16x8 o;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) o[j] = (__bf16)(sc[ms][pj][8 * h + j] + bs16[8 * h + j]);   // the shortcut launch's rounding
+              res[buf][ms][pj][h] = o;
+            }
+        }
+      }
     };
 #pragma unroll
     for (int pp = 0; pp < NPP; ++pp) {
@@ -346,6 +428,13 @@ __global__ __launch_bounds__(THREADS, 2) void bottleneck_block_bf16_kernel(
 #pragma unroll
         for (int k = 0; k < KS3; ++k)
           a[ms][k] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(Wf3) + (mbA + ms) * w3row + k * 1024 + woff3);
+      if constexpr (WS_RESIDENT) {
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+          for (int k = 0; k < KSX; ++k)
+            asr[ms][k] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(Wfs) + (mbA + ms) * wsrow + k * 1024 + woff3);
+      }
       res_issue(0, mbA, 0);
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
@@ -369,7 +458,7 @@ __global__ __launch_bounds__(THREADS, 2) void bottleneck_block_bf16_kernel(
           }
           __builtin_amdgcn_sched_barrier(0);
         }
-        if (g + 1 < NG) res_issue((g + 1) & 1, mbA, g + 1);   // the next group's rows fly under this group's epilogue
+        if (!PROJ && g + 1 < NG) res_issue((g + 1) & 1, mbA, g + 1);   // the next group's rows fly under this group's epilogue
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int pj = 0; pj < 2; ++pj) {
@@ -388,7 +477,7 @@ __global__ __launch_bounds__(THREADS, 2) void bottleneck_block_bf16_kernel(
               bf16x8 o;
 #pragma unroll
               for (int j = 0; j < 8; ++j)
-                o[j] = (__bf16)fmaxf((acc[ms][pj][8 * h + j] + bv[8 * h + j]) + (float)res[g & 1][ms][pj][h][j], 0.f);
+                o[j] = (__bf16)fmaxf((acc[ms][pj][8 * h + j] + bv[8 * h + j]) + (float)res[PROJ ? 0 : (g & 1)][ms][pj][h][j], 0.f);
               o2[h] = __builtin_bit_cast(u32x4_t, o);
             }
             __builtin_amdgcn_raw_buffer_store_b128(o2[0], rs_o, (int)(pofs == OOB ? OOB : pofs), (mbA + ms) * 64, 0);
@@ -407,6 +496,7 @@ __global__ __launch_bounds__(THREADS, 2) void bottleneck_block_bf16_kernel(
             __builtin_amdgcn_sched_barrier(0);
           }
         }
+        if (PROJ && g + 1 < NG) res_issue(0, mbA, g + 1);
       }
     }
     // ... and the last group's until well after its stores (the wave ends here)
@@ -414,22 +504,24 @@ __global__ __launch_bounds__(THREADS, 2) void bottleneck_block_bf16_kernel(
   }
 }
 
-template <int CM>
-int launch(const uint16_t* x, int64_t NB, int64_t H, int64_t W, const uint16_t* f1, const float* b1, const uint16_t* f2,
-           const float* b2, const uint16_t* f3, const float* b3, uint16_t* out, void* stream) {
-  const char* what = "tspn_bottleneck_block_bf16";
+template <int CM, int CIN, int ST, bool PROJ>
+int launch(const uint16_t* x, int64_t NB, int64_t Hin, int64_t Win, const uint16_t* f1, const float* b1, const uint16_t* f2,
+           const float* b2, const uint16_t* f3, const float* b3, const uint16_t* fs, const float* bs, uint16_t* out,
+           void* stream, const char* what) {
   constexpr int TR = tile_rows(CM);
+  const int64_t H = (Hin - 1) / ST + 1, W = (Win - 1) / ST + 1;
   const int64_t tiles_x = tspn::ceil_div(W, TW), tiles_y = tspn::ceil_div(H, TR);
   const int64_t ntiles = NB * tiles_x * tiles_y;
   TSPN_REQUIRE(ntiles < (1LL << 30), TSPN_EUNSUPPORTED, "%s: grid too large", what);
   const int64_t grid = tspn::ceil_div(ntiles, 8) * 8;            // whole rounds over the eight XCDs
-  constexpr size_t smem = (size_t)(CM / 8) * ((TR + 2) * 32 + 4) * 16 + 4 * CM * 4;   // the h1 image (h2 takes its place) + b3
+  constexpr size_t smem = (size_t)(CM / 8) * ((TR + 2) * 32 + 4) * 16 + (PROJ ? 2 : 1) * 4 * CM * 4;   // h1 image (h2 takes its place) + b3 (+ bs)
   static tspn::LdsLimit lds;
-  if (int rc = lds.ensure(reinterpret_cast<const void*>(bottleneck_block_bf16_kernel<CM>), smem, what)) return rc;
-  hipLaunchKernelGGL((bottleneck_block_bf16_kernel<CM>), dim3((unsigned)grid), dim3(THREADS), smem, TSPN_STREAM(stream),
-                     reinterpret_cast<const __bf16*>(x), reinterpret_cast<const __bf16*>(f1), b1,
+  if (int rc = lds.ensure(reinterpret_cast<const void*>(bottleneck_block_bf16_kernel<CM, CIN, ST, PROJ>), smem, what)) return rc;
+  hipLaunchKernelGGL((bottleneck_block_bf16_kernel<CM, CIN, ST, PROJ>), dim3((unsigned)grid), dim3(THREADS), smem,
+                     TSPN_STREAM(stream), reinterpret_cast<const __bf16*>(x), reinterpret_cast<const __bf16*>(f1), b1,
                      reinterpret_cast<const __bf16*>(f2), b2, reinterpret_cast<const __bf16*>(f3), b3,
-                     reinterpret_cast<__bf16*>(out), (int)H, (int)W, (int)tiles_x, (int)tiles_y, (int)ntiles);
+                     reinterpret_cast<const __bf16*>(fs), bs, reinterpret_cast<__bf16*>(out), (int)H, (int)W, (int)Hin,
+                     (int)Win, (int)tiles_x, (int)tiles_y, (int)ntiles);
   return tspn::check_launch(what);
 }
 
@@ -451,6 +543,32 @@ extern "C" int tspn_bottleneck_block_bf16(const uint16_t* x, int64_t NB, int64_t
                TSPN_EUNSUPPORTED, "%s: operands must be 16-byte aligned", what);
   // 32-bit byte offsets inside one image
   TSPN_REQUIRE(H * W * 4 * CM * 2 < (1LL << 31), TSPN_EUNSUPPORTED, "%s: one image's map must stay below 2 GB", what);
-  if (CM == 128) return launch<128>(x, NB, H, W, frag1, bias1, frag2, bias2, frag3, bias3, out, stream);
-  return launch<64>(x, NB, H, W, frag1, bias1, frag2, bias2, frag3, bias3, out, stream);
+  if (CM == 128)
+    return launch<128, 512, 1, false>(x, NB, H, W, frag1, bias1, frag2, bias2, frag3, bias3, nullptr, nullptr, out, stream, what);
+  return launch<64, 256, 1, false>(x, NB, H, W, frag1, bias1, frag2, bias2, frag3, bias3, nullptr, nullptr, out, stream, what);
+}
+
+extern "C" int tspn_bottleneck_block_proj_bf16(const uint16_t* x, int64_t NB, int64_t Hin, int64_t Win, int64_t CIN,
+                                               int64_t stride, int64_t CM, const uint16_t* frag1, const float* bias1,
+                                               const uint16_t* frag2, const float* bias2, const uint16_t* frag3,
+                                               const float* bias3, const uint16_t* frags, const float* biass,
+                                               uint16_t* out, void* stream) {
+  const char* what = "tspn_bottleneck_block_proj_bf16";
+  TSPN_REQUIRE(NB >= 0 && Hin > 0 && Win > 0, TSPN_EINVAL, "%s: bad sizes", what);
+  TSPN_REQUIRE((CM == 64 && CIN == 64 && stride == 1) || (CM == 128 && CIN == 256 && stride == 2), TSPN_EUNSUPPORTED,
+               "%s: built for the first blocks of res2 (64 -> 64 -> 256, stride 1) and res3 (256 -> 128 -> 512, stride 2); got "
+               "CIN=%lld CM=%lld stride=%lld", what, (long long)CIN, (long long)CM, (long long)stride);
+  if (NB == 0) return TSPN_OK;
+  TSPN_REQUIRE(x && frag1 && bias1 && frag2 && bias2 && frag3 && bias3 && frags && biass && out, TSPN_EINVAL,
+               "%s: null pointer", what);
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  TSPN_REQUIRE(al16(x) && al16(frag1) && al16(bias1) && al16(frag2) && al16(bias2) && al16(frag3) && al16(bias3) &&
+                   al16(frags) && al16(biass) && al16(out),
+               TSPN_EUNSUPPORTED, "%s: operands must be 16-byte aligned", what);
+  const int64_t H = (Hin - 1) / stride + 1, W = (Win - 1) / stride + 1;
+  TSPN_REQUIRE(H * W * 4 * CM * 2 < (1LL << 31) && Hin * Win * CIN * 2 < (1LL << 31), TSPN_EUNSUPPORTED,
+               "%s: one image's maps must stay below 2 GB", what);
+  if (CM == 128)
+    return launch<128, 256, 2, true>(x, NB, Hin, Win, frag1, bias1, frag2, bias2, frag3, bias3, frags, biass, out, stream, what);
+  return launch<64, 64, 1, true>(x, NB, Hin, Win, frag1, bias1, frag2, bias2, frag3, bias3, frags, biass, out, stream, what);
 }

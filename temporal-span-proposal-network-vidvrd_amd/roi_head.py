@@ -106,6 +106,11 @@ class BottleneckBlock(nn.Module):
         # ... and whole identity blocks of the memory-bound stages (64 / 128 bottleneck channels, stride 1, no projection)
         # as ONE launch that reads the 4 CM-channel map once (csrc/tspn_block_bf16.hip, round 5); same bits
         self.fuse_block = True
+        # ... and the FIRST block of res2 / res3 (projection shortcut, stride 1 / 2) as one launch that computes the shortcut
+        # on the tile's own input pixels instead of writing the 4 CM-channel shortcut map and reading it back
+        self.fuse_block_proj = True
+
+    PROJ_SHAPES = ((64, 64, 1),)        # (input channels, bottleneck channels, stride) tspn_bottleneck_block_proj_bf16 is enabled for
 
     def _can_fuse_block(self, x, h1):
         c1, c2, c3 = self.conv1, self.conv2, self.conv3
@@ -114,6 +119,18 @@ class BottleneckBlock(nn.Module):
                 and self.shortcut is None and self.stride == 1 and c1.kernel_size == 1 and c1.padding == 0
                 and tuple(c1.weight.shape[:2]) == (cm, 4 * cm) and c2.weight.shape[1] == cm and c2.kernel_size == 3
                 and c2.stride == 1 and c2.padding == 1 and tuple(c3.weight.shape[:2]) == (4 * cm, cm) and c3.kernel_size == 1)
+
+    def _can_fuse_block_proj(self, x, h1, presampled):
+        """First block of a stage (projection shortcut): the shapes tspn_bottleneck_block_proj_bf16 is built for."""
+        c1, c2, c3, sc = self.conv1, self.conv2, self.conv3, self.shortcut
+        if sc is None or not (self.fuse_tail and self.fuse_block and self.fuse_block_proj) or h1 is not None or presampled:
+            return False
+        cm, cin = c2.weight.shape[0], c1.weight.shape[1]
+        return (x.dtype == torch.bfloat16 and (cin, cm, self.stride) in self.PROJ_SHAPES and c1.kernel_size == 1
+                and c1.padding == 0 and c1.stride == self.stride and sc.kernel_size == 1 and sc.padding == 0
+                and sc.stride == self.stride and c1.weight.shape[0] == cm and tuple(sc.weight.shape[:2]) == (4 * cm, cin)
+                and c2.weight.shape[1] == cm and c2.kernel_size == 3 and c2.stride == 1 and c2.padding == 1
+                and tuple(c3.weight.shape[:2]) == (4 * cm, cm) and c3.kernel_size == 1)
 
     def _can_fuse(self, x):
         c2, c3 = self.conv2, self.conv3
@@ -142,6 +159,13 @@ class BottleneckBlock(nn.Module):
             f2, b2 = self.conv2.folded_bf16(x.device)
             f3, b3 = self.conv3.folded_bf16(x.device)
             y = ops.bottleneck_block_bf16(x.contiguous(), f1, b1, f2, b2, f3, b3, out=out)
+            return (y, None) if next_block is not None else y
+        if self._can_fuse_block_proj(x, h1, presampled):
+            f1, b1 = self.conv1.folded_bf16(x.device)
+            f2, b2 = self.conv2.folded_bf16(x.device)
+            f3, b3 = self.conv3.folded_bf16(x.device)
+            fs, bs = self.shortcut.folded_bf16(x.device)
+            y = ops.bottleneck_block_proj_bf16(x.contiguous(), self.stride, f1, b1, f2, b2, f3, b3, fs, bs, out=out)
             return (y, None) if next_block is not None else y
         h = h1 if h1 is not None else self.conv1(x, relu=True, stride=st)
         if self.shortcut is not None:
@@ -387,6 +411,8 @@ class ResNetC4(_CachedWeightsMixin, nn.Module):
         # identity blocks of res2 / res3 (64 / 128 bottleneck channels) as ONE launch each (round 5, tspn_bottleneck_block_bf16:
         # the 4 CM-channel map read once, h1 / h2 on the CU; same bits as conv1 + fused tail)
         self.fuse_blocks = True
+        # ... and the first block of res2 (projection shortcut) as one launch too (tspn_bottleneck_block_proj_bf16)
+        self.fuse_first_blocks = True
         # frame chunks alternate between this many HIP streams: a launch's workgroups run in lockstep (all in their MFMA
         # phase, then all in their memory phase), two chunks in flight put the memory phase of one under the MFMA phase
         # of the other (tools/probe_tail_stagger.py: -10 % on the res4 tails; backbone -5 %)
@@ -403,6 +429,7 @@ class ResNetC4(_CachedWeightsMixin, nn.Module):
                     m.fuse_tail = bool(self.fuse_bottlenecks)
                     m.fuse_next = bool(self.fuse_bottlenecks and self.fuse_next_conv1)
                     m.fuse_block = bool(self.fuse_bottlenecks and self.fuse_blocks)
+                    m.fuse_block_proj = bool(self.fuse_first_blocks)
             out = []
             nchunks = -(-images.shape[0] // self.frame_chunk)
             ns = min(int(self.streams), nchunks) if images.is_cuda else 1

@@ -444,6 +444,36 @@ def test_bottleneck_block_one_launch_bit_identical_to_conv1_plus_fused_tail(tspn
         assert float((err <= 2.0 ** -8 * ref.abs() + 1e-6).double().mean()) > 0.95
 
 
+@pytest.mark.parametrize("CIN,CM,stride,NB,H,W", [(64, 64, 1, 2, 9, 13), (64, 64, 1, 1, 1, 1), (64, 64, 1, 1, 10, 30),
+                                                 (64, 64, 1, 1, 11, 31), (64, 64, 1, 1, 45, 80), (64, 64, 1, 3, 23, 40)])
+def test_first_block_of_a_stage_one_launch_bit_identical_to_its_four_launches(tspn, device, CIN, CM, stride, NB, H, W):
+    """tspn_bottleneck_block_proj_bf16 (round 5): the first block of a stage -- conv1 and the PROJECTION shortcut (1x1 convs
+    of stride s on the same input), 3x3, expand, residual, ReLU -- in one launch; the shortcut is computed on the tile's
+    own input pixels and rounded to bf16 like the separate launch's output, so the result equals conv1 + shortcut + fused
+    tail BIT FOR BIT.  H, W here are the INPUT sizes."""
+    x = tspn.hashrng.uniform(96, "x", (NB, H, W, CIN), -1, 1)
+    w1 = tspn.hashrng.normal(96, "w1", (CM, CIN, 1, 1), std=float(np.sqrt(2.0 / CIN)))
+    w2 = tspn.hashrng.normal(96, "w2", (CM, CM, 3, 3), std=float(np.sqrt(2.0 / (9 * CM))))
+    w3 = tspn.hashrng.normal(96, "w3", (4 * CM, CM, 1, 1), std=float(np.sqrt(2.0 / CM)))
+    ws = tspn.hashrng.normal(96, "ws", (4 * CM, CIN, 1, 1), std=float(np.sqrt(1.0 / CIN)))
+    b1, b2 = (tspn.hashrng.normal(96, n, (CM,), std=0.1) for n in ("b1", "b2"))
+    b3, bs = (tspn.hashrng.normal(96, n, (4 * CM,), std=0.1) for n in ("b3", "bs"))
+    d = lambda a, dt=None: (t(a).to(device) if dt is None else t(a).to(device).to(dt))   # noqa: E731
+    f1, f2, f3, fs = (tspn.ops.pack_conv2d_frag_bf16(d(w)) for w in (w1, w2, w3, ws))
+    xd = d(x, torch.bfloat16)
+    h1 = tspn.ops.conv2d_nhwc_bf16(xd, f1, (1, 1), stride, 0, bias=d(b1), relu=True)
+    sc = tspn.ops.conv2d_nhwc_bf16(xd, fs, (1, 1), stride, 0, bias=d(bs), relu=False)
+    want = tspn.ops.bottleneck_tail_bf16(h1, f2, d(b2), f3, d(b3), sc)
+    got = tspn.ops.bottleneck_block_proj_bf16(xd, stride, f1, d(b1), f2, d(b2), f3, d(b3), fs, d(bs))
+    assert got.dtype == torch.bfloat16 and tuple(got.shape) == tuple(want.shape)
+    assert torch.equal(got, want), f"max diff {float((got.float() - want.float()).abs().max())}"
+    assert float(got.float().abs().max()) > 0.1
+    for _ in range(2):
+        assert torch.equal(tspn.ops.bottleneck_block_proj_bf16(xd, stride, f1, d(b1), f2, d(b2), f3, d(b3), fs, d(bs)), want)
+    with pytest.raises(ValueError):
+        tspn.ops.bottleneck_block_proj_bf16(xd, stride + 1, f1, d(b1), f2, d(b2), f3, d(b3), fs, d(bs))
+
+
 def test_backbone_with_one_launch_blocks_equals_the_chain(tspn, device):
     """ResNetC4 on bf16 maps: `fuse_block` on (identity blocks of res2 / res3 as one launch each) and off (conv1 + fused
     tail) give the same res4 maps bit for bit, on one stream and on two; the one-launch form really ran."""
@@ -459,6 +489,14 @@ def test_backbone_with_one_launch_blocks_equals_the_chain(tspn, device):
             return real(*a, **k)
         tspn.ops.bottleneck_block_bf16 = spy
         tspn.roi_head.ops.bottleneck_block_bf16 = spy
+        real_p = tspn.ops.bottleneck_block_proj_bf16
+        pcalls = []
+
+        def spy_p(*a, **k):
+            pcalls.append(tuple(a[0].shape[1:]))
+            return real_p(*a, **k)
+        tspn.ops.bottleneck_block_proj_bf16 = spy_p
+        tspn.roi_head.ops.bottleneck_block_proj_bf16 = spy_p
         for streams in (1, 2):
             for on in (True, False):
                 net.streams = streams
@@ -470,7 +508,10 @@ def test_backbone_with_one_launch_blocks_equals_the_chain(tspn, device):
     finally:
         tspn.ops.bottleneck_block_bf16 = real
         tspn.roi_head.ops.bottleneck_block_bf16 = real
+        tspn.ops.bottleneck_block_proj_bf16 = real_p
+        tspn.roi_head.ops.bottleneck_block_proj_bf16 = real_p
     assert set(calls) == {256, 512}
+    assert len(pcalls) == 2 * 3 and all(c[2] == 64 for c in pcalls)          # res2.0 of every chunk, with fuse_blocks on
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
 

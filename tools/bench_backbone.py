@@ -21,12 +21,14 @@ ap.add_argument("--streams", type=int, default=2)
 ap.add_argument("--no-next", action="store_true", help="(default) fuse_next_conv1 = False: every conv1 as its own launch")
 ap.add_argument("--next", action="store_true", help="fuse_next_conv1 = True: res4 tails also compute the follower's conv1")
 ap.add_argument("--no-block", action="store_true", help="identity blocks of res2 / res3 as conv1 + fused tail (round 4) instead of one launch")
+ap.add_argument("--no-proj", action="store_true", help="first blocks of the stages as conv1 + shortcut + fused tail")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 net = tspn.ResNetC4(depth=args.depth, frame_chunk=args.chunk).to(dev)
 net.streams = args.streams
 net.fuse_next_conv1 = bool(args.next) and not args.no_next
 net.fuse_blocks = not args.no_block
+net.fuse_first_blocks = not args.no_proj
 g = torch.Generator(device=dev).manual_seed(0)
 img = torch.rand((args.frames, args.h, args.w, 3), device=dev, generator=g) - 0.5
 
