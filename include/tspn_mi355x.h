@@ -527,7 +527,7 @@ int tspn_bottleneck_block_bf16(const uint16_t* x, int64_t NB, int64_t H, int64_t
  *   out = relu(W3 . relu(W2 (*) relu(W1 . x_s + b1) + b2) + b3 + bf16(Ws . x_s + bs)),   x_s = every stride-th pixel of x,
  * out [NB, (Hin-1)/stride+1, (Win-1)/stride+1, 4 CM]: the shortcut map (4 CM channels) is neither written nor read back.
  * frags = tspn_pack_conv2d_frag_bf16 of the folded shortcut weights [4 CM, CIN, 1, 1].  Built for detectron2's res2.0
- * (CIN = 64, CM = 64, stride 1) and res3.0 (CIN = 256, CM = 128, stride 2).  Bit-identical to the four launches it
+ * (CIN = 64, CM = 64, stride 1).  Bit-identical to the four launches it
  * replaces (conv1, shortcut, fused tail). */
 int tspn_bottleneck_block_proj_bf16(const uint16_t* x, int64_t NB, int64_t Hin, int64_t Win, int64_t CIN, int64_t stride,
                                     int64_t CM, const uint16_t* frag1, const float* bias1, const uint16_t* frag2,

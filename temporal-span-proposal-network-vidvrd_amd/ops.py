@@ -1008,7 +1008,7 @@ def bottleneck_block_bf16(x, frag1, bias1, frag2, bias2, frag3, bias3, out=None)
 def bottleneck_block_proj_bf16(x, stride, frag1, bias1, frag2, bias2, frag3, bias3, frags, biass, out=None):
     """The first block of a stage in one launch (tspn_bottleneck_block_proj_bf16): conv1 and the projection shortcut are
     1x1 convs of stride `stride` on x bf16 [NB,Hin,Win,CIN]; frags / biass = the folded shortcut [4CM,CIN,1,1].  Built for
-    (CIN, CM, stride) = (64, 64, 1) and (256, 128, 2).  Bit-identical to conv1 + shortcut + fused tail; the shortcut map
+    (CIN, CM, stride) = (64, 64, 1), detectron2's res2.0.  Bit-identical to conv1 + shortcut + fused tail; the shortcut map
     never goes to memory."""
     _dev(x, "x", torch.bfloat16)
     for nm, t in (("frag1", frag1), ("frag2", frag2), ("frag3", frag3), ("frags", frags)):
@@ -1017,8 +1017,8 @@ def bottleneck_block_proj_bf16(x, stride, frag1, bias1, frag2, bias2, frag3, bia
         _dev(t, nm)
     NB, Hin, Win, CIN = x.shape
     CM = frag2.shape[0] * 32
-    if (CIN, CM, int(stride)) not in ((64, 64, 1), (256, 128, 2)):
-        raise ValueError(f"bottleneck_block_proj_bf16: built for (CIN, CM, stride) = (64, 64, 1) / (256, 128, 2), got {(CIN, CM, stride)}")
+    if (CIN, CM, int(stride)) != (64, 64, 1):
+        raise ValueError(f"bottleneck_block_proj_bf16: built for (CIN, CM, stride) = (64, 64, 1), got {(CIN, CM, stride)}")
     if (tuple(frag1.shape) != (CM // 32, CIN // 64, 1, 4, 64, 8) or tuple(frag2.shape) != (CM // 32, CM // 64, 9, 4, 64, 8)
             or tuple(frag3.shape) != (CM // 8, CM // 64, 1, 4, 64, 8) or tuple(frags.shape) != (CM // 8, CIN // 64, 1, 4, 64, 8)):
         raise ValueError("bottleneck_block_proj_bf16: fragment shapes do not match [CM,CIN,1,1] / [CM,CM,3,3] / [4CM,CM,1,1] / [4CM,CIN,1,1]")

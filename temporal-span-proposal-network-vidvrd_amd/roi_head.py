@@ -106,7 +106,7 @@ class BottleneckBlock(nn.Module):
         # ... and whole identity blocks of the memory-bound stages (64 / 128 bottleneck channels, stride 1, no projection)
         # as ONE launch that reads the 4 CM-channel map once (csrc/tspn_block_bf16.hip, round 5); same bits
         self.fuse_block = True
-        # ... and the FIRST block of res2 / res3 (projection shortcut, stride 1 / 2) as one launch that computes the shortcut
+        # ... and the FIRST block of res2 (projection shortcut, stride 1) as one launch that computes the shortcut
         # on the tile's own input pixels instead of writing the 4 CM-channel shortcut map and reading it back
         self.fuse_block_proj = True
 
