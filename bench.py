@@ -785,8 +785,9 @@ class Cfg5Workload:
         self.bb_sd = tspn.synth.make_backbone_weights(0)
         self.r5_sd = tspn.synth.make_res5_weights(0)
         self.sd = tspn.synth.make_weights(0, c=2 * D, a=A_ANCH, k=K_PRED)
-        # 9 frames of 720p = 253 tiles of the res4 tails on 256 CUs (8 frames: 225); x 2 streams (ResNetC4.streams)
-        self.net = tspn.ResNetC4(depth=101, frame_chunk=9)
+        # 18 frames of 720p = 506 tiles of the res4 tails on 256 CUs x 2 workgroups (9 frames: 253; round 5: 18 is 1.8 % faster
+        # now that res2 / res3 run as one-launch blocks); x 2 streams (ResNetC4.streams)
+        self.net = tspn.ResNetC4(depth=101, frame_chunk=18)
         self.net.load_state_dict(t(self.bb_sd))
         self.net = self.net.to(dev)
         if hasattr(self.net, "fuse_bottlenecks"):

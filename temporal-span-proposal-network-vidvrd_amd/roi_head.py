@@ -387,7 +387,7 @@ class ResNetC4(_CachedWeightsMixin, nn.Module):
 
     BLOCKS = {50: (3, 4, 6), 101: (3, 4, 23)}
 
-    def __init__(self, depth=101, stem_out=64, res2_out=256, blocks=None, frame_chunk=9):
+    def __init__(self, depth=101, stem_out=64, res2_out=256, blocks=None, frame_chunk=18):
         super().__init__()
         blocks = tuple(blocks) if blocks is not None else self.BLOCKS[depth]
         self.stem = BasicStem(3, stem_out)
