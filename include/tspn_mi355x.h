@@ -39,8 +39,10 @@ extern "C" {
  * 4 (round 3): the Winograd F(2,3) and the three F(4,3) temporal-conv generations and their pack / repack
  * entry points are gone, tspn_fused_desc.conv_algo is TSPN_CONV_DIRECT | TSPN_CONV_WINOGRAD63;
  * 5 (round 3): tspn_pack_conv2d_frag_bf16 lays the fragments out channel chunk by chunk (was tap by tap) and
- * the bf16 convolutions contract in that order; tspn_stem_pool_bf16 added).                                  */
-#define TSPN_ABI_VERSION 5
+ * the bf16 convolutions contract in that order; tspn_stem_pool_bf16 added);
+ * 6 (round 5, additive): tspn_bottleneck_block_bf16, tspn_bottleneck_block_proj_bf16,
+ * tspn_conv3_tc_wino63_set_piece_form (replaces the TSPN_WINO63_PTRV environment switch).                     */
+#define TSPN_ABI_VERSION 6
 
 enum {
   TSPN_OK = 0,

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(HERE)
 LIB_PATH = os.environ.get("TSPN_LIB_PATH") or os.path.join(HERE, "libtspn_mi355x.so")
 HEADER_PATH = os.path.join(ROOT, "include", "tspn_mi355x.h")
 
-ABI_VERSION = 5   # TSPN_ABI_VERSION of include/tspn_mi355x.h
+ABI_VERSION = 6   # TSPN_ABI_VERSION of include/tspn_mi355x.h
 TSPN_OK = 0
 TSPN_EINVAL = -1
 TSPN_EUNSUPPORTED = -2
