@@ -474,6 +474,44 @@ def test_first_block_of_a_stage_one_launch_bit_identical_to_its_four_launches(ts
         tspn.ops.bottleneck_block_proj_bf16(xd, stride + 1, f1, d(b1), f2, d(b2), f3, d(b3), fs, d(bs))
 
 
+@pytest.mark.parametrize("CM,H,W", [(64, 180, 320), (128, 90, 160)])
+def test_one_launch_blocks_at_720p_scale_with_every_cu_busy(tspn, device, CM, H, W):
+    """The one-launch blocks at the backbone's own sizes (4 frames of 720p at res2 / res3: 800 / 360 tiles, several
+    workgroups per CU) into a poisoned output, six launches each: every launch equals conv1 (+ shortcut) + fused tail bit for
+    bit.  This is the test that catches TIMING-dependent faults -- the store-data hazard of round 5 showed up only with more
+    than one workgroup per CU, in 0.02 % of the outputs, differently in every launch (profiles/r5/bottleneck_block_study.md §3)."""
+    NB = 4
+    g = torch.Generator(device=device).manual_seed(5)
+    x = (torch.rand((NB, H, W, 4 * CM), device=device, generator=g) - 0.5).to(torch.bfloat16)
+    w1 = (torch.rand((CM, 4 * CM, 1, 1), device=device, generator=g) - 0.5) * 0.1
+    w2 = (torch.rand((CM, CM, 3, 3), device=device, generator=g) - 0.5) * 0.05
+    w3 = (torch.rand((4 * CM, CM, 1, 1), device=device, generator=g) - 0.5) * 0.1
+    b1, b2 = torch.rand(CM, device=device, generator=g) - 0.5, torch.rand(CM, device=device, generator=g) - 0.5
+    b3 = torch.rand(4 * CM, device=device, generator=g) - 0.5
+    f1, f2, f3 = (tspn.ops.pack_conv2d_frag_bf16(w) for w in (w1, w2, w3))
+    h1 = tspn.ops.conv2d_nhwc_bf16(x, f1, (1, 1), 1, 0, bias=b1, relu=True)
+    want = tspn.ops.bottleneck_tail_bf16(h1, f2, b2, f3, b3, x)
+    for trial in range(6):
+        out = torch.full_like(x, 777.0)
+        tspn.ops.bottleneck_block_bf16(x, f1, b1, f2, b2, f3, b3, out=out)
+        bad = int((out != want).sum())
+        assert bad == 0, f"trial {trial}: {bad} of {out.numel()} outputs differ"
+    if CM == 64:                                   # res2.0: the stem's 64-channel map in, projection shortcut inside
+        xs = (torch.rand((NB, H, W, 64), device=device, generator=g) - 0.5).to(torch.bfloat16)
+        w1s = (torch.rand((64, 64, 1, 1), device=device, generator=g) - 0.5) * 0.2
+        wsc = (torch.rand((256, 64, 1, 1), device=device, generator=g) - 0.5) * 0.2
+        bsc = torch.rand(256, device=device, generator=g) - 0.5
+        f1s, fsc = tspn.ops.pack_conv2d_frag_bf16(w1s), tspn.ops.pack_conv2d_frag_bf16(wsc)
+        h1s = tspn.ops.conv2d_nhwc_bf16(xs, f1s, (1, 1), 1, 0, bias=b1, relu=True)
+        sc = tspn.ops.conv2d_nhwc_bf16(xs, fsc, (1, 1), 1, 0, bias=bsc, relu=False)
+        want_p = tspn.ops.bottleneck_tail_bf16(h1s, f2, b2, f3, b3, sc)
+        for trial in range(6):
+            out = torch.full_like(want_p, 777.0)
+            tspn.ops.bottleneck_block_proj_bf16(xs, 1, f1s, b1, f2, b2, f3, b3, fsc, bsc, out=out)
+            bad = int((out != want_p).sum())
+            assert bad == 0, f"res2.0 trial {trial}: {bad} of {out.numel()} outputs differ"
+
+
 def test_backbone_with_one_launch_blocks_equals_the_chain(tspn, device):
     """ResNetC4 on bf16 maps: `fuse_block` on (identity blocks of res2 / res3 as one launch each) and off (conv1 + fused
     tail) give the same res4 maps bit for bit, on one stream and on two; the one-launch form really ran."""
