@@ -40,7 +40,7 @@ extern "C" {
  * entry points are gone, tspn_fused_desc.conv_algo is TSPN_CONV_DIRECT | TSPN_CONV_WINOGRAD63;
  * 5 (round 3): tspn_pack_conv2d_frag_bf16 lays the fragments out channel chunk by chunk (was tap by tap) and
  * the bf16 convolutions contract in that order; tspn_stem_pool_bf16 added);
- * 6 (round 5, additive): tspn_bottleneck_block_bf16, tspn_bottleneck_block_proj_bf16,
+ * 6 (round 5, additive): tspn_bottleneck_block_bf16, tspn_bottleneck_block_proj_bf16, tspn_bottleneck_block_res_bf16,
  * tspn_conv3_tc_wino63_set_piece_form (replaces the TSPN_WINO63_PTRV environment switch).                     */
 #define TSPN_ABI_VERSION 6
 
@@ -535,6 +535,14 @@ int tspn_bottleneck_block_proj_bf16(const uint16_t* x, int64_t NB, int64_t Hin, 
                                     int64_t CM, const uint16_t* frag1, const float* bias1, const uint16_t* frag2,
                                     const float* bias2, const uint16_t* frag3, const float* bias3, const uint16_t* frags,
                                     const float* biass, uint16_t* out, void* stream);
+/* The first block of res3 (CIN = 256, CM = 128, stride 2): conv1 (1x1, stride 2) + 3x3 + expand + residual + ReLU in one
+ * launch, the residual [NB, H, W, 4 CM] handed over (the output of the separately launched projection shortcut):
+ *   out = relu(W3 . relu(W2 (*) relu(W1 . x_s + b1) + b2) + b3 + residual).
+ * Bit-identical to tspn_conv2d_nhwc_bf16 (conv1) + tspn_bottleneck_tail_bf16. */
+int tspn_bottleneck_block_res_bf16(const uint16_t* x, int64_t NB, int64_t Hin, int64_t Win, int64_t CIN, int64_t stride,
+                                   int64_t CM, const uint16_t* frag1, const float* bias1, const uint16_t* frag2,
+                                   const float* bias2, const uint16_t* frag3, const float* bias3, const uint16_t* residual,
+                                   uint16_t* out, void* stream);
 
 /* The same launch + conv1 of the FOLLOWING block on the tile it has just produced (round 4; CM = 256 = every res4
  * block of an R-50 / R-101 C4 backbone): additionally

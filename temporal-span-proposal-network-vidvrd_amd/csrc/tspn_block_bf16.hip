@@ -52,13 +52,18 @@ constexpr int tile_rows(int cm) { return cm == 64 ? 10 : 6; }
 // to bf16 like the separate launch's output), computed in the expand phase from the tile's own input pixels instead of
 // being written to and read back from HBM (res2.0: 265 + 265 MB per 9 frames of 720p).  Identity blocks: CIN = 4 CM,
 // ST = 1, the input itself is the residual.
-template <int CM, int CIN, int ST, bool PROJ>
+// RES = 0: identity block, the input is the residual.  1: projection shortcut computed here (PROJ, above).  2: the
+// residual is a tensor of its own (`Wfs` then points at it: [NB, H, W, 4 CM], e.g. the output of a separately launched
+// projection shortcut) -- res3.0 (256 -> 128 -> 512, stride 2): conv1 + 3x3 + expand in one launch, the shortcut conv as
+// before (its GEMM inside this kernel needs the tile's input in all four row-waves and 384 registers: 230 against 222 us).
+template <int CM, int CIN, int ST, int RES>
 __global__ __launch_bounds__(THREADS, 2) void bottleneck_block_bf16_kernel(
     const __bf16* __restrict__ x, const __bf16* __restrict__ Wf1, const float* __restrict__ bias1,
     const __bf16* __restrict__ Wf2, const float* __restrict__ bias2, const __bf16* __restrict__ Wf3,
     const float* __restrict__ bias3, const __bf16* __restrict__ Wfs, const float* __restrict__ biass,
     __bf16* __restrict__ out, int H, int W, int Hin, int Win, int tiles_x, int tiles_y, int ntiles) {
-  static_assert(PROJ || (CIN == 4 * CM && ST == 1), "identity blocks take their input as the residual");
+  constexpr bool PROJ = RES == 1;
+  static_assert(RES != 0 || (CIN == 4 * CM && ST == 1), "identity blocks take their input as the residual");
   constexpr int C4 = 4 * CM;
   constexpr int C1 = CIN / 64, C2 = CM / 64;        // 64-channel parts of conv1's / the 3x3's and expand's K
   constexpr int TR = tile_rows(CM);
@@ -90,6 +95,9 @@ __global__ __launch_bounds__(THREADS, 2) void bottleneck_block_bf16_kernel(
       const_cast<__bf16*>(x) + (int64_t)img * Hin * Win * CIN, 0, (int)(unsigned)((int64_t)Hin * Win * CIN * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(
       out + (int64_t)img * H * W * C4, 0, (int)(unsigned)((int64_t)H * W * C4 * 2), 0x00020000);
+  // where the residual rows come from (32-bit offsets inside the image, like the output's)
+  const __amdgpu_buffer_rsrc_t rs_r = RES == 2 ? __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<__bf16*>(Wfs) + (int64_t)img * H * W * C4, 0, (int)(unsigned)((int64_t)H * W * C4 * 2), 0x00020000) : rs_x;
   // byte offset of the input pixel under output pixel (yy, xx): a 1x1 conv of stride ST reads pixel (ST yy, ST xx)
   auto xpix = [&](int yy, int xx) { return (unsigned)(((yy * ST) * Win + xx * ST) * CIN * 2); };
   constexpr unsigned OOB = 0x80000000u;             // beyond every descriptor: loads give zeros, stores are dropped
@@ -365,7 +373,7 @@ __global__ __launch_bounds__(THREADS, 2) void bottleneck_block_bf16_kernel(
 #pragma unroll
             for (int h = 0; h < 2; ++h)
               res[buf][ms][pj][h] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
-                  rs_x, (int)(po[2 * g + pj] == OOB ? OOB : po[2 * g + pj] + 16 * h), (mbA + ms) * 64, 0));
+                  rs_r, (int)(po[2 * g + pj] == OOB ? OOB : po[2 * g + pj] + 16 * h), (mbA + ms) * 64, 0));
       } else {
         f32x16 sc[2][2];
 #pragma unroll
@@ -504,7 +512,7 @@ __global__ __launch_bounds__(THREADS, 2) void bottleneck_block_bf16_kernel(
   }
 }
 
-template <int CM, int CIN, int ST, bool PROJ>
+template <int CM, int CIN, int ST, int RES>
 int launch(const uint16_t* x, int64_t NB, int64_t Hin, int64_t Win, const uint16_t* f1, const float* b1, const uint16_t* f2,
            const float* b2, const uint16_t* f3, const float* b3, const uint16_t* fs, const float* bs, uint16_t* out,
            void* stream, const char* what) {
@@ -514,10 +522,10 @@ int launch(const uint16_t* x, int64_t NB, int64_t Hin, int64_t Win, const uint16
   const int64_t ntiles = NB * tiles_x * tiles_y;
   TSPN_REQUIRE(ntiles < (1LL << 30), TSPN_EUNSUPPORTED, "%s: grid too large", what);
   const int64_t grid = tspn::ceil_div(ntiles, 8) * 8;            // whole rounds over the eight XCDs
-  constexpr size_t smem = (size_t)(CM / 8) * ((TR + 2) * 32 + 4) * 16 + (PROJ ? 2 : 1) * 4 * CM * 4;   // h1 image (h2 takes its place) + b3 (+ bs)
+  constexpr size_t smem = (size_t)(CM / 8) * ((TR + 2) * 32 + 4) * 16 + (RES == 1 ? 2 : 1) * 4 * CM * 4;   // h1 image (h2 takes its place) + b3 (+ bs)
   static tspn::LdsLimit lds;
-  if (int rc = lds.ensure(reinterpret_cast<const void*>(bottleneck_block_bf16_kernel<CM, CIN, ST, PROJ>), smem, what)) return rc;
-  hipLaunchKernelGGL((bottleneck_block_bf16_kernel<CM, CIN, ST, PROJ>), dim3((unsigned)grid), dim3(THREADS), smem,
+  if (int rc = lds.ensure(reinterpret_cast<const void*>(bottleneck_block_bf16_kernel<CM, CIN, ST, RES>), smem, what)) return rc;
+  hipLaunchKernelGGL((bottleneck_block_bf16_kernel<CM, CIN, ST, RES>), dim3((unsigned)grid), dim3(THREADS), smem,
                      TSPN_STREAM(stream), reinterpret_cast<const __bf16*>(x), reinterpret_cast<const __bf16*>(f1), b1,
                      reinterpret_cast<const __bf16*>(f2), b2, reinterpret_cast<const __bf16*>(f3), b3,
                      reinterpret_cast<const __bf16*>(fs), bs, reinterpret_cast<__bf16*>(out), (int)H, (int)W, (int)Hin,
@@ -544,8 +552,8 @@ extern "C" int tspn_bottleneck_block_bf16(const uint16_t* x, int64_t NB, int64_t
   // 32-bit byte offsets inside one image
   TSPN_REQUIRE(H * W * 4 * CM * 2 < (1LL << 31), TSPN_EUNSUPPORTED, "%s: one image's map must stay below 2 GB", what);
   if (CM == 128)
-    return launch<128, 512, 1, false>(x, NB, H, W, frag1, bias1, frag2, bias2, frag3, bias3, nullptr, nullptr, out, stream, what);
-  return launch<64, 256, 1, false>(x, NB, H, W, frag1, bias1, frag2, bias2, frag3, bias3, nullptr, nullptr, out, stream, what);
+    return launch<128, 512, 1, 0>(x, NB, H, W, frag1, bias1, frag2, bias2, frag3, bias3, nullptr, nullptr, out, stream, what);
+  return launch<64, 256, 1, 0>(x, NB, H, W, frag1, bias1, frag2, bias2, frag3, bias3, nullptr, nullptr, out, stream, what);
 }
 
 extern "C" int tspn_bottleneck_block_proj_bf16(const uint16_t* x, int64_t NB, int64_t Hin, int64_t Win, int64_t CIN,
@@ -570,5 +578,27 @@ extern "C" int tspn_bottleneck_block_proj_bf16(const uint16_t* x, int64_t NB, in
   const int64_t H = (Hin - 1) / stride + 1, W = (Win - 1) / stride + 1;
   TSPN_REQUIRE(H * W * 4 * CM * 2 < (1LL << 31) && Hin * Win * CIN * 2 < (1LL << 31), TSPN_EUNSUPPORTED,
                "%s: one image's maps must stay below 2 GB", what);
-  return launch<64, 64, 1, true>(x, NB, Hin, Win, frag1, bias1, frag2, bias2, frag3, bias3, frags, biass, out, stream, what);
+  return launch<64, 64, 1, 1>(x, NB, Hin, Win, frag1, bias1, frag2, bias2, frag3, bias3, frags, biass, out, stream, what);
+}
+
+extern "C" int tspn_bottleneck_block_res_bf16(const uint16_t* x, int64_t NB, int64_t Hin, int64_t Win, int64_t CIN,
+                                              int64_t stride, int64_t CM, const uint16_t* frag1, const float* bias1,
+                                              const uint16_t* frag2, const float* bias2, const uint16_t* frag3,
+                                              const float* bias3, const uint16_t* residual, uint16_t* out, void* stream) {
+  const char* what = "tspn_bottleneck_block_res_bf16";
+  TSPN_REQUIRE(NB >= 0 && Hin > 0 && Win > 0, TSPN_EINVAL, "%s: bad sizes", what);
+  TSPN_REQUIRE(CM == 128 && CIN == 256 && stride == 2, TSPN_EUNSUPPORTED,
+               "%s: built for the first block of res3 (256 -> 128 -> 512, stride 2); got CIN=%lld CM=%lld stride=%lld", what,
+               (long long)CIN, (long long)CM, (long long)stride);
+  if (NB == 0) return TSPN_OK;
+  TSPN_REQUIRE(x && frag1 && bias1 && frag2 && bias2 && frag3 && bias3 && residual && out, TSPN_EINVAL, "%s: null pointer", what);
+  TSPN_REQUIRE(residual != out, TSPN_EINVAL, "%s: out must not alias the residual", what);
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  TSPN_REQUIRE(al16(x) && al16(frag1) && al16(bias1) && al16(frag2) && al16(bias2) && al16(frag3) && al16(bias3) &&
+                   al16(residual) && al16(out),
+               TSPN_EUNSUPPORTED, "%s: operands must be 16-byte aligned", what);
+  const int64_t H = (Hin - 1) / stride + 1, W = (Win - 1) / stride + 1;
+  TSPN_REQUIRE(H * W * 4 * CM * 2 < (1LL << 31) && Hin * Win * CIN * 2 < (1LL << 31), TSPN_EUNSUPPORTED,
+               "%s: one image's maps must stay below 2 GB", what);
+  return launch<128, 256, 2, 2>(x, NB, Hin, Win, frag1, bias1, frag2, bias2, frag3, bias3, residual, nullptr, out, stream, what);
 }

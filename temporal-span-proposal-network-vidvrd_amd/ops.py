@@ -17,7 +17,7 @@ __all__ = [
     "forward_fused", "temporal_encoder_heads", "fused_workspace_bytes", "fused_bf16_workspace_bytes", "decode_topk", "decode_spans",
     "cast_bf16", "pack_conv3_bf16", "pack_heads_bf16", "conv3_tc_bf16", "heads_pairgrid_bf16",
     "transpose_cast_bf16", "temporal_encoder_heads_bf16",
-    "temporal_mean_bf16", "forward_fused_bf16", "span_predicate", "bottleneck_block_bf16", "bottleneck_block_proj_bf16",
+    "temporal_mean_bf16", "forward_fused_bf16", "span_predicate", "bottleneck_block_bf16", "bottleneck_block_proj_bf16", "bottleneck_block_res_bf16",
     "proposal_pair_filter", "gather_rows",
     "pack_conv2d", "pack_conv2d_frag", "conv2d_nhwc", "roi_align_nhwc", "pack_conv2d_frag_bf16", "conv2d_nhwc_bf16", "max_pool_nhwc", "pack_conv2d_frag_cin4", "conv2d_nhwc_cin4", "max_pool_nhwc_bf16", "pack_stem_bf16", "stem_conv_bf16", "stem_pool_bf16", "bottleneck_tail_bf16",
 ]
@@ -1034,6 +1034,36 @@ def bottleneck_block_proj_bf16(x, stride, frag1, bias1, frag2, bias2, frag3, bia
     _abi.check(_abi.lib().tspn_bottleneck_block_proj_bf16(_p(x), NB, Hin, Win, CIN, int(stride), CM, _p(frag1), _p(bias1),
                                                           _p(frag2), _p(bias2), _p(frag3), _p(bias3), _p(frags), _p(biass),
                                                           _p(out), _stream()))
+    return out
+
+
+def bottleneck_block_res_bf16(x, stride, frag1, bias1, frag2, bias2, frag3, bias3, residual, out=None):
+    """conv1 (1x1, stride `stride`) + 3x3 + expand + `residual` + ReLU in one launch (tspn_bottleneck_block_res_bf16): x bf16
+    [NB,Hin,Win,CIN], residual bf16 [NB,H,W,4CM] (e.g. the separately launched projection shortcut).  Built for res3.0:
+    (CIN, CM, stride) = (256, 128, 2).  Bit-identical to conv1 + bottleneck_tail_bf16."""
+    _dev(x, "x", torch.bfloat16); _dev(residual, "residual", torch.bfloat16)
+    for nm, t in (("frag1", frag1), ("frag2", frag2), ("frag3", frag3)):
+        _dev(t, nm, torch.bfloat16)
+    for nm, t in (("bias1", bias1), ("bias2", bias2), ("bias3", bias3)):
+        _dev(t, nm)
+    NB, Hin, Win, CIN = x.shape
+    CM = frag2.shape[0] * 32
+    if (CIN, CM, int(stride)) != (256, 128, 2):
+        raise ValueError(f"bottleneck_block_res_bf16: built for (CIN, CM, stride) = (256, 128, 2), got {(CIN, CM, stride)}")
+    if (tuple(frag1.shape) != (CM // 32, CIN // 64, 1, 4, 64, 8) or tuple(frag2.shape) != (CM // 32, CM // 64, 9, 4, 64, 8)
+            or tuple(frag3.shape) != (CM // 8, CM // 64, 1, 4, 64, 8)):
+        raise ValueError("bottleneck_block_res_bf16: fragment shapes do not match [CM,CIN,1,1] / [CM,CM,3,3] / [4CM,CM,1,1]")
+    H, W = (Hin - 1) // stride + 1, (Win - 1) // stride + 1
+    if bias1.shape != (CM,) or bias2.shape != (CM,) or bias3.shape != (4 * CM,) or tuple(residual.shape) != (NB, H, W, 4 * CM):
+        raise ValueError("bottleneck_block_res_bf16: bias / residual shape mismatch")
+    if out is None:
+        out = torch.empty((NB, H, W, 4 * CM), dtype=torch.bfloat16, device=x.device)
+    else:
+        _dev(out, "out", torch.bfloat16)
+        if tuple(out.shape) != (NB, H, W, 4 * CM):
+            raise ValueError(f"bottleneck_block_res_bf16: out must be {(NB, H, W, 4 * CM)}, got {tuple(out.shape)}")
+    _abi.check(_abi.lib().tspn_bottleneck_block_res_bf16(_p(x), NB, Hin, Win, CIN, int(stride), CM, _p(frag1), _p(bias1), _p(frag2),
+                                                         _p(bias2), _p(frag3), _p(bias3), _p(residual), _p(out), _stream()))
     return out
 
 

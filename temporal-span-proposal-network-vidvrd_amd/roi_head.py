@@ -132,6 +132,19 @@ class BottleneckBlock(nn.Module):
                 and c2.weight.shape[1] == cm and c2.kernel_size == 3 and c2.stride == 1 and c2.padding == 1
                 and tuple(c3.weight.shape[:2]) == (4 * cm, cm) and c3.kernel_size == 1)
 
+    RES_SHAPES = ((256, 128, 2),)       # ... tspn_bottleneck_block_res_bf16 (shortcut launched separately) is enabled for
+
+    def _can_fuse_block_res(self, x, h1, presampled):
+        c1, c2, c3, sc = self.conv1, self.conv2, self.conv3, self.shortcut
+        if sc is None or not (self.fuse_tail and self.fuse_block and self.fuse_block_proj) or h1 is not None or presampled:
+            return False
+        cm, cin = c2.weight.shape[0], c1.weight.shape[1]
+        return (x.dtype == torch.bfloat16 and (cin, cm, self.stride) in self.RES_SHAPES and c1.kernel_size == 1
+                and c1.padding == 0 and c1.stride == self.stride and sc.kernel_size == 1 and sc.padding == 0
+                and sc.stride == self.stride and c1.weight.shape[0] == cm and tuple(sc.weight.shape[:2]) == (4 * cm, cin)
+                and c2.weight.shape[1] == cm and c2.kernel_size == 3 and c2.stride == 1 and c2.padding == 1
+                and tuple(c3.weight.shape[:2]) == (4 * cm, cm) and c3.kernel_size == 1)
+
     def _can_fuse(self, x):
         c2, c3 = self.conv2, self.conv3
         cm = c2.weight.shape[0]
@@ -166,6 +179,13 @@ class BottleneckBlock(nn.Module):
             f3, b3 = self.conv3.folded_bf16(x.device)
             fs, bs = self.shortcut.folded_bf16(x.device)
             y = ops.bottleneck_block_proj_bf16(x.contiguous(), self.stride, f1, b1, f2, b2, f3, b3, fs, bs, out=out)
+            return (y, None) if next_block is not None else y
+        if self._can_fuse_block_res(x, h1, presampled):
+            # res3.0: the projection shortcut as its own launch, conv1 + 3x3 + expand + residual as one
+            f1, b1 = self.conv1.folded_bf16(x.device)
+            f2, b2 = self.conv2.folded_bf16(x.device)
+            f3, b3 = self.conv3.folded_bf16(x.device)
+            y = ops.bottleneck_block_res_bf16(x.contiguous(), self.stride, f1, b1, f2, b2, f3, b3, self.shortcut(x).contiguous(), out=out)
             return (y, None) if next_block is not None else y
         h = h1 if h1 is not None else self.conv1(x, relu=True, stride=st)
         if self.shortcut is not None:

@@ -474,6 +474,37 @@ def test_first_block_of_a_stage_one_launch_bit_identical_to_its_four_launches(ts
         tspn.ops.bottleneck_block_proj_bf16(xd, stride + 1, f1, d(b1), f2, d(b2), f3, d(b3), fs, d(bs))
 
 
+@pytest.mark.parametrize("NB,H,W", [(2, 9, 13), (1, 1, 1), (1, 12, 60), (1, 13, 61), (1, 90, 160), (2, 47, 81), (3, 180, 320)])
+def test_res3_first_block_conv1_3x3_expand_one_launch_bit_identical(tspn, device, NB, H, W):
+    """tspn_bottleneck_block_res_bf16 (round 5): res3.0 -- conv1 as a 1x1 of stride 2 on the 256-channel input, 3x3, expand,
+    + the separately launched projection shortcut as the residual, ReLU -- equals conv1 + fused tail BIT FOR BIT (H, W are
+    the INPUT sizes; odd sizes, single pixels, 720p's res2 map, several images; three launches each into a poisoned output)."""
+    CIN, CM, stride = 256, 128, 2
+    x = tspn.hashrng.uniform(97, "x", (NB, H, W, CIN), -1, 1)
+    w1 = tspn.hashrng.normal(97, "w1", (CM, CIN, 1, 1), std=float(np.sqrt(2.0 / CIN)))
+    w2 = tspn.hashrng.normal(97, "w2", (CM, CM, 3, 3), std=float(np.sqrt(2.0 / (9 * CM))))
+    w3 = tspn.hashrng.normal(97, "w3", (4 * CM, CM, 1, 1), std=float(np.sqrt(2.0 / CM)))
+    ws = tspn.hashrng.normal(97, "ws", (4 * CM, CIN, 1, 1), std=float(np.sqrt(1.0 / CIN)))
+    b1, b2 = (tspn.hashrng.normal(97, n, (CM,), std=0.1) for n in ("b1", "b2"))
+    b3, bs = (tspn.hashrng.normal(97, n, (4 * CM,), std=0.1) for n in ("b3", "bs"))
+    d = lambda a, dt=None: (t(a).to(device) if dt is None else t(a).to(device).to(dt))   # noqa: E731
+    f1, f2, f3, fs = (tspn.ops.pack_conv2d_frag_bf16(d(w)) for w in (w1, w2, w3, ws))
+    xd = d(x, torch.bfloat16)
+    h1 = tspn.ops.conv2d_nhwc_bf16(xd, f1, (1, 1), stride, 0, bias=d(b1), relu=True)
+    sc = tspn.ops.conv2d_nhwc_bf16(xd, fs, (1, 1), stride, 0, bias=d(bs), relu=False)
+    want = tspn.ops.bottleneck_tail_bf16(h1, f2, d(b2), f3, d(b3), sc)
+    for trial in range(3):
+        out = torch.full_like(want, 777.0)
+        ret = tspn.ops.bottleneck_block_res_bf16(xd, stride, f1, d(b1), f2, d(b2), f3, d(b3), sc, out=out)
+        assert ret.data_ptr() == out.data_ptr()
+        assert torch.equal(out, want), f"trial {trial}: max diff {float((out.float() - want.float()).abs().max())}"
+    assert float(want.float().abs().max()) > 0.1
+    with pytest.raises(ValueError):
+        tspn.ops.bottleneck_block_res_bf16(xd, 1, f1, d(b1), f2, d(b2), f3, d(b3), sc)
+    with pytest.raises(RuntimeError):
+        tspn.ops.bottleneck_block_res_bf16(xd, stride, f1, d(b1), f2, d(b2), f3, d(b3), sc, out=sc)
+
+
 @pytest.mark.parametrize("CM,H,W", [(64, 180, 320), (128, 90, 160)])
 def test_one_launch_blocks_at_720p_scale_with_every_cu_busy(tspn, device, CM, H, W):
     """The one-launch blocks at the backbone's own sizes (4 frames of 720p at res2 / res3: 800 / 360 tiles, several
@@ -535,6 +566,14 @@ def test_backbone_with_one_launch_blocks_equals_the_chain(tspn, device):
             return real_p(*a, **k)
         tspn.ops.bottleneck_block_proj_bf16 = spy_p
         tspn.roi_head.ops.bottleneck_block_proj_bf16 = spy_p
+        real_r = tspn.ops.bottleneck_block_res_bf16
+        rcalls = []
+
+        def spy_r(*a, **k):
+            rcalls.append(tuple(a[0].shape[1:]))
+            return real_r(*a, **k)
+        tspn.ops.bottleneck_block_res_bf16 = spy_r
+        tspn.roi_head.ops.bottleneck_block_res_bf16 = spy_r
         for streams in (1, 2):
             for on in (True, False):
                 net.streams = streams
@@ -548,8 +587,11 @@ def test_backbone_with_one_launch_blocks_equals_the_chain(tspn, device):
         tspn.roi_head.ops.bottleneck_block_bf16 = real
         tspn.ops.bottleneck_block_proj_bf16 = real_p
         tspn.roi_head.ops.bottleneck_block_proj_bf16 = real_p
+        tspn.ops.bottleneck_block_res_bf16 = real_r
+        tspn.roi_head.ops.bottleneck_block_res_bf16 = real_r
     assert set(calls) == {256, 512}
     assert len(pcalls) == 2 * 3 and all(c[2] == 64 for c in pcalls)          # res2.0 of every chunk, with fuse_blocks on
+    assert len(rcalls) == 2 * 3 and all(c[2] == 256 for c in rcalls)         # res3.0 likewise (shortcut launched separately)
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
 
