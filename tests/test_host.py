@@ -103,7 +103,7 @@ def test_abi_library_exports_every_declared_symbol(tspn):
     for n in names:
         assert hasattr(raw, n), f"library does not export {n}"
     lib = tspn._abi.lib()
-    assert lib.tspn_version() == tspn._abi.ABI_VERSION == 5
+    assert lib.tspn_version() == tspn._abi.ABI_VERSION == 6
     assert lib.tspn_fused_desc_size() == ctypes.sizeof(tspn._abi.FusedDesc)
     assert lib.tspn_fused_bf16_desc_size() == ctypes.sizeof(tspn._abi.FusedBf16Desc)
     assert lib.tspn_error_string(-3) == b"workspace too small"
