@@ -513,6 +513,13 @@ int tspn_max_pool_nhwc_f32(const float* x, int64_t NB, int64_t H, int64_t W, int
 int tspn_bottleneck_tail_bf16(const uint16_t* h1, int64_t NB, int64_t H, int64_t W, int64_t CM,
                               const uint16_t* frag2, const float* bias2, const uint16_t* frag3,
                               const float* bias3, const uint16_t* residual, uint16_t* out, void* stream);
+/* The same operator at CM = 256 with the workgroup's waves split by ROLE (tspn_tail_io_bf16.hip, round 5): four waves issue
+ * every MFMA and read only weights from L2, four waves do everything that touches HBM (the LDS-DMA of the h1 ranges, the
+ * residual rows, the epilogue and the stores); fp32 sums change hands through LDS.  Bit-identical to
+ * tspn_bottleneck_tail_bf16. */
+int tspn_bottleneck_tail_io_bf16(const uint16_t* h1, int64_t NB, int64_t H, int64_t W, int64_t CM,
+                                 const uint16_t* frag2, const float* bias2, const uint16_t* frag3,
+                                 const float* bias3, const uint16_t* residual, uint16_t* out, void* stream);
 
 /* A whole identity-shortcut bottleneck block in ONE launch (tspn_block_bf16.hip; detectron2 BottleneckBlock.forward,
  * modeling/backbone/resnet.py, with stride 1 and no projection shortcut -- every block of a stage but its first):

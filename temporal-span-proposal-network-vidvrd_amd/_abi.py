@@ -122,6 +122,7 @@ PROTOTYPES = {
     "tspn_bottleneck_block_proj_bf16": (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                                _vp, _vp]),
     "tspn_bottleneck_block_res_bf16": (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tspn_bottleneck_tail_io_bf16": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tspn_bottleneck_tail_pipe_bf16": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "tspn_bottleneck_tail_next_bf16": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tspn_stem_bf16_workspace_bytes": (_sz, [_i64, _i64, _i64]),

@@ -1068,7 +1068,7 @@ def bottleneck_block_res_bf16(x, stride, frag1, bias1, frag2, bias2, frag3, bias
 
 
 def bottleneck_tail_bf16(h1, frag2, bias2, frag3, bias3, residual, out=None, next_frag1=None, next_bias1=None,
-                         persistent=False, max_workgroups=0):
+                         persistent=False, max_workgroups=0, io_waves=False):
     """relu(conv1x1(relu(conv3x3(h1) + b2)) + b3 + residual) in one launch (tspn_bottleneck_tail_bf16): h1 bf16
     [NB,H,W,CM], CM in (64, 128, 256); frag2 / frag3 = pack_conv2d_frag_bf16 of the folded conv2 / conv3 weights;
     residual bf16 [NB,H,W,4 CM] -> bf16 [NB,H,W,4 CM] (written into `out` when given: a contiguous tensor of that
@@ -1094,6 +1094,13 @@ def bottleneck_tail_bf16(h1, frag2, bias2, frag3, bias3, residual, out=None, nex
         _dev(out, "out", torch.bfloat16)
         if tuple(out.shape) != (NB, H, W, 4 * CM):
             raise ValueError(f"bottleneck_tail_bf16: out must be {(NB, H, W, 4 * CM)}, got {tuple(out.shape)}")
+    if io_waves:
+        # (CM = 256) the role-split kernel: four MFMA waves + four waves that do all HBM traffic (tspn_bottleneck_tail_io_bf16)
+        if CM != 256 or next_frag1 is not None or persistent:
+            raise ValueError("bottleneck_tail_bf16: io_waves is built for 256 bottleneck channels, without next_frag1 / persistent")
+        _abi.check(_abi.lib().tspn_bottleneck_tail_io_bf16(_p(h1), NB, H, W, CM, _p(frag2), _p(bias2), _p(frag3), _p(bias3),
+                                                           _p(residual), _p(out), _stream()))
+        return out
     if persistent:
         if CM != 256 or next_frag1 is not None:
             raise ValueError("bottleneck_tail_bf16: the persistent form is built for 256 bottleneck channels, without next_frag1")
