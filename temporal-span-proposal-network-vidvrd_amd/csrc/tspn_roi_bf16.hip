@@ -9,8 +9,13 @@
 //     rounded to bf16 once (round to nearest even) -- the semantics restated in
 //     oracle/roi_head_oracle.py:conv2d_bf16;
 //   * K chunk = 64 channels of one tap = four MFMA k-steps of 16 channels (16 MFMAs per wave and chunk);
-//     a pixel's 64 channels are one 128-byte line of x, staged as eight 16-byte pieces
-//     [8 channel groups][132 slots][8 bf16];
+//     a pixel's 64 channels are one 128-byte line of x, staged as eight 16-byte pieces.  Tap chunks (round 5): LINE-MAJOR
+//     pieces -- lane l of a DMA instruction fetches piece (l & 7) ^ f of pixel 8 q + (l >> 3), so an instruction reads
+//     eight whole lines (a quad of lanes = one 64-byte half line) instead of 16 bytes of 64 different lines: L2-resident
+//     x enters the CU at 44 instead of 14.5 bytes per clock (tools/probes/tcp_line_coalesce_probe.hip; res4's conv1
+//     46 -> 39 us per 18 frames).  The LDS image is pixel-major [128 pixels][8 positions][8 bf16], position = piece ^
+//     f(pixel), f(P) = (P & 7) ^ ((P >> 3) & 1): 16 consecutive pixels reading the same piece hit 64 different banks.
+//     Linear ranges (RNG) keep [8 channel groups][132 slots][8 bf16];
 //   * weights  Wf[Cout/32][Cin/64][tap][ks = 0..3][lane = 32 kh + li][8] = w[32 mb + li][64 c + 16 ks + 8 kh + j][tap]:
 //     one global_load_dwordx4 per lane and k-step, refilled for the next chunk right after the k-step's MFMAs.
 //     The contraction runs in THIS order -- 64-channel chunk by chunk, all taps of a chunk in a row (chunk i = tap
@@ -122,7 +127,7 @@ __global__ __launch_bounds__(THREADS, (MI == 1 ? TSPN_ROI_BF16_MI1_WAVES : 2)) v
   // the descriptor's range -- the hardware then writes ZEROS into LDS (tools/probes/buffer_lds_oob_probe.hip), so there is
   // no zero page and no per-lane choice between two 64-bit pointers; beside MFMAs the buffer form is also the cheaper one
   // to issue (tools/probes/lds_dma_issue_probe.hip: 110 - 140 against 175 - 195 cycles per piece).
-  const int slot = 64 * (wave & 1) + lane;
+  const int slot = 64 * (wave & 1) + lane;         // (RNG: lane = pixel slot, channel groups bg, bg + 2, bg + 4, bg + 6)
   const int bg = wave >> 1;
   constexpr unsigned OOB = 0x80000000u;            // beyond num_records = 2^31 - 1: the piece arrives as zeros
   auto in_pixel = [&](int64_t n, int& ih0, int& iw0) {      // first tap's input pixel index of output pixel n (may be < 0)
@@ -135,18 +140,25 @@ __global__ __launch_bounds__(THREADS, (MI == 1 ? TSPN_ROI_BF16_MI1_WAVES : 2)) v
   // base = the first pixel of the image the tile starts in: every valid tap of the tile lies at or behind it
   const int64_t base_pix = ((n0 < npix ? n0 : 0) / ((int64_t)OH * OW)) * H * W;
   const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(x) + base_pix * Cin, 0, 0x7fffffff, 0x00020000);
-  unsigned pboff;                                  // byte offset of this lane's pixel (first tap, channel group bg) from the base
-  unsigned long long tapmask = 0;
-  {
-    const int64_t n = n0 + slot;
-    const bool okn = n < npix;
-    const int64_t nc = okn ? n : 0;
-    int ih0, iw0;
-    const int64_t ip = in_pixel(nc, ih0, iw0);
-    pboff = (unsigned)((ip - base_pix) * Cin * 2 + 16 * bg);
-    for (int a = 0; a < KH; ++a)
-      for (int b = 0; b < KW; ++b)
-        if (okn && ih0 + a >= 0 && ih0 + a < H && iw0 + b >= 0 && iw0 + b < W) tapmask |= 1ull << (a * KW + b);
+  // tap chunks: piece instruction q = 4 wave + p covers pixels 8 q .. 8 q + 7 of the tile; lane l: pixel 8 q + (l >> 3),
+  // LDS position l & 7 = piece ((l & 7) ^ f(pixel)), f = (l >> 3) ^ (q & 1)
+  unsigned pboff[4];                               // byte offset of the lane's piece (first tap) from the base, per instruction
+  unsigned long long tapmask[4];
+  if constexpr (!RNG) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int64_t n = n0 + 8 * (4 * wave + p) + (lane >> 3);
+      const bool okn = n < npix;
+      const int64_t nc = okn ? n : 0;
+      int ih0, iw0;
+      const int64_t ip = in_pixel(nc, ih0, iw0);
+      pboff[p] = (unsigned)((ip - base_pix) * Cin * 2 + 16 * ((lane & 7) ^ (lane >> 3) ^ (p & 1)));
+      unsigned long long m = 0;
+      for (int a = 0; a < KH; ++a)
+        for (int b = 0; b < KW; ++b)
+          if (okn && ih0 + a >= 0 && ih0 + a < H && iw0 + b >= 0 && iw0 + b < W) m |= 1ull << (a * KW + b);
+      tapmask[p] = m;
+    }
   }
   auto bglds16 = [&](unsigned voff, int soff, char* l) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)l, 16, (int)voff, soff, 0, 0);
@@ -155,12 +167,14 @@ __global__ __launch_bounds__(THREADS, (MI == 1 ? TSPN_ROI_BF16_MI1_WAVES : 2)) v
     const int ntaps = KH * KW;
     const int c = i / ntaps, tap = i - c * ntaps;
     const int ta = tap / KW, tb = tap - ta * KW;
-    const bool valid = (tapmask >> tap) & 1ull;
-    const unsigned voff = valid ? pboff + (unsigned)((ta * W + tb) * Cin * 2) : OOB;
+    const unsigned tapoff = (unsigned)((ta * W + tb) * Cin * 2);
     const int soff = c * KC * 2;
-    char* dst = Bs + buf * B_ST + (bg * SLP + 64 * (wave & 1)) * 16;
+    char* dst = Bs + buf * B_ST + 4 * wave * 1024;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) bglds16(voff + 32 * p, soff, dst + 2 * p * SLP * 16);
+    for (int p = 0; p < 4; ++p) {
+      const bool valid = (tapmask[p] >> tap) & 1ull;
+      bglds16(valid ? pboff[p] + tapoff : OOB, soff, dst + p * 1024);
+    }
   };
 
   f32x16 acc[MI][4];
@@ -172,10 +186,15 @@ __global__ __launch_bounds__(THREADS, (MI == 1 ? TSPN_ROI_BF16_MI1_WAVES : 2)) v
       for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
   f32x4 a[4][MI];      // weight fragments of the four k-steps (8 bf16 each, carried as 4 dwords)
+  // B fragment of k-step ks: pixel 32 ni + li, piece 2 ks + kh at position (2 ks + kh) ^ f(li); with the lane's base holding
+  // f's bits the k-step is one XOR on the offset
+  const unsigned fli = (unsigned)((li & 7) ^ ((li >> 3) & 1));
+  const unsigned lane_b = (unsigned)(li * 128) + (((unsigned)kh ^ (fli & 1)) << 4) + ((fli >> 1) << 5);
   auto read_b = [&](const char* Bb, int ks, bf16x8 (&b)[4]) {
+    const char* bp = Bb + (lane_b ^ (unsigned)(ks << 5));
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
-      b[ni] = *reinterpret_cast<const bf16x8*>(Bb + ((2 * ks) * SLP + ni * 32) * 16);
+      b[ni] = *reinterpret_cast<const bf16x8*>(bp + ni * 4096);
   };
   auto mfma_step = [&](const f32x4 (&aw)[MI], const bf16x8 (&b)[4]) {
 #pragma unroll
@@ -329,7 +348,7 @@ __global__ __launch_bounds__(THREADS, (MI == 1 ? TSPN_ROI_BF16_MI1_WAVES : 2)) v
     constexpr bool MORE = decltype(more_tag)::value;
     constexpr int NX = MORE ? 4 : 0, R = MORE ? MI : 0, L = MI;
     const int buf = i & 1;
-    const char* Bb = Bs + buf * B_ST + (kh * SLP + li) * 16;
+    const char* Bb = Bs + buf * B_ST;
     bf16x8 b0[4], b1[4];
     wait_step(std::integral_constant<int, 3 * L>{}, 0);            // younger: a1 a2 a3 of this chunk
     if (MORE) stage_x(buf ^ 1, i + 1);

@@ -222,7 +222,11 @@ __global__ __launch_bounds__(THREADS, 1) void tail_io_bf16_kernel(
     const unsigned woff = lane * 16;
     const char* const w2b0 = reinterpret_cast<const char*>(Wf2) + (int64_t)(2 * w4) * (9 * CCH * 4096) + woff;
     const char* const w2b1 = w2b0 + 9 * CCH * 4096;
-    constexpr int D2 = 4;                                    // W2 ring, k-steps
+    // B fragments of k-step j of a range: tap (ra, rb = j / 4), channels 16 (j % 4) ..  With ONE MFMA wave per SIMD every
+    // vector instruction between two MFMAs is a cycle the matrix pipe may idle, so the fragment addresses are prepared once
+    // per range: byte offset of channel group kh and the stride per channel group -- (stage, SLP 16) in the image,
+    // (side region, 32) for slots 128 / 129, (zero slot, 0) for taps that fall off the image -- one v_mad per read.
+    constexpr int D2 = 6;                                    // W2 ring, k-steps (fragments come from L2)
     f32x4 a2[D2][2];
     auto load_w2 = [&](int slot_, int f) {
       a2[slot_][0] = *reinterpret_cast<const f32x4*>(w2b0 + (int64_t)f * 1024);
@@ -231,32 +235,46 @@ __global__ __launch_bounds__(THREADS, 1) void tail_io_bf16_kernel(
 #pragma unroll
     for (int d = 0; d < D2; ++d) load_w2(d, d);
     role_barrier();                                          // [0]
-    for (int i = 0; i < NRNG; ++i) {
-      const int buf = i & (NST - 1), ra = i % 3;
-      const char* const stg = Bs + buf * B_ST;
-      const char* const ext = Bs + EXTRA_OFF + buf * 256;
+    static_assert(NRNG % 2 == 0 && 24 % D2 == 0, "two ranges = 24 k-steps per unrolled body: compile-time ring slots");
+    for (int i2 = 0; i2 < NRNG; i2 += 2) {
 #pragma unroll
-      for (int j = 0; j < 12; ++j) {                         // k-step j of the range: tap (ra, rb = j / 4), channels 16 (j % 4) ..
-        const int rb = j >> 2, ks = j & 3, tap = 3 * ra + rb;
-        const int g2 = 2 * ks + kh;
-        bf16x8 b[4];
+      for (int r = 0; r < 2; ++r) {
+        const int i = i2 + r;
+        const int buf = i & (NST - 1), ra = i % 3;
+        unsigned bo[3][4], bs[3][4];
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-          const char* bp = stg + (g2 * SLP + ni * 32 + li + rb) * 16;
-          if (ni == 3) bp = (li + rb >= 32) ? ext + (g2 * 2 + (li + rb - 32)) * 16 : bp;
-          if (!((rmask[ni] >> tap) & 1u)) bp = zslot;       // the tap falls off the image: read zeros
-          b[ni] = *reinterpret_cast<const bf16x8*>(bp);
+        for (int rb = 0; rb < 3; ++rb)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) {
+            unsigned o = (unsigned)(buf * B_ST + (ni * 32 + li + rb) * 16), st = SLP * 16;
+            if (ni == 3 && li + rb >= 32) { o = (unsigned)(EXTRA_OFF + buf * 256 + (li + rb - 32) * 16); st = 32; }
+            if (!((rmask[ni] >> (3 * ra + rb)) & 1u)) { o = ZERO_OFF; st = 0; }
+            bo[rb][ni] = o + kh * st;
+            bs[rb][ni] = 2 * st;
+          }
+        auto read_b = [&](int j, bf16x8 (&b)[4]) {
+          const int rb = j >> 2, ks = j & 3;
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) b[ni] = *reinterpret_cast<const bf16x8*>(Bs + bo[rb][ni] + ks * bs[rb][ni]);
+        };
+        bf16x8 bc[4], bn[4];
+        read_b(0, bc);
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+          if (j + 1 < 12) read_b(j + 1, bn);                 // the next k-step's fragments fly under this k-step's MFMAs
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) {
+            const bf16x8 av = __builtin_bit_cast(bf16x8, a2[(12 * r + j) % D2][mi]);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bc[ni], acc[mi][ni], 0, 0, 0);
+          }
+          if (12 * i + j + D2 < 12 * NRNG) load_w2((12 * r + j) % D2, 12 * i + j + D2);
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) bc[ni] = bn[ni];
+          __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-          const bf16x8 av = __builtin_bit_cast(bf16x8, a2[j % D2][mi]);
-#pragma unroll
-          for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b[ni], acc[mi][ni], 0, 0, 0);
-        }
-        if (12 * i + j + D2 < 12 * NRNG) load_w2(j % D2, 12 * i + j + D2);
-        __builtin_amdgcn_sched_barrier(0);
+        role_barrier();                                      // [1 + i]
       }
-      role_barrier();                                        // [1 + i]
     }
     // ---- h2 = relu(acc + b2) -> bf16 -> LDS (B-operand image [32 groups][SLP][8]) over the stages
 #pragma unroll
@@ -287,18 +305,25 @@ __global__ __launch_bounds__(THREADS, 1) void tail_io_bf16_kernel(
       for (int pj = 0; pj < 2; ++pj)
 #pragma unroll
         for (int e = 0; e < 16; ++e) c3[pj][e] = 0.f;
-      constexpr int D3 = 4;
+      constexpr int D3 = 8;
       f32x4 a3[D3];
 #pragma unroll
       for (int d = 0; d < D3; ++d) a3[d] = *reinterpret_cast<const f32x4*>(w3b + d * 1024);
+      bf16x8 hc[2], hn[2];
+#pragma unroll
+      for (int pj = 0; pj < 2; ++pj) hc[pj] = *reinterpret_cast<const bf16x8*>(hb + (nb + pj) * 32 * 16);
 #pragma unroll
       for (int k = 0; k < CM / 16; ++k) {
+        if (k + 1 < CM / 16) {
+#pragma unroll
+          for (int pj = 0; pj < 2; ++pj) hn[pj] = *reinterpret_cast<const bf16x8*>(hb + (2 * (k + 1) * SLP + (nb + pj) * 32) * 16);
+        }
         const bf16x8 av = __builtin_bit_cast(bf16x8, a3[k % D3]);
 #pragma unroll
-        for (int pj = 0; pj < 2; ++pj)
-          c3[pj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, *reinterpret_cast<const bf16x8*>(hb + (2 * k * SLP + (nb + pj) * 32) * 16),
-                                                           c3[pj], 0, 0, 0);
+        for (int pj = 0; pj < 2; ++pj) c3[pj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, hc[pj], c3[pj], 0, 0, 0);
         if (k + D3 < CM / 16) a3[k % D3] = *reinterpret_cast<const f32x4*>(w3b + (k + D3) * 1024);
+#pragma unroll
+        for (int pj = 0; pj < 2; ++pj) hc[pj] = hn[pj];
         __builtin_amdgcn_sched_barrier(0);
       }
       // set sp & 1 was read by the io wave before barrier [1 + NRNG + sp] (its sub-pass sp - 2)
