@@ -4,22 +4,28 @@
 // -- the arithmetic, tiling (128 linear pixels per workgroup, ring of linear h1 ranges, h2 image in LDS, W3 rows permuted
 // at load) and contraction order of bottleneck_bf16_kernel<256> (tspn_bottleneck_bf16.hip), bit-identical results.
 //
-// What round 4 established about that kernel (profiles/r4/bottleneck_pipeline_study.md): its 3x3 phase runs at ~1 PFLOP/s,
-// its expand MFMAs at 0.9, its 118 MB of residual + output per 8 frames at 5.4 TB/s -- and the launch takes their SUM,
-// because every vector-memory operation of a wave retires in order on one counter: a residual row (HBM, 2 - 3 us) issued
-// in front of a W3 fragment (L2) holds that fragment back, a store holds everything behind it, so the wave that feeds
-// the MFMA pipe spends its time waiting for memory it does not need.  Here a workgroup has EIGHT waves, two per SIMD:
+// Why (profiles/r5/tail_role_split.md): probe builds of that kernel without its residual loads and output stores need 76
+// instead of 165 us per 18 frames, and a workgroup ALONE on the chip needs 56 us for its tile (36 without them) -- every
+// vector-memory operation of a wave retires in order on one counter, so a residual row (HBM, 2 - 3 us) issued in front of a
+// W3 fragment (L2) holds that fragment back and a store holds everything behind it: the wave that feeds the MFMA pipe spends
+// half of its time waiting for memory it does not need.  Here a workgroup has EIGHT waves, two per SIMD:
 //   waves 0-3 (compute): all MFMAs.  Their only vector-memory traffic is the weight stream from L2 (W2, W3 fragments
-//                        straight into operand registers through small rings); B operands come from LDS.
+//                        straight into operand registers through rings); B operands come from LDS.
 //   waves 4-7 (io):      everything that touches HBM.  Phase 2: the LDS-DMA of the h1 ranges (a ring of four stages, three
-//                        ranges ahead, counted vmcnt on a queue that holds nothing else).  Phase 3: the epilogue -- they
-//                        take a sub-pass's fp32 sums from an LDS exchange buffer, add b3 and the residual rows (requested
-//                        four sub-passes ahead into their own registers), ReLU, round, store.
-// The two roles meet at one s_barrier per h1 range and one per expand sub-pass (fp32 sums double-buffered in LDS), with
-// explicit lgkmcnt / vmcnt waits in front of each (no __syncthreads: its fence would drain the weight rings).  Both roles
-// run the SAME barrier skeleton (the loops below are shared, the bodies are role-specific), so the counts match by
-// construction.  138 KB of LDS, one workgroup per CU.
+//                        ranges ahead, counted vmcnt) and, behind the last range, the residual rows of the first four expand
+//                        sub-passes.  Phase 3: the epilogue -- io wave w takes the fp32 sums of compute wave w's sub-pass
+//                        (64 channels x 64 pixels) from an LDS exchange buffer, adds b3 and the residual, ReLU, rounds,
+//                        stores -- LINE-MAJOR: lane l handles piece (l & 7) of pixel 8 t + (l >> 3), so every residual
+//                        load and every store is eight whole 128-byte lines per instruction (the MFMA accumulator layout
+//                        gives 16 bytes of 64 different lines, which the L1 serves at a third of the rate:
+//                        tools/probes/tcp_line_coalesce_probe.hip).
+// Phase 2: the two roles meet at one s_barrier per h1 range.  Phase 3: NO workgroup barrier -- compute wave w and io wave w
+// hand the exchange buffer back and forth through two counters in LDS (published / consumed sub-passes; LDS operations of a
+// wave execute in order, so a counter written behind the data is seen behind the data), the compute wave writes the sums of
+// sub-pass e in the middle of the MFMAs of sub-pass e + 1 (two accumulator sets) and never waits unless its io wave is a
+// whole sub-pass behind.  142 KB of LDS, one workgroup per CU.
 #include <algorithm>
+#include <type_traits>
 
 #include "tspn_common.h"
 
@@ -41,16 +47,40 @@ constexpr int NRNG = 3 * CCH;           // ranges per tile: (64-channel part, ta
 constexpr int EXTRA_OFF = NST * B_ST;   // slots 128, 129 of a stage: [stage][8 groups][2 slots] x 16 B
 constexpr int ZERO_OFF = EXTRA_OFF + NST * 256;
 constexpr int B3_OFF = ZERO_OFF + 256;
-constexpr int XCH_OFF = B3_OFF + C4 * 4;    // fp32 sums of a sub-pass: [2 sets][4 waves][2 blocks][4 quads][64 lanes] x 16 B
-constexpr int XCH_WAVE = 2 * 4 * 64 * 16, XCH_SET = 4 * XCH_WAVE;
-constexpr int SMEM = XCH_OFF + 2 * XCH_SET;
-constexpr int NSUB = 16;                // expand sub-passes per compute wave: (row block, pair of pixel blocks)
+constexpr int XCH_OFF = B3_OFF + C4 * 4;    // fp32 sums of a sub-pass, per wave pair: [64 pixels][64 channels + 4 floats of padding]
+constexpr int XP = 64 * 4 + 16;             // bytes per pixel row: 16 lanes writing / reading 16 B each touch 64 different banks
+constexpr int XCH_WAVE = 64 * XP;
+constexpr int FLAG_OFF = XCH_OFF + 4 * XCH_WAVE;   // [4 wave pairs][published, consumed] sub-pass counters
+constexpr int SMEM = FLAG_OFF + 64;
+constexpr int NSUB = 8;                 // expand sub-passes per compute wave: 64 channels (two row blocks) x 64 pixels
 constexpr int RD = 4;                   // residual rows requested this many sub-passes ahead
+constexpr int R3 = 8;                   // W3 ring, k-steps
 static_assert(CCH * B_ST == NST * B_ST && SMEM <= 160 * 1024, "h2 image = the four stages; LDS budget");
 
 // meet the other role: LDS traffic of this wave complete (reads consumed / writes landed), then the workgroup barrier
 __device__ __forceinline__ void role_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+// sub-pass counters in LDS.  A wave's LDS operations execute in order: the counter written behind the data is seen behind it.
+__device__ __forceinline__ void flag_set(unsigned addr, int v) {
+  asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void flag_wait(unsigned addr, int target) {     // until the counter has reached `target`
+  // one asm block: a C++ loop here makes hipcc spill ~430 registers of the 3 600-instruction straight-line code around it
+  int v, sv;
+  asm volatile(
+      "1:\n\t"
+      "ds_read_b32 %0, %2\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "v_readfirstlane_b32 %1, %0\n\t"
+      "s_cmp_ge_i32 %1, %3\n\t"
+      "s_cbranch_scc1 2f\n\t"
+      "s_sleep 1\n\t"
+      "s_branch 1b\n\t"
+      "2:"
+      : "=&v"(v), "=&s"(sv)
+      : "v"(addr), "s"(target)
+      : "memory", "scc");
 }
 
 __global__ __launch_bounds__(THREADS, 1) void tail_io_bf16_kernel(
@@ -71,128 +101,122 @@ __global__ __launch_bounds__(THREADS, 1) void tail_io_bf16_kernel(
   const int w4 = wave & 3;
   const int li = lane & 31, kh = lane >> 5;
   if (tid < 4) reinterpret_cast<float*>(Bs + ZERO_OFF)[tid] = 0.f;               // published by the first barrier
+  if (tid >= 64 && tid < 80) reinterpret_cast<int*>(Bs + FLAG_OFF)[tid - 64] = 0;  // likewise
   for (int i = tid; i < CM; i += THREADS)                                          // b3 -> LDS, likewise
     *reinterpret_cast<float4*>(Bs + B3_OFF + 16 * i) = *reinterpret_cast<const float4*>(bias3 + 4 * i);
   const char* const zslot = Bs + ZERO_OFF;
   constexpr unsigned OOB = 0x80000000u;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)Bs;
+  const unsigned f_pub = lds0 + FLAG_OFF + 8 * w4, f_con = f_pub + 4;            // counters of this wave pair
+  char* const xw = Bs + XCH_OFF + w4 * XCH_WAVE;                                   // exchange buffer of this wave pair
 
-  // ================================================================ phase 2: 3x3 conv, K = 4 parts x 9 taps x 64
-  // ---- io side: the ranges.  Range i = 3 c + ra holds pixels n0 + (ra - 1) W - 1 .. + 129 of channel part c; wave w4 stages
-  // the pixel (slot) 64 (w4 & 1) + lane, channel groups bg, bg + 2, bg + 4, bg + 6 (bg = w4 >> 1); slots 128, 129 go to a
-  // side region (every io wave issues that piece -- same bytes, same place -- so that each has FIVE pieces per range)
-  const int64_t rbase = n0 - W - 1 > 0 ? n0 - W - 1 : 0;
-  const __amdgpu_buffer_rsrc_t rsrc_h1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(h1) + rbase * CM, 0, 0x7fffffff, 0x00020000);
-  const int slot = 64 * (w4 & 1) + lane, bg = w4 >> 1;
-  auto stage_r = [&](int buf, int i) {
-    const int c = i / 3, ra = i - 3 * c;
-    const int soff = c * KC * 2;
-    const int64_t q = n0 + (int64_t)(ra - 1) * W - 1 + slot;
-    const unsigned voff = (q >= 0 && q < npix) ? (unsigned)((q - rbase) * CM * 2 + 16 * bg) : OOB;
-    char* dst = Bs + buf * B_ST + (bg * SLP + 64 * (w4 & 1)) * 16;
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_h1, (__attribute__((address_space(3))) void*)(dst + 2 * p * SLP * 16), 16,
-                                               (int)(voff == OOB ? OOB : voff + 32 * p), soff, 0, 0);
-    const int g = (lane >> 1) & 7, e = lane & 1;
-    const int64_t q2 = n0 + (int64_t)(ra - 1) * W - 1 + 128 + e;
-    const unsigned voff2 = (lane < 16 && q2 >= 0 && q2 < npix) ? (unsigned)((q2 - rbase) * CM * 2 + 16 * g) : OOB;
-    if (lane < 16)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_h1, (__attribute__((address_space(3))) void*)(Bs + EXTRA_OFF + buf * 256), 16,
-                                               (int)voff2, soff, 0, 0);
-  };
-  // wait until at most `ranges` of this wave's ranges (5 pieces each) are still in flight
-  auto wait_ranges = [&](int ranges) {
-    if (ranges >= 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    else if (ranges == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  };
-
-  // sub-pass e of wave w4 in phase 3: row block mb = 8 w4 + (e >> 1) (channels 32 mb ..), pixel blocks 2 (e & 1), 2 (e & 1) + 1
-  char* const xw = Bs + XCH_OFF + w4 * XCH_WAVE + lane * 16;   // exchange buffer of this wave pair: + set, + (block, quad) * 1024
-
-  // The two roles run SEPARATE straight-line programs with the same barrier sequence -- 1 + NRNG + 1 + NSUB -- instead of one
-  // loop nest with role branches inside: with the branches inside, the 128 accumulator registers are loop-carried through
-  // the io path as well and hipcc copies and spills them around every branch (1 200 spilled registers in that form).
+  // The two roles run SEPARATE straight-line programs with the same s_barrier sequence (1 + NRNG + 1) instead of one loop
+  // nest with role branches inside: with the branches inside, the 128 accumulator registers are loop-carried through the io
+  // path as well and hipcc copies and spills them around every branch (1 200 spilled registers in that form).
   if (io) {
     // ================================================================ io waves
+    // ---- phase 2: the ranges.  Range i = 3 c + ra holds pixels n0 + (ra - 1) W - 1 .. + 129 of channel part c; wave w4
+    // stages the pixel (slot) 64 (w4 & 1) + lane, channel groups bg, bg + 2, bg + 4, bg + 6 (bg = w4 >> 1); slots 128, 129 go
+    // to a side region (every io wave issues that piece -- same bytes, same place -- so that each has FIVE pieces per range)
+    const int64_t rbase = n0 - W - 1 > 0 ? n0 - W - 1 : 0;
+    const __amdgpu_buffer_rsrc_t rsrc_h1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(h1) + rbase * CM, 0, 0x7fffffff, 0x00020000);
+    const int slot = 64 * (w4 & 1) + lane, bg = w4 >> 1;
+    auto stage_r = [&](int buf, int i) {
+      const int c = i / 3, ra = i - 3 * c;
+      const int soff = c * KC * 2;
+      const int64_t q = n0 + (int64_t)(ra - 1) * W - 1 + slot;
+      const unsigned voff = (q >= 0 && q < npix) ? (unsigned)((q - rbase) * CM * 2 + 16 * bg) : OOB;
+      char* dst = Bs + buf * B_ST + (bg * SLP + 64 * (w4 & 1)) * 16;
 #pragma unroll
-    for (int i = 0; i < DIST; ++i) stage_r(i, i);
-    wait_ranges(DIST - 1);                                   // range 0 has landed
-    role_barrier();                                          // [0]
-    for (int i = 0; i < NRNG; ++i) {
-      // stage (i + DIST) % NST = (i - 1) % NST was read in the previous interval; its barrier lies behind us
-      if (i + DIST < NRNG) stage_r((i + DIST) & (NST - 1), i + DIST);
-      const int last_issued = i + DIST < NRNG ? i + DIST : NRNG - 1;
-      wait_ranges(last_issued - (i + 1));                   // range i + 1 has landed before the barrier publishes it
-      role_barrier();                                        // [1 + i]
-    }
-    // (the compute waves write the h2 image now)  residual rows of the first RD sub-passes meanwhile
+      for (int p = 0; p < 4; ++p)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_h1, (__attribute__((address_space(3))) void*)(dst + 2 * p * SLP * 16), 16,
+                                                 (int)(voff == OOB ? OOB : voff + 32 * p), soff, 0, 0);
+      const int g = (lane >> 1) & 7, e = lane & 1;
+      const int64_t q2 = n0 + (int64_t)(ra - 1) * W - 1 + 128 + e;
+      const unsigned voff2 = (lane < 16 && q2 >= 0 && q2 < npix) ? (unsigned)((q2 - rbase) * CM * 2 + 16 * g) : OOB;
+      if (lane < 16)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_h1, (__attribute__((address_space(3))) void*)(Bs + EXTRA_OFF + buf * 256), 16,
+                                                 (int)voff2, soff, 0, 0);
+    };
+    // ---- phase 3 addresses: sub-pass e of wave pair w4 = channels 256 w4 + 64 (e >> 1) .. + 63 of pixels 64 (e & 1) .. + 63;
+    // item t of a lane = piece (lane & 7) (8 channels) of pixel 64 (e & 1) + 8 t + (lane >> 3)
     const __amdgpu_buffer_rsrc_t rsrc_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(residual) + n0 * C4, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc(out + n0 * C4, 0, 0x7fffffff, 0x00020000);
-    unsigned po[4];                                          // byte offset of this lane's pixel of each pixel block (channel 16 kh)
+    const int pc = lane & 7, pp = lane >> 3;
+    const unsigned lvo = (unsigned)(pp * C4 * 2 + 16 * pc);                       // the lane's part of every global offset
+    const int64_t left = npix - n0 - pp;                                           // pixels 64 (e & 1) + 8 t below this exist
+    const int plimit = left > BN ? BN : (int)left;
+    auto soff_of = [&](int e, int t) { return ((64 * (e & 1) + 8 * t) * C4 + 256 * w4 + 64 * (e >> 1)) * 2; };
+    auto voff_of = [&](int e, int t) { return (int)(64 * (e & 1) + 8 * t < plimit ? lvo : OOB); };
+    bf16x8 res[RD][8];                                       // residual pieces in flight [sub-pass % RD][item]
+    auto res_issue = [&](int slot_, int e) {                // slot_ = e % RD, compile-time at every call site
 #pragma unroll
-    for (int b = 0; b < 4; ++b) po[b] = (n0 + b * 32 + li < npix) ? (unsigned)(((b * 32 + li) * C4 + 16 * kh) * 2) : OOB;
-    bf16x8 res[RD][2][2];                                    // residual rows in flight [sub-pass % RD][pixel block][half]
-    auto res_issue_slot = [&](int slot_, int e) {           // slot_ = e % RD, compile-time at every call site
-      const int mb = 8 * w4 + (e >> 1);
-#pragma unroll
-      for (int pj = 0; pj < 2; ++pj)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const unsigned p = (e & 1) ? po[2 + pj] : po[pj];
-          res[slot_][pj][h] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_res, (int)(p == OOB ? OOB : p + 16 * h), mb * 64, 0));
-        }
+      for (int t = 0; t < 8; ++t)
+        res[slot_][t] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_res, voff_of(e, t), soff_of(e, t), 0));
     };
+
 #pragma unroll
-    for (int e = 0; e < RD; ++e) res_issue_slot(e, e);
+    for (int i = 0; i < DIST; ++i) stage_r(i, i);
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");        // range 0 has landed (five pieces per range)
+    role_barrier();                                          // [0]
+    for (int i = 0; i + DIST + 1 < NRNG; ++i) {
+      // stage (i + DIST) % NST = (i - 1) % NST was read in the previous interval; its barrier lies behind us
+      stage_r((i + DIST) & (NST - 1), i + DIST);
+      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      // range i + 1 has landed before the barrier publishes it
+      role_barrier();                                        // [1 + i]
+    }
+    stage_r((NRNG - 1) & (NST - 1), NRNG - 1);               // the last range ...
+#pragma unroll
+    for (int e = 0; e < RD; ++e) res_issue(e, e);            // ... and behind it 32 residual pieces: the waits count them in
+    static_assert(10 + 8 * RD <= 63, "vmcnt is six bits");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(10 + 8 * RD) : "memory");
+    role_barrier();                                          // [NRNG - 3]
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 + 8 * RD) : "memory");
+    role_barrier();                                          // [NRNG - 2]
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * RD) : "memory");
+    role_barrier();                                          // [NRNG - 1]
+    role_barrier();                                          // [NRNG]: the last range has been read
     role_barrier();                                          // [1 + NRNG]: h2 complete (nothing of ours depends on it)
-    role_barrier();                                          // [2 + NRNG]: sub-pass 0's sums are in set 0
-    u32x4_t keep[2] = {};
+
+    u32x4_t keep = {};
     static_assert(NSUB % RD == 0, "the sub-pass loop is unrolled by the residual ring's depth");
     for (int e0 = 0; e0 < NSUB; e0 += RD) {
 #pragma unroll
       for (int u = 0; u < RD; ++u) {
-        const int e = e0 + u;                                // this sub-pass's sums were published by the last barrier
-        const int mb = 8 * w4 + (e >> 1);
-        const char* const src = xw + (e & 1) * XCH_SET;
-        const char* const b3s = Bs + B3_OFF + (32 * mb + 16 * kh) * 4;
-        float bv[16];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 t = *reinterpret_cast<const float4*>(b3s + 16 * q);
-          bv[4 * q] = t.x; bv[4 * q + 1] = t.y; bv[4 * q + 2] = t.z; bv[4 * q + 3] = t.w;
+        const int e = e0 + u;
+        float bv[8];
+        {
+          const char* const b3s = Bs + B3_OFF + (256 * w4 + 64 * (e >> 1) + 8 * pc) * 4;
+          const float4 t0 = *reinterpret_cast<const float4*>(b3s), t1 = *reinterpret_cast<const float4*>(b3s + 16);
+          bv[0] = t0.x; bv[1] = t0.y; bv[2] = t0.z; bv[3] = t0.w; bv[4] = t1.x; bv[5] = t1.y; bv[6] = t1.z; bv[7] = t1.w;
         }
+        flag_wait(f_pub, e + 1);                             // the sums of sub-pass e are in the exchange buffer
+        f32x4 sv[8][2];
 #pragma unroll
-        for (int pj = 0; pj < 2; ++pj) {
-          float v[16];
+        for (int t = 0; t < 8; ++t) {
+          const char* const src = xw + (8 * t + pp) * XP + 32 * pc;
+          sv[t][0] = *reinterpret_cast<const f32x4*>(src);
+          sv[t][1] = *reinterpret_cast<const f32x4*>(src + 16);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        flag_set(f_con, e + 1);                              // the buffer may take sub-pass e + 1
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(src + (pj * 4 + q) * 1024);
-            v[4 * q] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
-          }
-          u32x4_t o2[2];
+        for (int t = 0; t < 8; ++t) {
+          bf16x8 o;
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            bf16x8 o;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (__bf16)fmaxf((v[8 * h + j] + bv[8 * h + j]) + (float)res[u][pj][h][j], 0.f);
-            o2[h] = __builtin_bit_cast(u32x4_t, o);
-          }
-          const unsigned p = (e & 1) ? po[2 + pj] : po[pj];
-          __builtin_amdgcn_raw_buffer_store_b128(o2[0], rsrc_out, (int)(p == OOB ? OOB : p), mb * 64, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(o2[1], rsrc_out, (int)(p == OOB ? OOB : p + 16), mb * 64, 0);
+          for (int j = 0; j < 8; ++j) o[j] = (__bf16)fmaxf((sv[t][j >> 2][j & 3] + bv[j]) + (float)res[u][t][j], 0.f);
+          const u32x4_t o4 = __builtin_bit_cast(u32x4_t, o);
+          __builtin_amdgcn_raw_buffer_store_b128(o4, rsrc_out, voff_of(e, t), soff_of(e, t), 0);
           // store-data hazard (tools/lint_store_hazard.py, profiles/r5/bottleneck_block_study.md §3): the data registers
-          // of a group stay live until the next group's stores have been issued
-          asm volatile("" ::"v"(keep[0]), "v"(keep[1]));
-          keep[0] = o2[0];
-          keep[1] = o2[1];
+          // of a store stay live until the next store has been issued
+          asm volatile("" ::"v"(keep));
+          keep = o4;
         }
-        if (e + RD < NSUB) res_issue_slot(u, e + RD);        // its ring slot is free now
-        if (e + 1 < NSUB) role_barrier();                    // [3 + NRNG + e]: set e & 1 is free, sub-pass e + 1's sums are published
+        if (e + RD < NSUB) res_issue(u, e + RD);             // its ring slot is free now
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    asm volatile("s_nop 15\n s_nop 15" ::"v"(keep[0]), "v"(keep[1]));
+    asm volatile("s_nop 15\n s_nop 15" ::"v"(keep));
   } else {
     // ================================================================ compute waves: wave w4 = rows [64 w4, 64 w4 + 64) x all 128 pixels
     f32x16 acc[2][4];
@@ -225,8 +249,10 @@ __global__ __launch_bounds__(THREADS, 1) void tail_io_bf16_kernel(
     // B fragments of k-step j of a range: tap (ra, rb = j / 4), channels 16 (j % 4) ..  With ONE MFMA wave per SIMD every
     // vector instruction between two MFMAs is a cycle the matrix pipe may idle, so the fragment addresses are prepared once
     // per range: byte offset of channel group kh and the stride per channel group -- (stage, SLP 16) in the image,
-    // (side region, 32) for slots 128 / 129, (zero slot, 0) for taps that fall off the image -- one v_mad per read.
-    constexpr int D2 = 6;                                    // W2 ring, k-steps (fragments come from L2)
+    // (side region, 32) for slots 128 / 129, (zero slot, 0) for taps that fall off the image -- one v_mad per read; the
+    // reads of k-step j + 1 are issued IN FRONT of the MFMAs of k-step j (fenced: left alone, the scheduler moves them
+    // behind half of the MFMAs and the next k-step waits for LDS).
+    constexpr int D2 = 4;                                    // W2 ring, k-steps (fragments come from L2)
     f32x4 a2[D2][2];
     auto load_w2 = [&](int slot_, int f) {
       a2[slot_][0] = *reinterpret_cast<const f32x4*>(w2b0 + (int64_t)f * 1024);
@@ -257,25 +283,37 @@ __global__ __launch_bounds__(THREADS, 1) void tail_io_bf16_kernel(
 #pragma unroll
           for (int ni = 0; ni < 4; ++ni) b[ni] = *reinterpret_cast<const bf16x8*>(Bs + bo[rb][ni] + ks * bs[rb][ni]);
         };
-        bf16x8 bc[4], bn[4];
-        read_b(0, bc);
+        bf16x8 bb[2][4];
+        read_b(0, bb[0]);
 #pragma unroll
         for (int j = 0; j < 12; ++j) {
-          if (j + 1 < 12) read_b(j + 1, bn);                 // the next k-step's fragments fly under this k-step's MFMAs
+          if (j + 1 < 12) read_b(j + 1, bb[(j + 1) & 1]);    // the next k-step's fragments fly under this k-step's MFMAs
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int mi = 0; mi < 2; ++mi) {
             const bf16x8 av = __builtin_bit_cast(bf16x8, a2[(12 * r + j) % D2][mi]);
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bc[ni], acc[mi][ni], 0, 0, 0);
+            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bb[j & 1][ni], acc[mi][ni], 0, 0, 0);
           }
           if (12 * i + j + D2 < 12 * NRNG) load_w2((12 * r + j) % D2, 12 * i + j + D2);
-#pragma unroll
-          for (int ni = 0; ni < 4; ++ni) bc[ni] = bn[ni];
           __builtin_amdgcn_sched_barrier(0);
         }
         role_barrier();                                      // [1 + i]
       }
     }
+    // ---- the first R3 k-steps of the W3 stream fly while h2 is written
+    // sub-pass sp: row blocks 8 w4 + 2 (sp >> 1) + {0, 1}, pixel blocks 2 (sp & 1) + {0, 1}; k-step k of row block mb at
+    // (mb CCH 4 + k) KiB; the two pixel halves of a channel block fetch the same fragments (L2 hits)
+    const unsigned woff3 = (unsigned)((kh << 5) | (((li >> 2) & 1) << 4) | ((li >> 3) << 2) | (li & 3)) * 16;   // permuted W3 rows
+    const char* const w3w = reinterpret_cast<const char*>(Wf3) + (int64_t)(8 * w4) * (CCH * 4096) + woff3;
+    f32x4 a3[R3][2];
+    auto load_w3 = [&](int slot_, int sp, int k) {
+      const char* const pw = w3w + (int64_t)(2 * (sp >> 1)) * (CCH * 4096) + k * 1024;
+      a3[slot_][0] = *reinterpret_cast<const f32x4*>(pw);
+      a3[slot_][1] = *reinterpret_cast<const f32x4*>(pw + CCH * 4096);
+    };
+#pragma unroll
+    for (int d = 0; d < R3; ++d) load_w3(d, 0, d);
     // ---- h2 = relu(acc + b2) -> bf16 -> LDS (B-operand image [32 groups][SLP][8]) over the stages
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -294,47 +332,74 @@ __global__ __launch_bounds__(THREADS, 1) void tail_io_bf16_kernel(
         }
       }
     role_barrier();                                          // [1 + NRNG]: h2 complete
-    // ---- phase 3: 1x1 expand, K = 256; the fp32 sums of a sub-pass go to the io wave of the same number through LDS
-    const unsigned woff3 = (unsigned)((kh << 5) | (((li >> 2) & 1) << 4) | ((li >> 3) << 2) | (li & 3)) * 16;   // permuted W3 rows
+    // ---- phase 3: 1x1 expand, K = 256.  Sub-pass sp accumulates in set sp & 1; the sums of sub-pass sp - 1 go to the
+    // exchange buffer in the middle of sub-pass sp.
     const char* const hb = Bs + (kh * SLP + li) * 16;
-    for (int sp = 0; sp < NSUB; ++sp) {
-      const int mb = 8 * w4 + (sp >> 1), nb = 2 * (sp & 1);
-      const char* const w3b = reinterpret_cast<const char*>(Wf3) + (int64_t)mb * (CCH * 4096) + woff3;
-      f32x16 c3[2];
+    char* const xl = xw + li * XP + 64 * kh;                 // + (32 nj) XP + 128 ms + 16 q
+    auto write_sums = [&](f32x16 (&c)[2][2], int e) {       // sums of sub-pass e -> exchange buffer, then publish
+      flag_wait(f_con, e);                                   // the io wave has taken sub-pass e - 1 out of it
 #pragma unroll
-      for (int pj = 0; pj < 2; ++pj)
+      for (int ms = 0; ms < 2; ++ms)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) c3[pj][e] = 0.f;
-      constexpr int D3 = 8;
-      f32x4 a3[D3];
+        for (int nj = 0; nj < 2; ++nj)
 #pragma unroll
-      for (int d = 0; d < D3; ++d) a3[d] = *reinterpret_cast<const f32x4*>(w3b + d * 1024);
-      bf16x8 hc[2], hn[2];
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<f32x4*>(xl + nj * 32 * XP + 128 * ms + 16 * q) =
+                f32x4{c[ms][nj][4 * q], c[ms][nj][4 * q + 1], c[ms][nj][4 * q + 2], c[ms][nj][4 * q + 3]};
+      flag_set(f_pub, e + 1);
+    };
+    f32x16 cA[2][2], cB[2][2];
+    bf16x8 hh[2][2];
+    auto read_h = [&](int sp, int k, bf16x8 (&b)[2]) {
 #pragma unroll
-      for (int pj = 0; pj < 2; ++pj) hc[pj] = *reinterpret_cast<const bf16x8*>(hb + (nb + pj) * 32 * 16);
+      for (int nj = 0; nj < 2; ++nj) b[nj] = *reinterpret_cast<const bf16x8*>(hb + ((2 * k) * SLP + (2 * (sp & 1) + nj) * 32) * 16);
+    };
+    auto ksteps = [&](f32x16 (&c)[2][2], int sp, auto k0_tag, auto k1_tag) {     // k-steps k0 .. k1 - 1 of sub-pass sp
+      constexpr int k0 = decltype(k0_tag)::value, k1 = decltype(k1_tag)::value;
 #pragma unroll
-      for (int k = 0; k < CM / 16; ++k) {
-        if (k + 1 < CM / 16) {
+      for (int k = k0; k < k1; ++k) {
+        // the next k-step's h2 fragments (of the next sub-pass behind the last one) in front of this k-step's MFMAs
+        if (k + 1 < 16) read_h(sp, k + 1, hh[(k + 1) & 1]);
+        else if (sp + 1 < NSUB) read_h(sp + 1, 0, hh[0]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int pj = 0; pj < 2; ++pj) hn[pj] = *reinterpret_cast<const bf16x8*>(hb + (2 * (k + 1) * SLP + (nb + pj) * 32) * 16);
+        for (int ms = 0; ms < 2; ++ms) {
+          const bf16x8 av = __builtin_bit_cast(bf16x8, a3[k % R3][ms]);
+#pragma unroll
+          for (int nj = 0; nj < 2; ++nj) c[ms][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, hh[k & 1][nj], c[ms][nj], 0, 0, 0);
         }
-        const bf16x8 av = __builtin_bit_cast(bf16x8, a3[k % D3]);
-#pragma unroll
-        for (int pj = 0; pj < 2; ++pj) c3[pj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, hc[pj], c3[pj], 0, 0, 0);
-        if (k + D3 < CM / 16) a3[k % D3] = *reinterpret_cast<const f32x4*>(w3b + (k + D3) * 1024);
-#pragma unroll
-        for (int pj = 0; pj < 2; ++pj) hc[pj] = hn[pj];
+        if (k + R3 < 16) load_w3(k % R3, sp, k + R3);
+        else if (sp + 1 < NSUB) load_w3(k % R3, sp + 1, k + R3 - 16);
         __builtin_amdgcn_sched_barrier(0);
       }
-      // set sp & 1 was read by the io wave before barrier [1 + NRNG + sp] (its sub-pass sp - 2)
-      char* const dst = xw + (sp & 1) * XCH_SET;
+    };
+    auto zero = [&](f32x16 (&c)[2][2]) {
 #pragma unroll
-      for (int pj = 0; pj < 2; ++pj)
+      for (int ms = 0; ms < 2; ++ms)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          *reinterpret_cast<f32x4*>(dst + (pj * 4 + q) * 1024) = f32x4{c3[pj][4 * q], c3[pj][4 * q + 1], c3[pj][4 * q + 2], c3[pj][4 * q + 3]};
-      role_barrier();                                        // [2 + NRNG + sp]: sub-pass sp's sums are published
+        for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) c[ms][nj][e] = 0.f;
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I8 = std::integral_constant<int, 8>;
+    using I16 = std::integral_constant<int, 16>;
+    read_h(0, 0, hh[0]);
+    zero(cA);
+    ksteps(cA, 0, I0{}, I16{});
+    for (int sp = 1; sp < NSUB; sp += 2) {
+      zero(cB);
+      ksteps(cB, sp, I0{}, I8{});
+      write_sums(cA, sp - 1);
+      ksteps(cB, sp, I8{}, I16{});
+      if (sp + 1 < NSUB) {
+        zero(cA);
+        ksteps(cA, sp + 1, I0{}, I8{});
+        write_sums(cB, sp);
+        ksteps(cA, sp + 1, I8{}, I16{});
+      }
     }
+    write_sums(cB, NSUB - 1);
   }
 }
 
