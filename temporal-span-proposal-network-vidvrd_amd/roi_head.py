@@ -109,6 +109,9 @@ class BottleneckBlock(nn.Module):
         # ... and the FIRST block of res2 (projection shortcut, stride 1) as one launch that computes the shortcut
         # on the tile's own input pixels instead of writing the 4 CM-channel shortcut map and reading it back
         self.fuse_block_proj = True
+        # 256 bottleneck channels (res4): the fused tail with the work split by role -- four MFMA waves + four io waves per
+        # workgroup (tspn_bottleneck_tail_io_bf16, round 5; bit-identical, ~15 % faster); switched by ResNetC4 `tail_io_waves`
+        self.tail_io_waves = True
 
     PROJ_SHAPES = ((64, 64, 1),)        # (input channels, bottleneck channels, stride) tspn_bottleneck_block_proj_bf16 is enabled for
 
@@ -201,7 +204,8 @@ class BottleneckBlock(nn.Module):
             if hand_over:
                 f1n, b1n = next_block.conv1.folded_bf16(x.device)
                 return ops.bottleneck_tail_bf16(h, f2, b2, f3, b3, sc.contiguous(), out=out, next_frag1=f1n, next_bias1=b1n)
-            y = ops.bottleneck_tail_bf16(h, f2, b2, f3, b3, sc.contiguous(), out=out)
+            io = bool(self.tail_io_waves) and self.conv2.weight.shape[0] == 256
+            y = ops.bottleneck_tail_bf16(h, f2, b2, f3, b3, sc.contiguous(), out=out, io_waves=io)
             return (y, None) if next_block is not None else y
         y = self.conv3(self.conv2(h, relu=True), residual=sc, relu=True)
         if out is not None:
@@ -433,6 +437,9 @@ class ResNetC4(_CachedWeightsMixin, nn.Module):
         self.fuse_blocks = True
         # ... and the first block of res2 (projection shortcut) as one launch too (tspn_bottleneck_block_proj_bf16)
         self.fuse_first_blocks = True
+        # res4's fused tails with the work split by role (round 5, tspn_bottleneck_tail_io_bf16: four MFMA waves whose only
+        # memory traffic is the weight stream + four io waves that own the h1 DMA, the residual rows and the stores)
+        self.tail_io_waves = True
         # frame chunks alternate between this many HIP streams: a launch's workgroups run in lockstep (all in their MFMA
         # phase, then all in their memory phase), two chunks in flight put the memory phase of one under the MFMA phase
         # of the other (tools/probe_tail_stagger.py: -10 % on the res4 tails; backbone -5 %)
@@ -450,6 +457,7 @@ class ResNetC4(_CachedWeightsMixin, nn.Module):
                     m.fuse_next = bool(self.fuse_bottlenecks and self.fuse_next_conv1)
                     m.fuse_block = bool(self.fuse_bottlenecks and self.fuse_blocks)
                     m.fuse_block_proj = bool(self.fuse_first_blocks)
+                    m.tail_io_waves = bool(self.tail_io_waves)
             out = []
             nchunks = -(-images.shape[0] // self.frame_chunk)
             ns = min(int(self.streams), nchunks) if images.is_cuda else 1

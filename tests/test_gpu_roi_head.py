@@ -654,6 +654,99 @@ def test_bottleneck_tail_persistent_pipelined_bit_identical(tspn, device, NB, H,
         tspn.ops.bottleneck_tail_bf16(h1d[..., :128].contiguous(), f2, d(b2), f3, d(b3), resd, persistent=True)
 
 
+@pytest.mark.parametrize("NB,H,W", [(3, 7, 11), (1, 45, 80), (1, 1, 1), (2, 16, 8), (1, 13, 129), (9, 45, 80), (5, 31, 33),
+                                     (1, 8, 16), (1, 2, 65)])
+def test_bottleneck_tail_role_split_bit_identical(tspn, device, NB, H, W):
+    """tspn_bottleneck_tail_io_bf16 (round 5): four MFMA waves + four io waves per workgroup, the expand sums handed over
+    through LDS under two counters per wave pair, the epilogue line-major.  Equals tspn_bottleneck_tail_bf16 BIT FOR BIT
+    into a poisoned output: one pixel, one tile exactly (8 x 16), tiles that end inside a 64-pixel half (1 x 2 x 65: the
+    second half of a sub-pass has ONE pixel), fewer tiles than CUs, one per CU (9 frames of res4), image widths that are
+    no multiple of anything; repeated launches agree."""
+    CM = 256
+    h1 = tspn.hashrng.uniform(95, "h1", (NB, H, W, CM), 0, 1)
+    res = tspn.hashrng.uniform(95, "res", (NB, H, W, 4 * CM), -1, 1)
+    w2 = tspn.hashrng.normal(95, "w2", (CM, CM, 3, 3), std=float(np.sqrt(2.0 / (9 * CM))))
+    w3 = tspn.hashrng.normal(95, "w3", (4 * CM, CM, 1, 1), std=float(np.sqrt(2.0 / CM)))
+    b2 = tspn.hashrng.normal(95, "b2", (CM,), std=0.1)
+    b3 = tspn.hashrng.normal(95, "b3", (4 * CM,), std=0.1)
+    d = lambda a, dt=None: (t(a).to(device) if dt is None else t(a).to(device).to(dt))   # noqa: E731
+    f2, f3 = tspn.ops.pack_conv2d_frag_bf16(d(w2)), tspn.ops.pack_conv2d_frag_bf16(d(w3))
+    h1d, resd = d(h1, torch.bfloat16), d(res, torch.bfloat16)
+    want = tspn.ops.bottleneck_tail_bf16(h1d, f2, d(b2), f3, d(b3), resd)
+    assert float(want.float().abs().max()) > 0.1                 # not a vacuous comparison
+    for rep in range(3):
+        out = torch.full_like(want, 777.0)
+        got = tspn.ops.bottleneck_tail_bf16(h1d, f2, d(b2), f3, d(b3), resd, out=out, io_waves=True)
+        assert got.data_ptr() == out.data_ptr()
+        bad = int((got != want).sum())
+        assert bad == 0, f"rep {rep}: {bad} of {got.numel()} outputs differ, max diff {float((got.float() - want.float()).abs().max())}"
+    with pytest.raises(ValueError):
+        tspn.ops.bottleneck_tail_bf16(h1d[..., :128].contiguous(), f2, d(b2), f3, d(b3), resd, io_waves=True)
+
+
+def test_bottleneck_tail_role_split_at_backbone_scale(tspn, device):
+    """The role-split tail on 40 frames of the res4 shape (1125 tiles: four to five rounds of one workgroup per CU) and on
+    two HIP streams at once, eight launches into poisoned outputs: every one equals the one-role kernel bit for bit.  (Timing-
+    dependent faults -- a counter hand-over that loses a sub-pass, the store-data hazard -- show up at this scale, not on
+    a handful of tiles.)"""
+    CM, NB, H, W = 256, 40, 45, 80
+    g = torch.Generator(device=device).manual_seed(6)
+    h1 = torch.rand((NB, H, W, CM), device=device, generator=g).to(torch.bfloat16)
+    res = (torch.rand((NB, H, W, 4 * CM), device=device, generator=g) - 0.5).to(torch.bfloat16)
+    w2 = (torch.rand((CM, CM, 3, 3), device=device, generator=g) - 0.5) * 0.05
+    w3 = (torch.rand((4 * CM, CM, 1, 1), device=device, generator=g) - 0.5) * 0.1
+    b2, b3 = torch.rand(CM, device=device, generator=g) - 0.5, torch.rand(4 * CM, device=device, generator=g) - 0.5
+    f2, f3 = tspn.ops.pack_conv2d_frag_bf16(w2), tspn.ops.pack_conv2d_frag_bf16(w3)
+    want = tspn.ops.bottleneck_tail_bf16(h1, f2, b2, f3, b3, res)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=device)
+    outs = [torch.full_like(want, 777.0) for _ in range(2)]
+    for trial in range(4):
+        for o in outs:
+            o.fill_(777.0)
+        side.wait_stream(torch.cuda.current_stream(device))
+        tspn.ops.bottleneck_tail_bf16(h1, f2, b2, f3, b3, res, out=outs[0], io_waves=True)
+        with torch.cuda.stream(side):
+            tspn.ops.bottleneck_tail_bf16(h1, f2, b2, f3, b3, res, out=outs[1], io_waves=True)
+        torch.cuda.current_stream(device).wait_stream(side)
+        for k, o in enumerate(outs):
+            bad = int((o != want).sum())
+            assert bad == 0, f"trial {trial}, stream {k}: {bad} of {o.numel()} outputs differ"
+
+
+def test_backbone_with_role_split_tails_equals_the_one_role_kernel(tspn, device):
+    """ResNetC4 on bf16 maps: `tail_io_waves` on (res4's fused tails on tspn_bottleneck_tail_io_bf16) and off give the same
+    res4 maps bit for bit, on one stream and on two, with frame chunks whose pixel count is no multiple of the tile; the
+    role-split kernel really ran -- for the 256-channel tails only."""
+    net, _ = _backbone_and_weights(tspn, device, 64, 256, (3, 4, 3))
+    img = t(tspn.hashrng.uniform(98, "img", (5, 96, 144, 3), -1, 1)).to(device)
+    net.frame_chunk = 2
+    calls = []
+    real = tspn.ops.bottleneck_tail_bf16
+    outs = []
+    try:
+        def spy(*a, **k):
+            calls.append((a[0].shape[3], bool(k.get("io_waves", False))))
+            return real(*a, **k)
+        tspn.ops.bottleneck_tail_bf16 = spy
+        tspn.roi_head.ops.bottleneck_tail_bf16 = spy
+        for streams in (1, 2):
+            for on in (True, False):
+                net.streams = streams
+                net.tail_io_waves = on
+                n0 = len(calls)
+                outs.append(net(img, bf16=True))
+                torch.cuda.synchronize(device)
+                mine = calls[n0:]
+                assert sum(1 for cm, io in mine if cm == 256) == 3 * 3          # 3 frame chunks x 3 res4 blocks
+                assert all(io == (on and cm == 256) for cm, io in mine)
+    finally:
+        tspn.ops.bottleneck_tail_bf16 = real
+        tspn.roi_head.ops.bottleneck_tail_bf16 = real
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+
+
 def test_backbone_chain_with_next_conv1_equals_separate_launches(tspn, device):
     """ResNetC4 with res4 blocks of 256 bottleneck channels: `fuse_next_conv1` (every tail launch computes the follower's
     conv1) on and off give the same maps bit for bit, on one stream and on two, with frame chunks whose pixel count

@@ -22,6 +22,7 @@ ap.add_argument("--no-next", action="store_true", help="(default) fuse_next_conv
 ap.add_argument("--next", action="store_true", help="fuse_next_conv1 = True: res4 tails also compute the follower's conv1")
 ap.add_argument("--no-block", action="store_true", help="identity blocks of res2 / res3 as conv1 + fused tail (round 4) instead of one launch")
 ap.add_argument("--no-proj", action="store_true", help="first blocks of the stages as conv1 + shortcut + fused tail")
+ap.add_argument("--no-io-waves", action="store_true", help="res4 tails on the round-3 kernel (one role per wave) instead of the role-split one")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 net = tspn.ResNetC4(depth=args.depth, frame_chunk=args.chunk).to(dev)
@@ -29,6 +30,7 @@ net.streams = args.streams
 net.fuse_next_conv1 = bool(args.next) and not args.no_next
 net.fuse_blocks = not args.no_block
 net.fuse_first_blocks = not args.no_proj
+net.tail_io_waves = not args.no_io_waves
 g = torch.Generator(device=dev).manual_seed(0)
 img = torch.rand((args.frames, args.h, args.w, 3), device=dev, generator=g) - 0.5
 

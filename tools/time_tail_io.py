@@ -32,10 +32,13 @@ for frames in [int(a) for a in sys.argv[1:]] or [9, 18, 36]:
             fn()
         torch.cuda.synchronize()
         ts = []
-        for _ in range(11):
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(); fn(); b.record(); torch.cuda.synchronize()
-            ts.append(a.elapsed_time(b) * 1e3)
+        for _ in range(7):                     # ten launches back to back per event pair: the queue never runs dry, so the
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # host's launch latency is not in it
+            a.record()
+            for _ in range(10):
+                fn()
+            b.record(); torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b) * 1e2)
         t[name] = sorted(ts)[len(ts) // 2]
     fl = 2.0 * frames * H * W * CM * CM * 13
     print(f"[{tag}] {frames} frames: shipped {t['shipped']:.1f} us ({fl / t['shipped'] / 1e6:.0f} TFLOP/s)  role-split {t['io_waves']:.1f} us "
