@@ -14,16 +14,19 @@
 //   waves 4-7 (io):      everything that touches HBM.  Phase 2: the LDS-DMA of the h1 ranges (a ring of four stages, three
 //                        ranges ahead, counted vmcnt) and, behind the last range, the residual rows of the first four expand
 //                        sub-passes.  Phase 3: the epilogue -- io wave w takes the fp32 sums of compute wave w's sub-pass
-//                        (64 channels x 64 pixels) from an LDS exchange buffer, adds b3 and the residual, ReLU, rounds,
-//                        stores -- LINE-MAJOR: lane l handles piece (l & 7) of pixel 8 t + (l >> 3), so every residual
-//                        load and every store is eight whole 128-byte lines per instruction (the MFMA accumulator layout
-//                        gives 16 bytes of 64 different lines, which the L1 serves at a third of the rate:
-//                        tools/probes/tcp_line_coalesce_probe.hip).
+//                        (32 channels x all 128 pixels) from an LDS exchange buffer, adds b3 and the residual, ReLU, rounds,
+//                        stores -- with lane l on piece (l & 3) of pixel 16 t + (l >> 2), so every residual load and every
+//                        store covers 64 contiguous bytes per lane quad (the MFMA accumulator layout gives 16 bytes of 64
+//                        different lines per instruction, which the L1 serves at a third of the rate: tools/probes/
+//                        tcp_line_coalesce_probe.hip); the results of an even sub-pass wait in registers for the odd one, so
+//                        that the two halves of a 128-byte line are stored back to back.
 // Phase 2: the two roles meet at one s_barrier per h1 range.  Phase 3: NO workgroup barrier -- compute wave w and io wave w
 // hand the exchange buffer back and forth through two counters in LDS (published / consumed sub-passes; LDS operations of a
 // wave execute in order, so a counter written behind the data is seen behind the data), the compute wave writes the sums of
 // sub-pass e in the middle of the MFMAs of sub-pass e + 1 (two accumulator sets) and never waits unless its io wave is a
-// whole sub-pass behind.  142 KB of LDS, one workgroup per CU.
+// whole sub-pass behind.  A sub-pass is one 32-row block x ALL 128 pixels: every W3 fragment enters the CU once.
+// 147 KB of LDS, one workgroup per CU.
+// Measured (profiles/r5/tail_role_split.md): 122 - 125 against 146 - 151 us per 18 frames (ten launches back to back), bit-identical.
 #include <algorithm>
 #include <type_traits>
 
@@ -47,14 +50,16 @@ constexpr int NRNG = 3 * CCH;           // ranges per tile: (64-channel part, ta
 constexpr int EXTRA_OFF = NST * B_ST;   // slots 128, 129 of a stage: [stage][8 groups][2 slots] x 16 B
 constexpr int ZERO_OFF = EXTRA_OFF + NST * 256;
 constexpr int B3_OFF = ZERO_OFF + 256;
-constexpr int XCH_OFF = B3_OFF + C4 * 4;    // fp32 sums of a sub-pass, per wave pair: [64 pixels][64 channels + 4 floats of padding]
-constexpr int XP = 64 * 4 + 16;             // bytes per pixel row: 16 lanes writing / reading 16 B each touch 64 different banks
-constexpr int XCH_WAVE = 64 * XP;
+constexpr int XCH_OFF = B3_OFF + C4 * 4;    // fp32 sums of a sub-pass, per wave pair: [128 pixels][32 channels + 4 floats of padding]
+constexpr int XP = 32 * 4 + 16;             // bytes per pixel row: the 16 lanes of a 16-byte write touch 64 different banks
+constexpr int XCH_WAVE = BN * XP;
 constexpr int FLAG_OFF = XCH_OFF + 4 * XCH_WAVE;   // [4 wave pairs][published, consumed] sub-pass counters
 constexpr int SMEM = FLAG_OFF + 64;
-constexpr int NSUB = 8;                 // expand sub-passes per compute wave: 64 channels (two row blocks) x 64 pixels
+constexpr int NSUB = 8;                 // expand sub-passes per compute wave: 32 channels (one row block) x all 128 pixels --
+                                        // every W3 fragment enters the CU ONCE (with 64-pixel sub-passes it came twice, and the
+                                        // 1 MB of W3 per tile through the L1 took longer than the expand's MFMAs)
 constexpr int RD = 4;                   // residual rows requested this many sub-passes ahead
-constexpr int R3 = 8;                   // W3 ring, k-steps
+constexpr int R3 = 16;                  // W3 ring, k-steps (= one sub-pass ahead)
 static_assert(CCH * B_ST == NST * B_ST && SMEM <= 160 * 1024, "h2 image = the four stages; LDS budget");
 
 // meet the other role: LDS traffic of this wave complete (reads consumed / writes landed), then the workgroup barrier
@@ -138,16 +143,18 @@ __global__ __launch_bounds__(THREADS, 1) void tail_io_bf16_kernel(
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_h1, (__attribute__((address_space(3))) void*)(Bs + EXTRA_OFF + buf * 256), 16,
                                                  (int)voff2, soff, 0, 0);
     };
-    // ---- phase 3 addresses: sub-pass e of wave pair w4 = channels 256 w4 + 64 (e >> 1) .. + 63 of pixels 64 (e & 1) .. + 63;
-    // item t of a lane = piece (lane & 7) (8 channels) of pixel 64 (e & 1) + 8 t + (lane >> 3)
+    // ---- phase 3 addresses: sub-pass e of wave pair w4 = channels 256 w4 + 32 e .. + 31 (half a 128-byte line) of all 128
+    // pixels; item t of a lane = piece (lane & 3) (8 channels) of pixel 16 t + (lane >> 2): a quad of lanes = 64 contiguous
+    // bytes.  The results of an even sub-pass wait in registers and are stored together with the odd one's: the two halves of a
+    // line leave back to back (L2 hands part-written lines to the fabric as they are, profiles/r3)
     const __amdgpu_buffer_rsrc_t rsrc_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(residual) + n0 * C4, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc(out + n0 * C4, 0, 0x7fffffff, 0x00020000);
-    const int pc = lane & 7, pp = lane >> 3;
+    const int pc = lane & 3, pp = lane >> 2;
     const unsigned lvo = (unsigned)(pp * C4 * 2 + 16 * pc);                       // the lane's part of every global offset
-    const int64_t left = npix - n0 - pp;                                           // pixels 64 (e & 1) + 8 t below this exist
+    const int64_t left = npix - n0 - pp;                                           // pixels 16 t below this exist
     const int plimit = left > BN ? BN : (int)left;
-    auto soff_of = [&](int e, int t) { return ((64 * (e & 1) + 8 * t) * C4 + 256 * w4 + 64 * (e >> 1)) * 2; };
-    auto voff_of = [&](int e, int t) { return (int)(64 * (e & 1) + 8 * t < plimit ? lvo : OOB); };
+    auto soff_of = [&](int e, int t) { return (16 * t * C4 + 256 * w4 + 32 * e) * 2; };
+    auto voff_of = [&](int e, int t) { (void)e; return (int)(16 * t < plimit ? lvo : OOB); };
     bf16x8 res[RD][8];                                       // residual pieces in flight [sub-pass % RD][item]
     auto res_issue = [&](int slot_, int e) {                // slot_ = e % RD, compile-time at every call site
 #pragma unroll
@@ -178,15 +185,16 @@ __global__ __launch_bounds__(THREADS, 1) void tail_io_bf16_kernel(
     role_barrier();                                          // [NRNG]: the last range has been read
     role_barrier();                                          // [1 + NRNG]: h2 complete (nothing of ours depends on it)
 
-    u32x4_t keep = {};
-    static_assert(NSUB % RD == 0, "the sub-pass loop is unrolled by the residual ring's depth");
+    u32x4_t keep = {}, keep2 = {};
+    u32x4_t held[8];                                         // results of the even sub-pass of a pair
+    static_assert(NSUB % RD == 0 && RD % 2 == 0, "the sub-pass loop is unrolled by the residual ring's depth; pairs inside");
     for (int e0 = 0; e0 < NSUB; e0 += RD) {
 #pragma unroll
       for (int u = 0; u < RD; ++u) {
         const int e = e0 + u;
         float bv[8];
         {
-          const char* const b3s = Bs + B3_OFF + (256 * w4 + 64 * (e >> 1) + 8 * pc) * 4;
+          const char* const b3s = Bs + B3_OFF + (256 * w4 + 32 * e + 8 * pc) * 4;
           const float4 t0 = *reinterpret_cast<const float4*>(b3s), t1 = *reinterpret_cast<const float4*>(b3s + 16);
           bv[0] = t0.x; bv[1] = t0.y; bv[2] = t0.z; bv[3] = t0.w; bv[4] = t1.x; bv[5] = t1.y; bv[6] = t1.z; bv[7] = t1.w;
         }
@@ -194,7 +202,7 @@ __global__ __launch_bounds__(THREADS, 1) void tail_io_bf16_kernel(
         f32x4 sv[8][2];
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-          const char* const src = xw + (8 * t + pp) * XP + 32 * pc;
+          const char* const src = xw + (16 * t + pp) * XP + 32 * pc;
           sv[t][0] = *reinterpret_cast<const f32x4*>(src);
           sv[t][1] = *reinterpret_cast<const f32x4*>(src + 16);
         }
@@ -206,17 +214,23 @@ __global__ __launch_bounds__(THREADS, 1) void tail_io_bf16_kernel(
 #pragma unroll
           for (int j = 0; j < 8; ++j) o[j] = (__bf16)fmaxf((sv[t][j >> 2][j & 3] + bv[j]) + (float)res[u][t][j], 0.f);
           const u32x4_t o4 = __builtin_bit_cast(u32x4_t, o);
-          __builtin_amdgcn_raw_buffer_store_b128(o4, rsrc_out, voff_of(e, t), soff_of(e, t), 0);
-          // store-data hazard (tools/lint_store_hazard.py, profiles/r5/bottleneck_block_study.md §3): the data registers
-          // of a store stay live until the next store has been issued
-          asm volatile("" ::"v"(keep));
-          keep = o4;
+          if ((u & 1) == 0) {
+            held[t] = o4;
+          } else {
+            __builtin_amdgcn_raw_buffer_store_b128(held[t], rsrc_out, voff_of(e - 1, t), soff_of(e - 1, t), 0);
+            __builtin_amdgcn_raw_buffer_store_b128(o4, rsrc_out, voff_of(e, t), soff_of(e, t), 0);
+            // store-data hazard (tools/lint_store_hazard.py, profiles/r5/bottleneck_block_study.md §3): the data registers
+            // of a store stay live until the next stores have been issued
+            asm volatile("" ::"v"(keep), "v"(keep2));
+            keep = o4;
+            keep2 = held[t];
+          }
         }
         if (e + RD < NSUB) res_issue(u, e + RD);             // its ring slot is free now
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    asm volatile("s_nop 15\n s_nop 15" ::"v"(keep));
+    asm volatile("s_nop 15\n s_nop 15" ::"v"(keep), "v"(keep2));
   } else {
     // ================================================================ compute waves: wave w4 = rows [64 w4, 64 w4 + 64) x all 128 pixels
     f32x16 acc[2][4];
@@ -287,8 +301,9 @@ __global__ __launch_bounds__(THREADS, 1) void tail_io_bf16_kernel(
         read_b(0, bb[0]);
 #pragma unroll
         for (int j = 0; j < 12; ++j) {
-          if (j + 1 < 12) read_b(j + 1, bb[(j + 1) & 1]);    // the next k-step's fragments fly under this k-step's MFMAs
-          __builtin_amdgcn_sched_barrier(0);
+          // the next k-step's fragments fly under this k-step's MFMAs: one read (and its address arithmetic) behind each of
+          // the first four MFMAs, the two W2 fragments of k-step j + D2 behind the next two
+          if (j + 1 < 12) read_b(j + 1, bb[(j + 1) & 1]);
 #pragma unroll
           for (int mi = 0; mi < 2; ++mi) {
             const bf16x8 av = __builtin_bit_cast(bf16x8, a2[(12 * r + j) % D2][mi]);
@@ -296,21 +311,31 @@ __global__ __launch_bounds__(THREADS, 1) void tail_io_bf16_kernel(
             for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bb[j & 1][ni], acc[mi][ni], 0, 0, 0);
           }
           if (12 * i + j + D2 < 12 * NRNG) load_w2((12 * r + j) % D2, 12 * i + j + D2);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);      // VALU
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // DS read
+          }
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // VMEM read
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
         role_barrier();                                      // [1 + i]
       }
     }
     // ---- the first R3 k-steps of the W3 stream fly while h2 is written
-    // sub-pass sp: row blocks 8 w4 + 2 (sp >> 1) + {0, 1}, pixel blocks 2 (sp & 1) + {0, 1}; k-step k of row block mb at
-    // (mb CCH 4 + k) KiB; the two pixel halves of a channel block fetch the same fragments (L2 hits)
+    // sub-pass sp: row block 8 w4 + sp, all four pixel blocks; k-step k of row block mb at (mb CCH 4 + k) KiB
     const unsigned woff3 = (unsigned)((kh << 5) | (((li >> 2) & 1) << 4) | ((li >> 3) << 2) | (li & 3)) * 16;   // permuted W3 rows
     const char* const w3w = reinterpret_cast<const char*>(Wf3) + (int64_t)(8 * w4) * (CCH * 4096) + woff3;
-    f32x4 a3[R3][2];
+    f32x4 a3[R3];
     auto load_w3 = [&](int slot_, int sp, int k) {
-      const char* const pw = w3w + (int64_t)(2 * (sp >> 1)) * (CCH * 4096) + k * 1024;
-      a3[slot_][0] = *reinterpret_cast<const f32x4*>(pw);
-      a3[slot_][1] = *reinterpret_cast<const f32x4*>(pw + CCH * 4096);
+      a3[slot_] = *reinterpret_cast<const f32x4*>(w3w + (int64_t)sp * (CCH * 4096) + k * 1024);
     };
 #pragma unroll
     for (int d = 0; d < R3; ++d) load_w3(d, 0, d);
@@ -335,65 +360,48 @@ __global__ __launch_bounds__(THREADS, 1) void tail_io_bf16_kernel(
     // ---- phase 3: 1x1 expand, K = 256.  Sub-pass sp accumulates in set sp & 1; the sums of sub-pass sp - 1 go to the
     // exchange buffer in the middle of sub-pass sp.
     const char* const hb = Bs + (kh * SLP + li) * 16;
-    char* const xl = xw + li * XP + 64 * kh;                 // + (32 nj) XP + 128 ms + 16 q
-    auto write_sums = [&](f32x16 (&c)[2][2], int e) {       // sums of sub-pass e -> exchange buffer, then publish
+    char* const xl = xw + li * XP + 64 * kh;                 // + (32 nj) XP + 16 q
+    auto write_sums = [&](f32x16 (&c)[4], int e) {          // sums of sub-pass e -> exchange buffer, then publish
       flag_wait(f_con, e);                                   // the io wave has taken sub-pass e - 1 out of it
 #pragma unroll
-      for (int ms = 0; ms < 2; ++ms)
+      for (int nj = 0; nj < 4; ++nj)
 #pragma unroll
-        for (int nj = 0; nj < 2; ++nj)
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<f32x4*>(xl + nj * 32 * XP + 128 * ms + 16 * q) =
-                f32x4{c[ms][nj][4 * q], c[ms][nj][4 * q + 1], c[ms][nj][4 * q + 2], c[ms][nj][4 * q + 3]};
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<f32x4*>(xl + nj * 32 * XP + 16 * q) = f32x4{c[nj][4 * q], c[nj][4 * q + 1], c[nj][4 * q + 2], c[nj][4 * q + 3]};
       flag_set(f_pub, e + 1);
     };
-    f32x16 cA[2][2], cB[2][2];
-    bf16x8 hh[2][2];
-    auto read_h = [&](int sp, int k, bf16x8 (&b)[2]) {
+    f32x16 cA[4], cB[4];
+    bf16x8 hh[2][4];
+    auto read_h = [&](int k, bf16x8 (&b)[4]) {
 #pragma unroll
-      for (int nj = 0; nj < 2; ++nj) b[nj] = *reinterpret_cast<const bf16x8*>(hb + ((2 * k) * SLP + (2 * (sp & 1) + nj) * 32) * 16);
+      for (int nj = 0; nj < 4; ++nj) b[nj] = *reinterpret_cast<const bf16x8*>(hb + ((2 * k) * SLP + nj * 32) * 16);
     };
-    auto ksteps = [&](f32x16 (&c)[2][2], int sp, auto k0_tag, auto k1_tag) {     // k-steps k0 .. k1 - 1 of sub-pass sp
+    auto ksteps = [&](f32x16 (&c)[4], int sp, auto k0_tag, auto k1_tag) {     // k-steps k0 .. k1 - 1 of sub-pass sp
       constexpr int k0 = decltype(k0_tag)::value, k1 = decltype(k1_tag)::value;
 #pragma unroll
       for (int k = k0; k < k1; ++k) {
-        // the next k-step's h2 fragments (of the next sub-pass behind the last one) in front of this k-step's MFMAs
-        if (k + 1 < 16) read_h(sp, k + 1, hh[(k + 1) & 1]);
-        else if (sp + 1 < NSUB) read_h(sp + 1, 0, hh[0]);
+        read_h((k + 1) & 15, hh[(k + 1) & 1]);               // the next k-step's h2 fragments in front of this k-step's MFMAs
         __builtin_amdgcn_sched_barrier(0);
+        const bf16x8 av = __builtin_bit_cast(bf16x8, a3[k % R3]);
+        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ms = 0; ms < 2; ++ms) {
-          const bf16x8 av = __builtin_bit_cast(bf16x8, a3[k % R3][ms]);
-#pragma unroll
-          for (int nj = 0; nj < 2; ++nj) c[ms][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, hh[k & 1][nj], c[ms][nj], 0, 0, 0);
-        }
-        if (k + R3 < 16) load_w3(k % R3, sp, k + R3);
-        else if (sp + 1 < NSUB) load_w3(k % R3, sp + 1, k + R3 - 16);
+        for (int nj = 0; nj < 4; ++nj)       // the first k-step starts from a constant zero: no 64 v_mov per sub-pass
+          c[nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, hh[k & 1][nj], k == 0 ? z : c[nj], 0, 0, 0);
+        if (sp + 1 < NSUB) load_w3(k % R3, sp + 1, k);       // R3 = 16: the same k-step of the next sub-pass
         __builtin_amdgcn_sched_barrier(0);
       }
     };
-    auto zero = [&](f32x16 (&c)[2][2]) {
-#pragma unroll
-      for (int ms = 0; ms < 2; ++ms)
-#pragma unroll
-        for (int nj = 0; nj < 2; ++nj)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) c[ms][nj][e] = 0.f;
-    };
+    static_assert(R3 == 16, "the ring holds exactly one sub-pass");
     using I0 = std::integral_constant<int, 0>;
     using I8 = std::integral_constant<int, 8>;
     using I16 = std::integral_constant<int, 16>;
-    read_h(0, 0, hh[0]);
-    zero(cA);
+    read_h(0, hh[0]);
     ksteps(cA, 0, I0{}, I16{});
     for (int sp = 1; sp < NSUB; sp += 2) {
-      zero(cB);
       ksteps(cB, sp, I0{}, I8{});
       write_sums(cA, sp - 1);
       ksteps(cB, sp, I8{}, I16{});
       if (sp + 1 < NSUB) {
-        zero(cA);
         ksteps(cA, sp + 1, I0{}, I8{});
         write_sums(cB, sp);
         ksteps(cA, sp + 1, I8{}, I16{});
