@@ -121,6 +121,8 @@ def parse(argv=None):
                     help="cfg5: `off` runs every backbone convolution as its own launch (the round-2 path)")
     ap.add_argument("--fused-block", choices=["auto", "off"], default="auto",
                     help="cfg5: `off` runs the identity blocks of res2 / res3 as conv1 + fused tail (round 4) instead of one launch")
+    ap.add_argument("--tail-io-waves", choices=["auto", "off"], default="auto",
+                    help="cfg5: `off` runs res4's fused tails on the one-role kernel (round 3/4) instead of the role-split one (round 5)")
     ap.add_argument("--serial-tail", action="store_true",
                     help="A/B: RELPN.OVERLAP_TAIL = False (PPN and decode on the caller's stream, after the encoder)")
     ap.add_argument("--launch-check", action="store_true",
@@ -794,6 +796,8 @@ class Cfg5Workload:
             self.net.fuse_bottlenecks = args.fused_bottleneck == "auto"
         if hasattr(self.net, "fuse_blocks"):
             self.net.fuse_blocks = args.fused_block == "auto"
+        if hasattr(self.net, "tail_io_waves"):
+            self.net.tail_io_waves = args.tail_io_waves == "auto"
         self.head = tspn.Res5RoIHead()
         self.head.load_state_dict(t(self.r5_sd))
         self.head = self.head.to(dev)
@@ -862,10 +866,11 @@ class Cfg5Workload:
                        "stage_ms": {"backbone": bb_ms, "roi_head": roi_ms, "scoring_and_decode": sc_ms},
                        "backbone_ms_per_frame": bb_ms / self.T,
                        "fused_bottlenecks": bool(getattr(self.net, "fuse_bottlenecks", False)),
-                       "fused_blocks": bool(getattr(self.net, "fuse_bottlenecks", False) and getattr(self.net, "fuse_blocks", False))},
+                       "fused_blocks": bool(getattr(self.net, "fuse_bottlenecks", False) and getattr(self.net, "fuse_blocks", False)),
+                       "tail_io_waves": bool(getattr(self.net, "fuse_bottlenecks", False) and getattr(self.net, "tail_io_waves", False))},
             "roofline": {"bound": "mfma",
                          "kernel": "ResNet-101-C4 backbone, all convolutions of one video (bf16 32x32x16 MFMA implicit GEMMs: "
-                                   "bottleneck_bf16_kernel / conv2d_nhwc_bf16_kernel / stem_conv_bf16_kernel)",
+                                   "tail_io_bf16_kernel / bottleneck_block_bf16_kernel / conv2d_nhwc_bf16_kernel / stem_conv_bf16_kernel)",
                          "achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_MFMA_TFLOPS, **backbone_traffic(self.T, self.H, self.W),
                          "flop_per_launch": flop, "avg_launch_ms": bb_ms,

@@ -515,8 +515,10 @@ int tspn_bottleneck_tail_bf16(const uint16_t* h1, int64_t NB, int64_t H, int64_t
                               const float* bias3, const uint16_t* residual, uint16_t* out, void* stream);
 /* The same operator at CM = 256 with the workgroup's waves split by ROLE (tspn_tail_io_bf16.hip, round 5): four waves issue
  * every MFMA and read only weights from L2, four waves do everything that touches HBM (the LDS-DMA of the h1 ranges, the
- * residual rows, the epilogue and the stores); fp32 sums change hands through LDS.  Bit-identical to
- * tspn_bottleneck_tail_bf16. */
+ * residual rows, the epilogue and the stores); fp32 sums change hands through LDS under two counters per wave pair (no
+ * workgroup barrier in the expand phase), the epilogue's global accesses are line-major.  Bit-identical to
+ * tspn_bottleneck_tail_bf16 and 16 - 20 % faster at the res4 shape (profiles/r5/tail_role_split.md); what
+ * roi_head.BottleneckBlock launches for 256 bottleneck channels.  One workgroup of 512 threads and 147 KB of LDS per CU. */
 int tspn_bottleneck_tail_io_bf16(const uint16_t* h1, int64_t NB, int64_t H, int64_t W, int64_t CM,
                                  const uint16_t* frag2, const float* bias2, const uint16_t* frag3,
                                  const float* bias3, const uint16_t* residual, uint16_t* out, void* stream);

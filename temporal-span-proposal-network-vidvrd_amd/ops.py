@@ -1078,7 +1078,9 @@ def bottleneck_tail_bf16(h1, frag2, bias2, frag3, bias3, residual, out=None, nex
     (out, h1_next [NB,H,W,CM]) -- both bit-identical to the separate launches.
     `persistent` (CM = 256): the persistent kernel pipelined across tiles (tspn_bottleneck_tail_pipe_bf16: one
     workgroup per CU, the 3x3 phase of tile t beside the expand / store phase of tile t - 1), same results;
-    `max_workgroups` > 0 limits its grid (tests)."""
+    `max_workgroups` > 0 limits its grid (tests).
+    `io_waves` (CM = 256): the role-split kernel (tspn_bottleneck_tail_io_bf16, round 5: four MFMA waves + four waves that
+    own the h1 DMA, the residual rows and the stores; what the backbone uses for res4), same results."""
     _dev(h1, "h1", torch.bfloat16); _dev(frag2, "frag2", torch.bfloat16); _dev(frag3, "frag3", torch.bfloat16)
     _dev(bias2, "bias2"); _dev(bias3, "bias3"); _dev(residual, "residual", torch.bfloat16)
     NB, H, W, CM = h1.shape

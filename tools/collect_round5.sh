@@ -11,9 +11,11 @@ for w in cfg2 cfg3 cfg5 backbone; do
   python tools/kernel_stats.py $f profiles/r5/$n > /dev/null
 done
 cp $O/bench_latest.json $O/bench_ops_level.json $O/bench_cfg4_shard.json $O/bench_force_collective.json $O/bench_cfg3.json $O/bench_cfg5.json \
-   $O/bench_cfg5_fused_block_off.json profiles/r5/
+   $O/bench_cfg5_fused_block_off.json $O/bench_cfg5_tail_io_waves_off.json profiles/r5/
 cp $O/backbone.txt profiles/r5/backbone_blocks_on_off.txt
 cp $O/time_block.txt profiles/r5/time_block.txt
+cp $O/time_tail_io.txt profiles/r5/time_tail_io.txt
+cp $O/time_conv1x1.txt profiles/r5/time_conv1x1.txt
 python tools/pmc_summary.py $O/pmc_cfg2 profiles/r5 --videos 16 --workload cfg2 > /dev/null
 ( cd tools && python pmc_backbone.py ../$O/bb_pmc ../profiles/r5 --frames 72 --passes 4 --note "one-launch blocks, chunk 18" | tail -3
   python pmc_backbone.py ../$O/bb_pmc_chain ../profiles/r5 --frames 72 --passes 4 --note "--no-block (round-4 chain), chunk 18" --name pmc_hbm_traffic_backbone_chain.csv --no-json | tail -2 )

@@ -20,7 +20,7 @@ import os
 
 from pmc_summary import short
 
-BACKBONE_KERNELS = ("bottleneck_bf16_kernel", "conv2d_nhwc_bf16_kernel", "stem_conv_bf16_kernel", "stem_pool_bf16_kernel", "stem_s2d_bf16_kernel",
+BACKBONE_KERNELS = ("bottleneck_bf16_kernel", "bottleneck_block_bf16_kernel", "tail_io_bf16_kernel", "bottleneck_pipe_bf16_kernel", "conv2d_nhwc_bf16_kernel", "stem_conv_bf16_kernel", "stem_pool_bf16_kernel", "stem_s2d_bf16_kernel",
                     "max_pool_nhwc_bf16_kernel", "CatArrayBatchedCopy")
 
 
