@@ -266,7 +266,7 @@ __global__ __launch_bounds__(THREADS, 1) void tail_io_bf16_kernel(
     // (side region, 32) for slots 128 / 129, (zero slot, 0) for taps that fall off the image -- one v_mad per read; the
     // reads of k-step j + 1 are issued IN FRONT of the MFMAs of k-step j (fenced: left alone, the scheduler moves them
     // behind half of the MFMAs and the next k-step waits for LDS).
-    constexpr int D2 = 4;                                    // W2 ring, k-steps (fragments come from L2)
+    constexpr int D2 = 4;                                    // W2 ring, k-steps (fragments come from L2); six spill
     f32x4 a2[D2][2];
     auto load_w2 = [&](int slot_, int f) {
       a2[slot_][0] = *reinterpret_cast<const f32x4*>(w2b0 + (int64_t)f * 1024);
@@ -275,27 +275,29 @@ __global__ __launch_bounds__(THREADS, 1) void tail_io_bf16_kernel(
 #pragma unroll
     for (int d = 0; d < D2; ++d) load_w2(d, d);
     role_barrier();                                          // [0]
-    static_assert(NRNG % 2 == 0 && 24 % D2 == 0, "two ranges = 24 k-steps per unrolled body: compile-time ring slots");
+    // (fragment addresses of a tap = four k-steps are prepared under the MFMAs of the tap before it, two sets alternating)
+    unsigned bo[2][4], bs[2][4];                             // [tap parity][pixel block]
+    auto tap_addr = [&](int i, int rb, unsigned (&o_)[4], unsigned (&s_)[4]) {
+      const int buf = i & (NST - 1), ra = i % 3;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        unsigned o = (unsigned)(buf * B_ST + (ni * 32 + li + rb) * 16), st = SLP * 16;
+        if (ni == 3 && li + rb >= 32) { o = (unsigned)(EXTRA_OFF + buf * 256 + (li + rb - 32) * 16); st = 32; }
+        if (!((rmask[ni] >> (3 * ra + rb)) & 1u)) { o = ZERO_OFF; st = 0; }
+        o_[ni] = o + kh * st;
+        s_[ni] = 2 * st;
+      }
+    };
+    tap_addr(0, 0, bo[0], bs[0]);
+    static_assert(NRNG % 2 == 0 && 24 % D2 == 0, "two ranges = 24 k-steps = six taps per unrolled body: compile-time ring slots and tap parities");
     for (int i2 = 0; i2 < NRNG; i2 += 2) {
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const int i = i2 + r;
-        const int buf = i & (NST - 1), ra = i % 3;
-        unsigned bo[3][4], bs[3][4];
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb)
-#pragma unroll
-          for (int ni = 0; ni < 4; ++ni) {
-            unsigned o = (unsigned)(buf * B_ST + (ni * 32 + li + rb) * 16), st = SLP * 16;
-            if (ni == 3 && li + rb >= 32) { o = (unsigned)(EXTRA_OFF + buf * 256 + (li + rb - 32) * 16); st = 32; }
-            if (!((rmask[ni] >> (3 * ra + rb)) & 1u)) { o = ZERO_OFF; st = 0; }
-            bo[rb][ni] = o + kh * st;
-            bs[rb][ni] = 2 * st;
-          }
         auto read_b = [&](int j, bf16x8 (&b)[4]) {
-          const int rb = j >> 2, ks = j & 3;
+          const int rb = j >> 2, ks = j & 3, par = (3 * r + rb) & 1;
 #pragma unroll
-          for (int ni = 0; ni < 4; ++ni) b[ni] = *reinterpret_cast<const bf16x8*>(Bs + bo[rb][ni] + ks * bs[rb][ni]);
+          for (int ni = 0; ni < 4; ++ni) b[ni] = *reinterpret_cast<const bf16x8*>(Bs + bo[par][ni] + ks * bs[par][ni]);
         };
         bf16x8 bb[2][4];
         read_b(0, bb[0]);
@@ -303,6 +305,11 @@ __global__ __launch_bounds__(THREADS, 1) void tail_io_bf16_kernel(
         for (int j = 0; j < 12; ++j) {
           // the next k-step's fragments fly under this k-step's MFMAs: one read (and its address arithmetic) behind each of
           // the first four MFMAs, the two W2 fragments of k-step j + D2 behind the next two
+          if ((j & 3) == 0) {                                // first k-step of a tap: the addresses of the tap behind it
+            const int rb = j >> 2;
+            if (rb < 2) tap_addr(i, rb + 1, bo[(3 * r + rb + 1) & 1], bs[(3 * r + rb + 1) & 1]);
+            else if (i + 1 < NRNG) tap_addr(i + 1, 0, bo[(3 * r + 3) & 1], bs[(3 * r + 3) & 1]);
+          }
           if (j + 1 < 12) read_b(j + 1, bb[(j + 1) & 1]);
 #pragma unroll
           for (int mi = 0; mi < 2; ++mi) {
@@ -314,13 +321,13 @@ __global__ __launch_bounds__(THREADS, 1) void tail_io_bf16_kernel(
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);      // VALU
+            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);      // VALU
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // DS read
           }
 #pragma unroll
           for (int g = 0; g < 2; ++g) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // VMEM read
           }
           __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
