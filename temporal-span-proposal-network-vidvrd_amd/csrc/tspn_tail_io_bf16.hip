@@ -71,19 +71,25 @@ __device__ __forceinline__ void flag_set(unsigned addr, int v) {
   asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
 __device__ __forceinline__ void flag_wait(unsigned addr, int target) {     // until the counter has reached `target`
-  // one asm block: a C++ loop here makes hipcc spill ~430 registers of the 3 600-instruction straight-line code around it
-  int v, sv;
+  // one asm block: a C++ loop here makes hipcc spill ~430 registers of the 3 600-instruction straight-line code around it.
+  // The spin is BOUNDED (2^20 polls: tens of milliseconds, a tile takes ~55 us): a hand-over that were ever lost would give
+  // wrong results -- which every parity test sees -- instead of a wave that never ends and a GPU that has to be reset.
+  int v, sv, n;
   asm volatile(
+      "s_mov_b32 %2, 0x100000\n\t"
       "1:\n\t"
-      "ds_read_b32 %0, %2\n\t"
+      "ds_read_b32 %0, %3\n\t"
       "s_waitcnt lgkmcnt(0)\n\t"
       "v_readfirstlane_b32 %1, %0\n\t"
-      "s_cmp_ge_i32 %1, %3\n\t"
+      "s_cmp_ge_i32 %1, %4\n\t"
+      "s_cbranch_scc1 2f\n\t"
+      "s_sub_u32 %2, %2, 1\n\t"
+      "s_cmp_eq_u32 %2, 0\n\t"
       "s_cbranch_scc1 2f\n\t"
       "s_sleep 1\n\t"
       "s_branch 1b\n\t"
       "2:"
-      : "=&v"(v), "=&s"(sv)
+      : "=&v"(v), "=&s"(sv), "=&s"(n)
       : "v"(addr), "s"(target)
       : "memory", "scc");
 }
