@@ -44,7 +44,7 @@ def main():
             if r["Counter_Name"] != ctr:
                 continue
             k = short(r["Kernel_Name"])
-            if "(anonymous namespace)::" in r["Kernel_Name"]:
+            if r["Kernel_Name"].replace("void ", "", 1).startswith("(anonymous namespace)::"):
                 ours.add(k)                 # a kernel of this library (every csrc kernel lives in an anonymous namespace)
             tot[k][ctr] += float(r["Counter_Value"]) * 1024.0
             if ctr == "FETCH_SIZE":
