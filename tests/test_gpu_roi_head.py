@@ -924,6 +924,50 @@ def test_bottleneck_tail_and_stem_random_shapes(tspn, device, seed):
                        tspn.ops.max_pool_nhwc_bf16(y, 3, 2, 1)), (IH, IW, Cout)
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_bottleneck_tail_role_split_random_shapes(tspn, device, seed):
+    """Shape fuzz of the role-split res4 tail (hash-RNG shapes: single rows / columns, maps narrower than a tile, tiles that
+    straddle images): bit-identical to the one-role kernel into a poisoned output."""
+    r = lambda tag, lo, hi: int(tspn.hashrng.integers(900 + seed, tag, (1,), lo, hi)[0])   # noqa: E731
+    CM = 256
+    NB, H, W = r("nb", 1, 6), r("h", 1, 24), r("w", 1, 40)
+    h1 = t(tspn.hashrng.uniform(900 + seed, "h1", (NB, H, W, CM), 0, 1)).to(device).to(torch.bfloat16)
+    res = t(tspn.hashrng.uniform(900 + seed, "res", (NB, H, W, 4 * CM), -1, 1)).to(device).to(torch.bfloat16)
+    w2 = t(tspn.hashrng.normal(900 + seed, "w2", (CM, CM, 3, 3), std=float(np.sqrt(2.0 / (9 * CM))))).to(device)
+    w3 = t(tspn.hashrng.normal(900 + seed, "w3", (4 * CM, CM, 1, 1), std=float(np.sqrt(2.0 / CM)))).to(device)
+    b2 = t(tspn.hashrng.normal(900 + seed, "b2", (CM,), std=0.1)).to(device)
+    b3 = t(tspn.hashrng.normal(900 + seed, "b3", (4 * CM,), std=0.1)).to(device)
+    f2, f3 = tspn.ops.pack_conv2d_frag_bf16(w2), tspn.ops.pack_conv2d_frag_bf16(w3)
+    want = tspn.ops.bottleneck_tail_bf16(h1, f2, b2, f3, b3, res)
+    out = torch.full_like(want, 777.0)
+    tspn.ops.bottleneck_tail_bf16(h1, f2, b2, f3, b3, res, out=out, io_waves=True)
+    bad = int((out != want).sum())
+    assert bad == 0, (NB, H, W, bad)
+
+
+def test_bottleneck_tail_role_split_on_maps_beyond_two_gigabytes(tspn, device):
+    """300 res4 maps (residual and output 2.2 GB each): the role-split tail bases its descriptors at the tile, so image by
+    image it must give what the same image gives alone -- first, middle and last image."""
+    NB, H, W, CM = 300, 45, 80, 256
+    assert NB * H * W * 4 * CM * 2 > 2 ** 31
+    g = torch.Generator(device=device).manual_seed(7)
+    h1 = torch.empty((NB, H, W, CM), dtype=torch.bfloat16, device=device)
+    res = torch.empty((NB, H, W, 4 * CM), dtype=torch.bfloat16, device=device)
+    for lo in range(0, NB, 50):                                   # filled in slices: no multi-GB fp32 temporaries
+        h1[lo:lo + 50] = torch.rand((50, H, W, CM), device=device, generator=g).to(torch.bfloat16)
+        res[lo:lo + 50] = (torch.rand((50, H, W, 4 * CM), device=device, generator=g) - 0.5).to(torch.bfloat16)
+    w2 = (torch.rand((CM, CM, 3, 3), device=device, generator=g) - 0.5) * 0.05
+    w3 = (torch.rand((4 * CM, CM, 1, 1), device=device, generator=g) - 0.5) * 0.1
+    b2, b3 = torch.rand(CM, device=device, generator=g) - 0.5, torch.rand(4 * CM, device=device, generator=g) - 0.5
+    f2, f3 = tspn.ops.pack_conv2d_frag_bf16(w2), tspn.ops.pack_conv2d_frag_bf16(w3)
+    out = torch.full((NB, H, W, 4 * CM), 777.0, dtype=torch.bfloat16, device=device)
+    tspn.ops.bottleneck_tail_bf16(h1, f2, b2, f3, b3, res, out=out, io_waves=True)
+    for i in (0, NB // 2, NB - 1):
+        alone = tspn.ops.bottleneck_tail_bf16(h1[i:i + 1].contiguous(), f2, b2, f3, b3, res[i:i + 1].contiguous())
+        assert torch.equal(out[i:i + 1], alone), f"image {i}"
+    assert int((out == 777.0).sum()) < out.numel() // 100        # (a ReLU output is never 777 by construction; zeros are common)
+
+
 def test_bf16_convs_on_maps_beyond_two_gigabytes(tspn, device):
     """The operand pieces, residual reads and stores of the bf16 conv kernels are buffer instructions with 32-bit offsets
     from a per-tile base: a map of more than 2^31 bytes (76 res2 maps of 720p) must give, image by image, what the same
