@@ -121,6 +121,8 @@ def parse(argv=None):
                     help="cfg5: `off` runs every backbone convolution as its own launch (the round-2 path)")
     ap.add_argument("--fused-block", choices=["auto", "off"], default="auto",
                     help="cfg5: `off` runs the identity blocks of res2 / res3 as conv1 + fused tail (round 4) instead of one launch")
+    ap.add_argument("--frame-chunk", type=int, default=0,
+                    help="cfg5: frames per backbone launch (0 = the class default)")
     ap.add_argument("--tail-io-waves", choices=["auto", "off"], default="auto",
                     help="cfg5: `off` runs res4's fused tails on the one-role kernel (round 3/4) instead of the role-split one (round 5)")
     ap.add_argument("--serial-tail", action="store_true",
@@ -789,7 +791,7 @@ class Cfg5Workload:
         self.sd = tspn.synth.make_weights(0, c=2 * D, a=A_ANCH, k=K_PRED)
         # 18 frames of 720p = 506 tiles of the res4 tails on 256 CUs x 2 workgroups (9 frames: 253; round 5: 18 is 1.8 % faster
         # now that res2 / res3 run as one-launch blocks); x 2 streams (ResNetC4.streams)
-        self.net = tspn.ResNetC4(depth=101, frame_chunk=18)
+        self.net = tspn.ResNetC4(depth=101) if args.frame_chunk <= 0 else tspn.ResNetC4(depth=101, frame_chunk=args.frame_chunk)
         self.net.load_state_dict(t(self.bb_sd))
         self.net = self.net.to(dev)
         if hasattr(self.net, "fuse_bottlenecks"):

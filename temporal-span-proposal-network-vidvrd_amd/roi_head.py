@@ -411,7 +411,7 @@ class ResNetC4(_CachedWeightsMixin, nn.Module):
 
     BLOCKS = {50: (3, 4, 6), 101: (3, 4, 23)}
 
-    def __init__(self, depth=101, stem_out=64, res2_out=256, blocks=None, frame_chunk=18):
+    def __init__(self, depth=101, stem_out=64, res2_out=256, blocks=None, frame_chunk=36):
         super().__init__()
         blocks = tuple(blocks) if blocks is not None else self.BLOCKS[depth]
         self.stem = BasicStem(3, stem_out)
@@ -424,6 +424,8 @@ class ResNetC4(_CachedWeightsMixin, nn.Module):
             setattr(self, f"res{i + 2}", nn.Sequential(*stage))
             cout *= 2
         self.out_channels = cin
+        # frames per launch: 36 since the role-split res4 tails run one workgroup per CU (4 rounds of tiles per launch instead of
+        # 2: cfg5 391 -> 383 - 387 ms in one box, 72-frame backbone 70.2 -> 68.5 ms per 216 frames; 18 before, 9 in round 4)
         self.frame_chunk = int(frame_chunk)
         self.fuse_bottlenecks = True     # bf16 maps: conv2 + conv3 + residual of every block in one launch
         # ... which at res4 can also compute conv1 of the block that follows (round 4, tspn_bottleneck_tail_next_bf16): the

@@ -14,7 +14,7 @@ ap.add_argument("--frames", type=int, default=8)
 ap.add_argument("--h", type=int, default=720)
 ap.add_argument("--w", type=int, default=1280)
 ap.add_argument("--depth", type=int, default=101)
-ap.add_argument("--chunk", type=int, default=18)
+ap.add_argument("--chunk", type=int, default=36)
 ap.add_argument("--iters", type=int, default=3)
 ap.add_argument("--bf16", action="store_true")
 ap.add_argument("--streams", type=int, default=2)

@@ -14,10 +14,10 @@ python3 bench.py --workload cfg3 > $OUT/bench_cfg3.json 2>> $OUT/bench_latest.er
 python3 bench.py --workload cfg5 > $OUT/bench_cfg5.json 2>> $OUT/bench_latest.err; echo "cfg5 done"; cut -c1-200 $OUT/bench_cfg5.json
 python3 bench.py --workload cfg5 --no-cpu-baseline --tail-io-waves off > $OUT/bench_cfg5_tail_io_waves_off.json 2>> $OUT/bench_latest.err; echo "cfg5 (one-role tails) done"
 python3 bench.py --workload cfg5 --no-cpu-baseline --tail-io-waves off --fused-block off > $OUT/bench_cfg5_fused_block_off.json 2>> $OUT/bench_latest.err; echo "cfg5 (chain) done"
-python3 tools/bench_backbone.py --frames 72 --bf16 --iters 5 > $OUT/backbone.txt 2>> $OUT/bench_latest.err
-python3 tools/bench_backbone.py --frames 72 --bf16 --iters 5 --no-io-waves >> $OUT/backbone.txt 2>> $OUT/bench_latest.err
-python3 tools/bench_backbone.py --frames 72 --bf16 --iters 5 --no-io-waves --no-proj >> $OUT/backbone.txt 2>> $OUT/bench_latest.err
-python3 tools/bench_backbone.py --frames 72 --bf16 --iters 5 --no-io-waves --no-block >> $OUT/backbone.txt 2>> $OUT/bench_latest.err
+python3 tools/bench_backbone.py --frames 144 --bf16 --iters 5 > $OUT/backbone.txt 2>> $OUT/bench_latest.err
+python3 tools/bench_backbone.py --frames 144 --bf16 --iters 5 --no-io-waves >> $OUT/backbone.txt 2>> $OUT/bench_latest.err
+python3 tools/bench_backbone.py --frames 144 --bf16 --iters 5 --no-io-waves --no-proj >> $OUT/backbone.txt 2>> $OUT/bench_latest.err
+python3 tools/bench_backbone.py --frames 144 --bf16 --iters 5 --no-io-waves --no-block >> $OUT/backbone.txt 2>> $OUT/bench_latest.err
 python3 tools/time_block.py 9 > $OUT/time_block.txt 2>> $OUT/bench_latest.err
 python3 tools/time_block.py 18 >> $OUT/time_block.txt 2>> $OUT/bench_latest.err
 python3 tools/time_tail_io.py 9 18 36 > $OUT/time_tail_io.txt 2>> $OUT/bench_latest.err
@@ -27,7 +27,7 @@ P="--output-format csv"
 ( cd $ROOT && rocprofv3 --kernel-trace --stats $P -d $OUT/stats_cfg2 -- python3 bench.py --no-cpu-baseline > $OUT/rp_stats_cfg2.log 2>&1 ); echo "stats cfg2"
 ( cd $ROOT && rocprofv3 --kernel-trace --stats $P -d $OUT/stats_cfg3 -- python3 bench.py --workload cfg3 --no-cpu-baseline > $OUT/rp_stats_cfg3.log 2>&1 ); echo "stats cfg3"
 ( cd $ROOT && rocprofv3 --kernel-trace --stats $P -d $OUT/stats_cfg5 -- python3 bench.py --workload cfg5 --no-cpu-baseline --steps 2 > $OUT/rp_stats_cfg5.log 2>&1 ); echo "stats cfg5"
-BB="--frames 72 --bf16 --iters 3"
+BB="--frames 72 --chunk 18 --bf16 --iters 3"      # (kernel-level tables stay at 18 frames per launch, as in rounds 3 - 5; the product default is 36)
 ( cd $ROOT && rocprofv3 --kernel-trace --stats $P -d $OUT/stats_backbone -- python3 tools/bench_backbone.py $BB --streams 1 > $OUT/rp_stats_bb.log 2>&1 ); echo "stats backbone"
 S="--steps 3 --warmup 1 --no-cpu-baseline"
 ( cd $ROOT && rocprofv3 --pmc FETCH_SIZE $P -d $OUT/pmc_cfg2/fetch -- python3 bench.py $S > $OUT/rp_fetch2.log 2>&1 )
