@@ -86,6 +86,9 @@ def parse(argv=None):
     ap.add_argument("--batches", type=int, default=2,
                     help="different input batches resident in HBM, rotated step by step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="default cfg2 run on one GPU only: skip the short cfg2-direct / cfg3 / cfg5 legs that run AFTER the "
+                         "timed region and are printed under \"secondary\"")
     ap.add_argument("--cpu-runs", type=int, default=5, help="timed runs of the cfg2 CPU baseline (median reported)")
     ap.add_argument("--conv", choices=["winograd6", "direct"], default="winograd6",
                     help="temporal-conv algorithm of the tracklet projections (both fp32 MFMA): Winograd F(6,3) "
@@ -301,9 +304,13 @@ def pmc_traffic(workload, videos, conv):
     try:
         data = json.load(open(path))
         ms = data["sets"][f"{'cfg2' if workload == 'cfg4' else workload}:{videos}"]
-        return {"traffic": ms["kernels"][kernel]["hbm_bytes"],
-                "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE)", "traffic_source": ms["kernels"][kernel].get("source", ms["source"])}
-    except (OSError, KeyError, ValueError, TypeError):
+        # the profiler names template instances (`conv3_wino63_kernel<true>`): match the instances too, and prefer an entry
+        # of the set's own pass over one carried along from an older pass (those keep their own `source`)
+        names = [k for k in ms["kernels"] if k == kernel or k.startswith(kernel + "<")]
+        name = sorted(names, key=lambda k: ("source" in ms["kernels"][k], k))[0]
+        return {"traffic": ms["kernels"][name]["hbm_bytes"],
+                "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE)", "traffic_source": ms["kernels"][name].get("source", ms["source"])}
+    except (OSError, KeyError, ValueError, TypeError, IndexError):
         return {"traffic": None}
 
 
@@ -789,8 +796,9 @@ class Cfg5Workload:
         self.bb_sd = tspn.synth.make_backbone_weights(0)
         self.r5_sd = tspn.synth.make_res5_weights(0)
         self.sd = tspn.synth.make_weights(0, c=2 * D, a=A_ANCH, k=K_PRED)
-        # 18 frames of 720p = 506 tiles of the res4 tails on 256 CUs x 2 workgroups (9 frames: 253; round 5: 18 is 1.8 % faster
-        # now that res2 / res3 run as one-launch blocks); x 2 streams (ResNetC4.streams)
+        # frames per backbone launch: ResNetC4.frame_chunk (36 since round 5: 1 013 tiles of the role-split res4 tails, one
+        # workgroup per CU = 3.96 rounds of the 256 CUs; 18 frames = 1.98 rounds is 1.5 - 2.5 % slower); x 2 streams
+        # (ResNetC4.streams)
         self.net = tspn.ResNetC4(depth=101) if args.frame_chunk <= 0 else tspn.ResNetC4(depth=101, frame_chunk=args.frame_chunk)
         self.net.load_state_dict(t(self.bb_sd))
         self.net = self.net.to(dev)
@@ -885,6 +893,53 @@ class Cfg5Workload:
 
     def cpu_baseline(self):
         return cpu_baseline_cfg5(self.bb_sd, self.r5_sd, oracle_weights(self.sd), self.N, self.T, self.H, self.W)
+
+
+def secondary_legs(args, tspn, torch, np, dev):
+    """Short runs of the OTHER workloads behind the timed headline region (never inside it), in the same process, so that
+    the driver's one bench line also carries driver-observed numbers for them: the reference-order fp32 conv
+    (`--conv direct`), cfg3 (bf16 long clips) and cfg5 (frames -> triplets).  Each leg is what `python bench.py --workload X`
+    times, with fewer steps; a leg that fails reports its error instead of taking the headline line down."""
+    import copy
+    import gc
+    legs = {}
+    for name, over in (("cfg2_direct", {"workload": "cfg2", "conv": "direct", "steps": 3, "warmup": 1}),
+                       ("cfg3", {"workload": "cfg3", "steps": 5, "warmup": 2}),
+                       ("cfg5", {"workload": "cfg5", "steps": 2, "warmup": 1})):
+        a = copy.copy(args)
+        a.videos = a.total_videos = None
+        for k, v in over.items():
+            setattr(a, k, v)
+        t_leg = time.perf_counter()
+        wl = None
+        try:
+            g = Gatherer(tspn, a, 1, False, rank=0, torch=torch, on_gpu=True)
+            wl = (Cfg5Workload if a.workload == "cfg5" else ScoringWorkload)(a, tspn, torch, np, dev, 1, 0, g)
+            for i in range(a.warmup):
+                wl.step(i)
+            wl.sync()
+            t0 = time.perf_counter()
+            for i in range(a.warmup, a.warmup + a.steps):
+                wl.step(i)
+            wl.sync()
+            el = time.perf_counter() - t0
+            rep = wl.report(el, None)
+            leg = {"metric": rep["metric"], "value": wl.total_units_per_step * a.steps / el, "unit": "tracklet-pairs/s",
+                   "ms_per_step": el / a.steps * 1e3, "steps": a.steps, "warmup": a.warmup, "dtype": rep["dtype"],
+                   "workload": rep["config"]["workload"],
+                   "roofline": {k: rep["roofline"].get(k) for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms",
+                                                                    "traffic", "traffic_source")}}
+            for k in ("videos_per_gpu_per_step", "conv_algo", "stage_ms", "backbone_ms_per_frame", "videos_per_s", "frames_per_s"):
+                if k in rep["config"]:
+                    leg[k] = rep["config"][k]
+        except Exception as exc:   # noqa: BLE001 -- the headline line must still be printed
+            leg = {"error": f"{type(exc).__name__}: {exc}"[:400]}
+        leg["wall_s"] = round(time.perf_counter() - t_leg, 2)
+        legs[name] = leg
+        del wl
+        gc.collect()
+        torch.cuda.empty_cache()
+    return legs
 
 
 # ------------------------------------------------------------------------------------------------ rank body
@@ -1004,6 +1059,9 @@ def main():
             out["stub"] = True
         if per_rank is not None:
             out["per_rank"] = per_rank
+        if (world == 1 and not use_dist and not stub and not args.no_secondary and args.workload == "cfg2"
+                and args.conv == "winograd6" and not args.ops_level and args.host_inputs == "off"):
+            out["secondary"] = secondary_legs(args, tspn, torch, np, dev)
         if world == 1 and not args.no_cpu_baseline and not stub:
             out["cpu_baseline"] = wl.cpu_baseline()
         sys.stdout.flush()

@@ -41,16 +41,52 @@ extern "C" {
  * 5 (round 3): tspn_pack_conv2d_frag_bf16 lays the fragments out channel chunk by chunk (was tap by tap) and
  * the bf16 convolutions contract in that order; tspn_stem_pool_bf16 added);
  * 6 (round 5, additive): tspn_bottleneck_block_bf16, tspn_bottleneck_block_proj_bf16, tspn_bottleneck_block_res_bf16,
- * tspn_conv3_tc_wino63_set_piece_form (replaces the TSPN_WINO63_PTRV environment switch).                     */
-#define TSPN_ABI_VERSION 6
+ * tspn_bottleneck_tail_io_bf16, tspn_conv3_tc_wino63_set_piece_form (replaces the TSPN_WINO63_PTRV environment switch);
+ * 7 (round 6): the device status block (tspn_status_attach / _fault / _clear / _selftest, TSPN_EDEVICE: a kernel can
+ * raise a fault that the NEXT launch entry reports without a synchronisation); tspn_fused_desc gained conv_weight /
+ * conv_check (the a-posteriori accuracy guard of the F(6,3) temporal conv, tspn_conv3_spot_check_f32);
+ * tspn_traj_iou_tail_batch_f64.                                                                                  */
+#define TSPN_ABI_VERSION 7
 
 enum {
   TSPN_OK = 0,
   TSPN_EINVAL = -1,       /* bad argument (null pointer, negative size, misalignment) */
   TSPN_EUNSUPPORTED = -2, /* shape outside what the kernels implement */
   TSPN_EWORKSPACE = -3,   /* workspace too small */
-  TSPN_ELAUNCH = -4       /* HIP runtime error at launch */
+  TSPN_ELAUNCH = -4,      /* HIP runtime error at launch */
+  TSPN_EDEVICE = -5       /* a kernel of an EARLIER launch raised a fault through the device status block (below) */
 };
+
+/* ---- device status block (round 6) ----------------------------------------
+ * The reference reports failures as Python exceptions only; a kernel has no such channel, and a
+ * synchronisation after every launch to ask it would serialise the host.  Instead the caller allocates
+ * TSPN_STATUS_WORDS int32 words of PINNED, DEVICE-MAPPED HOST memory (hipHostMalloc / torch .pin_memory(); zeroed,
+ * 64-byte aligned) and attaches them once per device; kernels write them with system-scope atomics, the host reads
+ * them with plain loads.  While word TSPN_STATUS_FAULT is non-zero every launch entry of the library on that device
+ * returns TSPN_EDEVICE (checked where the HIP launch error is checked: the call that LAUNCHED the faulting kernel
+ * returns TSPN_OK, the next one fails) until tspn_status_clear().  Without an attached block a kernel that has to
+ * raise traps instead (the launch fails with a HIP error at the next synchronisation).  Attachment is per device
+ * (the CURRENT device of the calling thread) and process-wide; the library never frees the block.            */
+#define TSPN_STATUS_WORDS 16
+enum {
+  TSPN_STATUS_FAULT = 0,       /* OR of TSPN_FAULT_* bits; 0 = healthy */
+  TSPN_STATUS_FAULT_INFO = 1,  /* raiser's detail (workgroup id of the last raiser) */
+  TSPN_STATUS_CONV_ERR = 2,    /* float bits: largest |y - reference| any tspn_conv3_spot_check_f32 has measured since the
+                                  host last zeroed the word (not a fault: the host policy decides) */
+  TSPN_STATUS_CONV_CHECKS = 3  /* number of outputs spot-checked since the host last zeroed the word */
+};
+enum {
+  TSPN_FAULT_HANDOVER = 1      /* an LDS hand-over between the waves of a workgroup timed out (tspn_bottleneck_tail_io_bf16,
+                                  tspn_bottleneck_tail_pipe_bf16): the waiting wave raised and ENDED without touching the
+                                  data it did not receive; the launch's output is incomplete */
+};
+int tspn_status_attach(int32_t* host_words);   /* NULL detaches */
+int tspn_status_fault(void);                    /* the fault word of the current device's block (0 if none attached) */
+int tspn_status_clear(void);                    /* zero fault + info (the caller has dealt with it) */
+/* Raises TSPN_FAULT_HANDOVER on purpose: one wave waits, with a short bound, for an LDS counter that nobody sets --
+ * through the same device code as the role-split res4 tail.  `reached_end` (device int32, optional) stays 0: the wave
+ * ends inside the wait.  Tests of the channel: the call itself returns TSPN_OK, the next launch entry TSPN_EDEVICE. */
+int tspn_status_selftest(int32_t* reached_end, void* stream);
 
 #define TSPN_GEOM_CHANNELS 8
 
@@ -336,10 +372,30 @@ typedef struct tspn_fused_desc {
    * only on the tracklet means, so the driver computes them FIRST; a caller can start the top-k decode, the PPN
    * and the result gather on a second stream behind this event while the encoder is still running. */
   void* ev_logits_ready;
+  /* optional accuracy guard of TSPN_CONV_WINOGRAD63 (round 6; tspn_conv3_spot_check_f32 below): the RAW conv.weight
+   * [C, C, 3] and the number of output rows to spot-check per call (0 / NULL = off; needs an attached status block) */
+  const float* conv_weight;
+  int64_t conv_check;
 } tspn_fused_desc;
 
 size_t tspn_forward_fused_workspace_bytes(const tspn_fused_desc* d);
 int tspn_forward_fused_f32(const tspn_fused_desc* d, void* stream);
+
+/* ---- a-posteriori accuracy guard of the temporal conv (round 6) ------------
+ * The encoder's contract is a plain fp32 Conv1d (lib/modeling/relpn/dpn.py:69-73).  Behind a conv launch, `rows`
+ * workgroups each pick one output row (stratified over the rows, a different draw every call) and recompute that
+ * row at up to 24 columns -- the six frames of four 6-frame groups ("sextets": the one named by `hot`, three hashed
+ * ones) -- in float64 from the RAW weights, and compare with y:
+ *   x [B, T, Cin]; W = conv.weight [M, Cw, 3] with `split` as in tspn_pack_conv3_f32 (split > 0: Cw = 2 split,
+ *   Cin = split, y has 2M rows: [0, M) from W[:, :split], [M, 2M) from W[:, split:]); bias per y row or NULL;
+ *   y [B, rows of y, ldy] (ldy >= T);  hot: NULL or the device word the F(6,3) input transform wrote
+ *   ((float bits of the launch's largest |x|) << 32 | its sextet b * ceil(T/6) + q) -- the Winograd error peaks in
+ *   the sextet that holds an input outlier.
+ * Result (no fault): status word TSPN_STATUS_CONV_ERR = max(itself, float bits of the largest |y - y_ref|),
+ * TSPN_STATUS_CONV_CHECKS += outputs checked.  Needs an attached status block.                                   */
+int tspn_conv3_spot_check_f32(const float* x, int64_t B, int64_t T, int64_t Cin, const float* W, int64_t M,
+                              int64_t Cw, int64_t split, const float* bias, int relu, const float* y, int64_t ldy,
+                              const uint64_t* hot, int64_t rows, void* stream);
 
 /* ---- span-restricted RelOIPool + predicate head --------------------------
  * Build-defined meaning of RelOIPool with duration proposals (reference lib/modeling/model.py:68-73 indexes

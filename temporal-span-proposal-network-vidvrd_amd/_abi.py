@@ -15,12 +15,16 @@ ROOT = os.path.dirname(HERE)
 LIB_PATH = os.environ.get("TSPN_LIB_PATH") or os.path.join(HERE, "libtspn_mi355x.so")
 HEADER_PATH = os.path.join(ROOT, "include", "tspn_mi355x.h")
 
-ABI_VERSION = 6   # TSPN_ABI_VERSION of include/tspn_mi355x.h
+ABI_VERSION = 7   # TSPN_ABI_VERSION of include/tspn_mi355x.h
 TSPN_OK = 0
 TSPN_EINVAL = -1
 TSPN_EUNSUPPORTED = -2
 TSPN_EWORKSPACE = -3
 TSPN_ELAUNCH = -4
+TSPN_EDEVICE = -5     # a kernel of an earlier launch raised a fault through the device status block
+STATUS_WORDS = 16
+STATUS_FAULT, STATUS_FAULT_INFO, STATUS_CONV_ERR, STATUS_CONV_CHECKS = 0, 1, 2, 3
+FAULT_HANDOVER = 1
 GEOM_CHANNELS = 8
 CONV_DIRECT, CONV_WINOGRAD63 = 0, 1   # tspn_fused_desc.conv_algo
 
@@ -44,6 +48,7 @@ class FusedDesc(ctypes.Structure):
         ("out_heads", _vp), ("out_logits", _vp),
         ("workspace", _vp), ("workspace_bytes", _sz),
         ("ev_conv_begin", _vp), ("ev_conv_end", _vp), ("ev_logits_ready", _vp),
+        ("conv_weight", _vp), ("conv_check", _i64),
     ]
 
 
@@ -69,6 +74,11 @@ PROTOTYPES = {
     "tspn_fused_bf16_desc_size": (_sz, []),
     "tspn_last_error": (ctypes.c_char_p, []),
     "tspn_error_string": (ctypes.c_char_p, [_int]),
+    "tspn_status_attach": (_int, [_vp]),
+    "tspn_status_fault": (_int, []),
+    "tspn_status_clear": (_int, []),
+    "tspn_status_selftest": (_int, [_vp, _vp]),
+    "tspn_conv3_spot_check_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _int, _vp, _i64, _vp, _i64, _vp]),
     "tspn_predicate_head_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "tspn_predicate_head_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _int, _vp, _sz, _vp]),
     "tspn_predicate_head_norm_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _i64, _i64]),

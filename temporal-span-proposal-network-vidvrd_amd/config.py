@@ -67,6 +67,12 @@ _DEFAULTS = {
                 # "auto" = Winograd F(6,3) where the shape allows it (D % 32 == 0; 4/9 of the direct MFMA work,
                 # error bound in DESIGN.md §4), else the direct taps; "direct" = always the direct taps
                 "CONV_ALGO": "auto",
+                # build extension (round 6): accuracy guard of "auto".  Every fused pass that runs F(6,3) recomputes
+                # CONV_CHECK_ROWS output rows (x up to 24 columns, the sextet with the largest |x| among them) in float64
+                # on the GPU; when the measured error exceeds CONV_TOL the model warns once and uses the direct taps from
+                # its next call on (model.BaseModel._winograd).  0 rows = guard off.
+                "CONV_TOL": 1e-4,
+                "CONV_CHECK_ROWS": 128,
                 # build extension: tracklet features handed over in HOST memory (predict.py:50-57) go to the device in
                 # chunks of this many videos, pipelined under the encoder (model._HostPipeline)
                 "HOST_CHUNK_VIDEOS": 4},

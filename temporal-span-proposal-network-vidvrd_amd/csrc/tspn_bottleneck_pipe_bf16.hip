@@ -26,6 +26,7 @@
 #include <type_traits>
 
 #include "tspn_common.h"
+#include "tspn_status.h"
 
 namespace {
 
@@ -73,16 +74,17 @@ __device__ __forceinline__ void lds_add1(char* Bs, int off, int lane) {
   if (lane == 0)
     __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(Bs + off), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ __forceinline__ void lds_wait_ge(char* Bs, int off, unsigned target) {
-  while (__hip_atomic_load(reinterpret_cast<unsigned*>(Bs + off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target)
-    __builtin_amdgcn_s_sleep(1);
+// (round 6) bounded, through the asm wait of tspn_status.h: a wave that gives up raises TSPN_FAULT_HANDOVER and ends --
+// until then this was an unbounded `while` (a lost arrival = a GPU reset)
+__device__ __forceinline__ void lds_wait_ge(char* Bs, int off, unsigned target, int32_t* status) {
+  tspn_dev::flag_wait((unsigned)(size_t)(__attribute__((address_space(3))) char*)Bs + off, (int)target, status, (int)blockIdx.x);
   __builtin_amdgcn_sched_barrier(0);
 }
 // barrier of team A's four waves (the caller has already waited for its own DMA / LDS operations)
-__device__ __forceinline__ void a_barrier(char* Bs, int lane, unsigned& epoch) {
+__device__ __forceinline__ void a_barrier(char* Bs, int lane, unsigned& epoch, int32_t* status) {
   epoch += 4;
   lds_add1(Bs, SYNC_OFF, lane);
-  lds_wait_ge(Bs, SYNC_OFF, epoch);
+  lds_wait_ge(Bs, SYNC_OFF, epoch, status);
 }
 
 // tile of workgroup-slot `v` (0 .. tiles - 1): consecutive tiles stay on one XCD (shared halo rows), as in the
@@ -95,7 +97,7 @@ __device__ __forceinline__ int64_t tile_of(int v, int ntiles) {
 // ------------------------------------------------------------------------------------------------ team A: phase 2
 __device__ __forceinline__ void team_a(const __bf16* __restrict__ h1, const __bf16* __restrict__ Wf2,
                                        const float* __restrict__ bias2, int H, int W, int64_t npix, int ntiles,
-                                       char* Bs, int w4_in, int lane_in) {
+                                       char* Bs, int w4_in, int lane_in, int32_t* status) {
   using K0 = std::integral_constant<int, 0>;
   using K1 = std::integral_constant<int, 1>;
   using K2 = std::integral_constant<int, 2>;
@@ -185,7 +187,7 @@ __device__ __forceinline__ void team_a(const __bf16* __restrict__ h1, const __bf
 #pragma unroll
     for (int i = 0; i < DIST; ++i) stage_r(i, i);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    a_barrier(Bs, lane, epoch);                            // the first ranges of the tile have landed
+    a_barrier(Bs, lane, epoch, status);                            // the first ranges of the tile have landed
     load_step(K0{}); load_step(K1{}); load_step(K2{}); load_step(K3{});
     bump();
     __builtin_amdgcn_sched_barrier(0);
@@ -233,7 +235,7 @@ __device__ __forceinline__ void team_a(const __bf16* __restrict__ h1, const __bf
       if (LAST) {      // every LDS read of this range has returned; the next range has landed
         if (MORE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        a_barrier(Bs, lane, epoch);                        // one per range: 12 per tile
+        a_barrier(Bs, lane, epoch, status);                        // one per range: 12 per tile
       }
     };
     {
@@ -257,7 +259,7 @@ __device__ __forceinline__ void team_a(const __bf16* __restrict__ h1, const __bf
       round_body(i, buf, ra, R1{}, F{}, T{}, F{});
       round_body(i, buf, ra, R2{}, F{}, F{}, T{});          // ends with a ring barrier: nobody reads the stages any more
     }
-    lds_wait_ge(Bs, SYNC_OFF + 8, 4u * it);                // team B has finished reading the previous tile's h2
+    lds_wait_ge(Bs, SYNC_OFF + 8, 4u * it, status);                // team B has finished reading the previous tile's h2
     // h2 = relu(acc + b2) -> bf16 -> the h2 image (B-operand layout)
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -283,7 +285,7 @@ __device__ __forceinline__ void team_a(const __bf16* __restrict__ h1, const __bf
 // ------------------------------------------------------------------------------------------------ team B: phase 3
 __device__ __forceinline__ void team_b(const __bf16* __restrict__ Wf3, const float* __restrict__ bias3,
                                        const __bf16* __restrict__ residual, __bf16* __restrict__ out, int64_t npix,
-                                       int ntiles, char* Bs, int w4_in, int lane_in) {
+                                       int ntiles, char* Bs, int w4_in, int lane_in, int32_t* status) {
   constexpr int KSTEPS = CM / 16;                  // 16
   constexpr int MS = 2, NS = 2, NSUB = 8;
   constexpr int NGRP = MS * NS;                    // epilogue groups per sub-pass
@@ -420,7 +422,7 @@ __device__ __forceinline__ void team_b(const __bf16* __restrict__ Wf3, const flo
       res_issue(0, std::integral_constant<int, 3>{});
     }
     static_assert(NRES == 2 || NRES == 4, "residual ring: two or four groups");
-    lds_wait_ge(Bs, SYNC_OFF + 4, 4u * (it + 1));          // ... team A finishes h2 of this tile
+    lds_wait_ge(Bs, SYNC_OFF + 4, 4u * (it + 1), status);          // ... team A finishes h2 of this tile
     subpass(accA, accB, 0, std::false_type{});
 #pragma unroll 1
     for (int sp = 1; sp < NSUB; sp += 2) {
@@ -443,7 +445,7 @@ __device__ __forceinline__ void team_b(const __bf16* __restrict__ Wf3, const flo
 __global__ __launch_bounds__(THREADS, 2) void bottleneck_pipe_bf16_kernel(
     const __bf16* __restrict__ h1, const __bf16* __restrict__ Wf2, const float* __restrict__ bias2,
     const __bf16* __restrict__ Wf3, const float* __restrict__ bias3, const __bf16* __restrict__ residual,
-    __bf16* __restrict__ out, int H, int W, int64_t npix, int ntiles) {
+    __bf16* __restrict__ out, int H, int W, int64_t npix, int ntiles, int32_t* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) char Bs[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -452,8 +454,8 @@ __global__ __launch_bounds__(THREADS, 2) void bottleneck_pipe_bf16_kernel(
   if (tid >= 16 && tid < 19) reinterpret_cast<unsigned*>(Bs + SYNC_OFF)[tid - 16] = 0u;   // ... and the three counters
   if (tid < CM) *reinterpret_cast<float4*>(Bs + BIAS_OFF + 16 * tid) = *reinterpret_cast<const float4*>(bias3 + 4 * tid);
   __syncthreads();                                                       // the only workgroup barrier of the kernel
-  if (wave < 4) team_a(h1, Wf2, bias2, H, W, npix, ntiles, Bs, wave, lane);
-  else team_b(Wf3, bias3, residual, out, npix, ntiles, Bs, wave - 4, lane);
+  if (wave < 4) team_a(h1, Wf2, bias2, H, W, npix, ntiles, Bs, wave, lane, status);
+  else team_b(Wf3, bias3, residual, out, npix, ntiles, Bs, wave - 4, lane, status);
 }
 
 }  // namespace
@@ -485,6 +487,6 @@ extern "C" int tspn_bottleneck_tail_pipe_bf16(const uint16_t* h1, int64_t NB, in
   hipLaunchKernelGGL(bottleneck_pipe_bf16_kernel, dim3((unsigned)grid), dim3(THREADS), SMEM, TSPN_STREAM(stream),
                      reinterpret_cast<const __bf16*>(h1), reinterpret_cast<const __bf16*>(frag2), bias2,
                      reinterpret_cast<const __bf16*>(frag3), bias3, reinterpret_cast<const __bf16*>(residual),
-                     reinterpret_cast<__bf16*>(out), (int)H, (int)W, npix, (int)tiles);
+                     reinterpret_cast<__bf16*>(out), (int)H, (int)W, npix, (int)tiles, tspn::status_device_ptr());
   return tspn::check_launch("tspn_bottleneck_tail_pipe_bf16");
 }

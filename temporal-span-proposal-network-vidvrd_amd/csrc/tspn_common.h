@@ -23,10 +23,15 @@ inline int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+// (tspn_status.hip) TSPN_EDEVICE if a kernel of an earlier launch raised a fault through the device status block
+int status_check(const char* what);
+
+// Every launch entry ends here: the HIP launch error of THIS call, else a device fault raised by an EARLIER one
+// (read from pinned host memory: no synchronisation).
 inline int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(TSPN_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
-  return TSPN_OK;
+  return status_check(what);
 }
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
@@ -62,7 +67,7 @@ int conv3_tc_direct(const float* x, int64_t B, int64_t T, int64_t Cin, const flo
 bool wino63_supported(int64_t Cin, int64_t M);
 size_t wino63_workspace_bytes(int64_t B, int64_t T, int64_t Cin);
 int wino63_input_transform(const float* x, int64_t B, int64_t T, int64_t Cin, void* workspace,
-                           size_t workspace_bytes, void* stream);
+                           size_t workspace_bytes, void* stream, uint64_t* hot = nullptr);
 int wino63_contract(const void* workspace, int64_t B, int64_t T, int64_t Cin, const float* frag, int64_t M,
                     const float* bias, int relu, float* y, int64_t ldy, void* stream);
 int conv3_tc_wino63(const float* x, int64_t B, int64_t T, int64_t Cin, const float* frag, int64_t M,

@@ -21,6 +21,7 @@ extern "C" const char* tspn_error_string(int code) {
     case TSPN_EUNSUPPORTED: return "unsupported shape";
     case TSPN_EWORKSPACE: return "workspace too small";
     case TSPN_ELAUNCH: return "HIP launch error";
+    case TSPN_EDEVICE: return "device fault raised by an earlier launch";
     default: return "unknown error";
   }
 }

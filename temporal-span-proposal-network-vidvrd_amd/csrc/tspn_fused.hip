@@ -20,7 +20,7 @@
 namespace {
 
 struct FusedLayout {
-  size_t xt, y, bias2, fbar, pooled, lin, vt, hwp, total;
+  size_t xt, y, bias2, fbar, pooled, lin, vt, hwp, hot, total;
   size_t vt_bytes;
   size_t lin_bytes;
 };
@@ -46,6 +46,7 @@ FusedLayout layout_of(const tspn_fused_desc* d) {
   L.vt_bytes = (D % 32 == 0) ? tspn::wino63_workspace_bytes((int64_t)NT, (int64_t)T, (int64_t)D) : 0;
   L.vt = take(L.vt_bytes);
   L.hwp = take(C * 12 * sizeof(float));   // head weights packed [C][12] for the scalar-weight pair stage (H == 12)
+  L.hot = take(256);                      // accuracy guard: where the launch's largest |x| sits (tspn_conv_guard.hip)
   L.total = off;
   return L;
 }
@@ -128,7 +129,13 @@ extern "C" int tspn_forward_fused_f32(const tspn_fused_desc* d, void* stream) {
   if (!tc && (rc = tspn_transpose_td_f32(d->feats, NT, T, D, xt, stream))) return rc;
   // F(6,3): the Winograd input transform runs as its own HBM-bound pass; the profiling events bracket the
   // MFMA kernel only
-  if (w63 && (rc = tspn::wino63_input_transform(d->feats, NT, T, D, ws + L.vt, L.vt_bytes, stream))) return rc;
+  // Accuracy guard of F(6,3) (d->conv_check rows, needs the raw weights and an attached status block): the transform
+  // reports the sextet with the largest |x|; behind the conv a few outputs are recomputed in float64 (tspn_conv_guard.hip)
+  const bool guard = w63 && d->conv_check > 0 && d->conv_weight != nullptr;
+  uint64_t* hot = guard ? reinterpret_cast<uint64_t*>(ws + L.hot) : nullptr;
+  if (guard && hipMemsetAsync(hot, 0, sizeof(uint64_t), s) != hipSuccess)
+    return tspn::fail(TSPN_ELAUNCH, "tspn_forward_fused: guard staging: %s", hipGetErrorString(hipGetLastError()));
+  if (w63 && (rc = tspn::wino63_input_transform(d->feats, NT, T, D, ws + L.vt, L.vt_bytes, stream, hot))) return rc;
   if (d->ev_conv_begin) (void)hipEventRecord(static_cast<hipEvent_t>(d->ev_conv_begin), s);
   if (w63)
     rc = tspn::wino63_contract(ws + L.vt, NT, T, D, d->conv_packed, 2 * C, bias2, 0, y, ldy, stream);
@@ -137,6 +144,9 @@ extern "C" int tspn_forward_fused_f32(const tspn_fused_desc* d, void* stream) {
             : tspn_conv3_f32(xt, NT, D, T, d->conv_packed, 2 * C, bias2, 0, y, stream);
   if (rc) return rc;
   if (d->ev_conv_end) (void)hipEventRecord(static_cast<hipEvent_t>(d->ev_conv_end), s);
+  if (guard && (rc = tspn_conv3_spot_check_f32(d->feats, NT, T, D, d->conv_weight, C, C, D, bias2, 0, y, ldy, hot,
+                                               d->conv_check, stream)))
+    return rc;
   // 3. pair stage + relationness / span heads
   if (d->canonical_pairs) {
     TSPN_REQUIRE(d->P == d->B * d->N * (d->N - 1), TSPN_EINVAL,

@@ -31,6 +31,7 @@
 #include <type_traits>
 
 #include "tspn_common.h"
+#include "tspn_status.h"
 
 namespace {
 
@@ -66,38 +67,16 @@ static_assert(CCH * B_ST == NST * B_ST && SMEM <= 160 * 1024, "h2 image = the fo
 __device__ __forceinline__ void role_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
-// sub-pass counters in LDS.  A wave's LDS operations execute in order: the counter written behind the data is seen behind it.
-__device__ __forceinline__ void flag_set(unsigned addr, int v) {
-  asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
-}
-__device__ __forceinline__ void flag_wait(unsigned addr, int target) {     // until the counter has reached `target`
-  // one asm block: a C++ loop here makes hipcc spill ~430 registers of the 3 600-instruction straight-line code around it.
-  // The spin is BOUNDED (2^20 polls: tens of milliseconds, a tile takes ~55 us): a hand-over that were ever lost would give
-  // wrong results -- which every parity test sees -- instead of a wave that never ends and a GPU that has to be reset.
-  int v, sv, n;
-  asm volatile(
-      "s_mov_b32 %2, 0x100000\n\t"
-      "1:\n\t"
-      "ds_read_b32 %0, %3\n\t"
-      "s_waitcnt lgkmcnt(0)\n\t"
-      "v_readfirstlane_b32 %1, %0\n\t"
-      "s_cmp_ge_i32 %1, %4\n\t"
-      "s_cbranch_scc1 2f\n\t"
-      "s_sub_u32 %2, %2, 1\n\t"
-      "s_cmp_eq_u32 %2, 0\n\t"
-      "s_cbranch_scc1 2f\n\t"
-      "s_sleep 1\n\t"
-      "s_branch 1b\n\t"
-      "2:"
-      : "=&v"(v), "=&s"(sv), "=&s"(n)
-      : "v"(addr), "s"(target)
-      : "memory", "scc");
-}
+// sub-pass counters in LDS: tspn_status.h (flag_set / flag_wait).  The wait is BOUNDED; a wave that gives up raises
+// TSPN_FAULT_HANDOVER through the device status block and ENDS -- it never reads or overwrites an exchange buffer it was
+// not handed (round 6; until then it fell through with wrong data and only a parity test would have noticed).
+using tspn_dev::flag_set;
+using tspn_dev::flag_wait;
 
 __global__ __launch_bounds__(THREADS, 1) void tail_io_bf16_kernel(
     const __bf16* __restrict__ h1, const __bf16* __restrict__ Wf2, const float* __restrict__ bias2,
     const __bf16* __restrict__ Wf3, const float* __restrict__ bias3, const __bf16* __restrict__ residual,
-    __bf16* __restrict__ out, int H, int W, int64_t npix) {
+    __bf16* __restrict__ out, int H, int W, int64_t npix, int32_t* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) char Bs[];
 
   const int nwg = gridDim.x, bid = blockIdx.x;
@@ -111,11 +90,10 @@ __global__ __launch_bounds__(THREADS, 1) void tail_io_bf16_kernel(
   const bool io = wave >= 4;
   const int w4 = wave & 3;
   const int li = lane & 31, kh = lane >> 5;
-  if (tid < 4) reinterpret_cast<float*>(Bs + ZERO_OFF)[tid] = 0.f;               // published by the first barrier
+  if (tid < 64) reinterpret_cast<float*>(Bs + ZERO_OFF)[tid] = 0.f;              // 16 zero slots; published by the first barrier
   if (tid >= 64 && tid < 80) reinterpret_cast<int*>(Bs + FLAG_OFF)[tid - 64] = 0;  // likewise
   for (int i = tid; i < CM; i += THREADS)                                          // b3 -> LDS, likewise
     *reinterpret_cast<float4*>(Bs + B3_OFF + 16 * i) = *reinterpret_cast<const float4*>(bias3 + 4 * i);
-  const char* const zslot = Bs + ZERO_OFF;
   constexpr unsigned OOB = 0x80000000u;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)Bs;
   const unsigned f_pub = lds0 + FLAG_OFF + 8 * w4, f_con = f_pub + 4;            // counters of this wave pair
@@ -155,7 +133,13 @@ __global__ __launch_bounds__(THREADS, 1) void tail_io_bf16_kernel(
     // line leave back to back (L2 hands part-written lines to the fabric as they are, profiles/r3)
     const __amdgpu_buffer_rsrc_t rsrc_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(residual) + n0 * C4, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc(out + n0 * C4, 0, 0x7fffffff, 0x00020000);
-    const int pc = lane & 3, pp = lane >> 2;
+    // The quad -> pixel map is a permutation chosen for the LDS side (round 6): a ds_read_b128 is served in the lane
+    // groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+ 32) and a quad covers 64 of a pixel row's 144 bytes in two
+    // reads of alternate 16-byte slots, so with pp = lane >> 2 the quads of a group met on the same banks (two-way: 2 050
+    // of the 4 230 conflict cycles per tile, SQ_LDS_BANK_CONFLICT in profiles/r5/probes/tail_io_sq_counters.txt).  With
+    // the quads of a group on pixels {p, p + 1, p + 8, p + 9} their row bases (9 p mod 16 slots) are 0, 9, 8, 1 -- even
+    // and odd slots interleave, all sixteen distinct.  Global side unchanged: a quad still owns 64 contiguous bytes.
+    const int pc = lane & 3, pp = (int)((0xFDCE5764B98A1320ull >> (4 * (lane >> 2))) & 15);
     const unsigned lvo = (unsigned)(pp * C4 * 2 + 16 * pc);                       // the lane's part of every global offset
     const int64_t left = npix - n0 - pp;                                           // pixels 16 t below this exist
     const int plimit = left > BN ? BN : (int)left;
@@ -204,7 +188,7 @@ __global__ __launch_bounds__(THREADS, 1) void tail_io_bf16_kernel(
           const float4 t0 = *reinterpret_cast<const float4*>(b3s), t1 = *reinterpret_cast<const float4*>(b3s + 16);
           bv[0] = t0.x; bv[1] = t0.y; bv[2] = t0.z; bv[3] = t0.w; bv[4] = t1.x; bv[5] = t1.y; bv[6] = t1.z; bv[7] = t1.w;
         }
-        flag_wait(f_pub, e + 1);                             // the sums of sub-pass e are in the exchange buffer
+        flag_wait(f_pub, e + 1, status, (int)blockIdx.x);                             // the sums of sub-pass e are in the exchange buffer
         f32x4 sv[8][2];
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
@@ -247,19 +231,26 @@ __global__ __launch_bounds__(THREADS, 1) void tail_io_bf16_kernel(
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
     unsigned rmask[4];                                       // taps of this lane's B columns that fall inside the image
+    {
+      // (round 6) n0 is wave-uniform: ONE division for the tile's first pixel, the lane's part in 32 bits with a
+      // float reciprocal + correction, the nine tap bits in closed form.  The per-lane 64-bit divisions and the nine-tap
+      // loop this replaces were ~1 500 vector instructions in front of the first MFMA of every tile.
+      const int HW = H * W;                                  // < 2^30 (launcher)
+      const int r0 = (npix >> 31) == 0 ? (int)((unsigned)n0 % (unsigned)HW) : (int)(n0 % HW);
+      const float rcpW = 1.0f / (float)W;
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const int64_t n = n0 + ni * 32 + li;
-      unsigned m = 0;
-      if (n < npix) {
-        const int64_t nb = n / ((int64_t)H * W);
-        const int r = (int)(n - nb * H * W);
-        const int oh = r / W, ow = r - oh * W;
-        for (int a = 0; a < 3; ++a)
-          for (int b = 0; b < 3; ++b)
-            if (oh - 1 + a >= 0 && oh - 1 + a < H && ow - 1 + b >= 0 && ow - 1 + b < W) m |= 1u << (a * 3 + b);
+      for (int ni = 0; ni < 4; ++ni) {
+        int rr = r0 + ni * 32 + li;                          // pixel index inside ITS image, after the wrap
+        if (HW >= BN) rr -= rr >= HW ? HW : 0;
+        else rr = (int)((unsigned)rr % (unsigned)HW);
+        int oh = (int)((float)rr * rcpW);                    // within one of rr / W for rr < 2^30, H < 2^20
+        int ow = rr - oh * W;
+        if (ow < 0) { --oh; ow += W; }
+        if (ow >= W) { ++oh; ow -= W; }
+        const unsigned cm = (ow >= 1 ? 1u : 0u) | 2u | (ow <= W - 2 ? 4u : 0u);
+        const unsigned m = (oh >= 1 ? cm : 0u) | (cm << 3) | (oh <= H - 2 ? cm << 6 : 0u);
+        rmask[ni] = (n0 + ni * 32 + li < npix) ? m : 0u;
       }
-      rmask[ni] = m;
     }
     // W2 fragments of this wave: one contiguous stream per row block, fragment f = 12 i + j (range i, k-step j = 4 rb + ks)
     // at f KiB -- fragment-major packing of tspn_pack_conv2d_frag_bf16, [row block][part][tap][k-step]
@@ -272,7 +263,7 @@ __global__ __launch_bounds__(THREADS, 1) void tail_io_bf16_kernel(
     // (side region, 32) for slots 128 / 129, (zero slot, 0) for taps that fall off the image -- one v_mad per read; the
     // reads of k-step j + 1 are issued IN FRONT of the MFMAs of k-step j (fenced: left alone, the scheduler moves them
     // behind half of the MFMAs and the next k-step waits for LDS).
-    constexpr int D2 = 4;                                    // W2 ring, k-steps (fragments come from L2); six spill
+    constexpr int D2 = 4;                                    // W2 ring, k-steps (fragments come from L2); a ring of six spills
     f32x4 a2[D2][2];
     auto load_w2 = [&](int slot_, int f) {
       a2[slot_][0] = *reinterpret_cast<const f32x4*>(w2b0 + (int64_t)f * 1024);
@@ -289,7 +280,9 @@ __global__ __launch_bounds__(THREADS, 1) void tail_io_bf16_kernel(
       for (int ni = 0; ni < 4; ++ni) {
         unsigned o = (unsigned)(buf * B_ST + (ni * 32 + li + rb) * 16), st = SLP * 16;
         if (ni == 3 && li + rb >= 32) { o = (unsigned)(EXTRA_OFF + buf * 256 + (li + rb - 32) * 16); st = 32; }
-        if (!((rmask[ni] >> (3 * ra + rb)) & 1u)) { o = ZERO_OFF; st = 0; }
+        // (a tap off the image reads the zero slot ON THE BANKS its pixel slot would have used: one shared zero slot made
+        // every fragment read with a masked lane two-way conflicted with the lane whose slot is = 0 mod 16)
+        if (!((rmask[ni] >> (3 * ra + rb)) & 1u)) { o = (unsigned)(ZERO_OFF + ((li + rb) & 15) * 16); st = 0; }
         o_[ni] = o + kh * st;
         s_[ni] = 2 * st;
       }
@@ -375,7 +368,7 @@ __global__ __launch_bounds__(THREADS, 1) void tail_io_bf16_kernel(
     const char* const hb = Bs + (kh * SLP + li) * 16;
     char* const xl = xw + li * XP + 64 * kh;                 // + (32 nj) XP + 16 q
     auto write_sums = [&](f32x16 (&c)[4], int e) {          // sums of sub-pass e -> exchange buffer, then publish
-      flag_wait(f_con, e);                                   // the io wave has taken sub-pass e - 1 out of it
+      flag_wait(f_con, e, status, (int)blockIdx.x);                                   // the io wave has taken sub-pass e - 1 out of it
 #pragma unroll
       for (int nj = 0; nj < 4; ++nj)
 #pragma unroll
@@ -437,7 +430,7 @@ extern "C" int tspn_bottleneck_tail_io_bf16(const uint16_t* h1, int64_t NB, int6
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   TSPN_REQUIRE(al16(h1) && al16(frag2) && al16(bias2) && al16(frag3) && al16(bias3) && al16(residual) && al16(out),
                TSPN_EUNSUPPORTED, "%s: operands must be 16-byte aligned", what);
-  TSPN_REQUIRE(H < (1 << 20) && W < (1 << 20), TSPN_EUNSUPPORTED, "%s: dimension too large", what);
+  TSPN_REQUIRE(H < (1 << 20) && W < (1 << 20) && H * W < (1LL << 30), TSPN_EUNSUPPORTED, "%s: dimension too large", what);
   const int64_t npix = NB * H * W;
   const int64_t tiles = tspn::ceil_div(npix, BN);
   TSPN_REQUIRE(tiles < (1LL << 31), TSPN_EUNSUPPORTED, "%s: grid too large", what);
@@ -446,6 +439,6 @@ extern "C" int tspn_bottleneck_tail_io_bf16(const uint16_t* h1, int64_t NB, int6
   hipLaunchKernelGGL(tail_io_bf16_kernel, dim3((unsigned)tiles), dim3(THREADS), SMEM, TSPN_STREAM(stream),
                      reinterpret_cast<const __bf16*>(h1), reinterpret_cast<const __bf16*>(frag2), bias2,
                      reinterpret_cast<const __bf16*>(frag3), bias3, reinterpret_cast<const __bf16*>(residual),
-                     reinterpret_cast<__bf16*>(out), (int)H, (int)W, npix);
+                     reinterpret_cast<__bf16*>(out), (int)H, (int)W, npix, tspn::status_device_ptr());
   return tspn::check_launch(what);
 }

@@ -112,9 +112,12 @@ __global__ void pack_wino63_frag_kernel(const float* __restrict__ W, int64_t M, 
 // Input transform V = B^T d.  A wave = 8 sextets x 8 channel groups (loads: whole 128-byte lines of x; stores:
 // 128-byte runs of Vg).  Frames outside the tracklet are zero (the conv's padding); sextets past the end of the
 // launch are zero too.
+// `hot` (optional, for the accuracy guard of tspn_conv_guard.hip): the kernel reads every input value anyway, so it also
+// reports WHERE the launch's largest |x| sits -- (float bits << 32 | sextet) by a 64-bit atomic max, one per wave and only
+// when the wave beats what is already there.
 __global__ __launch_bounds__(256) void wino63_input_transform_kernel(
     const float* __restrict__ x, float* __restrict__ Vg, int T, int Cin, int nq, int64_t nsext, int64_t nsp,
-    int64_t ncols) {
+    int64_t ncols, unsigned long long* __restrict__ hot) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int cgl = lane & 7, ql = lane >> 3;
   const int64_t S = ((int64_t)blockIdx.x * 4 + wave) * 8 + ql;     // < nsp by construction of the grid
@@ -131,6 +134,20 @@ __global__ __launch_bounds__(256) void wino63_input_transform_kernel(
     n = n < 0 ? 0 : (n < ncols ? n : ncols - 1);
     const f32x4 v = *reinterpret_cast<const f32x4*>(x + n * Cin + 4 * cg);
     d[i] = (ok && t >= 0 && t < T) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  if (hot) {                                                         // uniform
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(d[i][0]), fabsf(d[i][1]))), fmaxf(fabsf(d[i][2]), fabsf(d[i][3])));
+    unsigned long long key = ((unsigned long long)__float_as_uint(m) << 32) | (unsigned)(S < nsext ? S : 0);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long other = __shfl_xor(key, o, 64);
+      key = other > key ? other : key;
+    }
+    if (lane == 0 && key > __hip_atomic_load(hot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      __hip_atomic_fetch_max(hot, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   f32x4 V[8];
   V[0] = d[0] - d[6] + 5.25f * (d[4] - d[2]);
@@ -455,7 +472,7 @@ extern "C" int tspn_pack_conv3_wino63_frag_f32(const float* W, int64_t M, int64_
 
 // step 1: V = B^T d of x [B, T, Cin] into `workspace` (HBM-bound)
 int tspn::wino63_input_transform(const float* x, int64_t B, int64_t T, int64_t Cin, void* workspace,
-                                 size_t workspace_bytes, void* stream) {
+                                 size_t workspace_bytes, void* stream, uint64_t* hot) {
   const char* what = "tspn_conv3_tc_wino63_f32(input transform)";
   if (int rc = check_common(what, B, T, Cin, 32, T)) return rc;
   if (B == 0) return TSPN_OK;
@@ -470,7 +487,7 @@ int tspn::wino63_input_transform(const float* x, int64_t B, int64_t T, int64_t C
   TSPN_REQUIRE(nsp / 32 < (1LL << 31) && Cin / 32 < 65536, TSPN_EUNSUPPORTED, "%s: grid too large", what);
   hipLaunchKernelGGL(wino63_input_transform_kernel, dim3((unsigned)(nsp / 32), (unsigned)(Cin / 32)), dim3(256), 0,
                      TSPN_STREAM(stream), x, static_cast<float*>(workspace), (int)T, (int)Cin, (int)nq, nsext, nsp,
-                     B * T);
+                     B * T, reinterpret_cast<unsigned long long*>(hot));
   return tspn::check_launch(what);
 }
 

@@ -19,6 +19,7 @@ Differences from the reference, all in code the reference cannot execute:
 There is no CPU execution path: without the HIP library or a HIP device,
 forward raises.
 """
+import warnings
 from collections import namedtuple
 
 import numpy as np
@@ -26,7 +27,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import _abi, ops
 from .sampler import BalancedPositiveNegativePairSampler
 
 TemporalProposals = namedtuple("TemporalProposals", ["relness", "duration", "heads", "geom"], defaults=[None])
@@ -537,6 +538,10 @@ class DPN(nn.Module):
         return self._cache.get("conv_split", (c.weight, c.bias), dev,
                                lambda ts: (ops.pack_conv3(ts[0], split=half), ts[1]))
 
+    def _conv_raw(self, dev):
+        """conv.weight as it is (fp32, contiguous, on `dev`): what the accuracy guard recomputes outputs from."""
+        return self._cache.get("conv_raw", (self.dpn_head.conv.weight,), dev, lambda ts: ts[0])
+
     def _bf16_weights(self, dev):
         """bf16 operand set of the factorised path (csrc/tspn_bf16.hip): packed conv / head weights
         in bf16, biases as fp32 tensors holding bf16-rounded values."""
@@ -808,11 +813,49 @@ class BaseModel(_CachedWeightsMixin, nn.Module):
         self.conv_algo = str(getattr(cfg.RELPN.DPN, "CONV_ALGO", "auto"))
         if self.conv_algo not in ("auto", "direct"):
             raise ValueError(f"RELPN.DPN.CONV_ALGO must be auto or direct (got {self.conv_algo})")
+        # accuracy guard of "auto" (round 6): every fused pass that runs F(6,3) also spot-checks CONV_CHECK_ROWS output
+        # rows against a float64 recomputation (csrc/tspn_conv_guard.hip); a measured error above CONV_TOL makes this
+        # model warn once and use the direct kernel from its next call on (`conv_fallback`)
+        self.conv_tol = float(getattr(cfg.RELPN.DPN, "CONV_TOL", 1e-4))
+        self.conv_check_rows = int(getattr(cfg.RELPN.DPN, "CONV_CHECK_ROWS", 128))
+        self.conv_fallback = False
+        self.conv_err_seen = 0.0     # largest spot-check error this model has read back so far
 
     def forward(self, pair_list, target_list=None):
         if self.training:
             return self._forward_train(pair_list, target_list)
         return self._forward_test(pair_list)
+
+    def _winograd(self, d, dev):
+        """Temporal conv algorithm of this call: True = Winograd F(6,3) (RELPN.DPN.CONV_ALGO "auto", D % 32 == 0, and the
+        accuracy guard has not tripped).  Reads what the guard measured in EARLIER calls from the device's status block
+        (pinned host memory: no synchronisation) -- the contract is a plain fp32 Conv1d (reference relpn/dpn.py:69-73) to
+        1e-4, and F(6,3)'s fp32 error depends on the data."""
+        if self.conv_algo != "auto" or d % 32 or self.conv_fallback:
+            return False
+        if self.conv_check_rows > 0:
+            words = ops.status_words(dev)
+            err = float(words[_abi.STATUS_CONV_ERR:_abi.STATUS_CONV_ERR + 1].view(np.float32)[0])
+            self.conv_err_seen = max(self.conv_err_seen, err)
+            if err > self.conv_tol:
+                checks = int(words[_abi.STATUS_CONV_CHECKS])
+                words[_abi.STATUS_CONV_ERR] = 0
+                words[_abi.STATUS_CONV_CHECKS] = 0
+                self.conv_fallback = True
+                warnings.warn(
+                    f"TSPN: the Winograd F(6,3) temporal conv measured an absolute error of {err:.3g} against float64 "
+                    f"on this model's inputs ({checks} outputs spot-checked), above RELPN.DPN.CONV_TOL = {self.conv_tol:g}: "
+                    "using the direct kernel (reference-order fp32 taps, about 2.2x slower) from this call on.  Set "
+                    "RELPN.DPN.CONV_ALGO = 'direct' to start there, or raise CONV_TOL if the features' scale makes "
+                    "1e-4 absolute meaningless (INTEGRATION.md §3).", RuntimeWarning, stacklevel=3)
+                return False
+        return True
+
+    def _conv_guard(self, dpn, dev, winograd):
+        """(raw conv.weight, rows) for the fused pass's spot check, or (None, 0)."""
+        if winograd and self.conv_check_rows > 0:
+            return dpn._conv_raw(dev), self.conv_check_rows
+        return None, 0
 
     # ------------------------------------------------------------------ train
     def _forward_train(self, pair_list, target_list):
@@ -1027,11 +1070,14 @@ class BaseModel(_CachedWeightsMixin, nn.Module):
                         side.wait_stream(main)     # the geometry launch on the side stream reads this table
                 # temporal conv algorithm: RELPN.DPN.CONV_ALGO = "auto" (Winograd F(6,3) when D % 32 == 0: 4/9 of the
                 # MFMA work; its fp32 error bound is in DESIGN.md §4) or "direct" (the k=3 taps as one implicit GEMM)
-                packed, cbias = dpn._conv_split(dev, winograd=(self.conv_algo == "auto" and d % 32 == 0))
+                wino = self._winograd(d, dev)
+                packed, cbias = dpn._conv_split(dev, winograd=wino)
+                craw, crows = self._conv_guard(dpn, dev, wino)
                 need = ops.fused_workspace_bytes(nm, n, t, d, hb.numel() // 3, cw.shape[0], allp.shape[0])
                 heads, lg = ops.forward_fused(feats, allp, nm, n, packed, cbias, hw, hb, cw, cb,
                                               workspace=self._workspace(dev, need), check_pairs=False,
                                               canonical_pairs=canonical, conv_events=self._conv_events,
+                                              conv_weight=craw, conv_check=crows,
                                               logits_event=ev_logits if (overlap and len(groups) == 1) else None)
                 if self.pool_top_span and allp.shape[0]:
                     # RelOIPool over each pair's best span (decode + NMS, top-1) instead of the whole segment
@@ -1094,7 +1140,9 @@ class BaseModel(_CachedWeightsMixin, nn.Module):
                 lambda ts: tuple(ops.cast_bf16(x.contiguous()).float() for x in ts))
             a3, k_out = hb16.numel(), cw16.shape[0]
         else:
-            packed, cbias = dpn._conv_split(dev, winograd=(self.conv_algo == "auto" and d % 32 == 0))
+            wino = self._winograd(d, dev)
+            packed, cbias = dpn._conv_split(dev, winograd=wino)
+            craw, crows = self._conv_guard(dpn, dev, wino)
             a3, k_out = hb.numel(), cw.shape[0]
         chunks = pipe.schedule(nm, self.host_chunk_videos)
         feats = pipe.begin(src, torch.bfloat16 if bf16 else torch.float32)
@@ -1126,7 +1174,7 @@ class BaseModel(_CachedWeightsMixin, nn.Module):
                                        out_heads=heads_dev[rows], out_logits=lg_dev[rows])
             else:
                 ops.forward_fused(feats[lo * n:hi * n], allp, c, n, packed, cbias, hw, hb, cw, cb, workspace=ws,
-                                  check_pairs=False, canonical_pairs=True,
+                                  check_pairs=False, canonical_pairs=True, conv_weight=craw, conv_check=crows,
                                   conv_events=self._conv_events if k == len(chunks) - 1 else None,
                                   out_heads=heads_dev[rows], out_logits=lg_dev[rows])
             back = [(heads_host[rows], heads_dev[rows]), (lg_host[rows], lg_dev[rows])]

@@ -6,6 +6,7 @@ fp32 / int64, contiguous, on a HIP device — anything else raises; there is no
 CPU path.
 """
 import ctypes
+import threading
 
 import torch
 
@@ -18,15 +19,69 @@ __all__ = [
     "cast_bf16", "pack_conv3_bf16", "pack_heads_bf16", "conv3_tc_bf16", "heads_pairgrid_bf16",
     "transpose_cast_bf16", "temporal_encoder_heads_bf16",
     "temporal_mean_bf16", "forward_fused_bf16", "span_predicate", "bottleneck_block_bf16", "bottleneck_block_proj_bf16", "bottleneck_block_res_bf16",
-    "proposal_pair_filter", "gather_rows",
+    "proposal_pair_filter", "gather_rows", "wino63_set_piece_form", "conv3_spot_check",
     "pack_conv2d", "pack_conv2d_frag", "conv2d_nhwc", "roi_align_nhwc", "pack_conv2d_frag_bf16", "conv2d_nhwc_bf16", "max_pool_nhwc", "pack_conv2d_frag_cin4", "conv2d_nhwc_cin4", "max_pool_nhwc_bf16", "pack_stem_bf16", "stem_conv_bf16", "stem_pool_bf16", "bottleneck_tail_bf16",
 ]
 
 
+_status_blocks = {}          # device index -> pinned int32 [STATUS_WORDS] the kernels of that device can write
+_status_lock = threading.Lock()
+
+
+def _status_block(index=None):
+    """The device status block of device `index` (default: the current one), allocated and attached on first use:
+    `_abi.STATUS_WORDS` int32 of pinned host memory (include/tspn_mi355x.h, "device status block").  A kernel that
+    detects a fault raises it there; the next launch entry of the library then returns TSPN_EDEVICE, which
+    `_abi.check` turns into a `TspnError` -- without any synchronisation."""
+    idx = torch.cuda.current_device() if index is None else int(index)
+    blk = _status_blocks.get(idx)
+    if blk is not None:
+        return blk
+    with _status_lock:
+        blk = _status_blocks.get(idx)
+        if blk is None:
+            raw = torch.zeros(_abi.STATUS_WORDS + 16, dtype=torch.int32).pin_memory()
+            off = (-(raw.data_ptr() // 4)) % 16                     # 64-byte aligned
+            blk = raw[off:off + _abi.STATUS_WORDS]
+            with torch.cuda.device(idx):
+                _abi.check(_abi.lib().tspn_status_attach(ctypes.c_void_p(blk.data_ptr())))
+            _status_blocks[idx] = blk
+    return blk
+
+
 def _stream():
     """Current stream of the CURRENT device; every public op runs under `_on_tensor_device`, which makes
-    the device of its tensor arguments current for the duration of the call."""
+    the device of its tensor arguments current for the duration of the call.  Every launch passes here: the
+    device's status block is attached before its first kernel runs."""
+    _status_block()
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def status_words(device=None):
+    """Live numpy view of a device's status block (words: _abi.STATUS_*)."""
+    return _status_block(None if device is None else torch.device(device).index).numpy()
+
+
+def status_fault(device=None):
+    """The fault word of a device (0 = healthy), read from pinned host memory: no synchronisation."""
+    return int(status_words(device)[_abi.STATUS_FAULT])
+
+
+def status_clear(device=None):
+    """Re-arm after a fault has been dealt with (results since the fault are not to be trusted)."""
+    w = status_words(device)
+    w[_abi.STATUS_FAULT_INFO] = 0
+    w[_abi.STATUS_FAULT] = 0
+
+
+def status_selftest(device=None):
+    """Raise TSPN_FAULT_HANDOVER on purpose, through the device code of the role-split res4 tail's bounded wait
+    (tspn_status_selftest).  Returns a device int32 that stays 0: the wave ends inside the wait."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    with torch.cuda.device(dev):
+        reached = torch.zeros(1, dtype=torch.int32, device=dev)
+        _abi.check(_abi.lib().tspn_status_selftest(_p(reached), _stream()))
+    return reached
 
 
 def _first_hip_device(obj, depth=0):
@@ -593,8 +648,12 @@ def fused_workspace_bytes(B, N, T, D, A, K, P):
 
 def forward_fused(feats, pairs, B, N, conv_packed, conv_bias, head_w, head_b, cls_w, cls_b,
                   workspace=None, out_heads=None, out_logits=None, check_pairs=True,
-                  conv_events=None, canonical_pairs=False, logits_event=None):
+                  conv_events=None, canonical_pairs=False, logits_event=None, conv_weight=None, conv_check=0):
     """Whole scoring pass on tracklet tensors (tspn_forward_fused_f32).
+
+    `conv_weight` (raw conv.weight [C,C,3]) + `conv_check` (rows): the a-posteriori accuracy guard of the F(6,3)
+    conv -- that many output rows are recomputed in float64 behind the conv and the largest deviation lands in the
+    device's status block (status_words()[_abi.STATUS_CONV_ERR], float bits); ignored with direct-tap weights.
 
     feats [B*N,T,D]; pairs int64 [P,2] global tracklet ids.
     `canonical_pairs`: `pairs` is cat_b(pair_index(N, base=b*N)) — the caller built it with
@@ -628,8 +687,30 @@ def forward_fused(feats, pairs, B, N, conv_packed, conv_bias, head_w, head_b, cl
         d.ev_conv_begin, d.ev_conv_end = conv_events[0].cuda_event, conv_events[1].cuda_event
     if logits_event is not None:
         d.ev_logits_ready = logits_event.cuda_event
+    if conv_weight is not None and conv_check > 0 and d.conv_algo == _abi.CONV_WINOGRAD63:
+        _dev(conv_weight, "conv_weight")
+        if tuple(conv_weight.shape) != (2 * d.D, 2 * d.D, 3):
+            raise ValueError(f"forward_fused: conv_weight must be conv.weight [C, C, 3] with C = {2 * d.D}")
+        d.conv_weight, d.conv_check = conv_weight.data_ptr(), int(conv_check)
     _abi.check(l.tspn_forward_fused_f32(ctypes.byref(d), _stream()))
     return out_heads, out_logits
+
+
+def conv3_spot_check(x, weight, y, split=0, bias=None, relu=False, hot=None, rows=128, ldy=None):
+    """A-posteriori accuracy check of a temporal conv launch (tspn_conv3_spot_check_f32): x [B,T,Cin], raw
+    weight [M,Cw,3] (`split` as in pack_conv3), y = the launch's output [B, rows of y, ldy]; `rows` output rows are
+    recomputed at up to 24 columns each in float64.  The largest |y - y_ref| is max-ed into the device's status
+    block (status_words()[_abi.STATUS_CONV_ERR] holds its float bits)."""
+    _dev(x, "x"); _dev(weight, "weight"); _dev(y, "y")
+    B, T, Cin = x.shape
+    M, Cw = weight.shape[0], weight.shape[1]
+    if bias is not None:
+        _dev(bias, "bias")
+    if hot is not None:
+        _dev(hot, "hot", torch.int64)
+    ld = int(ldy) if ldy is not None else y.shape[-1]
+    _abi.check(_abi.lib().tspn_conv3_spot_check_f32(_p(x), B, T, Cin, _p(weight), M, Cw, split, _p(bias), 1 if relu else 0,
+                                                    _p(y), ld, _p(hot), rows, _stream()))
 
 
 def temporal_encoder_heads(x, conv_packed, conv_bias, head_w, head_b, h_ws=None):

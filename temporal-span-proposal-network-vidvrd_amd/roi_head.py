@@ -110,7 +110,7 @@ class BottleneckBlock(nn.Module):
         # on the tile's own input pixels instead of writing the 4 CM-channel shortcut map and reading it back
         self.fuse_block_proj = True
         # 256 bottleneck channels (res4): the fused tail with the work split by role -- four MFMA waves + four io waves per
-        # workgroup (tspn_bottleneck_tail_io_bf16, round 5; bit-identical, ~15 % faster); switched by ResNetC4 `tail_io_waves`
+        # workgroup (tspn_bottleneck_tail_io_bf16, round 5; bit-identical, 16 - 20 % faster per launch at the res4 shape); switched by ResNetC4 `tail_io_waves`
         self.tail_io_waves = True
 
     PROJ_SHAPES = ((64, 64, 1),)        # (input channels, bottleneck channels, stride) tspn_bottleneck_block_proj_bf16 is enabled for

@@ -1,0 +1,192 @@
+"""Round 6: the device status block (a kernel can raise a fault that the next launch entry reports, no synchronisation)
+and the a-posteriori accuracy guard of the F(6,3) temporal conv (csrc/tspn_status.*, csrc/tspn_conv_guard.hip), through
+the C ABI and through BaseModel.  The contract the guard protects: the encoder is a plain fp32 Conv1d
+(reference lib/modeling/relpn/dpn.py:69-73) and north_star allows 1e-4 on its outputs."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def t(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def conv_ref(x_tc, w, b=None):
+    y = torch.nn.functional.conv1d(t(x_tc).double().transpose(1, 2), t(w).double(), None if b is None else t(b).double(),
+                                   padding=1)
+    return y.numpy()
+
+
+def heavy_tailed(tspn, seed, shape, scale=4.0, outlier=50.0, frac=1e-3, zeros=0.4):
+    """Post-ReLU-like features (tools/conv_error_realistic.py): |N(0,1)| * scale, 0.1 % of 50x outliers, 40 % zeros."""
+    x = np.abs(tspn.hashrng.normal(seed, "x", shape, std=1.0)) * scale
+    x = np.where(tspn.hashrng.uniform(seed, "o", shape) < frac, x * outlier, x)
+    return np.where(tspn.hashrng.uniform(seed, "z", shape) < zeros, 0.0, x).astype(np.float32)
+
+
+def conv_err_word(tspn, device):
+    w = tspn.ops.status_words(device)
+    return float(w[tspn._abi.STATUS_CONV_ERR:tspn._abi.STATUS_CONV_ERR + 1].view(np.float32)[0]), int(w[tspn._abi.STATUS_CONV_CHECKS])
+
+
+def zero_conv_words(tspn, device):
+    w = tspn.ops.status_words(device)
+    w[tspn._abi.STATUS_CONV_ERR] = 0
+    w[tspn._abi.STATUS_CONV_CHECKS] = 0
+
+
+def test_device_fault_is_reported_by_the_next_launch_entry_and_clear_rearms(tspn, device):
+    """A wave whose bounded LDS hand-over wait gives up (the device code of the role-split res4 tail, here on a counter
+    nobody sets) ORs TSPN_FAULT_HANDOVER into the status block and ENDS; the call that launched it returns TSPN_OK, every
+    later launch entry TSPN_EDEVICE -> TspnError, until status_clear()."""
+    x = torch.rand(4, 30, 32, device=device)
+    assert tspn.ops.status_fault(device) == 0
+    tspn.ops.temporal_mean(x, True)                               # healthy
+    reached = tspn.ops.status_selftest(device)                    # returns TSPN_OK: the fault is raised by the kernel
+    torch.cuda.synchronize(device)
+    assert int(reached.item()) == 0, "the waiting wave must end inside the wait, not fall through"
+    assert tspn.ops.status_fault(device) == tspn._abi.FAULT_HANDOVER
+    assert int(tspn.ops.status_words(device)[tspn._abi.STATUS_FAULT_INFO]) == 0x5e1f
+    with pytest.raises(tspn._abi.TspnError) as ei:
+        tspn.ops.temporal_mean(x, True)
+    assert ei.value.code == tspn._abi.TSPN_EDEVICE and "hand-over" in str(ei.value)
+    with pytest.raises(tspn._abi.TspnError):                      # it stays set
+        tspn.ops.cast_bf16(x)
+    tspn.ops.status_clear(device)
+    assert tspn.ops.status_fault(device) == 0
+    want = x.mean(dim=1)
+    np.testing.assert_allclose(tspn.ops.temporal_mean(x, True).cpu().numpy(), want.cpu().numpy(), rtol=0, atol=1e-6)
+
+
+def test_fault_is_visible_without_a_synchronisation(tspn, device):
+    """The block is pinned host memory written with system-scope atomics: the host sees the fault while later work is
+    still queued -- no synchronize() between the raise and the read (bounded polling of host memory only)."""
+    import time
+    big = torch.rand(64, 150, 2048, device=device)
+    tspn.ops.status_selftest(device)
+    for _ in range(20):
+        try:
+            tspn.ops.temporal_mean(big, True)                     # keeps the queue busy; fails once the fault is seen
+        except tspn._abi.TspnError:
+            break
+    t0 = time.time()
+    while tspn.ops.status_fault(device) == 0 and time.time() - t0 < 5.0:
+        time.sleep(0.001)
+    assert tspn.ops.status_fault(device) == tspn._abi.FAULT_HANDOVER
+    torch.cuda.synchronize(device)
+    tspn.ops.status_clear(device)
+
+
+@pytest.mark.parametrize("split", [0, 64])
+def test_spot_check_measures_the_error_of_a_conv_launch(tspn, device, split):
+    """tspn_conv3_spot_check_f32 against the float64 conv on the host: what it reports is an error that EXISTS in y
+    (<= the true maximum), it finds a deviation planted in the `hot` sextet exactly, and it counts what it checked."""
+    B, T, Cin, M = 5, 33, 64, 96
+    x = tspn.hashrng.uniform(90, "x", (B, T, Cin), -1, 1)
+    if split:
+        w = tspn.hashrng.normal(90, "w", (M, 2 * Cin, 3), std=0.1)
+        wst = np.concatenate([w[:, :Cin], w[:, Cin:]], axis=0)    # the 2M rows the split packing contracts
+    else:
+        w = tspn.hashrng.normal(90, "w", (M, Cin, 3), std=0.1)
+        wst = w
+    bias = tspn.hashrng.normal(90, "b", (wst.shape[0],), std=0.1)
+    ref = conv_ref(x, wst, bias)
+    xd, wd, bd = t(x).to(device), t(w).to(device), t(bias).to(device)
+    y = tspn.ops.conv3_tc_wino63(xd, tspn.ops.pack_conv3_wino63(wd, split=split), bd)
+    true_max = float(np.abs(y.cpu().numpy() - ref).max())
+    zero_conv_words(tspn, device)
+    tspn.ops.conv3_spot_check(xd, wd, y, split=split, bias=bd, rows=32)
+    torch.cuda.synchronize(device)
+    err, checks = conv_err_word(tspn, device)
+    assert checks == 32 * 24 or 0 < checks <= 32 * 24
+    assert 0.0 < err <= true_max * (1 + 1e-6) + 1e-12, (err, true_max)
+    # a planted deviation in the hot sextet is found to the bit (every checked row sees its six frames)
+    nq = (T + 5) // 6
+    S = 2 * nq + 3                                                # tracklet 2, frames 18 .. 23
+    hot = torch.tensor([(0x42000000 << 32) | S], dtype=torch.int64, device=device)
+    y2 = y.clone()
+    y2[2, :, 20] += 0.25
+    zero_conv_words(tspn, device)
+    tspn.ops.conv3_spot_check(xd, wd, y2, split=split, bias=bd, hot=hot, rows=32)
+    torch.cuda.synchronize(device)
+    err2, _ = conv_err_word(tspn, device)
+    assert abs(err2 - 0.25) < 1e-4
+    zero_conv_words(tspn, device)
+
+
+def _model(tspn, D, seed, conv_std, **over):
+    cfg = cases.baseline_cfg(**{"RELPN.USE_PPN": False, "RELPN.USE_DPN": True, "RELPN.DPN.IN_CHANNELS": 2 * D,
+                                "PREDICT.FEATURE_DIM": 2 * D, **over})
+    model = tspn.BaseModel(cfg)
+    sd = tspn.synth.make_weights(seed, c=2 * D, bias_std=0.0)
+    own = model.state_dict()
+    sd = {k: t(v) for k, v in sd.items() if k in own}
+    key = "relpn.duration_proposal_network.dpn_head.conv.weight"
+    sd[key] = t(tspn.hashrng.normal(seed, "cw", tuple(sd[key].shape), std=conv_std))
+    model.load_state_dict(sd)
+    return model.eval()
+
+
+def test_guard_switches_a_model_to_the_direct_kernel_on_heavy_tailed_features(tspn, device):
+    """The heavy-tailed case of tools/conv_error_realistic.py at the headline depth (K = 3 x 2048; F(6,3): 4e-4, direct:
+    8e-5, profiles/r3/conv_error_realistic.txt) through BaseModel with the shipped defaults: the first forward runs
+    F(6,3) and measures, the second warns ONCE and runs the direct kernel, whose outputs it then reproduces bit for
+    bit with a model configured CONV_ALGO = "direct".  On the benchmark's distribution nothing trips."""
+    D, N, T = 2048, 3, 150
+    zero_conv_words(tspn, device)
+    feats = heavy_tailed(tspn, 71, (N, T, D))
+    boxes = tspn.synth.make_video(5, N, T, 32)["tracklet_boxes"]
+    cls = tspn.synth.make_video(5, N, T, 32)["track_cls_logits"]
+    mk = lambda: [tspn.PairList.from_tracklets(t(feats).to(device), t(boxes).to(device), t(cls).to(device))]  # noqa: E731
+    model = _model(tspn, D, 71, 1.0 / np.sqrt(3 * D)).to(device)
+    assert model.conv_algo == "auto" and model.conv_check_rows == 128 and model.conv_tol == 1e-4
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        _, dp1, _ = model(mk(), None)
+        torch.cuda.synchronize(device)
+        assert not model.conv_fallback and not rec
+        err, checks = conv_err_word(tspn, device)
+        print(f"guard on heavy-tailed features: measured {err:.3g} over {checks} outputs")
+        assert err > 1e-4 and checks > 0
+        _, dp2, _ = model(mk(), None)
+        _, dp3, _ = model(mk(), None)
+        torch.cuda.synchronize(device)
+    msgs = [str(r.message) for r in rec if issubclass(r.category, RuntimeWarning)]
+    assert len(msgs) == 1 and "direct kernel" in msgs[0] and "CONV_TOL" in msgs[0]
+    assert model.conv_fallback and model.conv_err_seen > 1e-4
+    direct = _model(tspn, D, 71, 1.0 / np.sqrt(3 * D), **{"RELPN.DPN.CONV_ALGO": "direct"}).to(device)
+    _, dpd, _ = direct(mk(), None)
+    assert torch.equal(dp2[0].heads, dpd[0].heads) and torch.equal(dp3[0].heads, dpd[0].heads)
+    assert not torch.equal(dp1[0].heads, dpd[0].heads)
+    assert conv_err_word(tspn, device) == (0.0, 0)                # consumed by the switch; the direct kernel is not checked
+
+    # BASELINE's synthetic distribution (U[0,1) features, N(0, 0.01^2) weights): measured ~1e-5, no switch
+    model = _model(tspn, D, 48, 0.01).to(device)
+    v = tspn.hashrng.uniform(48, "x", (N, T, D))
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        for _ in range(3):
+            model([tspn.PairList.from_tracklets(t(v).to(device), t(boxes).to(device), t(cls).to(device))], None)
+            torch.cuda.synchronize(device)
+    err, checks = conv_err_word(tspn, device)
+    print(f"guard on the benchmark's distribution: measured {err:.3g} over {checks} outputs")
+    assert not model.conv_fallback and not rec and 0.0 < err < 5e-5 and checks >= 3 * 128 * 18
+    zero_conv_words(tspn, device)
+
+
+def test_guard_off_and_direct_leave_the_status_words_alone(tspn, device):
+    D, N, T = 32, 4, 30
+    zero_conv_words(tspn, device)
+    v = tspn.synth.make_video(9, N, T, D)
+    for over in ({"RELPN.DPN.CONV_CHECK_ROWS": 0}, {"RELPN.DPN.CONV_ALGO": "direct"}):
+        model = _model(tspn, D, 3, 0.05, **over).to(device)
+        model([tspn.PairList.from_tracklets(t(v["tracklet_feats"]).to(device), t(v["tracklet_boxes"]).to(device),
+                                            t(v["track_cls_logits"]).to(device))], None)
+        torch.cuda.synchronize(device)
+        assert conv_err_word(tspn, device) == (0.0, 0)

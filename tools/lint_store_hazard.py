@@ -21,14 +21,25 @@ import argparse
 import glob
 import os
 import re
+import shutil
 import subprocess
 import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CSRC = os.path.join(ROOT, "temporal-span-proposal-network-vidvrd_amd", "csrc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-gpu-rdc", "-Wno-everything",
-         f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}"]
+PKG = os.path.join(ROOT, "temporal-span-proposal-network-vidvrd_amd")
+CSRC = os.path.join(PKG, "csrc")
+
+
+def build_flags():
+    """The flags of the REAL build (build.py FLAGS: the linted ISA must be the shipped ISA), minus the resource remarks
+    and warnings that only add noise here."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_tspn_build_lint", os.path.join(PKG, "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    return [f for f in b.FLAGS if not f.startswith(("-Rpass", "-Wall"))] + ["-Wno-everything"]
+
 
 STORE = re.compile(r"^\s*buffer_store_dwordx([34])\s+v\[(\d+):(\d+)\],\s*(\S+),\s*s\[\d+:\d+\],\s*(\S+)")
 VREG = re.compile(r"v\[(\d+):(\d+)\]|v(\d+)")
@@ -94,17 +105,26 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("files", nargs="*")
     ap.add_argument("--window", type=int, default=3)
+    ap.add_argument("--jobs", type=int, default=6)
     args = ap.parse_args()
     files = [os.path.abspath(f) for f in args.files] or sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     bad = 0
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    flags = build_flags()
+    jobs = max(1, min(args.jobs, os.cpu_count() or 1))
     with tempfile.TemporaryDirectory() as tmp:
-        procs = []
-        for f in files:
+        from concurrent.futures import ThreadPoolExecutor
+
+        def compile_one(f):
             out = os.path.join(tmp, os.path.basename(f) + ".s")
-            procs.append((f, out, subprocess.Popen(["hipcc"] + FLAGS + ["-S", "--cuda-device-only", f, "-o", out],
-                                                   stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, cwd=CSRC)))
+            p = subprocess.run([hipcc] + flags + ["-S", "--cuda-device-only", f, "-o", out], stdout=subprocess.DEVNULL,
+                               stderr=subprocess.PIPE, text=True, cwd=CSRC)
+            return f, out, p
+
+        with ThreadPoolExecutor(max_workers=jobs) as pool:      # (it used to start every hipcc at once)
+            procs = list(pool.map(compile_one, files))
         for f, out, p in procs:
-            err = p.communicate()[1]
+            err = p.stderr
             if p.returncode != 0:
                 print(f"{os.path.basename(f)}: hipcc failed\n{err[-400:]}")
                 bad = 1
