@@ -384,18 +384,25 @@ int tspn_forward_fused_f32(const tspn_fused_desc* d, void* stream);
 /* ---- a-posteriori accuracy guard of the temporal conv (round 6) ------------
  * The encoder's contract is a plain fp32 Conv1d (lib/modeling/relpn/dpn.py:69-73).  Behind a conv launch, `rows`
  * workgroups each pick one output row (stratified over the rows, a different draw every call) and recompute that
- * row at up to 24 columns -- the six frames of four 6-frame groups ("sextets": the one named by `hot`, three hashed
+ * row at up to 24 columns -- the six frames of four 6-frame groups ("sextets": the one named in scratch word 0, three hashed
  * ones) -- in float64 from the RAW weights, and compare with y:
  *   x [B, T, Cin]; W = conv.weight [M, Cw, 3] with `split` as in tspn_pack_conv3_f32 (split > 0: Cw = 2 split,
  *   Cin = split, y has 2M rows: [0, M) from W[:, :split], [M, 2M) from W[:, split:]); bias per y row or NULL;
- *   y [B, rows of y, ldy] (ldy >= T);  hot: NULL or the device word the F(6,3) input transform wrote
- *   ((float bits of the launch's largest |x|) << 32 | its sextet b * ceil(T/6) + q) -- the Winograd error peaks in
- *   the sextet that holds an input outlier.
+ *   y [B, rows of y, ldy] (ldy >= T);  scratch: TSPN_CONV_CHECK_SCRATCH_BYTES of 8-byte aligned DEVICE memory, zeroed
+ *   by the caller before the conv it belongs to: bytes [0, 32) = where the workgroups meet (the kernel leaves them
+ *   zeroed); from TSPN_CONV_CHECK_HOT_OFFSET on, TSPN_CONV_CHECK_HOT_SLOTS 64-bit keys 256 bytes apart, into which the
+ *   F(6,3) input transform reports (float bits of the largest |x| a wave saw) << 32 | its sextet b * ceil(T/6) + q:
+ *   the sextet of the largest key is the first of the four checked -- the Winograd error peaks in the sextet that holds
+ *   an input outlier.  All keys 0 = four hashed sextets.
  * Result (no fault): status word TSPN_STATUS_CONV_ERR = max(itself, float bits of the largest |y - y_ref|),
- * TSPN_STATUS_CONV_CHECKS += outputs checked.  Needs an attached status block.                                   */
+ * TSPN_STATUS_CONV_CHECKS += outputs checked -- written once per launch by the last workgroup to finish.  Needs an
+ * attached status block.                                                                                          */
+#define TSPN_CONV_CHECK_HOT_SLOTS 64
+#define TSPN_CONV_CHECK_HOT_OFFSET 256
+#define TSPN_CONV_CHECK_SCRATCH_BYTES (TSPN_CONV_CHECK_HOT_OFFSET + 256 * TSPN_CONV_CHECK_HOT_SLOTS)
 int tspn_conv3_spot_check_f32(const float* x, int64_t B, int64_t T, int64_t Cin, const float* W, int64_t M,
                               int64_t Cw, int64_t split, const float* bias, int relu, const float* y, int64_t ldy,
-                              const uint64_t* hot, int64_t rows, void* stream);
+                              uint64_t* scratch, int64_t rows, void* stream);
 
 /* ---- span-restricted RelOIPool + predicate head --------------------------
  * Build-defined meaning of RelOIPool with duration proposals (reference lib/modeling/model.py:68-73 indexes

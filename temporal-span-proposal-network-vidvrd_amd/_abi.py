@@ -25,6 +25,7 @@ TSPN_EDEVICE = -5     # a kernel of an earlier launch raised a fault through the
 STATUS_WORDS = 16
 STATUS_FAULT, STATUS_FAULT_INFO, STATUS_CONV_ERR, STATUS_CONV_CHECKS = 0, 1, 2, 3
 FAULT_HANDOVER = 1
+CONV_CHECK_HOT_OFFSET, CONV_CHECK_SCRATCH_BYTES = 256, 256 + 256 * 64   # tspn_conv3_spot_check_f32's scratch layout
 GEOM_CHANNELS = 8
 CONV_DIRECT, CONV_WINOGRAD63 = 0, 1   # tspn_fused_desc.conv_algo
 

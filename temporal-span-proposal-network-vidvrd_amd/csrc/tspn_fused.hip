@@ -46,7 +46,7 @@ FusedLayout layout_of(const tspn_fused_desc* d) {
   L.vt_bytes = (D % 32 == 0) ? tspn::wino63_workspace_bytes((int64_t)NT, (int64_t)T, (int64_t)D) : 0;
   L.vt = take(L.vt_bytes);
   L.hwp = take(C * 12 * sizeof(float));   // head weights packed [C][12] for the scalar-weight pair stage (H == 12)
-  L.hot = take(256);                      // accuracy guard: where the launch's largest |x| sits (tspn_conv_guard.hip)
+  L.hot = take(TSPN_CONV_CHECK_SCRATCH_BYTES);   // accuracy guard: scratch of tspn_conv3_spot_check_f32 (tspn_conv_guard.hip)
   L.total = off;
   return L;
 }
@@ -133,9 +133,12 @@ extern "C" int tspn_forward_fused_f32(const tspn_fused_desc* d, void* stream) {
   // reports the sextet with the largest |x|; behind the conv a few outputs are recomputed in float64 (tspn_conv_guard.hip)
   const bool guard = w63 && d->conv_check > 0 && d->conv_weight != nullptr;
   uint64_t* hot = guard ? reinterpret_cast<uint64_t*>(ws + L.hot) : nullptr;
-  if (guard && hipMemsetAsync(hot, 0, sizeof(uint64_t), s) != hipSuccess)
+  // (scratch of the spot check: the workgroups' meeting point + the slots the transform reports the hot sextet into)
+  if (guard && hipMemsetAsync(hot, 0, TSPN_CONV_CHECK_SCRATCH_BYTES, s) != hipSuccess)
     return tspn::fail(TSPN_ELAUNCH, "tspn_forward_fused: guard staging: %s", hipGetErrorString(hipGetLastError()));
-  if (w63 && (rc = tspn::wino63_input_transform(d->feats, NT, T, D, ws + L.vt, L.vt_bytes, stream, hot))) return rc;
+  if (w63 && (rc = tspn::wino63_input_transform(d->feats, NT, T, D, ws + L.vt, L.vt_bytes, stream,
+                                                hot ? hot + TSPN_CONV_CHECK_HOT_OFFSET / 8 : nullptr)))
+    return rc;
   if (d->ev_conv_begin) (void)hipEventRecord(static_cast<hipEvent_t>(d->ev_conv_begin), s);
   if (w63)
     rc = tspn::wino63_contract(ws + L.vt, NT, T, D, d->conv_packed, 2 * C, bias2, 0, y, ldy, stream);

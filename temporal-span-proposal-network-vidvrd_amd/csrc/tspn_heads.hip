@@ -548,12 +548,17 @@ __device__ __forceinline__ void pkfma_hi(f32x2& acc, f32x2 w_sgpr, f32x2 act) {
   asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(w_sgpr), "v"(act));
 }
 
-__global__ __launch_bounds__(256, 2) void heads_pairgrid4_kernel(
+// CK = channels per LDS stage (round 6): 16 (two workgroups per CU, as in rounds 2 - 5) or 8 -- 16-KB stages, THREE workgroups
+// per CU: a third wave per SIMD to issue from while the other two sit at their chunk barriers (profiles/r6/pair_stage_counters.md:
+// with two, the vector pipe issues in 78 % of the cycles).  Same sums in the same order either way.
+template <int CK>
+__global__ __launch_bounds__(256, CK == 8 ? 3 : 2) void heads_pairgrid4_kernel(
     const float* __restrict__ y, int64_t ldt, int C, int T, int N, const float* __restrict__ Wp,
     const float* __restrict__ bh, float* __restrict__ out, int ntb, int nob, int nsb, int64_t ngroups) {
   constexpr int H = 12;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* S = reinterpret_cast<float*>(smem_raw);  // [2][16 rows][16 ch][32 t]
+  float* S = reinterpret_cast<float*>(smem_raw);  // [2][16 rows][CK ch][32 t]
+  constexpr int STAGE = PG_ROWS * CK * PG_T;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -591,12 +596,12 @@ __global__ __launch_bounds__(256, 2) void heads_pairgrid4_kernel(
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh)
+      for (int hh = 0; hh < CK / 8; ++hh)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
-            rsrc_y, (__attribute__((address_space(3))) void*)(S + buf * PG_STAGE + ((4 * wave + r) * PG_CK + 8 * hh) * PG_T), 16,
+            rsrc_y, (__attribute__((address_space(3))) void*)(S + buf * STAGE + ((4 * wave + r) * CK + 8 * hh) * PG_T), 16,
             (int)voff[r], y_soff + hh * half_bytes, 0, 0);
     }
-    y_soff += 2 * half_bytes;
+    y_soff += (CK / 8) * half_bytes;
   };
 
   f32x2 acc[PG_O / 2][H];     // (object 2 op, object 2 op + 1) x head
@@ -617,7 +622,7 @@ __global__ __launch_bounds__(256, 2) void heads_pairgrid4_kernel(
       const int ch = 2 * kk + e;
       st.u[e] = ub[ch * PG_T];
 #pragma unroll
-      for (int oj = 0; oj < PG_O; ++oj) st.v[oj][e] = vb[(oj * PG_CK + ch) * PG_T];
+      for (int oj = 0; oj < PG_O; ++oj) st.v[oj][e] = vb[(oj * CK + ch) * PG_T];
     }
   };
   auto compute = [&](const Step& st, const f32x4 (&w)[6]) {
@@ -642,12 +647,12 @@ __global__ __launch_bounds__(256, 2) void heads_pairgrid4_kernel(
   sload4<(2 * (KK) + 1) * 48 + 16>(W[4], BASE); sload4<(2 * (KK) + 1) * 48 + 32>(W[5], BASE);
 #define TSPN_WWAIT(W) swait6(W[0], W[1], W[2], W[3], W[4], W[5]);
 
-  const int nchunks = C / PG_CK;
+  const int nchunks = C / CK;
   stage_chunk(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed before the barrier publishes them
   __syncthreads();
-  const float* urow = S + ((2 * wave + si) * PG_CK) * PG_T + tl;   // + buffer + channel * 32
-  const float* vrow = S + (PG_S * PG_CK) * PG_T + tl;              // + buffer + (object * 16 + channel) * 32
+  const float* urow = S + ((2 * wave + si) * CK) * PG_T + tl;   // + buffer + channel * 32
+  const float* vrow = S + (PG_S * CK) * PG_T + tl;              // + buffer + (object * 16 + channel) * 32
   const float* wbase = Wp;                                         // wave-uniform: weights of the current chunk
   Step s0, s1;
   f32x4 w0[6], w1[6];
@@ -656,8 +661,8 @@ __global__ __launch_bounds__(256, 2) void heads_pairgrid4_kernel(
   for (int c = 0; c < nchunks; ++c) {
     const int buf = c & 1;
     if (c + 1 < nchunks) stage_chunk(buf ^ 1);
-    const float* ub = urow + buf * PG_STAGE;
-    const float* vb = vrow + buf * PG_STAGE;
+    const float* ub = urow + buf * STAGE;
+    const float* vb = vrow + buf * STAGE;
     __builtin_amdgcn_sched_barrier(0);
 #define TSPN_STEP2(KK)                                           \
     fetch_uv(s1, ub, vb, (KK) + 1);                              \
@@ -666,23 +671,24 @@ __global__ __launch_bounds__(256, 2) void heads_pairgrid4_kernel(
     compute(s0, w0);                                             \
     __builtin_amdgcn_sched_barrier(0);                           \
     TSPN_WWAIT(w1)                                               \
-    if ((KK) + 2 < PG_CK / 2) {                                  \
+    if ((KK) + 2 < CK / 2) {                                     \
       fetch_uv(s0, ub, vb, (KK) + 2);                            \
       TSPN_WLOAD(w0, ((KK) + 2) & 7, wbase)                      \
     }                                                            \
     __builtin_amdgcn_sched_barrier(0);                           \
     compute(s1, w1);                                             \
     __builtin_amdgcn_sched_barrier(0);                           \
-    if ((KK) + 2 < PG_CK / 2) { TSPN_WWAIT(w0) }
+    if ((KK) + 2 < CK / 2) { TSPN_WWAIT(w0) }
     TSPN_WWAIT(w0)
-    TSPN_STEP2(0) TSPN_STEP2(2) TSPN_STEP2(4) TSPN_STEP2(6)
+    TSPN_STEP2(0) TSPN_STEP2(2)
+    if constexpr (CK == 16) { TSPN_STEP2(4) TSPN_STEP2(6) }
 #undef TSPN_STEP2
-    wbase += PG_CK * H;
+    wbase += CK * H;
     if (c + 1 < nchunks) { TSPN_WLOAD(w0, 0, wbase) }   // weights do not depend on the barrier
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed before the barrier publishes them
     __syncthreads();
     if (c + 1 < nchunks)      // first step of the next chunk: its tile landed before the barrier
-      fetch_uv(s0, urow + (buf ^ 1) * PG_STAGE, vrow + (buf ^ 1) * PG_STAGE, 0);
+      fetch_uv(s0, urow + (buf ^ 1) * STAGE, vrow + (buf ^ 1) * STAGE, 0);
   }
 #undef TSPN_WLOAD
 #undef TSPN_WWAIT
@@ -780,10 +786,16 @@ int tspn::heads_pairgrid(const float* y, int64_t ldt, int64_t B, int64_t N, int6
   if (v3 && H == 12 && Wp12 != nullptr && fits32) {   // scalar-weight VALU form (no 12 -> 16 row padding, no MFMA / VALU serialisation)
     hipLaunchKernelGGL(pack_heads12_kernel, dim3((unsigned)tspn::ceil_div(C * 12, 256)), dim3(256), 0,
                        TSPN_STREAM(stream), Wh, (int)C, Wp12);
+#ifndef TSPN_PAIRGRID4_CK
+#define TSPN_PAIRGRID4_CK 8      /* channels per LDS stage of heads_pairgrid4_kernel: 8 (three workgroups per CU) or 16 (two) */
+#endif
+    constexpr int CK4 = TSPN_PAIRGRID4_CK;
+    static_assert(CK4 == 8 || CK4 == 16, "heads_pairgrid4_kernel is built for 8- or 16-channel stages");
+    const size_t smem4 = sizeof(float) * 2 * PG_ROWS * CK4 * PG_T;
     static tspn::LdsLimit lds4;
-    if (int rc = lds4.ensure(reinterpret_cast<const void*>(heads_pairgrid4_kernel), smem, "tspn_heads_pairgrid_f32"))
+    if (int rc = lds4.ensure(reinterpret_cast<const void*>(heads_pairgrid4_kernel<CK4>), smem4, "tspn_heads_pairgrid_f32"))
       return rc;
-    hipLaunchKernelGGL(heads_pairgrid4_kernel, dim3((unsigned)nwg), dim3(256), smem, TSPN_STREAM(stream), y, ldt,
+    hipLaunchKernelGGL(heads_pairgrid4_kernel<CK4>, dim3((unsigned)nwg), dim3(256), smem4, TSPN_STREAM(stream), y, ldt,
                        (int)C, (int)T, (int)N, Wp12, bh, out, ntb, nob, nsb, ngroups);
     return tspn::check_launch("tspn_heads_pairgrid_f32");
   }

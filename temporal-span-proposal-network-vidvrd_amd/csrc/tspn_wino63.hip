@@ -113,8 +113,11 @@ __global__ void pack_wino63_frag_kernel(const float* __restrict__ W, int64_t M, 
 // 128-byte runs of Vg).  Frames outside the tracklet are zero (the conv's padding); sextets past the end of the
 // launch are zero too.
 // `hot` (optional, for the accuracy guard of tspn_conv_guard.hip): the kernel reads every input value anyway, so it also
-// reports WHERE the launch's largest |x| sits -- (float bits << 32 | sextet) by a 64-bit atomic max, one per wave and only
-// when the wave beats what is already there.
+// reports WHERE the launch's largest |x| sits -- key = (float bits << 32 | sextet), one 64-bit atomic max per wave, no return
+// value, into one of TSPN_CONV_CHECK_HOT_SLOTS slots 256 bytes apart (the reader takes the max over the slots).  Measured
+// forms (profiles/r6/conv_guard.md): ONE word with an atomic load as a filter in front: +50 - 70 us (100 000 waves on one
+// L2 line); one word with a cached plain load as the filter: +300 - 600 us (the stale filter lets thousands of atomics
+// through to one address); 64 slots, unfiltered: within the noise of the kernel without it.
 __global__ __launch_bounds__(256) void wino63_input_transform_kernel(
     const float* __restrict__ x, float* __restrict__ Vg, int T, int Cin, int nq, int64_t nsext, int64_t nsp,
     int64_t ncols, unsigned long long* __restrict__ hot) {
@@ -146,8 +149,9 @@ __global__ __launch_bounds__(256) void wino63_input_transform_kernel(
       const unsigned long long other = __shfl_xor(key, o, 64);
       key = other > key ? other : key;
     }
-    if (lane == 0 && key > __hip_atomic_load(hot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-      __hip_atomic_fetch_max(hot, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0)
+      __hip_atomic_fetch_max(hot + 32 * ((blockIdx.x * 4 + wave + 7 * blockIdx.y) & (TSPN_CONV_CHECK_HOT_SLOTS - 1)), key,
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   f32x4 V[8];
   V[0] = d[0] - d[6] + 5.25f * (d[4] - d[2]);

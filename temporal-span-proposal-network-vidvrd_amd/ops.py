@@ -699,18 +699,21 @@ def forward_fused(feats, pairs, B, N, conv_packed, conv_bias, head_w, head_b, cl
 def conv3_spot_check(x, weight, y, split=0, bias=None, relu=False, hot=None, rows=128, ldy=None):
     """A-posteriori accuracy check of a temporal conv launch (tspn_conv3_spot_check_f32): x [B,T,Cin], raw
     weight [M,Cw,3] (`split` as in pack_conv3), y = the launch's output [B, rows of y, ldy]; `rows` output rows are
-    recomputed at up to 24 columns each in float64.  The largest |y - y_ref| is max-ed into the device's status
+    recomputed at up to 24 columns each in float64 (`hot`: optional int64 [1] naming a sextet every row must cover, as the
+    F(6,3) input transform reports it).  The largest |y - y_ref| is max-ed into the device's status
     block (status_words()[_abi.STATUS_CONV_ERR] holds its float bits)."""
     _dev(x, "x"); _dev(weight, "weight"); _dev(y, "y")
     B, T, Cin = x.shape
     M, Cw = weight.shape[0], weight.shape[1]
     if bias is not None:
         _dev(bias, "bias")
+    scratch = torch.zeros(_abi.CONV_CHECK_SCRATCH_BYTES // 8, dtype=torch.int64, device=x.device)
     if hot is not None:
         _dev(hot, "hot", torch.int64)
+        scratch[_abi.CONV_CHECK_HOT_OFFSET // 8:_abi.CONV_CHECK_HOT_OFFSET // 8 + 1] = hot.reshape(-1)[0:1]
     ld = int(ldy) if ldy is not None else y.shape[-1]
     _abi.check(_abi.lib().tspn_conv3_spot_check_f32(_p(x), B, T, Cin, _p(weight), M, Cw, split, _p(bias), 1 if relu else 0,
-                                                    _p(y), ld, _p(hot), rows, _stream()))
+                                                    _p(y), ld, _p(scratch), rows, _stream()))
 
 
 def temporal_encoder_heads(x, conv_packed, conv_bias, head_w, head_b, h_ws=None):
