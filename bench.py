@@ -128,6 +128,12 @@ def parse(argv=None):
                     help="cfg5: frames per backbone launch (0 = the class default)")
     ap.add_argument("--tail-io-waves", choices=["auto", "off"], default="auto",
                     help="cfg5: `off` runs res4's fused tails on the one-role kernel (round 3/4) instead of the role-split one (round 5)")
+    ap.add_argument("--associate", choices=["off", "process", "thread"], default="off",
+                    help="cfg5: frames -> VIDEO-LEVEL relations.  Behind every video's triplets the greedy relational association "
+                         "(reference lib/modeling/association.py:117-175; 59 segments x --tracklets tracklets x 200 predictions, "
+                         "device IoU tables) runs in a worker process (`thread`: on a thread of this process, the A/B arm) while the GPU works on the next "
+                         "video; the line reports the steady-state ms per video with it, the association's time alone and "
+                         "beside the GPU pipeline, the GPU's idle fraction and the host's call rate")
     ap.add_argument("--serial-tail", action="store_true",
                     help="A/B: RELPN.OVERLAP_TAIL = False (PPN and decode on the caller's stream, after the encoder)")
     ap.add_argument("--launch-check", action="store_true",
@@ -834,11 +840,78 @@ class Cfg5Workload:
             for e in ev:
                 e.record()
         torch.cuda.synchronize()
+        self.assoc = None
+        if getattr(args, "associate", "off") != "off":
+            self._init_association()
+
+    # -- frames -> video-level relations: the association of video k on a worker thread beside video k + 1 on the GPU
+    def _init_association(self):
+        import concurrent.futures
+        tspn = self.tspn
+        gold = os.path.join(ROOT, "tests", "golden")
+        if gold not in sys.path:
+            sys.path.insert(0, gold)
+        import cases     # the synthetic multi-segment video of the association tests (a generator, not the oracle)
+        nseg = max(2, (self.T - 30) // 15 + 1)                 # 30-frame segments, stride 15 (lib/modeling/__init__.py:35-41)
+        rels, trajs = cases.g9_scenario(seed=31, n_seg=nseg, n_trk=self.N, n_pred=TOPK_SEG)
+        # the association runs in a worker PROCESS (tspn.association.AssociationWorker): on a thread of this process its
+        # ~0.3 s of pure Python per video holds the interpreter lock while this thread issues ~2 000 launches per video
+        # (489 ms per video against 385 without it, profiles/r6/cfg5_associate.md).  A hand-over thread waits for the
+        # video's triplets (an event), ships the short-term relations to the worker and collects its answer -- all of it
+        # blocking calls that do not hold the lock.
+        if self.args.associate == "process":
+            worker = tspn.association.AssociationWorker(device=str(self.dev), max_traj_num_in_clip=TOPK_SEG)
+            self._assoc_worker = worker
+
+            # what the decode of a video's segments yields: arrays per segment (scores [K], triplets [K,3], pairs [K,2])
+            # and the tracklet boxes [N,30,4]
+            np = self.np
+            segs = [index for index, _ in rels]
+            arr = {"scores": [np.array([p[0] for p in pr[0]]) for _, pr in rels],
+                   "triplets": [np.stack([p[1] for p in pr[0]]) for _, pr in rels],
+                   "pairs": [np.stack([p[2] for p in pr[0]]) for _, pr in rels],
+                   "boxes": [trajs[index] for index in segs]}
+
+            def run(wait_event):
+                if wait_event is not None:
+                    wait_event.synchronize()                    # this video's triplets exist (blocks this thread only)
+                worker.submit_arrays("video", segs, arr["scores"], arr["triplets"], arr["pairs"], arr["boxes"],
+                                     return_relations=False)
+                _, count, ms, _ = worker.result()
+                return ms, count
+        else:                                                   # A/B arm: the same work on a thread of THIS process, own stream
+            import copy
+            torch = self.torch
+            stream = torch.cuda.Stream(device=self.dev)
+
+            def run(wait_event):
+                r = copy.deepcopy(rels)                         # the association sorts / aliases its input in place
+                if wait_event is not None:
+                    wait_event.synchronize()
+                t0 = time.perf_counter()
+                with torch.cuda.stream(stream):                 # torch's current stream is per thread
+                    out = tspn.association.greedy_relational_association(None, r, max_traj_num_in_clip=TOPK_SEG,
+                                                                         trajectories=trajs, device=self.dev)
+                return (time.perf_counter() - t0) * 1e3, len(out)
+
+        run(None)                                               # warm-up
+        alone = sorted(run(None)[0] for _ in range(3))
+        self.assoc = {"pool": concurrent.futures.ThreadPoolExecutor(1), "run": run, "pending": None, "alone_ms": alone[1],
+                      "beside_ms": [], "wait_ms": [], "issue_ms": [], "relations": None, "segments": nseg, "calls": 0}
+        # host call rate: every ABI call of the library passes _abi.check
+        check = tspn._abi.check
+        st = self.assoc
+
+        def counting_check(rc):
+            st["calls"] += 1
+            return check(rc)
+        tspn._abi.check = counting_check
 
     def step(self, i):
         tspn, torch = self.tspn, self.torch
         img, boxes, cls = self.imgs[i % self.nb], self.boxes[i % self.nb], self.cls[i % self.nb]
         e0, e1, e2, e3 = self.events[i]
+        t_issue = time.perf_counter()
         e0.record()
         maps = self.net(img, bf16=True)                 # [T, H/16, W/16, 1024] bf16
         e1.record()
@@ -848,11 +921,52 @@ class Cfg5Workload:
         pair_props, _, rel_logits = self.model([plist], None)
         dec = self.model.decode([plist], rel_logits, topk_per_pair=TOPK_PAIR, topk_per_seg=TOPK_SEG)
         e3.record()
+        if self.assoc is not None:
+            st = self.assoc
+            st["issue_ms"].append((time.perf_counter() - t_issue) * 1e3)
+            if st["pending"] is not None:                       # one video in flight on the worker: a pipeline of depth one
+                t0 = time.perf_counter()
+                ms, st["relations"] = st["pending"].result()
+                st["wait_ms"].append((time.perf_counter() - t0) * 1e3)
+                st["beside_ms"].append(ms)
+            st["pending"] = st["pool"].submit(st["run"], e3)
         sc, trip, tid = (torch.stack([d[k] for d in dec]) for k in range(3))
         self.gather(sc, trip, tid, torch.stack(pair_props))
 
     def sync(self):
         self.torch.cuda.synchronize()
+        if self.assoc is not None and self.assoc["pending"] is not None:   # the last video's association belongs to the job:
+            st = self.assoc                                                  # the pipeline drains (reported as drain_ms)
+            t0 = time.perf_counter()
+            ms, st["relations"] = st["pending"].result()
+            st["drain_ms"] = (time.perf_counter() - t0) * 1e3
+            st["beside_ms"].append(ms)
+            st["pending"] = None
+
+    def _association_report(self, elapsed):
+        np, args, st = self.np, self.args, self.assoc
+        k = args.steps
+        span = [e[0].elapsed_time(e[3]) for e in self.events[args.warmup:]]
+        issue = st["issue_ms"][-k:]
+        calls = st["calls"] / float(len(st["issue_ms"]) or 1)
+        return {"what": "greedy relational association of video k (reference lib/modeling/association.py:117-175) "
+                        + ("in a worker PROCESS (tspn.association.AssociationWorker, its own HIP context for the IoU tables)"
+                           if args.associate == "process" else "on a THREAD of the driving process (own HIP stream)")
+                        + " while the GPU works on video k + 1; one video in flight on the worker",
+                "mode": args.associate,
+                "segments": st["segments"], "predictions_per_segment": TOPK_SEG, "relations_per_video": st["relations"],
+                "ms_per_video_with_association": elapsed / k * 1e3,
+                "drain_ms": st.get("drain_ms", 0.0),
+                "steady_state_ms_per_video": (elapsed * 1e3 - st.get("drain_ms", 0.0)) / k,
+                "note": "ms_per_video_with_association = wall time of the K timed videos INCLUDING the drain of the last video's "
+                        "association behind the GPU's last kernel (drain_ms, paid once per run, not per video); "
+                        "steady_state_ms_per_video excludes it",
+                "association_ms_alone": st["alone_ms"], "association_ms_beside_the_gpu_pipeline": float(np.mean(st["beside_ms"][-k:])),
+                "main_thread_wait_for_worker_ms": float(np.mean(st["wait_ms"][-k:])),
+                "host_issue_ms_per_video": float(np.mean(issue)), "abi_calls_per_video": calls,
+                "abi_calls_per_s_while_issuing": calls / (float(np.mean(issue)) * 1e-3),
+                "gpu_ms_per_video": float(np.mean(span)),
+                "gpu_idle_fraction": max(0.0, 1.0 - float(np.sum(span)) * 1e-3 / elapsed)}
 
     def report(self, elapsed, clock_mhz):
         np, args, tspn = self.np, self.args, self.tspn
@@ -877,7 +991,8 @@ class Cfg5Workload:
                        "backbone_ms_per_frame": bb_ms / self.T,
                        "fused_bottlenecks": bool(getattr(self.net, "fuse_bottlenecks", False)),
                        "fused_blocks": bool(getattr(self.net, "fuse_bottlenecks", False) and getattr(self.net, "fuse_blocks", False)),
-                       "tail_io_waves": bool(getattr(self.net, "fuse_bottlenecks", False) and getattr(self.net, "tail_io_waves", False))},
+                       "tail_io_waves": bool(getattr(self.net, "fuse_bottlenecks", False) and getattr(self.net, "tail_io_waves", False)),
+                       **({"association": self._association_report(elapsed)} if self.assoc is not None else {})},
             "roofline": {"bound": "mfma",
                          "kernel": "ResNet-101-C4 backbone, all convolutions of one video (bf16 32x32x16 MFMA implicit GEMMs: "
                                    "tail_io_bf16_kernel / bottleneck_block_bf16_kernel / conv2d_nhwc_bf16_kernel / stem_conv_bf16_kernel)",

@@ -130,3 +130,25 @@ def test_numpy_pairwise_summation_order_restated():
     for n in list(range(0, 140)) + [255, 256, 257, 300, 511, 777, 1024, 1100, 1300]:
         a = (rs.uniform(1, 2, size=n) * 10.0 ** rs.randint(-3, 6, size=n)).astype(np.float64)
         assert float(np.sum(a)) == pairwise([float(v) for v in a]), n
+
+
+def test_vectorised_host_iou_rows_equal_the_pairwise_form_bit_for_bit():
+    """`_cubic_iou_1xn` (round 6: the rows of a segment's IoU table that merges have made stale are refreshed on the host,
+    one trajectory against all tracklets at once) must reproduce `_cubic_iou_1x1` -- the roundings of
+    lib/modeling/trajectory.py:85-141 -- to the bit, on integer boxes and on the half-integer boxes merges produce."""
+    import tspn_mi355x as tspn
+    A = tspn.association
+    rs = np.random.RandomState(5)
+    for k in (1, 7, 15, 30):
+        for scale in (1.0, 0.5, 0.25):
+            xy = np.round(rs.uniform(0, 600, size=(33, k, 2)) / scale) * scale
+            wh = np.round(rs.uniform(5, 300, size=(33, k, 2)) / scale) * scale
+            b = np.concatenate([xy, xy + wh], axis=2)
+            a = b[0] + np.round(rs.uniform(-20, 20, size=(k, 4)) / scale) * scale
+            a[:, 2:] = np.maximum(a[:, 2:], a[:, :2] + 1)
+            far = b[1] + 5000.0                                   # no overlap at all -> exactly 0
+            row = A._cubic_iou_1xn(a, np.concatenate([b, far[None]]))
+            want = np.array([A._cubic_iou_1x1(a, bb) for bb in np.concatenate([b, far[None]])], dtype=np.float32)
+            assert row.dtype == np.float32 and row.shape == (34,)
+            np.testing.assert_array_equal(row.view(np.uint32), want.view(np.uint32))
+            assert row[-1] == 0.0 and row[0] > 0.0

@@ -101,3 +101,30 @@ def test_device_association_ragged_segment_raises_like_the_reference(tspn, devic
     rels[1][1][0][0] = (np.array(0.8), np.array([9, 9, 9]), np.array([0, 1]))    # another triplet: never compared
     out = A.greedy_relational_association(None, copy.deepcopy(rels), trajectories=trajs, device=device)
     assert len(out) == 2
+
+
+def test_association_worker_process_gives_the_same_relations(tspn, device):
+    """Round 6: `AssociationWorker` runs `greedy_relational_association` for whole videos in a worker process (its own HIP
+    context, a high-priority stream for the IoU tables; stale rows refreshed on the host) -- the relations must equal the
+    in-process host result, from the tuple form and from the array form of the hand-over, and a failing job must
+    come back as an error, not kill the worker."""
+    import copy
+    A = tspn.association
+    rels, trajs = cases.g9_scenario(seed=31, n_seg=9, n_trk=16, n_pred=60)
+    want = A.greedy_relational_association(None, copy.deepcopy(rels), max_traj_num_in_clip=60, trajectories=trajs)
+    segs = [index for index, _ in rels]
+    arr = {"scores": [np.array([p[0] for p in pr[0]]) for _, pr in rels],
+           "triplets": [np.stack([p[1] for p in pr[0]]) for _, pr in rels],
+           "pairs": [np.stack([p[2] for p in pr[0]]) for _, pr in rels], "boxes": [trajs[i] for i in segs]}
+    with A.AssociationWorker(device=str(device), max_traj_num_in_clip=60) as w:
+        w.submit("tuples", copy.deepcopy(rels), trajs)
+        w.submit_arrays("arrays", segs, arr["scores"], arr["triplets"], arr["pairs"], arr["boxes"])
+        w.submit("broken", [(("v", 0, 30), ([], None, None))], {})
+        key, out, ms, stats = w.result()
+        assert key == "tuples" and out == want and stats["iou_launches"] >= 1 and stats["iou_host_rows"] >= 1
+        key, out, ms, stats = w.result()
+        assert key == "arrays" and out == want
+        with pytest.raises(RuntimeError, match="KeyError"):
+            w.result()
+        w.submit("again", copy.deepcopy(rels), trajs, return_relations=False)
+        assert w.result()[1] == len(want)
