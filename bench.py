@@ -802,9 +802,7 @@ class Cfg5Workload:
         self.bb_sd = tspn.synth.make_backbone_weights(0)
         self.r5_sd = tspn.synth.make_res5_weights(0)
         self.sd = tspn.synth.make_weights(0, c=2 * D, a=A_ANCH, k=K_PRED)
-        # frames per backbone launch: ResNetC4.frame_chunk (36 since round 5: 1 013 tiles of the role-split res4 tails, one
-        # workgroup per CU = 3.96 rounds of the 256 CUs; 18 frames = 1.98 rounds is 1.5 - 2.5 % slower); x 2 streams
-        # (ResNetC4.streams)
+        # frames per backbone launch: ResNetC4.frame_chunk (90 since round 6, see there); x 2 streams (ResNetC4.streams)
         self.net = tspn.ResNetC4(depth=101) if args.frame_chunk <= 0 else tspn.ResNetC4(depth=101, frame_chunk=args.frame_chunk)
         self.net.load_state_dict(t(self.bb_sd))
         self.net = self.net.to(dev)

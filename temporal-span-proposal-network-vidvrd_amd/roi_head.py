@@ -411,7 +411,7 @@ class ResNetC4(_CachedWeightsMixin, nn.Module):
 
     BLOCKS = {50: (3, 4, 6), 101: (3, 4, 23)}
 
-    def __init__(self, depth=101, stem_out=64, res2_out=256, blocks=None, frame_chunk=36):
+    def __init__(self, depth=101, stem_out=64, res2_out=256, blocks=None, frame_chunk=90):
         super().__init__()
         blocks = tuple(blocks) if blocks is not None else self.BLOCKS[depth]
         self.stem = BasicStem(3, stem_out)
@@ -424,8 +424,12 @@ class ResNetC4(_CachedWeightsMixin, nn.Module):
             setattr(self, f"res{i + 2}", nn.Sequential(*stage))
             cout *= 2
         self.out_channels = cin
-        # frames per launch: 36 since the role-split res4 tails run one workgroup per CU (4 rounds of tiles per launch instead of
-        # 2: cfg5 391 -> 383 - 387 ms in one box, 72-frame backbone 70.2 -> 68.5 ms per 216 frames; 18 before, 9 in round 4)
+        # frames per launch: 90 (round 6; 36 in round 5, 18 before, 9 in round 4).  Measured on whole cfg5 videos, backbone ms
+        # per 900 frames in one box (profiles/r6/frame_chunk_sweep.txt): 9: 304.7, 18: 302.1, 36: 298.5, 45: 295.0 | another
+        # box: 45: 288 - 290, 63: 286.5, 90: 285.8, 180: 284.5.  Ten launches of 90 frames: 9.9 rounds of res4-tail tiles per
+        # launch (2 531 tiles on 256 CUs, one workgroup each) instead of 3.96, 2.5 x fewer launches; the maps of a chunk
+        # (2.7 GB at res2) are nothing beside 288 GB of HBM.  Fitting a chunk's res4 map into the 256-MB Infinity Cache
+        # (27 frames) buys nothing: 299.3 against 298.5 ms.
         self.frame_chunk = int(frame_chunk)
         self.fuse_bottlenecks = True     # bf16 maps: conv2 + conv3 + residual of every block in one launch
         # ... which at res4 can also compute conv1 of the block that follows (round 4, tspn_bottleneck_tail_next_bf16): the
