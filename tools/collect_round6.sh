@@ -1,5 +1,6 @@
 #!/bin/bash
 # Turn gpurun_out/prof6 (tools/profile_round6.sh) into the tracked summaries under profiles/r6/ (run in the build container).
+# gpurun MERGES a run's files into gpurun_out/ next to those of earlier runs: every lookup below takes the newest file.
 set -e
 cd "$(dirname "$0")/.."
 O=gpurun_out/prof6
@@ -31,13 +32,13 @@ json.dump(d, open(p, 'w'), indent=1, sort_keys=True)
 PY
 # pair builder: per-kernel fabric bytes
 python - <<'PY'
-import csv, glob, collections, re
+import csv, glob, collections, os, re
 O = 'gpurun_out/prof6'
 def short(n):
     m = re.search(r"(?:\(anonymous namespace\)::)?([A-Za-z0-9_]+)(<[^>]*>)?\(", n); return (m.group(1) + (m.group(2) or "")) if m else n[:60]
 rows = collections.defaultdict(dict)
 for sub, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-    f = glob.glob(f"{O}/pb_pmc/{sub}/**/*counter_collection.csv", recursive=True)[0]
+    f = max(glob.glob(f"{O}/pb_pmc/{sub}/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)   # gpurun merges runs
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == ctr:
@@ -55,8 +56,8 @@ with open('profiles/r6/pair_builder.csv', 'w') as fh:
 print(open('profiles/r6/pair_builder.csv').read())
 PY
 # SQ counter tables
-for d in sq_cfg2_a sq_cfg2_b sq_cfg2_c; do echo "== $d (bench.py, cfg2)"; python tools/pmc_table.py $(find $O/$d -name "*counter_collection.csv") heads_pairgrid4 conv3_wino63; done > profiles/r6/sq_counters_cfg2.txt
-for d in sq_cfg3_a sq_cfg3_b; do echo "== $d (bench.py --workload cfg3)"; python tools/pmc_table.py $(find $O/$d -name "*counter_collection.csv") heads_pairgrid_bf16 conv3_bf16_big; done > profiles/r6/sq_counters_cfg3.txt
+for d in sq_cfg2_a sq_cfg2_b sq_cfg2_c; do echo "== $d (bench.py, cfg2)"; python tools/pmc_table.py $(ls -t $(find $O/$d -name "*counter_collection.csv") | head -1) heads_pairgrid4 conv3_wino63; done > profiles/r6/sq_counters_cfg2.txt
+for d in sq_cfg3_a sq_cfg3_b; do echo "== $d (bench.py --workload cfg3)"; python tools/pmc_table.py $(ls -t $(find $O/$d -name "*counter_collection.csv") | head -1) heads_pairgrid_bf16 conv3_bf16_big; done > profiles/r6/sq_counters_cfg3.txt
 cp temporal-span-proposal-network-vidvrd_amd/kernel_resources.json profiles/r6/kernel_resources.json
 python - <<'PY'
 import json, glob
