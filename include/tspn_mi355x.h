@@ -44,8 +44,7 @@ extern "C" {
  * tspn_bottleneck_tail_io_bf16, tspn_conv3_tc_wino63_set_piece_form (replaces the TSPN_WINO63_PTRV environment switch);
  * 7 (round 6): the device status block (tspn_status_attach / _fault / _clear / _selftest, TSPN_EDEVICE: a kernel can
  * raise a fault that the NEXT launch entry reports without a synchronisation); tspn_fused_desc gained conv_weight /
- * conv_check (the a-posteriori accuracy guard of the F(6,3) temporal conv, tspn_conv3_spot_check_f32);
- * tspn_traj_iou_tail_batch_f64.                                                                                  */
+ * conv_check at its END (the a-posteriori accuracy guard of the F(6,3) temporal conv, tspn_conv3_spot_check_f32). */
 #define TSPN_ABI_VERSION 7
 
 enum {
