@@ -64,6 +64,52 @@ __global__ __launch_bounds__(256) void transpose_gather_kernel(
   }
 }
 
+// (round 6) The same move for whole tracklets: a workgroup = 64 channels x ALL T frames of one (pair, role).  The destination
+// of such a block, [64 rows][T], is ONE contiguous run of 64 T floats, so the tile is laid down in LDS in the destination's
+// own order and leaves as plain 16-byte copies (whole lines; the 32 x 32 form above writes 128-byte pieces that straddle
+// two lines whenever a row is not a multiple of 128 bytes: T = 150 -> 600).  Loads are 16 bytes per lane too: lane =
+// (frame t & 15, channel quad), a quad = 64 contiguous bytes of a frame row, and the four floats of a lane go to four rows
+// of the tile with the lanes of a wave along t: bank-consecutive LDS writes.
+// The workgroup index runs CHANNEL-BLOCK-major (all pairs of channels [64 b, 64 b + 64), then the next block): every
+// workgroup in flight then reads from the same 64-channel slice of the N tracklets -- N T 256 bytes, 1.2 MB at N = 32,
+// T = 150: resident in every XCD's L2 -- where the pair-major order of the 32 x 32 form re-fetched the object tracklet of
+// almost every pair from beyond L2 (FETCH_SIZE 1.24 GB for 39 MB of unique input, profiles/r6/pair_builder.csv).
+// Needs D % 64 == 0, T <= TG_TMAX and 16-byte aligned operands; the 32 x 32 form serves everything else.
+constexpr int TG_C = 64;
+constexpr int TG_TMAX = 160;          // 40 KB of LDS per workgroup
+
+__global__ __launch_bounds__(256) void transpose_gather_rows_kernel(
+    const float* __restrict__ src, const int64_t* __restrict__ pairs, int T, int64_t D, float* __restrict__ dst,
+    int gather, int64_t nz) {
+  extern __shared__ __attribute__((aligned(16))) float tile_rows[];      // [64][T], the destination block's own order
+  const int64_t wg = blockIdx.x;
+  const int64_t dblk = wg / nz, z = wg - dblk * nz;
+  int64_t srow, drow_off;
+  if (gather) {
+    srow = pairs[z];                          // z = 2 p + role; destination [P, 2D, T]: channel offset role * D
+    drow_off = (z >> 1) * 2 * D + (z & 1) * D;
+  } else {
+    srow = z;
+    drow_off = z * D;
+  }
+  const int tid = threadIdx.x;
+  const int tl = tid & 15, cq = tid >> 4;     // a wave: 16 frames x 4 channel quads
+  const float* s = src + srow * T * D + dblk * TG_C + 4 * cq;
+  for (int t = tl; t < T; t += 16) {
+    const float4 v = *reinterpret_cast<const float4*>(s + (int64_t)t * D);
+    float* w = tile_rows + (4 * cq) * T + t;
+    w[0] = v.x;
+    w[T] = v.y;
+    w[2 * T] = v.z;
+    w[3 * T] = v.w;
+  }
+  __syncthreads();
+  float4* o = reinterpret_cast<float4*>(dst + (drow_off + dblk * TG_C) * T);
+  const float4* ti = reinterpret_cast<const float4*>(tile_rows);
+  const int n4 = TG_C * T / 4;
+  for (int i = tid; i < n4; i += 256) o[i] = ti[i];
+}
+
 // --------------------------------------------------- relative box geometry
 // One lane per (pair, frame).  The motion channels need the previous frame's
 // offsets: they come from the neighbouring lane by a wavefront shuffle; only the
@@ -233,7 +279,15 @@ extern "C" int tspn_pair_gather_f32(const float* feats, const float* boxes, int6
   TSPN_REQUIRE(!boxes || (reinterpret_cast<uintptr_t>(boxes) & 15) == 0, TSPN_EINVAL,
                "tspn_pair_gather_f32: boxes must be 16-byte aligned");
   hipStream_t s = TSPN_STREAM(stream);
-  if (out_feat) {
+  const bool rows_form = out_feat && D % TG_C == 0 && T <= TG_TMAX && ((reinterpret_cast<uintptr_t>(feats) & 15) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(out_feat) & 15) == 0) && (2 * P) * (D / TG_C) < (1LL << 31);
+  if (rows_form) {
+    const size_t smem = sizeof(float) * TG_C * T;
+    hipLaunchKernelGGL(transpose_gather_rows_kernel, dim3((unsigned)((2 * P) * (D / TG_C))), dim3(256), smem, s, feats, pairs,
+                       (int)T, D, out_feat, 1, 2 * P);
+    int rc = tspn::check_launch("tspn_pair_gather_f32(feat)");
+    if (rc) return rc;
+  } else if (out_feat) {
     const int64_t gy = tspn::ceil_div(T, TT);
     // blockIdx.z is limited to 65535: walk the pair list in slabs
     const int64_t zmax = 65534;

@@ -172,7 +172,10 @@ def test_pair_index(tspn, device, N):
     np.testing.assert_array_equal(got.numpy(), ref.numpy())
 
 
-@pytest.mark.parametrize("N,T,D", [(2, 1, 1), (3, 7, 5), (5, 30, 64), (4, 33, 70), (6, 150, 96)])
+# (5, 30, 64), (4, 150, 128), (3, 160, 192), (3, 1, 64), (4, 7, 64): the whole-tracklet form of round 6 (D % 64 == 0, T <= 160,
+# odd T included); (3, 161, 64) and the others: the 32 x 32 form
+@pytest.mark.parametrize("N,T,D", [(2, 1, 1), (3, 7, 5), (5, 30, 64), (4, 33, 70), (6, 150, 96), (4, 150, 128), (3, 160, 192),
+                                   (3, 1, 64), (4, 7, 64), (3, 161, 64)])
 def test_pair_gather(tspn, device, N, T, D):
     v = tspn.synth.make_video(31, N, T, D)
     pairs = oracle.pair_index(N)
