@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The materialising N^2 pair builder at BASELINE cfg2's shape (N = 32, T = 150, D = 2048 -> [992, 4096, 150] fp32 = 2.44 GB
-written per video, + 8 geometry channels per pair and frame): `transpose_gather_kernel` / `pair_geometry_kernel`
+written per video, + 8 geometry channels per pair and frame): `transpose_gather_rows_kernel` / `pair_geometry_kernel`
 (csrc/tspn_pairs.hip).  It is NOT on the product path -- the fused pass never materialises the pair tensor --
 but north_star names the kernel and asks for its HBM rate.  HIP events over back-to-back calls; run it under
 `rocprofv3 --kernel-trace --stats` / `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` for the per-kernel evidence.
@@ -23,7 +23,7 @@ wh = torch.floor(10.0 + torch.rand((N, T, 2), device=dev, generator=g) * 290.0)
 boxes = torch.cat([xy, xy + wh], dim=2).contiguous()
 pairs = tspn.ops.pair_index(N, dev)
 P = pairs.shape[0]
-for want_feat, want_geom, name in ((True, False, "transpose_gather_kernel (features)"), (False, True, "pair_geometry_kernel (boxes)"),
+for want_feat, want_geom, name in ((True, False, "transpose_gather_rows_kernel (features)"), (False, True, "pair_geometry_kernel (boxes)"),
                                    (True, True, "both")):
     for _ in range(2):
         out = tspn.ops.pair_gather(feats, boxes, pairs, want_feat=want_feat, want_geom=want_geom, check_pairs=False)
