@@ -491,7 +491,11 @@ class AssociationWorker:
     def result(self):
         if self._inflight == 0:
             raise RuntimeError("AssociationWorker.result: nothing in flight")
-        key, out, ms, stats, err = self._conn.recv()
+        try:
+            key, out, ms, stats, err = self._conn.recv()
+        except (EOFError, ConnectionError, OSError) as exc:
+            self._inflight = 0
+            raise RuntimeError(f"AssociationWorker: the worker process is gone (exit code {self._proc.poll()}): {exc}") from None
         self._inflight -= 1
         if err is not None:
             raise RuntimeError(f"association of {key!r} failed in the worker: {err}")
@@ -499,6 +503,9 @@ class AssociationWorker:
 
     def close(self):
         import shutil
+        if getattr(self, "_closed", False) or not hasattr(self, "_proc"):
+            return
+        self._closed = True
         if self._proc.poll() is None:
             try:
                 self._conn.send(None)
@@ -510,6 +517,12 @@ class AssociationWorker:
                 self._proc.kill()
         self._conn.close()
         shutil.rmtree(self._dir, ignore_errors=True)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                                        # noqa: BLE001 -- interpreter shutdown
+            pass
 
     def __enter__(self):
         return self

@@ -20,6 +20,7 @@ There is no CPU execution path: without the HIP library or a HIP device,
 forward raises.
 """
 import warnings
+import weakref
 from collections import namedtuple
 
 import numpy as np
@@ -826,6 +827,8 @@ class BaseModel(_CachedWeightsMixin, nn.Module):
             return self._forward_train(pair_list, target_list)
         return self._forward_test(pair_list)
 
+    _conv_guard_owner = {}       # device index -> weakref of the model whose guarded F(6,3) pass ran last on that device
+
     def _winograd(self, d, dev):
         """Temporal conv algorithm of this call: True = Winograd F(6,3) (RELPN.DPN.CONV_ALGO "auto", D % 32 == 0, and the
         accuracy guard has not tripped).  Reads what the guard measured in EARLIER calls from the device's status block
@@ -835,6 +838,15 @@ class BaseModel(_CachedWeightsMixin, nn.Module):
             return False
         if self.conv_check_rows > 0:
             words = ops.status_words(dev)
+            # the words are per DEVICE: a measurement belongs to the model whose guarded pass ran last there; what another
+            # model (or a direct caller of ops.conv3_spot_check) left is discarded, not attributed to this one
+            owner = BaseModel._conv_guard_owner.get(dev.index)
+            mine = owner is not None and owner() is self
+            BaseModel._conv_guard_owner[dev.index] = weakref.ref(self)
+            if not mine:
+                words[_abi.STATUS_CONV_ERR] = 0
+                words[_abi.STATUS_CONV_CHECKS] = 0
+                return True
             err = float(words[_abi.STATUS_CONV_ERR:_abi.STATUS_CONV_ERR + 1].view(np.float32)[0])
             self.conv_err_seen = max(self.conv_err_seen, err)
             if err > self.conv_tol:
