@@ -262,3 +262,41 @@ def test_lost_handover_in_the_role_split_tail_raises_instead_of_returning_wrong_
     #                                                                # of them or behind them was stored
     assert lib.tspn_status_attach(vp(0)) == 0                      # detach the probe library's registry (its own copy)
     assert tspn.ops.status_fault(device) == 0                      # the product library's block was never involved
+
+
+def test_input_transform_reports_the_sextet_of_the_largest_input(tspn, device):
+    """The accuracy guard's targeting: with `conv_check` on, the Winograd input transform leaves (float bits of the largest
+    |x| a wave saw) << 32 | sextet in 64 slots of the pass's workspace; the largest key must name the planted outlier's
+    sextet and carry its magnitude exactly (the scratch is the last region of the workspace: header,
+    TSPN_CONV_CHECK_SCRATCH_BYTES / TSPN_CONV_CHECK_HOT_OFFSET)."""
+    B, N, T, D = 2, 3, 40, 64
+    sd = tspn.synth.make_weights(50, c=2 * D, bias_std=0.05)
+    pre = "relpn.duration_proposal_network.dpn_head."
+    d = lambda a: t(a).to(device).contiguous()   # noqa: E731
+    conv_w, conv_b = d(sd[pre + "conv.weight"]), d(sd[pre + "conv.bias"])
+    hw = d(np.concatenate([sd[pre + "relness_pred.weight"][:, :, 0], sd[pre + "duration_pred.weight"][:, :, 0]]))
+    hb = d(np.concatenate([sd[pre + "relness_pred.bias"], sd[pre + "duration_pred.bias"]]))
+    cw, cb = d(sd["classifier.rel_predictor.weight"]), d(sd["classifier.rel_predictor.bias"])
+    feats = tspn.hashrng.uniform(7, "x", (B * N, T, D), -1, 1)
+    trk, frame, ch = 4, 27, 13                                     # video 1, tracklet 1: sextet 4 * 7 + 27 // 6
+    feats[trk, frame, ch] = -37.5
+    pairs = torch.cat([tspn.ops.pair_index(N, device, base=b * N) for b in range(B)])
+    packed = tspn.ops.pack_conv3_wino63(conv_w, split=D)
+    need = tspn.ops.fused_workspace_bytes(B, N, T, D, 4, cw.shape[0], pairs.shape[0])
+    ws = torch.zeros(need, dtype=torch.uint8, device=device)
+    zero_conv_words(tspn, device)
+    tspn.ops.forward_fused(d(feats), pairs, B, N, packed, conv_b, hw, hb, cw, cb, workspace=ws, canonical_pairs=True,
+                           conv_weight=conv_w, conv_check=16)
+    torch.cuda.synchronize(device)
+    scratch = ws[need - tspn._abi.CONV_CHECK_SCRATCH_BYTES:].view(torch.int64)
+    slots = scratch[tspn._abi.CONV_CHECK_HOT_OFFSET // 8::32][:64].cpu().numpy().astype(np.uint64)
+    assert int((slots != 0).sum()) >= 2                            # several waves reported, into different slots
+    key = int(slots.max())
+    nq = (T + 5) // 6
+    assert key & 0xFFFFFFFF == trk * nq + frame // 6
+    assert np.array([key >> 32], dtype=np.uint32).view(np.float32)[0] == np.float32(37.5)
+    assert bool((scratch[:4] == 0).all())                          # the spot check left its meeting words zeroed
+    err, checks = conv_err_word(tspn, device)
+    # 16 rows x (hot sextet + 3 hashed ones, a new draw per call) x up to 6 frames (the last sextet of a tracklet has 4 at T = 40)
+    assert 0.0 < err < 1e-4 and checks % 16 == 0 and 16 * 18 <= checks <= 16 * 24
+    zero_conv_words(tspn, device)
