@@ -60,10 +60,11 @@ class Track:
         return self.pend - self.pstart
 
     def serialize_rois(self):
-        """[(l, t, r, b), ...] of Python floats; relations that share this trajectory share the list."""
+        """[(l, t, r, b), ...] of Python floats: a new list per call (as in the reference), converted once per trajectory
+        version -- relations that share a trajectory share the (immutable) tuples, not the list."""
         if self._ser is None or self._ser[0] != self._ver:
             self._ser = (self._ver, list(map(tuple, self.rois.tolist())))
-        return self._ser[1]
+        return list(self._ser[1])
 
 
 def _cubic_iou_1x1(boxes1, boxes2):
@@ -121,7 +122,8 @@ def _merge_trajs(t1, t2):
     overlap = max(t1.pend - t2.pstart, 0)
     n1, n2 = t1.length(), t2.length()
     if overlap > n1 or overlap > n2:
-        # (segments out of order: the reference's index arithmetic wraps around / runs off the end there; same here)
+        # (only with segments out of order, which the sort by fstart excludes: the reference's index arithmetic then runs off
+        # the end of t2 -- IndexError, as here -- or wraps around inside t1)
         raise IndexError("merge of trajectories whose overlap exceeds one of them")
     if overlap:
         t1.rois[n1 - overlap:n1] = (t1.rois[n1 - overlap:n1] + t2.rois[:overlap]) / 2
