@@ -24,7 +24,7 @@ __all__ = [
 ]
 
 
-_status_blocks = {}          # device index -> pinned int32 [STATUS_WORDS] the kernels of that device can write
+_status_blocks = {}          # device index -> numpy view of the pinned int32 [STATUS_WORDS] the kernels of that device can write
 _status_lock = threading.Lock()
 
 
@@ -45,7 +45,7 @@ def _status_block(index=None):
             blk = raw[off:off + _abi.STATUS_WORDS]
             with torch.cuda.device(idx):
                 _abi.check(_abi.lib().tspn_status_attach(ctypes.c_void_p(blk.data_ptr())))
-            _status_blocks[idx] = blk
+            blk = _status_blocks[idx] = blk.numpy()             # live view of the pinned words (it keeps the tensor alive)
     return blk
 
 
@@ -53,13 +53,22 @@ def _stream():
     """Current stream of the CURRENT device; every public op runs under `_on_tensor_device`, which makes
     the device of its tensor arguments current for the duration of the call.  Every launch passes here: the
     device's status block is attached before its first kernel runs."""
-    _status_block()
+    blk = _status_block()
+    # fail fast: with a fault standing on this device nothing more is launched from here (the C entries report it too, but
+    # only where they check the launch error, i.e. after enqueueing their kernel)
+    fault = int(blk[_abi.STATUS_FAULT])
+    if fault:
+        raise _abi.TspnError(_abi.TSPN_EDEVICE,
+                             f"device {torch.cuda.current_device()} reported fault 0x{fault:x}"
+                             + (" (an LDS hand-over between waves timed out)" if fault & _abi.FAULT_HANDOVER else "")
+                             + f", info 0x{int(blk[_abi.STATUS_FAULT_INFO]) & 0xffffffff:x}, in an earlier launch of this library: "
+                             "results produced since are not to be trusted; ops.status_clear() re-arms")
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def status_words(device=None):
     """Live numpy view of a device's status block (words: _abi.STATUS_*)."""
-    return _status_block(None if device is None else torch.device(device).index).numpy()
+    return _status_block(None if device is None else torch.device(device).index)
 
 
 def status_fault(device=None):
@@ -80,7 +89,8 @@ def status_selftest(device=None):
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     with torch.cuda.device(dev):
         reached = torch.zeros(1, dtype=torch.int32, device=dev)
-        _abi.check(_abi.lib().tspn_status_selftest(_p(reached), _stream()))
+        _status_block()
+        _abi.check(_abi.lib().tspn_status_selftest(_p(reached), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
     return reached
 
 

@@ -58,6 +58,14 @@ def test_device_fault_is_reported_by_the_next_launch_entry_and_clear_rearms(tspn
     assert ei.value.code == tspn._abi.TSPN_EDEVICE and "hand-over" in str(ei.value)
     with pytest.raises(tspn._abi.TspnError):                      # it stays set
         tspn.ops.cast_bf16(x)
+    # (the wrappers fail fast from the host-visible word; the C entries report it themselves, where they check the launch)
+    import ctypes
+    out = torch.empty((4, 32), dtype=torch.float32, device=device)
+    lib = tspn._abi.lib()
+    assert lib.tspn_status_fault() == tspn._abi.FAULT_HANDOVER
+    rc = lib.tspn_temporal_mean_f32(ctypes.c_void_p(x.data_ptr()), 4, 30, 32, 1, ctypes.c_void_p(out.data_ptr()),
+                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == tspn._abi.TSPN_EDEVICE and b"hand-over" in lib.tspn_last_error()
     tspn.ops.status_clear(device)
     assert tspn.ops.status_fault(device) == 0
     want = x.mean(dim=1)
