@@ -87,7 +87,7 @@ def parse(argv=None):
                     help="different input batches resident in HBM, rotated step by step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
-                    help="default cfg2 run on one GPU only: skip the short cfg2-direct / cfg3 / cfg5 legs that run AFTER the "
+                    help="default cfg2 run on one GPU only: skip the short cfg2-direct / cfg4-shard / cfg3 / cfg5 legs that run AFTER the "
                          "timed region and are printed under \"secondary\"")
     ap.add_argument("--cpu-runs", type=int, default=5, help="timed runs of the cfg2 CPU baseline (median reported)")
     ap.add_argument("--conv", choices=["winograd6", "direct"], default="winograd6",
@@ -1011,12 +1011,13 @@ class Cfg5Workload:
 def secondary_legs(args, tspn, torch, np, dev):
     """Short runs of the OTHER workloads behind the timed headline region (never inside it), in the same process, so that
     the driver's one bench line also carries driver-observed numbers for them: the reference-order fp32 conv
-    (`--conv direct`), cfg3 (bf16 long clips) and cfg5 (frames -> triplets).  Each leg is what `python bench.py --workload X`
+    (`--conv direct`), one GPU's 64-video shard of cfg4, cfg3 (bf16 long clips) and cfg5 (frames -> triplets).  Each leg is what `python bench.py --workload X`
     times, with fewer steps; a leg that fails reports its error instead of taking the headline line down."""
     import copy
     import gc
     legs = {}
     for name, over in (("cfg2_direct", {"workload": "cfg2", "conv": "direct", "steps": 3, "warmup": 1}),
+                       ("cfg4_shard", {"workload": "cfg4", "steps": 3, "warmup": 1}),
                        ("cfg3", {"workload": "cfg3", "steps": 5, "warmup": 2}),
                        ("cfg5", {"workload": "cfg5", "steps": 2, "warmup": 1})):
         a = copy.copy(args)
