@@ -91,6 +91,29 @@ def test_fault_is_visible_without_a_synchronisation(tspn, device):
     tspn.ops.status_clear(device)
 
 
+def test_spot_check_with_relu_short_tracklets_and_no_bias(tspn, device):
+    """Edges of the spot check: T = 7 (the second sextet of a tracklet has one frame), ReLU applied to the reference, no
+    bias, fewer rows than strata."""
+    B, T, Cin, M = 3, 7, 32, 32
+    x = tspn.hashrng.uniform(91, "x", (B, T, Cin), -1, 1)
+    w = tspn.hashrng.normal(91, "w", (M, Cin, 3), std=0.2)
+    ref = np.maximum(conv_ref(x, w), 0.0)
+    xd, wd = t(x).to(device), t(w).to(device)
+    y = tspn.ops.conv3_tc_wino63(xd, tspn.ops.pack_conv3_wino63(wd), None, relu=True)
+    true_max = float(np.abs(y.cpu().numpy() - ref).max())
+    zero_conv_words(tspn, device)
+    tspn.ops.conv3_spot_check(xd, wd, y, relu=True, rows=64)       # 64 strata over 32 rows: every row twice
+    torch.cuda.synchronize(device)
+    err, checks = conv_err_word(tspn, device)
+    assert 64 * 4 <= checks <= 64 * 24 and err <= true_max * (1 + 1e-6) + 1e-12
+    y_wrong = tspn.ops.conv3_tc_wino63(xd, tspn.ops.pack_conv3_wino63(wd), None, relu=False)    # no ReLU: differs wherever y < 0
+    zero_conv_words(tspn, device)
+    tspn.ops.conv3_spot_check(xd, wd, y_wrong, relu=True, rows=64)
+    torch.cuda.synchronize(device)
+    assert conv_err_word(tspn, device)[0] > 1e-2
+    zero_conv_words(tspn, device)
+
+
 @pytest.mark.parametrize("split", [0, 64])
 def test_spot_check_measures_the_error_of_a_conv_launch(tspn, device, split):
     """tspn_conv3_spot_check_f32 against the float64 conv on the host: what it reports is an error that EXISTS in y
